@@ -1,0 +1,820 @@
+/*
+ * oracle/dsp_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's effects_chain hot path (see dsp_oracle.h
+ * for the rules on who may use it and how it is pinned).  Each function cites
+ * the reference file:line whose behaviour it restates.  FFTs go through the
+ * FFTW3 ABI declared in oracle/fftw3_abi/fftw3.h (own FFT; FFTW3 is an
+ * un-vendored, un-pinned third-party dependency of the reference).
+ *
+ * Compiled with -ffp-contract=off: the reference is built for baseline x86-64
+ * (no FMA), so every multiply and add rounds separately.
+ */
+#include <complex.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "fftw3.h"
+#include "dsp_oracle.h"
+
+typedef double _Complex cplx;
+
+/* ------------------------------------------------------------------ util */
+
+/* util.c:434-458: smallest 2^a 3^b 5^c 7^d >= min_len */
+ssize_t orc_next_fast_fftw_len(ssize_t min_len)
+{
+	ssize_t best = min_len * 7;
+	const ssize_t bound = min_len * 2;
+	for (ssize_t p2 = 1; p2 <= bound; p2 *= 2)
+		for (ssize_t p3 = p2; p3 <= bound; p3 *= 3)
+			for (ssize_t p5 = p3; p5 <= bound; p5 *= 5)
+				for (ssize_t p7 = p5; p7 <= bound; p7 *= 7)
+					if (p7 >= min_len && p7 < best) best = p7;
+	return best;
+}
+
+/* ---------------------------------------------------------------- biquad */
+
+/* biquad.c:27-89: width argument: number + unit suffix, or bwN[.k] Butterworth Q */
+double orc_parse_width(const char *s, int *type, int *ok)
+{
+	char *end;
+	double w = M_SQRT1_2;
+	*type = ORC_WIDTH_Q;
+	*ok = 0;
+	if (s[0] == 'b' && s[1] == 'w' && s[2] != '\0') {
+		const long order = strtol(s + 2, &end, 10);
+		if (end == s + 2 || (*end != '\0' && *end != '.') || order < 2) return w;
+		const int n_biquads = (int) (order / 2);
+		long idx = 0;
+		if (*end == '.') {
+			const char *q = end + 1;
+			idx = strtol(q, &end, 10);
+			if (end == q || *end != '\0' || idx < 0 || idx >= n_biquads) return w;
+		}
+		idx = n_biquads - idx;  /* index from the outermost conjugate pair */
+		w = 1.0 / (2.0 * sin(M_PI / order * (idx - 0.5)));
+		*ok = 1;
+		return w;
+	}
+	w = strtod(s, &end);
+	if (end == s) return w;
+	switch (*end) {
+	case 'q': *type = ORC_WIDTH_Q; ++end; break;
+	case 's': *type = ORC_WIDTH_SLOPE; ++end; break;
+	case 'd': *type = ORC_WIDTH_SLOPE_DB; ++end; break;
+	case 'o': *type = ORC_WIDTH_BW_OCT; ++end; break;
+	case 'k': w *= 1000.0;  /* fall through */
+	case 'h': *type = ORC_WIDTH_BW_HZ; ++end; break;
+	}
+	*ok = (*end == '\0');
+	return w;
+}
+
+/* biquad.c:91-99: normalise by a0 */
+void orc_biquad_coefs(double b0, double b1, double b2, double a0, double a1, double a2, double c[5])
+{
+	c[0] = b0 / a0;
+	c[1] = b1 / a0;
+	c[2] = b2 / a0;
+	c[3] = a1 / a0;
+	c[4] = a2 / a0;
+}
+
+/* biquad.c:111-294: RBJ cookbook designs + first-order and Linkwitz-transform variants */
+void orc_biquad_design(int type, double fs, double arg0, double arg1, double arg2, double arg3, int width_type, double c[5])
+{
+	double b0 = 1.0, b1 = 0.0, b2 = 0.0, a0 = 1.0, a1 = 0.0, a2 = 0.0;
+	if (type == ORC_BIQUAD_LOWPASS_TRANSFORM || type == ORC_BIQUAD_HIGHPASS_TRANSFORM) {
+		const int lp = (type == ORC_BIQUAD_LOWPASS_TRANSFORM);
+		const double wz = 2*M_PI*arg0 / fs, wp = 2*M_PI*arg2 / fs;
+		const double cz = cos(wz), cp = cos(wp);
+		const double alz = sin(wz) / (2.0*arg1), alp = sin(wp) / (2.0*arg3);
+		const double kz = lp ? 2.0/(1.0-cz) : 2.0/(1.0+cz);
+		const double kp = lp ? 2.0/(1.0-cp) : 2.0/(1.0+cp);
+		b0 = (1.0 + alz)*kz;  b1 = (-2.0 * cz)*kz;  b2 = (1.0 - alz)*kz;
+		a0 = (1.0 + alp)*kp;  a1 = (-2.0 * cp)*kp;  a2 = (1.0 - alp)*kp;
+		orc_biquad_coefs(b0, b1, b2, a0, a1, a2, c);
+		return;
+	}
+	double f0 = arg0, width = arg1, alpha, t;
+	const double gain = arg2;
+	if (width_type == ORC_WIDTH_SLOPE_DB) {
+		width_type = ORC_WIDTH_SLOPE;
+		width /= 12.0;
+		if (type == ORC_BIQUAD_LOWSHELF) f0 *= pow(10.0, fabs(gain) / 80.0 / width);
+		else if (type == ORC_BIQUAD_HIGHSHELF) f0 /= pow(10.0, fabs(gain) / 80.0 / width);
+	}
+	const double a = pow(10.0, gain / 40.0);
+	const double w0 = 2*M_PI*f0 / fs;
+	const double sn = sin(w0), cs = cos(w0);
+	switch (width_type) {
+	case ORC_WIDTH_SLOPE:  alpha = sn/2.0 * sqrt((a + 1.0/a) * (1.0/width - 1.0) + 2.0); break;
+	case ORC_WIDTH_BW_OCT: alpha = sn * sinh(M_LN2/2 * width * w0 / sn); break;
+	case ORC_WIDTH_BW_HZ:  alpha = sn / (2.0 * f0 / width); break;
+	default:               alpha = sn / (2.0 * width);
+	}
+	switch (type) {
+	case ORC_BIQUAD_LOWPASS_1:
+		t = 1.0 + cs;  b0 = sn; b1 = sn; a0 = sn + t; a1 = sn - t; break;
+	case ORC_BIQUAD_HIGHPASS_1:
+		t = 1.0 + cs;  b0 = t; b1 = -t; a0 = sn + t; a1 = sn - t; break;
+	case ORC_BIQUAD_ALLPASS_1:
+		t = 1.0 + cs;  b0 = sn - t; b1 = sn + t; a0 = b1; a1 = b0; break;
+	case ORC_BIQUAD_LOWSHELF_1:
+		t = 1.0 + cs;  b0 = a*sn + t; b1 = a*sn - t; a0 = sn/a + t; a1 = sn/a - t; break;
+	case ORC_BIQUAD_HIGHSHELF_1:
+		t = 1.0 + cs;  b0 = sn + t*a; b1 = sn - t*a; a0 = sn + t/a; a1 = sn - t/a; break;
+	case ORC_BIQUAD_LOWPASS_1P:
+		t = 1.0 - cs;  b0 = -t + sqrt(t*t + 2.0*t); b1 = 0.0; a0 = 1.0; a1 = -1.0 + b0; break;
+	case ORC_BIQUAD_LOWPASS:
+		b0 = (1.0 - cs) / 2.0; b1 = 1.0 - cs; b2 = b0;
+		a0 = 1.0 + alpha; a1 = -2.0*cs; a2 = 1.0 - alpha; break;
+	case ORC_BIQUAD_HIGHPASS:
+		b0 = (1.0 + cs) / 2.0; b1 = -(1.0 + cs); b2 = b0;
+		a0 = 1.0 + alpha; a1 = -2.0*cs; a2 = 1.0 - alpha; break;
+	case ORC_BIQUAD_BANDPASS_SKIRT:
+		b0 = sn / 2.0; b1 = 0.0; b2 = -b0;
+		a0 = 1.0 + alpha; a1 = -2.0*cs; a2 = 1.0 - alpha; break;
+	case ORC_BIQUAD_BANDPASS_PEAK:
+		b0 = alpha; b1 = 0.0; b2 = -alpha;
+		a0 = 1.0 + alpha; a1 = -2.0*cs; a2 = 1.0 - alpha; break;
+	case ORC_BIQUAD_NOTCH:
+		b0 = 1.0; b1 = -2.0*cs; b2 = 1.0;
+		a0 = 1.0 + alpha; a1 = b1; a2 = 1.0 - alpha; break;
+	case ORC_BIQUAD_ALLPASS:
+		b0 = 1.0 - alpha; b1 = -2.0*cs; b2 = 1.0 + alpha;
+		a0 = b2; a1 = b1; a2 = b0; break;
+	case ORC_BIQUAD_PEAK:
+		b0 = 1.0 + alpha*a; b1 = -2.0*cs; b2 = 1.0 - alpha*a;
+		a0 = 1.0 + alpha/a; a1 = b1; a2 = 1.0 - alpha/a; break;
+	case ORC_BIQUAD_LOWSHELF:
+		t = 2.0 * sqrt(a) * alpha;
+		b0 = a * ((a + 1.0) - (a - 1.0)*cs + t);
+		b1 = 2.0 * a * ((a - 1.0) - (a + 1.0)*cs);
+		b2 = a * ((a + 1.0) - (a - 1.0)*cs - t);
+		a0 = (a + 1.0) + (a - 1.0)*cs + t;
+		a1 = -2.0 * ((a - 1.0) + (a + 1.0)*cs);
+		a2 = (a + 1.0) + (a - 1.0)*cs - t; break;
+	case ORC_BIQUAD_HIGHSHELF:
+		t = 2.0 * sqrt(a) * alpha;
+		b0 = a * ((a + 1.0) + (a - 1.0)*cs + t);
+		b1 = -2.0 * a * ((a - 1.0) + (a + 1.0)*cs);
+		b2 = a * ((a + 1.0) + (a - 1.0)*cs - t);
+		a0 = (a + 1.0) - (a - 1.0)*cs + t;
+		a1 = 2.0 * ((a - 1.0) - (a + 1.0)*cs);
+		a2 = (a + 1.0) - (a - 1.0)*cs - t; break;
+	}
+	orc_biquad_coefs(b0, b1, b2, a0, a1, a2, c);
+}
+
+/* biquad.h:76-92 (BIQUAD_USE_TDF_2) + loops biquad.c:296-315: in-place, one channel */
+void orc_biquad_run(const double c[5], double m[2], double *buf, ssize_t frames, int stride)
+{
+	double m0 = m[0], m1 = m[1];
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double s = buf[i*stride];
+		const double r = (c[0] * s) + m0;
+		m0 = m1 + (c[1] * s) - (c[3] * r);
+		m1 = (c[2] * s) - (c[4] * r);
+		buf[i*stride] = r;
+	}
+	m[0] = m0;
+	m[1] = m1;
+}
+
+/* -------------------------------------------------- gain / remix / delay */
+
+/* gain.c:25-33 */
+void orc_gain_run(double *buf, ssize_t frames, int channels, const double *mult)
+{
+	for (ssize_t i = 0; i < frames; ++i)
+		for (int k = 0; k < channels; ++k)
+			buf[i*channels + k] *= mult[k];
+}
+
+/* gain.c:35-43 */
+void orc_add_run(double *buf, ssize_t frames, int channels, const double *add)
+{
+	for (ssize_t i = 0; i < frames; ++i)
+		for (int k = 0; k < channels; ++k)
+			buf[i*channels + k] += add[k];
+}
+
+/* remix.c:39-54 (generic form; the 1a/4 fast paths :56-101 give identical bits:
+ * 0.0 + x is exact and the summation order is ascending input channel in all three) */
+void orc_remix_run(const double *in, double *out, ssize_t frames, int in_channels, int out_channels, const char *sel)
+{
+	for (ssize_t i = 0; i < frames; ++i) {
+		for (int k = 0; k < out_channels; ++k) {
+			double acc = 0.0;
+			for (int j = 0; j < in_channels; ++j)
+				if (sel[k*in_channels + j]) acc += in[i*in_channels + j];
+			out[i*out_channels + k] = acc;
+		}
+	}
+}
+
+/* align.c:35-44: circular swap delay of `len` frames for one channel */
+void orc_delay_run(double *buf, ssize_t frames, int stride, double *ring, ssize_t len, ssize_t *p)
+{
+	if (len <= 0) return;
+	ssize_t q = *p;
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double s = buf[i*stride];
+		buf[i*stride] = ring[q];
+		ring[q] = s;
+		q = (q + 1 >= len) ? 0 : q + 1;
+	}
+	*p = q;
+}
+
+/* ------------------------------------------------------------ fir direct */
+
+struct fir_direct {
+	ssize_t len, mask, p;
+	double *filter, *acc;
+};
+
+/* fir.c:262-299: power-of-two circular accumulator sized to the tap count */
+void *orc_fir_direct_new(const double *taps, ssize_t n_taps)
+{
+	struct fir_direct *st = calloc(1, sizeof(*st));
+	st->len = 1;
+	while (st->len < n_taps) st->len <<= 1;
+	st->mask = st->len - 1;
+	st->filter = calloc(st->len, sizeof(double));
+	st->acc = calloc(st->len, sizeof(double));
+	memcpy(st->filter, taps, n_taps * sizeof(double));
+	return st;
+}
+
+/* fir.c:43-62: scatter-add each input sample over the accumulator, emit slot p */
+void orc_fir_direct_run(void *stp, double *buf, ssize_t frames, int stride)
+{
+	struct fir_direct *st = stp;
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double s = buf[i*stride];
+		ssize_t n = st->p;
+		for (ssize_t m = 0; m < st->len; ++m) {
+			st->acc[n] += s * st->filter[m];
+			n = (n + 1) & st->mask;
+		}
+		buf[i*stride] = st->acc[st->p];
+		st->acc[st->p] = 0.0;
+		st->p = (st->p + 1) & st->mask;
+	}
+}
+
+void orc_fir_direct_free(void *stp)
+{
+	struct fir_direct *st = stp;
+	free(st->filter);
+	free(st->acc);
+	free(st);
+}
+
+/* --------------------------------------------------------- fir (one OLA) */
+
+struct fir_ola {
+	ssize_t len, fr_len, p;
+	double *buf, *olap;
+	cplx *filter_fr, *tmp_fr;
+	fftw_plan r2c, c2r;
+};
+
+/* fir.c:301-367: len = next_fast_fftw_len(taps), FFT size 2*len, filter spectrum precomputed */
+void *orc_fir_new(const double *taps, ssize_t n_taps)
+{
+	struct fir_ola *st = calloc(1, sizeof(*st));
+	st->len = orc_next_fast_fftw_len(n_taps);
+	st->fr_len = st->len + ((st->len & 1) ? 1 : 2);
+	st->buf = fftw_malloc(st->len * 2 * sizeof(double));
+	st->olap = fftw_malloc(st->len * sizeof(double));
+	st->filter_fr = fftw_malloc(st->fr_len * sizeof(cplx));
+	st->tmp_fr = fftw_malloc(st->fr_len * sizeof(cplx));
+	memset(st->filter_fr, 0, st->fr_len * sizeof(cplx));
+	memset(st->tmp_fr, 0, st->fr_len * sizeof(cplx));
+	st->r2c = fftw_plan_dft_r2c_1d(st->len * 2, st->buf, (fftw_complex *) st->tmp_fr, FFTW_ESTIMATE);
+	st->c2r = fftw_plan_dft_c2r_1d(st->len * 2, (fftw_complex *) st->tmp_fr, st->buf, FFTW_ESTIMATE);
+	memset(st->buf, 0, st->len * 2 * sizeof(double));
+	memset(st->olap, 0, st->len * sizeof(double));
+	memcpy(st->buf, taps, n_taps * sizeof(double));
+	fftw_execute(st->r2c);
+	memcpy(st->filter_fr, st->tmp_fr, (st->len + 1) * sizeof(cplx));
+	memset(st->buf, 0, st->len * 2 * sizeof(double));
+	return st;
+}
+
+ssize_t orc_fir_latency(void *stp)
+{
+	return ((struct fir_ola *) stp)->len;  /* fir.c:208-217 */
+}
+
+/* fir.c:109-149: swap samples through a len-frame buffer; every len frames
+ * r2c -> multiply -> c2r -> scale by 1/(2 len) -> add/save overlap */
+void orc_fir_run(void *stp, double *buf, ssize_t frames, int stride)
+{
+	struct fir_ola *st = stp;
+	const double norm = 1.0 / (st->len * 2.0);
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double s = buf[i*stride];
+		buf[i*stride] = st->buf[st->p];
+		st->buf[st->p] = s;
+		if (++st->p == st->len) {
+			fftw_execute_dft_r2c(st->r2c, st->buf, (fftw_complex *) st->tmp_fr);
+			for (ssize_t j = 0; j <= st->len; ++j)
+				st->tmp_fr[j] *= st->filter_fr[j];
+			fftw_execute_dft_c2r(st->c2r, (fftw_complex *) st->tmp_fr, st->buf);
+			for (ssize_t j = 0; j < st->len * 2; ++j)
+				st->buf[j] *= norm;
+			for (ssize_t j = 0; j < st->len; ++j) {
+				st->buf[j] += st->olap[j];
+				st->olap[j] = st->buf[st->len + j];
+				st->buf[st->len + j] = 0.0;
+			}
+			st->p = 0;
+		}
+	}
+}
+
+void orc_fir_free(void *stp)
+{
+	struct fir_ola *st = stp;
+	fftw_destroy_plan(st->r2c);
+	fftw_destroy_plan(st->c2r);
+	fftw_free(st->buf);
+	fftw_free(st->olap);
+	fftw_free(st->filter_fr);
+	fftw_free(st->tmp_fr);
+	free(st);
+}
+
+/* ------------------------------------------------------------------ fir_p */
+
+#define P_DIRECT 32  /* fir_p.c:34 */
+#define P_MAX_GROUPS 4
+#define P_MAX_PART_DEFAULT (1 << 14)
+
+/* fir_p.c:290-335 (find_partitions) + :337-360 (delay derivation).
+ * Returns the number of FFT groups, or -1 if the plan is invalid. */
+int orc_fir_p_plan(ssize_t n_taps, int max_part_len, int single_thread, int len[4], int n[4], int delay[4])
+{
+	const int delay_fact = single_thread ? 1 : 2;
+	if (max_part_len == 0) max_part_len = P_MAX_PART_DEFAULT;
+	int step = 4, ng;
+	for (;; step <<= 1) {
+		ng = 0;
+		int overflow = 0;
+		ssize_t j = P_DIRECT, k = P_DIRECT;
+		while (k < n_taps) {
+			if (++ng > P_MAX_GROUPS) { overflow = 1; break; }
+			len[ng-1] = (int) j;
+			n[ng-1] = 1;
+			k += j;
+			while (k < n_taps && k < j * step * delay_fact) { ++n[ng-1]; k += len[ng-1]; }
+			j *= step;
+			if (j > max_part_len || k + j * step > n_taps) {
+				while (k < n_taps) { ++n[ng-1]; k += len[ng-1]; }
+				break;
+			}
+		}
+		if (!overflow) break;
+	}
+	for (int g = ng - 1; g > 0; --g) {  /* widen late groups while that shortens the FDL */
+		while (len[g] * 2 <= max_part_len) {
+			const int new_n = n[g-1] + len[g] * delay_fact / len[g-1];
+			if (n[g] <= new_n) break;
+			n[g-1] = new_n;
+			len[g] *= 2;
+			n[g] -= delay_fact;
+			n[g] = n[g] / 2 + (n[g] & 1);
+		}
+	}
+	ssize_t total = P_DIRECT, last_total = P_DIRECT;
+	for (int g = 0; g < ng; ++g) {
+		delay[g] = (int) (last_total - len[g]);
+		if (((single_thread || g == 0) && delay[g] != 0) || (!single_thread && g > 0 && delay[g] != len[g]))
+			return -1;
+		total += (ssize_t) len[g] * n[g];
+		last_total = total;
+	}
+	return (total < n_taps) ? -1 : ng;
+}
+
+struct p_group {
+	int n, len, fr_len, p, fdl_p, delay;
+	cplx *filter_fr, *fdl, *tmp_fr;
+	double *fft_buf, *olap, *ibuf, *obuf;
+	fftw_plan r2c, c2r;
+};
+
+struct fir_p {
+	double filter0[P_DIRECT], acc0[P_DIRECT];
+	int p0, ng;
+	struct p_group g[P_MAX_GROUPS];
+};
+
+/* fir_p.c:64-103: r2c, store in FDL, sum FDL[j-q] * H[q], c2r, scale, overlap-add */
+static void p_group_compute(struct p_group *g)
+{
+	const double norm = 1.0 / (g->len * 2.0);
+	cplx *fdl_p = g->fdl + (size_t) g->fr_len * g->fdl_p;
+	const cplx *h = g->filter_fr;
+	fftw_execute_dft_r2c(g->r2c, g->fft_buf, (fftw_complex *) g->tmp_fr);
+	memcpy(fdl_p, g->tmp_fr, g->fr_len * sizeof(cplx));
+	for (int l = 0; l < g->fr_len; ++l) g->tmp_fr[l] *= h[l];
+	for (int q = 1; q < g->n; ++q) {
+		h += g->fr_len;
+		fdl_p = (fdl_p == g->fdl) ? g->fdl + (size_t) g->fr_len * (g->n - 1) : fdl_p - g->fr_len;
+		for (int l = 0; l < g->fr_len; ++l) g->tmp_fr[l] += fdl_p[l] * h[l];
+	}
+	fftw_execute_dft_c2r(g->c2r, (fftw_complex *) g->tmp_fr, g->fft_buf);
+	for (int l = 0; l < g->len * 2; ++l) g->fft_buf[l] *= norm;
+	for (int l = 0; l < g->len; ++l) {
+		g->fft_buf[l] += g->olap[l];
+		g->olap[l] = g->fft_buf[g->len + l];
+		g->fft_buf[g->len + l] = 0.0;
+	}
+	g->fdl_p = (g->fdl_p + 1 < g->n) ? g->fdl_p + 1 : 0;
+}
+
+/* fir_p.c:362-539 for one channel; taps <= 32 is the caller's business (fir_p.c:364) */
+void *orc_fir_p_new(const double *taps, ssize_t n_taps, int max_part_len)
+{
+	struct fir_p *st = calloc(1, sizeof(*st));
+	int len[4], n[4], delay[4];
+	const int single = (n_taps < 4096);  /* fir_p.c:407 */
+	st->ng = orc_fir_p_plan(n_taps, max_part_len, single, len, n, delay);
+	if (st->ng < 0) { free(st); return NULL; }
+	memcpy(st->filter0, taps, P_DIRECT * sizeof(double));
+	ssize_t pos = P_DIRECT;
+	for (int i = 0; i < st->ng; ++i) {
+		struct p_group *g = &st->g[i];
+		g->len = len[i]; g->n = n[i]; g->delay = delay[i]; g->fr_len = len[i] + 2;
+		g->filter_fr = fftw_malloc((size_t) g->fr_len * g->n * sizeof(cplx));
+		g->fdl = fftw_malloc((size_t) g->fr_len * g->n * sizeof(cplx));
+		g->tmp_fr = fftw_malloc(g->fr_len * sizeof(cplx));
+		g->fft_buf = fftw_malloc(g->len * 2 * sizeof(double));
+		g->olap = fftw_malloc(g->len * sizeof(double));
+		memset(g->fdl, 0, (size_t) g->fr_len * g->n * sizeof(cplx));
+		memset(g->tmp_fr, 0, g->fr_len * sizeof(cplx));
+		memset(g->fft_buf, 0, g->len * 2 * sizeof(double));
+		memset(g->olap, 0, g->len * sizeof(double));
+		g->r2c = fftw_plan_dft_r2c_1d(g->len * 2, g->fft_buf, (fftw_complex *) g->tmp_fr, FFTW_ESTIMATE);
+		g->c2r = fftw_plan_dft_c2r_1d(g->len * 2, (fftw_complex *) g->tmp_fr, g->fft_buf, FFTW_ESTIMATE);
+		for (int q = 0; q < g->n; ++q) {
+			const ssize_t cnt = (n_taps - pos < g->len) ? n_taps - pos : g->len;
+			if (cnt > 0) memcpy(g->fft_buf, taps + pos, cnt * sizeof(double));
+			fftw_execute(g->r2c);
+			memcpy(g->filter_fr + (size_t) q * g->fr_len, g->tmp_fr, g->fr_len * sizeof(cplx));
+			/* the reference's r2c writes len+1 bins into an fr_len = len+2 buffer; bin len+1 stays 0 */
+			g->filter_fr[(size_t) q * g->fr_len + g->len + 1] = 0.0;
+			pos += g->len;
+			memset(g->fft_buf, 0, g->len * 2 * sizeof(double));
+		}
+		if (g->delay > 0) {
+			g->ibuf = calloc(g->len, sizeof(double));
+			g->obuf = calloc(g->len, sizeof(double));
+		}
+		else g->ibuf = g->obuf = g->fft_buf;
+	}
+	return st;
+}
+
+/* fir_p.c:127-181.  Groups with delay > 0 run on worker threads in the
+ * reference (fir_p.c:105-125, 163-169); the hand-off (copy previous result
+ * out, copy staged input in, start compute) is restated inline -- the values
+ * are the same, only the wall-clock overlap is gone. */
+void orc_fir_p_run(void *stp, double *buf, ssize_t frames, int stride)
+{
+	struct fir_p *st = stp;
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double s = buf[i*stride];
+		for (int m = 0, nn = st->p0; m < P_DIRECT; ++m) {
+			st->acc0[nn] += s * st->filter0[m];
+			nn = (nn + 1) & (P_DIRECT - 1);
+		}
+		double y = st->acc0[st->p0];
+		st->acc0[st->p0] = 0.0;
+		for (int j = 0; j < st->ng; ++j) {
+			struct p_group *g = &st->g[j];
+			y += g->obuf[g->p + st->p0];
+			g->ibuf[g->p + st->p0] = s;
+		}
+		buf[i*stride] = y;
+		st->p0 = (st->p0 + 1) & (P_DIRECT - 1);
+		if (st->p0 == 0) {
+			for (int j = 0; j < st->ng; ++j) {
+				struct p_group *g = &st->g[j];
+				g->p += P_DIRECT;
+				if (g->p == g->len) {
+					g->p = 0;
+					if (g->delay > 0) {
+						memcpy(g->obuf, g->fft_buf, g->len * sizeof(double));
+						memcpy(g->fft_buf, g->ibuf, g->len * sizeof(double));
+					}
+					p_group_compute(g);
+				}
+			}
+		}
+	}
+}
+
+void orc_fir_p_free(void *stp)
+{
+	struct fir_p *st = stp;
+	for (int i = 0; i < st->ng; ++i) {
+		struct p_group *g = &st->g[i];
+		fftw_destroy_plan(g->r2c);
+		fftw_destroy_plan(g->c2r);
+		fftw_free(g->filter_fr); fftw_free(g->fdl); fftw_free(g->tmp_fr);
+		fftw_free(g->fft_buf); fftw_free(g->olap);
+		if (g->delay > 0) { free(g->ibuf); free(g->obuf); }
+	}
+	free(st);
+}
+
+/* --------------------------------------------------------------- resample */
+
+struct resampler {
+	int n, d, m;
+	int sinc_fr_len, tmp_fr_len, in_len, out_len, out_delay;
+	int in_pos, out_pos, has_output;
+	int is_draining, drain_pos, drain_frames;
+	cplx *sinc_fr, *tmp_fr, *tmp_fr_2;
+	double *input, *output, *overlap;
+	fftw_plan r2c, c2r;
+};
+
+/* resample.c:52-79, WINDOW_FUNCTION 3: Albrecht 9-term */
+static double rs_window(double x)
+{
+	static const double a[9] = {
+		2.318028013590306028393e-1, 3.932575471789488615081e-1, 2.385434764970747429454e-1,
+		1.014370437785239811268e-1, 2.911516061918003918645e-2, 5.280988177252078698806e-3,
+		5.382909093381945363528e-4, 2.442086527507867730168e-5, 2.706153764205043532817e-7,
+	};
+	if (x >= 1.0 || x <= 0.0) return 0.0;
+	double w = a[0];
+	for (int i = 1; i < 9; ++i)
+		w += ((i & 1) ? -a[i] : a[i]) * cos(2*i*M_PI*x);
+	return w;
+}
+
+/* resample.c:81-87 */
+static double rs_sinc(double x, double fc)
+{
+	return (fabs(x) < 1e-9) ? fc : sin(M_PI*fc*x) / (M_PI*x);
+}
+
+static int rs_gcd(int a, int b) { while (b) { const int t = b; b = a % b; a = t; } return a; }
+
+/* resample.c:274-375 for one channel (M_FACT 17.7822, SINC_MAX_OVERSAMPLE 2, no self-convolve) */
+void *orc_resample_new(int fs_in, int fs_out, double bw)
+{
+	const double m_fact = 17.7822;
+	struct resampler *st = calloc(1, sizeof(*st));
+	const int max_rate = fs_out > fs_in ? fs_out : fs_in, min_rate = fs_out > fs_in ? fs_in : fs_out;
+	const int g = rs_gcd(fs_out, fs_in);
+	st->n = fs_out / g;
+	st->d = fs_in / g;
+	const int max_factor = st->n > st->d ? st->n : st->d, min_factor = st->n > st->d ? st->d : st->n;
+	const int m = (int) lround(2.0*m_fact*max_rate / (min_rate*(1.0-bw)));
+	const double width = m_fact*max_rate / m;
+	const double fc = (min_rate-width) / max_rate;
+	const int sinc_os = min_factor < 2 ? min_factor : 2;
+	const double fc_os = fc / sinc_os;
+	const int m_os = (m + 1) * sinc_os - 1;
+	st->m = m;
+	int len_mult = (m + 1) / max_factor;
+	if ((m + 1) % max_factor != 0) len_mult += 1;
+	if (len_mult > 16) {
+		const int fast = (int) orc_next_fast_fftw_len(len_mult);
+		if (fast != len_mult && (st->n <= 16 || st->d <= 16
+				|| orc_next_fast_fftw_len(st->n) == st->n || orc_next_fast_fftw_len(st->d) == st->d))
+			len_mult = fast;
+	}
+	const int sinc_len = max_factor * len_mult * sinc_os;
+	st->in_len = st->d * len_mult;
+	st->out_len = st->n * len_mult;
+	st->tmp_fr_len = max_factor * len_mult + 1;
+	st->sinc_fr_len = sinc_len + 1;
+	st->out_delay = (fs_out == max_rate) ? m / 2 : (int) lround(m / 2 * ((double) st->n / st->d));
+
+	double *sinc = fftw_malloc((size_t) sinc_len * 2 * sizeof(double));
+	st->sinc_fr = fftw_malloc(st->sinc_fr_len * sizeof(cplx));
+	st->tmp_fr = fftw_malloc(st->tmp_fr_len * sizeof(cplx));
+	st->tmp_fr_2 = fftw_malloc(st->tmp_fr_len * sizeof(cplx));
+	st->input = fftw_malloc(st->in_len * 2 * sizeof(double));
+	st->output = fftw_malloc(st->out_len * 2 * sizeof(double));
+	st->overlap = fftw_malloc(st->out_len * sizeof(double));
+	memset(sinc, 0, (size_t) sinc_len * 2 * sizeof(double));
+	memset(st->sinc_fr, 0, st->sinc_fr_len * sizeof(cplx));
+	memset(st->tmp_fr, 0, st->tmp_fr_len * sizeof(cplx));
+	memset(st->tmp_fr_2, 0, st->tmp_fr_len * sizeof(cplx));
+	memset(st->input, 0, st->in_len * 2 * sizeof(double));
+	memset(st->output, 0, st->out_len * 2 * sizeof(double));
+	memset(st->overlap, 0, st->out_len * sizeof(double));
+	st->r2c = fftw_plan_dft_r2c_1d(st->in_len * 2, st->input, (fftw_complex *) st->tmp_fr, FFTW_ESTIMATE);
+	st->c2r = fftw_plan_dft_c2r_1d(st->out_len * 2, (fftw_complex *) st->tmp_fr_2, st->output, FFTW_ESTIMATE);
+	for (int i = 1; i < m_os; ++i)
+		sinc[i] = rs_sinc((i*2 - m_os)/2.0, fc_os) * rs_window((double) i / m_os);
+	fftw_plan sp = fftw_plan_dft_r2c_1d(sinc_len * 2, sinc, (fftw_complex *) st->sinc_fr, FFTW_ESTIMATE);
+	fftw_execute(sp);
+	fftw_destroy_plan(sp);
+	fftw_free(sinc);
+	return st;
+}
+
+void orc_resample_params(void *stp, int p[8])
+{
+	struct resampler *st = stp;
+	p[0] = st->n; p[1] = st->d; p[2] = st->m; p[3] = st->in_len; p[4] = st->out_len;
+	p[5] = st->out_delay; p[6] = st->sinc_fr_len; p[7] = st->tmp_fr_len;
+}
+
+/* resample.c:111-147: one block transform for the buffered in_len samples */
+static void rs_block(struct resampler *st)
+{
+	fftw_execute(st->r2c);
+	memset(st->tmp_fr_2, 0, st->tmp_fr_len * sizeof(cplx));
+	st->tmp_fr_2[0] = st->tmp_fr[0] * st->sinc_fr[0];
+	/* walk sinc bin k; j bounces over the input spectrum (images), l over the output spectrum (folds) */
+	for (int k = 1, j = 1, l = 1, dj = 1, dl = 1;; ++k) {
+		const cplx s = (dj == 1) ? st->tmp_fr[j] : conj(st->tmp_fr[j]);
+		const cplx v = s * st->sinc_fr[k];
+		st->tmp_fr_2[l] += (dl == 1) ? v : conj(v);
+		if (k + 1 == st->sinc_fr_len) break;
+		if (l == st->out_len) st->tmp_fr_2[l] += v;
+		else if (l == 0) st->tmp_fr_2[l] += conj(v);
+		j += dj;
+		l += dl;
+		if (j == 0) dj = 1; else if (j == st->in_len) dj = -1;
+		if (l == 0) dl = 1; else if (l == st->out_len) dl = -1;
+	}
+	fftw_execute(st->c2r);
+	for (int k = 0; k < st->out_len * 2; ++k)
+		st->output[k] /= st->in_len * 2;
+	for (int k = 0; k < st->out_len; ++k) {
+		st->output[k] += st->overlap[k];
+		st->overlap[k] = st->output[k + st->out_len];
+	}
+}
+
+/* resample.c:89-152 for one channel; returns frames written to out */
+ssize_t orc_resample_run(void *stp, const double *in, ssize_t frames, int istride, double *out, int ostride)
+{
+	struct resampler *st = stp;
+	ssize_t iframes = 0, oframes = 0;
+	const long long r = (long long) frames * st->n;
+	const ssize_t max_oframes = (ssize_t) ((r % st->d) ? r / st->d + 1 : r / st->d);  /* util.h:180-184 */
+	while (iframes < frames) {
+		while (st->in_pos < st->in_len && iframes < frames)
+			st->input[st->in_pos++] = in[(iframes++) * istride];
+		while (st->out_pos < st->out_len && oframes < max_oframes && st->has_output)
+			out[(oframes++) * ostride] = st->output[st->out_pos++];
+		if (st->in_pos == st->in_len && (!st->has_output || st->out_pos == st->out_len)) {
+			rs_block(st);
+			st->in_pos = st->out_pos = 0;
+			if (!st->has_output) {
+				st->out_pos = st->out_delay;
+				st->has_output = 1;
+			}
+		}
+	}
+	return oframes;
+}
+
+/* resample.c:163-188: returns -1 when dry; scratch_in must hold `frames` doubles */
+ssize_t orc_resample_drain(void *stp, ssize_t frames, double *scratch_in, double *out)
+{
+	struct resampler *st = stp;
+	if (!st->has_output && st->in_pos == 0) return -1;
+	if (!st->is_draining) {
+		if (st->has_output) {
+			st->drain_frames += st->out_delay;
+			st->drain_frames += st->out_len - st->out_pos;
+		}
+		const long long r = (long long) st->in_pos * st->n;
+		st->drain_frames += (int) ((r % st->d) ? r / st->d + 1 : r / st->d);
+		st->is_draining = 1;
+	}
+	if (st->drain_pos >= st->drain_frames) return -1;
+	memset(scratch_in, 0, frames * sizeof(double));
+	ssize_t f = orc_resample_run(st, scratch_in, frames, 1, out, 1);
+	st->drain_pos += (int) f;
+	if (st->drain_pos > st->drain_frames) f -= st->drain_pos - st->drain_frames;
+	return f;
+}
+
+void orc_resample_free(void *stp)
+{
+	struct resampler *st = stp;
+	fftw_destroy_plan(st->r2c);
+	fftw_destroy_plan(st->c2r);
+	fftw_free(st->sinc_fr); fftw_free(st->tmp_fr); fftw_free(st->tmp_fr_2);
+	fftw_free(st->input); fftw_free(st->output); fftw_free(st->overlap);
+	free(st);
+}
+
+/* ------------------------------------------------ hilbert / sgen / misc */
+
+/* hilbert.c:65-77: odd-length Blackman-windowed Hilbert transformer, angle in degrees */
+void orc_hilbert_taps(ssize_t taps, double angle_deg, double *h)
+{
+	const double angle = angle_deg / 180.0 * M_PI;
+	const double w_h = sin(-angle), w_d = cos(-angle);
+	for (ssize_t i = 0, k = -taps / 2; i < taps; ++i, ++k) {
+		if (k == 0) h[i] = w_d;
+		else if (k % 2 == 0) h[i] = 0;
+		else {
+			const double x = 2.0*M_PI*i/(taps-1);
+			h[i] = w_h * 2.0/(M_PI*k) * (0.42 - 0.5*cos(x) + 0.08*cos(2.0*x));
+		}
+	}
+}
+
+/* sgen.c:55-67 (fixed-frequency branch, v == 0): freq0 is stored as 2 pi f (sgen.c:150-160) */
+void orc_sgen_sine(double *buf, ssize_t frames, int channels, int fs, double freq_hz, ssize_t pos0)
+{
+	const double w = 2.0 * M_PI * freq_hz;
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double t = (double) (pos0 + i) / fs;
+		const double s = sin(w * t);
+		for (int k = 0; k < channels; ++k)
+			buf[i*channels + k] = 0.0 + s;
+	}
+}
+
+/* plain definition of linear convolution, Kahan-free, ascending k (second oracle, B.2) */
+void orc_conv_full(const double *x, ssize_t n_x, const double *taps, ssize_t n_taps, double *y)
+{
+	const ssize_t n_y = n_x + n_taps - 1;
+	for (ssize_t i = 0; i < n_y; ++i) {
+		long double acc = 0.0L;
+		const ssize_t k0 = (i >= n_x) ? i - n_x + 1 : 0;
+		const ssize_t k1 = (i < n_taps) ? i : n_taps - 1;
+		for (ssize_t k = k0; k <= k1; ++k)
+			acc += (long double) taps[k] * (long double) x[i - k];
+		y[i] = (double) acc;
+	}
+}
+
+/* ------------------------------------------------------- zita-equivalent */
+
+/*
+ * zita_convolver.cpp:36-61, 93-113, 135-151 + README.md:426-431.  libzita-convolver
+ * is absent (parity unpinned): the restatement is its documented contract --
+ * float32 filter, float32 input, float32 output, `part_len` frames of latency --
+ * with the convolution itself evaluated in fp64.
+ */
+struct zita_eq {
+	ssize_t n_taps, part_len, p, hist_len, hist_p;
+	double *taps, *hist, *obuf, *ibuf;
+};
+
+void *orc_zita_equiv_new(const double *taps, ssize_t n_taps, int part_len)
+{
+	struct zita_eq *st = calloc(1, sizeof(*st));
+	st->n_taps = n_taps;
+	st->part_len = part_len > 0 ? part_len : 64;
+	st->taps = malloc(n_taps * sizeof(double));
+	for (ssize_t i = 0; i < n_taps; ++i) st->taps[i] = (double) (float) taps[i];
+	st->hist = calloc(n_taps, sizeof(double));
+	st->obuf = calloc(st->part_len, sizeof(double));
+	st->ibuf = calloc(st->part_len, sizeof(double));
+	return st;
+}
+
+void orc_zita_equiv_run(void *stp, double *buf, ssize_t frames, int stride)
+{
+	struct zita_eq *st = stp;
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double s = buf[i*stride];
+		buf[i*stride] = st->obuf[st->p];
+		st->ibuf[st->p] = (double) (float) s;
+		if (++st->p == st->part_len) {
+			for (ssize_t q = 0; q < st->part_len; ++q) {
+				st->hist[st->hist_p] = st->ibuf[q];
+				long double acc = 0.0L;
+				ssize_t h = st->hist_p;
+				for (ssize_t k = 0; k < st->n_taps; ++k) {
+					acc += (long double) st->taps[k] * (long double) st->hist[h];
+					h = (h == 0) ? st->n_taps - 1 : h - 1;
+				}
+				st->obuf[q] = (double) (float) (double) acc;
+				st->hist_p = (st->hist_p + 1 == st->n_taps) ? 0 : st->hist_p + 1;
+			}
+			st->p = 0;
+		}
+	}
+}
+
+void orc_zita_equiv_free(void *stp)
+{
+	struct zita_eq *st = stp;
+	free(st->taps); free(st->hist); free(st->obuf); free(st->ibuf);
+	free(st);
+}
