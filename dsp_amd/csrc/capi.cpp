@@ -1,0 +1,195 @@
+// capi.cpp -- the stand-alone C ABI declared in include/dsp_amd.h.
+#include "dsp_amd.h"
+#include "chain.h"
+#include "engine.h"
+#include <cstring>
+
+using namespace dspamd;
+
+struct dspamd_batch {
+	ChainPlan plan;
+	std::unique_ptr<Pipeline> pipe;
+	std::string plan_str;
+	ssize_t drain_left = 0;
+	ssize_t iframes = 0;
+	DevBuf zeros;
+	ssize_t zeros_frames = 0;
+};
+
+struct dspamd_chain {
+	dspamd_batch *b = nullptr;
+	DevBuf d_in, d_out;
+	ssize_t cap = 0, out_cap = 0;
+};
+
+extern "C" {
+
+const char *dspamd_version(void) { return "dsp_amd 0.1 (gfx950)"; }
+const char *dspamd_last_error(void) { return last_error(); }
+int dspamd_device_count(void) { return device_count(); }
+
+int dspamd_set_device(int device)
+{
+	return hip_ok(hipSetDevice(device), "hipSetDevice") ? 0 : -1;
+}
+
+void dspamd_set_loglevel(int level) { g_loglevel = level; }
+
+const struct effect_info *dspamd_get_effect_info(const char *name) { return registry_lookup(name); }
+
+// ---------------------------------------------------------------- batch
+
+dspamd_batch *dspamd_batch_create(const char *chain_str, int fs, int channels, int n_streams, ssize_t max_frames, const char *dir)
+{
+	if (n_streams < 1 || max_frames < 1) { set_error("batch: invalid n_streams/max_frames"); return nullptr; }
+	if (device_count() < 1) { set_error("batch: no HIP device available (the GPU backend has no CPU fallback)"); return nullptr; }
+	std::unique_ptr<dspamd_batch> b(new dspamd_batch);
+	if (!build_chain(chain_str, fs, channels, dir, b->plan)) return nullptr;
+	b->pipe = Pipeline::compile(b->plan.specs(), fs, channels, n_streams, max_frames);
+	if (!b->pipe) return nullptr;
+	b->plan_str = b->pipe->plan();
+	b->drain_left = b->plan.drain_frames;
+	log_msg(LL_VERBOSE, "batch: %s", b->plan_str.c_str());
+	return b.release();
+}
+
+int dspamd_batch_out_fs(dspamd_batch *b) { return b->pipe->fs_out; }
+int dspamd_batch_out_channels(dspamd_batch *b) { return b->pipe->ch_out; }
+ssize_t dspamd_batch_max_out_frames(dspamd_batch *b, ssize_t in_frames) { return b->pipe->max_out_frames(in_frames); }
+ssize_t dspamd_batch_drain_frames(dspamd_batch *b) { return b->plan.drain_frames; }
+const char *dspamd_batch_plan(dspamd_batch *b) { return b->plan_str.c_str(); }
+int dspamd_batch_n_stages(dspamd_batch *b) { return b->pipe->n_stages(); }
+
+ssize_t dspamd_batch_run(dspamd_batch *b, const void *d_in, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream)
+{
+	if (frames < 1) return 0;
+	b->iframes += frames;
+	return b->pipe->run(static_cast<const double *>(d_in), frames, static_cast<double *>(d_out), (long) out_stride_frames, static_cast<hipStream_t>(stream));
+}
+
+ssize_t dspamd_batch_drain(dspamd_batch *b, ssize_t block_frames, void *d_out, ssize_t out_stride_frames, void *stream)
+{
+	// drain_effects_chain(), effects_chain.c:1186-1218
+	if (b->iframes < 1 || block_frames < 1) return -1;
+	block_frames = std::min<ssize_t>(block_frames, b->pipe->max_frames);
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (b->drain_left > 0) {
+		const ssize_t n = std::min(block_frames, b->drain_left);
+		if (b->zeros_frames < n) {
+			if (!b->zeros.alloc((size_t) b->pipe->S * block_frames * b->pipe->ch_in * sizeof(double), true)) return -2;
+			b->zeros_frames = block_frames;
+		}
+		b->drain_left -= n;
+		return b->pipe->run(b->zeros.as<double>(), n, static_cast<double *>(d_out), (long) out_stride_frames, st);
+	}
+	long stride = (long) out_stride_frames;
+	if (stride <= 0) stride = (long) b->pipe->max_out_frames(block_frames);
+	return b->pipe->drain2(block_frames, static_cast<double *>(d_out), stride, st);
+}
+
+void dspamd_batch_reset(dspamd_batch *b, void *stream)
+{
+	b->pipe->reset(static_cast<hipStream_t>(stream));
+	b->drain_left = b->plan.drain_frames;
+	b->iframes = 0;
+}
+
+void dspamd_batch_destroy(dspamd_batch *b)
+{
+	if (!b) return;
+	(void) hipDeviceSynchronize();
+	delete b;
+}
+
+// ---------------------------------------------------------------- chain (host buffers, one stream)
+
+dspamd_chain *dspamd_chain_build(const char *chain_str, int fs, int channels, const char *dir, int *out_fs, int *out_channels)
+{
+	const ssize_t cap = 1 << 16;
+	dspamd_batch *b = dspamd_batch_create(chain_str, fs, channels, 1, cap, dir);
+	if (!b) return nullptr;
+	dspamd_chain *c = new dspamd_chain;
+	c->b = b;
+	c->cap = cap;
+	c->out_cap = std::max<ssize_t>(b->pipe->max_out_frames(cap), 1);
+	if (!c->d_in.alloc((size_t) cap * channels * sizeof(double), false) || !c->d_out.alloc((size_t) c->out_cap * b->pipe->ch_out * sizeof(double), false)) {
+		dspamd_chain_destroy(c);
+		return nullptr;
+	}
+	if (out_fs) *out_fs = b->pipe->fs_out;
+	if (out_channels) *out_channels = b->pipe->ch_out;
+	return c;
+}
+
+ssize_t dspamd_chain_run(dspamd_chain *c, const double *in, ssize_t frames, double *out, ssize_t out_capacity_frames)
+{
+	const int ci = c->b->pipe->ch_in, co = c->b->pipe->ch_out;
+	ssize_t done = 0, produced = 0;
+	while (done < frames) {
+		const ssize_t nb = std::min(frames - done, c->cap);
+		if (!hip_ok(hipMemcpy(c->d_in.p, in + done * ci, (size_t) nb * ci * sizeof(double), hipMemcpyHostToDevice), "H2D")) return -1;
+		const ssize_t f = dspamd_batch_run(c->b, c->d_in.p, nb, c->d_out.p, c->out_cap, nullptr);
+		if (f < 0) return f;
+		if (produced + f > out_capacity_frames) { set_error("chain_run: output capacity exceeded"); return -1; }
+		if (f > 0 && !hip_ok(hipMemcpy(out + produced * co, c->d_out.p, (size_t) f * co * sizeof(double), hipMemcpyDeviceToHost), "D2H")) return -1;
+		produced += f;
+		done += nb;
+	}
+	return produced;
+}
+
+ssize_t dspamd_chain_drain(dspamd_chain *c, ssize_t block_frames, double *out, ssize_t out_capacity_frames)
+{
+	const int co = c->b->pipe->ch_out;
+	const ssize_t f = dspamd_batch_drain(c->b, std::min(block_frames, c->cap), c->d_out.p, c->out_cap, nullptr);
+	if (f < 0) return -1;
+	if (f > out_capacity_frames) { set_error("chain_drain: output capacity exceeded"); return -2; }
+	if (f > 0 && !hip_ok(hipMemcpy(out, c->d_out.p, (size_t) f * co * sizeof(double), hipMemcpyDeviceToHost), "D2H")) return -2;
+	return f;
+}
+
+ssize_t dspamd_chain_max_out_frames(dspamd_chain *c, ssize_t in_frames) { return c->b->pipe->max_out_frames(in_frames); }
+ssize_t dspamd_chain_drain_frames(dspamd_chain *c) { return c->b->plan.drain_frames; }
+
+void dspamd_chain_reset(dspamd_chain *c)
+{
+	dspamd_batch_reset(c->b, nullptr);
+	(void) hipStreamSynchronize(nullptr);
+}
+
+void dspamd_chain_destroy(dspamd_chain *c)
+{
+	if (!c) return;
+	dspamd_batch_destroy(c->b);
+	delete c;
+}
+
+int dspamd_chain_n_effects(dspamd_chain *c) { return (int) c->b->plan.effects.size(); }
+
+const char *dspamd_chain_effect_name(dspamd_chain *c, int i)
+{
+	if (i < 0 || i >= (int) c->b->plan.effects.size()) return nullptr;
+	return c->b->plan.effects[i]->name;
+}
+
+// ---------------------------------------------------------------- bench endpoints
+
+int dspamd_sgen_sine(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double dfreq, ssize_t pos0, void *stream)
+{
+	launch_sgen_sine(static_cast<double *>(d_buf), n_streams, frames, channels, fs, freq0, dfreq, pos0, static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "sgen") ? 0 : -1;
+}
+
+int dspamd_digest(const void *d_buf, int n_streams, ssize_t frames, ssize_t stride_frames, int channels, void *d_out, void *stream)
+{
+	launch_digest(static_cast<const double *>(d_buf), n_streams, frames, stride_frames, channels, static_cast<double *>(d_out), static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "digest") ? 0 : -1;
+}
+
+int dspamd_copy_probe(const void *d_src, void *d_dst, size_t bytes, void *stream)
+{
+	launch_copy_probe(d_src, d_dst, bytes, static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "copy_probe") ? 0 : -1;
+}
+
+}  // extern "C"

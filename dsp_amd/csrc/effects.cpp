@@ -1,0 +1,753 @@
+// effects.cpp -- init-time parsing and filter design (host only; libm on the host so that
+// coefficients agree with the reference's to the last bit -- SURVEY.md section 8 a4).
+#include "effects.h"
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace dspamd {
+
+static Selector copy_sel(const char *sel, int n)
+{
+	return Selector(sel, sel + n);
+}
+
+static SpecPtr new_spec(Kind k, const char *name, const stream_info *is, const char *sel)
+{
+	SpecPtr s(new Spec);
+	s->kind = k;
+	s->name = name;
+	s->fs_in = s->fs_out = is->fs;
+	s->ch_in = s->ch_out = is->channels;
+	s->sel = copy_sel(sel, is->channels);
+	return s;
+}
+
+static void usage(const char *name)
+{
+	const effect_info *ei = registry_lookup(name);
+	if (ei) log_msg(LL_ERROR, "%s: usage: %s %s", ei->name, ei->name, ei->usage);
+}
+
+// ------------------------------------------------------------------ biquad
+
+enum { W_Q = 1, W_SLOPE, W_SLOPE_DB, W_BW_OCT, W_BW_HZ };   // biquad.h:53-59
+
+void biquad_normalise(double b0, double b1, double b2, double a0, double a1, double a2, std::array<double, 5> &c)
+{
+	c = { b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0 };       // biquad.c:91-99
+}
+
+// Audio-EQ-cookbook designs; argument conventions of biquad.c:111-294
+void biquad_design(int type, double fs, double arg0, double arg1, double arg2, double arg3, int width_type, std::array<double, 5> &c)
+{
+	struct { double b0 = 1, b1 = 0, b2 = 0, a0 = 1, a1 = 0, a2 = 0; } q;
+	if (type == DSPAMD_BIQUAD_LOWPASS_TRANSFORM || type == DSPAMD_BIQUAD_HIGHPASS_TRANSFORM) {
+		// Linkwitz transform: zeros cancel the existing (fz, qz) response, poles put (fp, qp) in its place
+		const bool lp = (type == DSPAMD_BIQUAD_LOWPASS_TRANSFORM);
+		const double w0z = 2*M_PI*arg0 / fs, w0p = 2*M_PI*arg2 / fs;
+		const double cz = cos(w0z), cp = cos(w0p);
+		const double az = sin(w0z) / (2.0*arg1), ap = sin(w0p) / (2.0*arg3);
+		const double kz = lp ? 2.0/(1.0-cz) : 2.0/(1.0+cz);
+		const double kp = lp ? 2.0/(1.0-cp) : 2.0/(1.0+cp);
+		q.b0 = (1.0 + az)*kz; q.b1 = (-2.0 * cz)*kz; q.b2 = (1.0 - az)*kz;
+		q.a0 = (1.0 + ap)*kp; q.a1 = (-2.0 * cp)*kp; q.a2 = (1.0 - ap)*kp;
+		biquad_normalise(q.b0, q.b1, q.b2, q.a0, q.a1, q.a2, c);
+		return;
+	}
+	double f0 = arg0, width = arg1;
+	const double gain = arg2;
+	if (width_type == W_SLOPE_DB) {
+		width_type = W_SLOPE;
+		width /= 12.0;
+		if (type == DSPAMD_BIQUAD_LOWSHELF) f0 *= pow(10.0, fabs(gain) / 80.0 / width);
+		else if (type == DSPAMD_BIQUAD_HIGHSHELF) f0 /= pow(10.0, fabs(gain) / 80.0 / width);
+	}
+	const double A = pow(10.0, gain / 40.0);
+	const double w0 = 2*M_PI*f0 / fs;
+	const double sn = sin(w0), cs = cos(w0);
+	double alpha;
+	if (width_type == W_SLOPE) alpha = sn/2.0 * sqrt((A + 1.0/A) * (1.0/width - 1.0) + 2.0);
+	else if (width_type == W_BW_OCT) alpha = sn * sinh(M_LN2/2 * width * w0 / sn);
+	else if (width_type == W_BW_HZ) alpha = sn / (2.0 * f0 / width);
+	else alpha = sn / (2.0 * width);
+	const double k1 = 1.0 + cs;   // first-order helpers
+	switch (type) {
+	case DSPAMD_BIQUAD_LOWPASS_1:   q.b0 = sn; q.b1 = sn; q.a0 = sn + k1; q.a1 = sn - k1; break;
+	case DSPAMD_BIQUAD_HIGHPASS_1:  q.b0 = k1; q.b1 = -k1; q.a0 = sn + k1; q.a1 = sn - k1; break;
+	case DSPAMD_BIQUAD_ALLPASS_1:   q.b0 = sn - k1; q.b1 = sn + k1; q.a0 = q.b1; q.a1 = q.b0; break;
+	case DSPAMD_BIQUAD_LOWSHELF_1:  q.b0 = A*sn + k1; q.b1 = A*sn - k1; q.a0 = sn/A + k1; q.a1 = sn/A - k1; break;
+	case DSPAMD_BIQUAD_HIGHSHELF_1: q.b0 = sn + k1*A; q.b1 = sn - k1*A; q.a0 = sn + k1/A; q.a1 = sn - k1/A; break;
+	case DSPAMD_BIQUAD_LOWPASS_1P: {
+		const double t = 1.0 - cs;
+		q.b0 = -t + sqrt(t*t + 2.0*t); q.b1 = 0.0; q.a0 = 1.0; q.a1 = -1.0 + q.b0;
+		break;
+	}
+	case DSPAMD_BIQUAD_LOWPASS:
+		q.b0 = (1.0 - cs) / 2.0; q.b1 = 1.0 - cs; q.b2 = q.b0;
+		q.a0 = 1.0 + alpha; q.a1 = -2.0*cs; q.a2 = 1.0 - alpha; break;
+	case DSPAMD_BIQUAD_HIGHPASS:
+		q.b0 = (1.0 + cs) / 2.0; q.b1 = -(1.0 + cs); q.b2 = q.b0;
+		q.a0 = 1.0 + alpha; q.a1 = -2.0*cs; q.a2 = 1.0 - alpha; break;
+	case DSPAMD_BIQUAD_BANDPASS_SKIRT:
+		q.b0 = sn / 2.0; q.b1 = 0.0; q.b2 = -q.b0;
+		q.a0 = 1.0 + alpha; q.a1 = -2.0*cs; q.a2 = 1.0 - alpha; break;
+	case DSPAMD_BIQUAD_BANDPASS_PEAK:
+		q.b0 = alpha; q.b1 = 0.0; q.b2 = -alpha;
+		q.a0 = 1.0 + alpha; q.a1 = -2.0*cs; q.a2 = 1.0 - alpha; break;
+	case DSPAMD_BIQUAD_NOTCH:
+		q.b0 = 1.0; q.b1 = -2.0*cs; q.b2 = 1.0;
+		q.a0 = 1.0 + alpha; q.a1 = q.b1; q.a2 = 1.0 - alpha; break;
+	case DSPAMD_BIQUAD_ALLPASS:
+		q.b0 = 1.0 - alpha; q.b1 = -2.0*cs; q.b2 = 1.0 + alpha;
+		q.a0 = q.b2; q.a1 = q.b1; q.a2 = q.b0; break;
+	case DSPAMD_BIQUAD_PEAK:
+		q.b0 = 1.0 + alpha*A; q.b1 = -2.0*cs; q.b2 = 1.0 - alpha*A;
+		q.a0 = 1.0 + alpha/A; q.a1 = q.b1; q.a2 = 1.0 - alpha/A; break;
+	case DSPAMD_BIQUAD_LOWSHELF: {
+		const double t = 2.0 * sqrt(A) * alpha;
+		q.b0 = A * ((A + 1.0) - (A - 1.0)*cs + t);
+		q.b1 = 2.0 * A * ((A - 1.0) - (A + 1.0)*cs);
+		q.b2 = A * ((A + 1.0) - (A - 1.0)*cs - t);
+		q.a0 = (A + 1.0) + (A - 1.0)*cs + t;
+		q.a1 = -2.0 * ((A - 1.0) + (A + 1.0)*cs);
+		q.a2 = (A + 1.0) + (A - 1.0)*cs - t;
+		break;
+	}
+	case DSPAMD_BIQUAD_HIGHSHELF: {
+		const double t = 2.0 * sqrt(A) * alpha;
+		q.b0 = A * ((A + 1.0) + (A - 1.0)*cs + t);
+		q.b1 = -2.0 * A * ((A - 1.0) + (A + 1.0)*cs);
+		q.b2 = A * ((A + 1.0) + (A - 1.0)*cs - t);
+		q.a0 = (A + 1.0) - (A - 1.0)*cs + t;
+		q.a1 = 2.0 * ((A - 1.0) - (A + 1.0)*cs);
+		q.a2 = (A + 1.0) - (A - 1.0)*cs - t;
+		break;
+	}
+	}
+	biquad_normalise(q.b0, q.b1, q.b2, q.a0, q.a1, q.a2, c);
+}
+
+// biquad.c:27-89: "<number>[q|s|d|o|h|k]" or "bw<order>[.<index>]"
+static double parse_width(const char *s, int *type, char **endptr)
+{
+	*type = W_Q;
+	double w = M_SQRT1_2;
+	if (s[0] == 'b' && s[1] == 'w' && s[2] != '\0') {
+		const char *p = s + 2;
+		const long order = strtol(p, endptr, 10);
+		if (*endptr == p || (**endptr != '\0' && **endptr != '.')) goto fail;
+		if (order < 2) { set_error("parse_width(): filter order must be >= 2"); goto fail; }
+		{
+			const int nb = (int) (order / 2);
+			long idx = 0;
+			if (**endptr == '.') {
+				p = *endptr + 1;
+				idx = strtol(p, endptr, 10);
+				if (*endptr == p || **endptr != '\0') goto fail;
+				if (idx < 0 || idx >= nb) { set_error("parse_width(): filter index out of range"); goto fail; }
+			}
+			idx = nb - idx;
+			w = 1.0 / (2.0 * sin(M_PI / order * (idx - 0.5)));
+		}
+		return w;
+	}
+	w = strtod(s, endptr);
+	if (*endptr != s) {
+		switch (**endptr) {
+		case 'q': *type = W_Q; ++*endptr; break;
+		case 's': *type = W_SLOPE; ++*endptr; break;
+		case 'd': *type = W_SLOPE_DB; ++*endptr; break;
+		case 'o': *type = W_BW_OCT; ++*endptr; break;
+		case 'k': w *= 1000.0;  // fall through
+		case 'h': *type = W_BW_HZ; ++*endptr; break;
+		}
+	}
+	return w;
+fail:
+	*endptr = const_cast<char *>(s);
+	return w;
+}
+
+SpecPtr parse_biquad(int num, const stream_info *is, const char *sel, int argc, const char *const *argv, bool *reverse)
+{
+	const char *name = argv[0];
+	GetOpt g;
+	int opt;
+	*reverse = false;
+	static const int n_args_of[] = { 0, 1, 1, 1, 2, 2, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 4, 4, 0, 6 };
+	if (num < 1 || num > DSPAMD_BIQUAD_BIQUAD) { set_error("%s: BUG: unknown effect number %d", name, num); return nullptr; }
+	const int n_args = n_args_of[num];
+	while ((opt = g.next(argc - n_args, argv, "r::")) != -1) {
+		if (opt == 'r') *reverse = true;
+		else { g.print_error(opt, name); usage(name); return nullptr; }
+	}
+	if (argc - g.ind != n_args) { usage(name); return nullptr; }
+	if (*reverse) {
+		set_error("%s: error: -r (time-reversed IIR, reverse_iir.c) is not provided by the GPU backend", name);
+		return nullptr;
+	}
+	const char *const *a = argv + g.ind;
+	char *end;
+	int wt = W_Q, type = num;
+	double v[4] = { 0, 0, 0, 0 };
+	std::array<double, 5> c;
+	auto freq = [&](const char *s, const char *what, double &out) {
+		out = parse_freq(s, &end);
+		if (bad_endptr(name, s, end, what)) return false;
+		if (!(out >= 0.0 && out < is->fs / 2.0)) { set_error("%s: error: %s out of range", name, what); return false; }
+		return true;
+	};
+	auto num_arg = [&](const char *s, const char *what, double &out) {
+		out = strtod(s, &end);
+		return !bad_endptr(name, s, end, what);
+	};
+	auto width = [&](const char *s, const char *what, double &out) {
+		out = parse_width(s, &wt, &end);
+		if (bad_endptr(name, s, end, what)) return false;
+		if (!(out > 0.0)) { set_error("%s: error: %s out of range", name, what); return false; }
+		return true;
+	};
+	const bool slope = (wt == W_SLOPE || wt == W_SLOPE_DB);
+	(void) slope;
+	switch (num) {
+	case DSPAMD_BIQUAD_LOWPASS_1: case DSPAMD_BIQUAD_HIGHPASS_1: case DSPAMD_BIQUAD_ALLPASS_1: case DSPAMD_BIQUAD_LOWPASS_1P:
+		if (!freq(a[0], "f0", v[0])) return nullptr;
+		break;
+	case DSPAMD_BIQUAD_LOWSHELF_1: case DSPAMD_BIQUAD_HIGHSHELF_1:
+		if (!freq(a[0], "f0", v[0]) || !num_arg(a[1], "gain", v[2])) return nullptr;
+		break;
+	case DSPAMD_BIQUAD_LOWPASS: case DSPAMD_BIQUAD_HIGHPASS: case DSPAMD_BIQUAD_BANDPASS_SKIRT:
+	case DSPAMD_BIQUAD_BANDPASS_PEAK: case DSPAMD_BIQUAD_NOTCH: case DSPAMD_BIQUAD_ALLPASS:
+		if (!freq(a[0], "f0", v[0]) || !width(a[1], "width", v[1])) return nullptr;
+		if (wt == W_SLOPE || wt == W_SLOPE_DB) { set_error("%s: error: invalid width type", name); return nullptr; }
+		break;
+	case DSPAMD_BIQUAD_PEAK: case DSPAMD_BIQUAD_LOWSHELF: case DSPAMD_BIQUAD_HIGHSHELF:
+		if (!freq(a[0], "f0", v[0]) || !width(a[1], "width", v[1])) return nullptr;
+		if (num == DSPAMD_BIQUAD_PEAK && (wt == W_SLOPE || wt == W_SLOPE_DB)) { set_error("%s: error: invalid width type", name); return nullptr; }
+		if (!num_arg(a[2], "gain", v[2])) return nullptr;
+		break;
+	case DSPAMD_BIQUAD_LOWPASS_TRANSFORM: case DSPAMD_BIQUAD_HIGHPASS_TRANSFORM:
+		if (!freq(a[0], "fz", v[0]) || !width(a[1], "width_z", v[1])) return nullptr;
+		if (wt != W_Q) { set_error("%s: error: invalid width type", name); return nullptr; }
+		if (!freq(a[2], "fp", v[2]) || !width(a[3], "width_p", v[3])) return nullptr;
+		if (wt != W_Q) { set_error("%s: error: invalid width type", name); return nullptr; }
+		break;
+	case DSPAMD_BIQUAD_DEEMPH:  // CD de-emphasis presets, biquad.c:503-521
+		type = DSPAMD_BIQUAD_HIGHSHELF;
+		wt = W_SLOPE;
+		if (is->fs == 44100) { v[0] = 5283; v[1] = 0.4845; v[2] = -9.477; }
+		else if (is->fs == 48000) { v[0] = 5356; v[1] = 0.479; v[2] = -9.62; }
+		else { set_error("%s: error: sample rate must be 44100 or 48000", name); return nullptr; }
+		break;
+	case DSPAMD_BIQUAD_BIQUAD: {
+		double r[6];
+		static const char *nm[6] = { "b0", "b1", "b2", "a0", "a1", "a2" };
+		for (int i = 0; i < 6; ++i) if (!num_arg(a[i], nm[i], r[i])) return nullptr;
+		biquad_normalise(r[0], r[1], r[2], r[3], r[4], r[5], c);
+		break;
+	}
+	}
+	if (num != DSPAMD_BIQUAD_BIQUAD) biquad_design(type, is->fs, v[0], v[1], v[2], v[3], wt, c);
+	SpecPtr s = new_spec(Kind::Biquad, name, is, sel);
+	s->flags = EFFECT_FLAG_OPT_REORDERABLE | EFFECT_FLAG_CH_DEPS_IDENTITY;
+	s->bq.assign(is->channels, std::array<double, 5>{ 1, 0, 0, 0, 0 });
+	for (int k = 0; k < is->channels; ++k) if (sel[k]) s->bq[k] = c;
+	return s;
+}
+
+// ------------------------------------------------------------- gain / add
+
+SpecPtr parse_gain(int num, const stream_info *is, const char *sel, int argc, const char *const *argv)
+{
+	const char *name = argv[0];
+	if (argc != 2) { usage(name); return nullptr; }
+	char *end;
+	double v = strtod(argv[1], &end);
+	const char *what = (num == DSPAMD_GAIN_GAIN) ? "gain" : (num == DSPAMD_GAIN_MULT) ? "multiplier" : "value";
+	if (bad_endptr(name, argv[1], end, what)) return nullptr;
+	if (num == DSPAMD_GAIN_GAIN) v = pow(10.0, v / 20.0);   // gain.c:94
+	const bool is_add = (num == DSPAMD_GAIN_ADD);
+	SpecPtr s = new_spec(is_add ? Kind::Add : Kind::Gain, name, is, sel);
+	s->flags = EFFECT_FLAG_CH_DEPS_IDENTITY | (is_add ? 0 : EFFECT_FLAG_OPT_REORDERABLE);
+	s->vec.resize(is->channels);
+	for (int k = 0; k < is->channels; ++k) s->vec[k] = sel[k] ? v : (is_add ? 0.0 : 1.0);
+	return s;
+}
+
+// ------------------------------------------------------------------ remix
+
+// remix.c:123-215: one selector per selected input channel position; extra selectors append channels;
+// "." leaves an output silent; unselected channels pass through.
+SpecPtr parse_remix(const stream_info *is, const char *sel, int argc, const char *const *argv)
+{
+	const char *name = argv[0];
+	if (argc <= 1) { usage(name); return nullptr; }
+	const int nin = is->channels;
+	const Selector mask = copy_sel(sel, nin);
+	const int n_sel = argc - 1, mask_bits = num_set(mask);
+	const int nout = nin + n_sel - mask_bits;
+	if (nout < 1) { set_error("%s: error: no output channels", name); return nullptr; }
+	SpecPtr s = new_spec(Kind::Remix, name, is, sel);
+	s->ch_out = nout;
+	s->flags = EFFECT_FLAG_PLOT_MIX;
+	s->remix.assign(nout, Selector(nin, 0));
+	bool pure_routing = true;
+	for (int k = 0, i = 0, ch = 0; k < nout; ++k, ++ch) {
+		if (ch >= nin || mask[ch]) {
+			if (i < n_sel) {
+				if (strcmp(argv[i + 1], ".") != 0 && !parse_selector_masked(argv[i + 1], s->remix[k], mask, nin))
+					return nullptr;
+				if (num_set(s->remix[k]) > 1) pure_routing = false;
+				++i;
+			}
+			else {
+				while (ch < nin && mask[ch]) ++ch;
+				if (ch < nin) s->remix[k][ch] = 1;
+			}
+		}
+		else s->remix[k][ch] = 1;
+	}
+	if (pure_routing) s->flags |= EFFECT_FLAG_NO_DITHER;
+	return s;
+}
+
+// ------------------------------------------------------------------ delay
+
+SpecPtr make_delay_spec(const char *name, const stream_info *is, const char *sel, ssize_t samples, bool *noop)
+{
+	*noop = (samples == 0);   // delay.c:204-205: nothing to do -> run stays NULL
+	SpecPtr s = new_spec(Kind::Delay, name, is, sel);
+	s->flags = EFFECT_FLAG_OPT_REORDERABLE | EFFECT_FLAG_CH_DEPS_IDENTITY;
+	s->delay.assign(is->channels, 0);
+	for (int k = 0; k < is->channels; ++k) if (sel[k]) s->delay[k] = samples;
+	return s;
+}
+
+SpecPtr parse_delay(const stream_info *is, const char *sel, int argc, const char *const *argv, bool *noop)
+{
+	const char *name = argv[0];
+	GetOpt g;
+	int opt;
+	while ((opt = g.next(argc - 1, argv, "f::m:M:b:q:")) != -1) {
+		if (opt == 'f' || opt == 'm' || opt == 'M' || opt == 'b' || opt == 'q') {
+			set_error("%s: error: option -%c (fractional / modulated delay, delay.c:51-53,567-593) is not provided by the GPU backend", name, opt);
+			return nullptr;
+		}
+		g.print_error(opt, name);
+		usage(name);
+		return nullptr;
+	}
+	if (g.ind != argc - 1) { usage(name); return nullptr; }
+	char *end;
+	const double samples = parse_len_frac(argv[g.ind], is->fs, &end);
+	if (bad_endptr(name, argv[g.ind], end, "delay")) return nullptr;
+	const ssize_t si = (ssize_t) lrint(samples);
+	if (fabs(samples - si) >= DBL_EPSILON)
+		log_msg(LL_VERBOSE, "%s: info: delay rounded to %gs (%zd samples)", name, (double) si / is->fs, si);
+	return make_delay_spec(name, is, sel, si, noop);
+}
+
+SpecPtr make_align_spec(int fs, int channels, const std::vector<ssize_t> &len, ssize_t discard)
+{
+	SpecPtr s(new Spec);
+	s->kind = Kind::Align;
+	s->name = "align";
+	s->fs_in = s->fs_out = fs;
+	s->ch_in = s->ch_out = channels;
+	s->sel.assign(channels, 1);
+	s->flags = EFFECT_FLAG_CH_DEPS_IDENTITY;
+	s->delay = len;
+	s->discard = discard;
+	return s;
+}
+
+// -------------------------------------------------------------------- fir
+
+SpecPtr make_fir_spec(const char *name, const stream_info *is, const char *sel, const double *filter, int fch, ssize_t T, ssize_t ref,
+	int mode, int force_direct, int part_len)
+{
+	const int nsel = num_set(sel, is->channels);
+	if (fch != 1 && fch != nsel) {
+		set_error("%s: error: channels mismatch: channels=%d filter_channels=%d", name, nsel, fch);
+		return nullptr;
+	}
+	if (T < 1) { set_error("%s: error: filter length must be >= 1", name); return nullptr; }
+	// fir.c:241 (<= 16 taps), fir_p.c:364 (<= 32 taps forces the direct form)
+	const bool direct = (mode != CONV_ZITA_EQUIV) && (force_direct || (mode == CONV_LATENCY_LEN && T <= 16) || (mode == CONV_ZERO_LATENCY && T <= 32));
+	SpecPtr s = new_spec(direct ? Kind::FirDirect : Kind::Conv, name, is, sel);
+	s->flags = EFFECT_FLAG_OPT_REORDERABLE | EFFECT_FLAG_CH_DEPS_IDENTITY;
+	s->taps.assign(filter, filter + T * fch);
+	s->fch = fch;
+	s->T = T;
+	s->ref = ref;
+	s->conv_mode = direct ? CONV_ZERO_LATENCY : mode;
+	if (!direct && mode == CONV_LATENCY_LEN) s->latency = next_fast_fftw_len(T);        // fir.c:303, 208-217
+	if (mode == CONV_ZITA_EQUIV) s->latency = part_len > 0 ? part_len : 64;            // zita_convolver.cpp:93-102, README.md:428
+	return s;
+}
+
+struct FirOpts {
+	bool do_align = false;
+	ssize_t offset = 0;
+	const char *type = nullptr, *enc = nullptr;
+	int channels = 0;
+	bool big_endian = false;
+};
+
+// option grammar of fir_util.c:122-185 ("a::t:e:BLNr:c:")
+static bool parse_fir_opts(const char *name, const stream_info *is, GetOpt &g, int argc, const char *const *argv, FirOpts &o)
+{
+	int opt;
+	char *end;
+	o.channels = is->channels;
+	while ((opt = g.next(argc - 1, argv, "a::t:e:BLNr:c:")) != -1) {
+		switch (opt) {
+		case 'a':
+			o.do_align = true;
+			if (g.arg) {
+				o.offset = parse_len(g.arg, is->fs, &end);
+				if (bad_endptr(name, g.arg, end, "offset")) return false;
+			}
+			break;
+		case 't': o.type = g.arg; break;
+		case 'e': o.enc = g.arg; break;
+		case 'B': o.big_endian = true; break;
+		case 'L': case 'N': o.big_endian = false; break;
+		case 'r':
+			if (strcmp(g.arg, "any") != 0) {
+				const long fs = lround(parse_freq(g.arg, &end));
+				if (bad_endptr(name, g.arg, end, "sample rate")) return false;
+				if (fs <= 0) { set_error("%s: error: sample rate must be > 0", name); return false; }
+				if (fs != is->fs) { set_error("%s: error: sample rate mismatch: stream_fs=%d requested_fs=%ld", name, is->fs, fs); return false; }
+			}
+			break;
+		case 'c':
+			o.channels = (int) strtol(g.arg, &end, 10);
+			if (bad_endptr(name, g.arg, end, "number of channels")) return false;
+			if (o.channels <= 0) { set_error("%s: error: number of channels must be > 0", name); return false; }
+			break;
+		default:
+			g.print_error(opt, name);
+			return false;
+		}
+	}
+	return true;
+}
+
+// fir_util.c:25-120.  "coefs:a,b,c/d,e,f" literals, or a raw PCM file (-t pcm -e double|float|s32|s24|s16, -c N).
+// Container formats (wav/flac/...) go through libsndfile/ffmpeg in the reference and are not available here.
+static bool read_filter(const char *name, const stream_info *is, const char *sel, const char *dir, const FirOpts &o, const char *spec,
+	std::vector<double> &data, int *fch, ssize_t *T)
+{
+	if (strncmp(spec, "coefs:", 6) == 0) {
+		const char *p = spec + 6;
+		int channels = 1;
+		ssize_t i = 1, frames = 1;
+		for (const char *q = p; *q; ++q) {
+			if (*q == ',') ++i;
+			else if (*q == '/') { ++channels; if (i > frames) frames = i; i = 1; }
+		}
+		if (i > frames) frames = i;
+		data.assign((size_t) frames * channels, 0.0);
+		int ch = 0;
+		std::string str(p);
+		size_t pos = 0;
+		while (pos <= str.size()) {
+			size_t e = str.find('/', pos);
+			if (e == std::string::npos) e = str.size();
+			std::string chs = str.substr(pos, e - pos);
+			size_t cp = 0;
+			ssize_t idx = 0;
+			while (cp <= chs.size()) {
+				size_t ce = chs.find(',', cp);
+				if (ce == std::string::npos) ce = chs.size();
+				std::string tok = chs.substr(cp, ce - cp);
+				const size_t a = tok.find_first_not_of(" \t"), b = tok.find_last_not_of(" \t");
+				if (a != std::string::npos) {
+					tok = tok.substr(a, b - a + 1);
+					char *end;
+					const double v = strtod(tok.c_str(), &end);
+					if (bad_endptr(name, tok.c_str(), end, "coefficient")) return false;
+					data[(size_t) idx * channels + ch] = v;
+				}
+				++idx;
+				cp = ce + 1;
+			}
+			++ch;
+			pos = e + 1;
+			if (e == str.size()) break;
+		}
+		*fch = channels;
+		*T = frames;
+		return true;
+	}
+	if (strncmp(spec, "file:", 5) == 0) spec += 5;
+	if (!o.type || strcmp(o.type, "pcm") != 0) {
+		set_error("%s: error: only raw filter files are supported by the GPU backend (use -t pcm -e double -c N): %s", name, spec);
+		return false;
+	}
+	std::string path = join_path(dir, spec);
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) { set_error("%s: error: failed to open filter file: %s", name, path.c_str()); return false; }
+	fseek(f, 0, SEEK_END);
+	const long sz = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	std::vector<unsigned char> raw(sz > 0 ? sz : 0);
+	if (sz > 0 && fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); set_error("%s: error: read failed: %s", name, path.c_str()); return false; }
+	fclose(f);
+	const char *enc = o.enc ? o.enc : "s16";   // pcm.c:47 default
+	int bytes;
+	if (!strcmp(enc, "double")) bytes = 8;
+	else if (!strcmp(enc, "float") || !strcmp(enc, "s32") || !strcmp(enc, "s24")) bytes = 4;
+	else if (!strcmp(enc, "s16")) bytes = 2;
+	else { set_error("%s: error: unsupported pcm encoding for filter files: %s", name, enc); return false; }
+	const size_t n = raw.size() / bytes;
+	*fch = o.channels;
+	*T = (ssize_t) (n / o.channels);
+	data.resize((size_t) *T * *fch);
+	for (size_t i = 0; i < data.size(); ++i) {
+		unsigned char b[8];
+		memcpy(b, &raw[i * bytes], bytes);
+		if (o.big_endian) for (int k = 0; k < bytes / 2; ++k) std::swap(b[k], b[bytes - 1 - k]);
+		if (bytes == 8) { double v; memcpy(&v, b, 8); data[i] = v; }
+		else if (!strcmp(enc, "float")) { float v; memcpy(&v, b, 4); data[i] = (double) v; }
+		else if (!strcmp(enc, "s32")) { int32_t v; memcpy(&v, b, 4); data[i] = (double) v / 2147483648.0; }     // sampleconv.h:52
+		else if (!strcmp(enc, "s24")) { int32_t v; memcpy(&v, b, 4); data[i] = (double) v / 8388608.0; }
+		else { int16_t v; memcpy(&v, b, 2); data[i] = (double) v / 32768.0; }
+	}
+	if (*T < 1) { set_error("%s: error: filter length must be >= 1", name); return false; }
+	(void) is; (void) sel;
+	return true;
+}
+
+// fir_util.c:187-205
+static ssize_t filter_offset(const FirOpts &o, const std::vector<double> &d, ssize_t T)
+{
+	if (!o.do_align) return 0;
+	if (o.offset > 0) return o.offset;
+	if (o.offset < 0) return T + o.offset;
+	ssize_t off = 0;
+	double peak = 0.0;
+	for (size_t i = 0; i < d.size(); ++i) if (d[i] > peak) { peak = d[i]; off = (ssize_t) i; }
+	return off;
+}
+
+SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	GetOpt g;
+	FirOpts o;
+	if (!parse_fir_opts(name, is, g, argc, argv, o)) { usage(name); return nullptr; }
+	long max_part_len = 0;
+	if (partitioned) {
+		if (g.ind < argc - 2 || g.ind > argc - 1) { usage(name); return nullptr; }
+		if (g.ind == argc - 2) {
+			char *end;
+			max_part_len = strtol(argv[g.ind], &end, 10);
+			if (bad_endptr(name, argv[g.ind], end, "max_part_len")) return nullptr;
+			++g.ind;
+			// fir_p.c:374-382: accepted values are powers of two in [32, INT_MAX]; it only shapes the reference's
+			// latency-driven partition plan, which the GPU engine does not need
+			if (max_part_len != 0 && ((max_part_len & (max_part_len - 1)) || max_part_len < 32)) {
+				set_error("%s: error: max_part_len must be a power of two >= 32 or 0 for default", name);
+				return nullptr;
+			}
+		}
+	}
+	else if (g.ind != argc - 1) { usage(name); return nullptr; }
+	std::vector<double> data;
+	int fch;
+	ssize_t T;
+	if (!read_filter(name, is, sel, dir, o, argv[g.ind], data, &fch, &T)) return nullptr;
+	const ssize_t ref = filter_offset(o, data, T);
+	return make_fir_spec(name, is, sel, data.data(), fch, T, ref, partitioned ? CONV_ZERO_LATENCY : CONV_LATENCY_LEN, 0, 0);
+}
+
+SpecPtr parse_zita(const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	const char *name = argv[0];
+	GetOpt g;
+	FirOpts o;
+	if (!parse_fir_opts(name, is, g, argc, argv, o) || g.ind < argc - 3 || g.ind > argc - 1) { usage(name); return nullptr; }
+	long part[2] = { 0, 0 };
+	char *end;
+	for (int i = 0; g.ind < argc - 1 && i < 2; ++i, ++g.ind) {
+		part[i] = strtol(argv[g.ind], &end, 10);
+		if (bad_endptr(name, argv[g.ind], end, i ? "max_part_len" : "min_part_len")) return nullptr;
+	}
+	// Convproc::MINPART / MAXPART of zita-convolver 4.x are 64 / 8192
+	const long minp = part[0] ? part[0] : 64, maxp = part[1] ? part[1] : 8192;
+	if (minp < 64 || minp > 8192 || maxp < 64 || maxp > 8192 || (minp & (minp - 1))) {
+		set_error("%s: error: partition lengths must be within [64,8192] or 0 for default", name);
+		return nullptr;
+	}
+	std::vector<double> data;
+	int fch;
+	ssize_t T;
+	if (!read_filter(name, is, sel, dir, o, argv[g.ind], data, &fch, &T)) return nullptr;
+	const ssize_t ref = filter_offset(o, data, T);
+	return make_fir_spec(name, is, sel, data.data(), fch, T, ref, CONV_ZITA_EQUIV, 0, (int) minp);
+}
+
+// ---------------------------------------------------------------- hilbert
+
+void hilbert_design(ssize_t taps, double angle, std::vector<double> &h)
+{
+	// Blackman-windowed ideal Hilbert transformer mixed with a centre tap: hilbert.c:65-77
+	h.assign(taps, 0.0);
+	const double w_h = sin(-angle), w_d = cos(-angle);
+	const ssize_t mid = taps / 2;
+	for (ssize_t i = 0; i < taps; ++i) {
+		const ssize_t k = i - mid;
+		if (k == 0) h[i] = w_d;
+		else if (k % 2 != 0) {
+			const double x = 2.0*M_PI*i/(taps-1);
+			h[i] = w_h * 2.0/(M_PI*k) * (0.42 - 0.5*cos(x) + 0.08*cos(2.0*x));
+		}
+	}
+}
+
+SpecPtr parse_hilbert(const stream_info *is, const char *sel, int argc, const char *const *argv)
+{
+	const char *name = argv[0];
+	GetOpt g;
+	int opt, conv = 0;
+	bool do_align = false;
+	double angle = -M_PI_2;
+	char *end;
+	while ((opt = g.next(argc - 1, argv, "pzca:")) != -1) {
+		switch (opt) {
+		case 'p': conv = 1; break;
+		case 'z': conv = 2; break;
+		case 'c': do_align = true; break;
+		case 'a':
+			angle = strtod(g.arg, &end) / 180.0 * M_PI;
+			if (bad_endptr(name, g.arg, end, "angle")) return nullptr;
+			break;
+		default:
+			g.print_error(opt, name);
+			usage(name);
+			return nullptr;
+		}
+	}
+	if (g.ind != argc - 1) { usage(name); return nullptr; }
+	const long taps = strtol(argv[g.ind], &end, 10);
+	if (bad_endptr(name, argv[g.ind], end, "taps")) return nullptr;
+	if (taps <= 3) { set_error("%s: error: taps must be > 3", name); return nullptr; }
+	if (taps % 2 == 0) { set_error("%s: error: taps must be odd", name); return nullptr; }
+	std::vector<double> h;
+	hilbert_design(taps, angle, h);
+	const ssize_t ref = do_align ? taps / 2 : 0;
+	const int mode = (conv == 1) ? CONV_ZERO_LATENCY : (conv == 2) ? CONV_ZITA_EQUIV : CONV_LATENCY_LEN;
+	return make_fir_spec(name, is, sel, h.data(), 1, taps, ref, mode, 0, 0);
+}
+
+// --------------------------------------------------------------- resample
+
+static double rs_window(double x)
+{
+	// Albrecht 9-term window, resample.c:52-79 (WINDOW_FUNCTION 3)
+	static const double a[9] = {
+		2.318028013590306028393e-1, 3.932575471789488615081e-1, 2.385434764970747429454e-1,
+		1.014370437785239811268e-1, 2.911516061918003918645e-2, 5.280988177252078698806e-3,
+		5.382909093381945363528e-4, 2.442086527507867730168e-5, 2.706153764205043532817e-7,
+	};
+	if (x >= 1.0 || x <= 0.0) return 0.0;
+	double w = a[0];
+	for (int i = 1; i < 9; ++i) w += ((i & 1) ? -a[i] : a[i]) * cos(2*i*M_PI*x);
+	return w;
+}
+
+static int gcd_i(int a, int b) { while (b) { const int t = b; b = a % b; a = t; } return a; }
+
+SpecPtr parse_resample(const stream_info *is, const char *sel, int argc, const char *const *argv, bool *noop)
+{
+	const char *name = argv[0];
+	*noop = false;
+	if (argc < 2 || argc > 3) { usage(name); return nullptr; }
+	const char *rate_arg = argv[argc - 1], *bw_arg = (argc == 3) ? argv[1] : nullptr;
+	char *end;
+	double bw = 0.939;
+	if (bw_arg) {
+		bw = strtod(bw_arg, &end);
+		if (bad_endptr(name, bw_arg, end, "bandwidth")) return nullptr;
+		if (!(bw >= 0.7 && bw <= 0.999)) { set_error("%s: error: bandwidth out of range", name); return nullptr; }
+	}
+	long rate;
+	if (rate_arg[0] == 'x') {
+		rate = is->fs * strtol(rate_arg + 1, &end, 10);
+		if (bad_endptr(name, rate_arg, end, "fs multiplier")) return nullptr;
+	}
+	else if (rate_arg[0] == '/') {
+		const long div = strtol(rate_arg + 1, &end, 10);
+		if (bad_endptr(name, rate_arg, end, "fs divisor")) return nullptr;
+		if (div == 0 || is->fs % div != 0) { set_error("%s: error: %ld is not a factor of %d", name, div, is->fs); return nullptr; }
+		rate = is->fs / div;
+	}
+	else {
+		rate = lround(parse_freq(rate_arg, &end));
+		if (bad_endptr(name, rate_arg, end, "fs")) return nullptr;
+	}
+	if (rate <= 0) { set_error("%s: error: rate out of range", name); return nullptr; }
+	SpecPtr s = new_spec(Kind::Resample, name, is, sel);
+	s->sel.assign(is->channels, 1);            // resample ignores the selector (README.md:389-391)
+	s->flags = EFFECT_FLAG_CH_DEPS_IDENTITY;
+	s->fs_out = (int) rate;
+	if (rate == is->fs) {
+		log_msg(LL_VERBOSE, "%s: info: sample rates match; no proccessing will be done", name);
+		*noop = true;
+		return s;
+	}
+	// prototype design: resample.c:274-287, 363-364
+	const double M_FACT = 17.7822;
+	const int max_rate = rate > is->fs ? (int) rate : is->fs, min_rate = rate > is->fs ? is->fs : (int) rate;
+	const int g = gcd_i((int) rate, is->fs);
+	s->rs_n = (int) rate / g;
+	s->rs_d = is->fs / g;
+	const int min_factor = s->rs_n < s->rs_d ? s->rs_n : s->rs_d;
+	const int m = (int) lround(2.0*M_FACT*max_rate / (min_rate*(1.0-bw)));
+	const double width = M_FACT*max_rate / m;
+	const double fc = (min_rate-width) / max_rate;
+	const int os = min_factor < 2 ? min_factor : 2;
+	const double fc_os = fc / os;
+	const int m_os = (m + 1) * os - 1;
+	s->rs_m = m;
+	s->rs_fc = fc;
+	s->rs_os = os;
+	s->rs_proto.assign(m_os + 1, 0.0);
+	for (int i = 1; i < m_os; ++i) {
+		const double x = (i*2 - m_os)/2.0;
+		const double sinc = (fabs(x) < 1e-9) ? fc_os : sin(M_PI*fc_os*x) / (M_PI*x);
+		s->rs_proto[i] = sinc * rs_window((double) i / m_os);
+	}
+	log_msg(LL_VERBOSE, "%s: info: gcd=%d ratio=%d/%d width=%fHz fc=%f filter_len=%d sinc_oversample=%d", name, g, s->rs_n, s->rs_d, width, fc, m + 1, os);
+	return s;
+}
+
+// ------------------------------------------------------------------ merge
+
+bool merge_specs(Spec &d, const Spec &s)
+{
+	if (d.kind != s.kind) return false;
+	const int n = d.ch_in;
+	switch (d.kind) {
+	case Kind::Gain:
+		for (int k = 0; k < n; ++k) d.vec[k] *= s.vec[k];   // gain.c:57-67
+		return true;
+	case Kind::Add:
+		for (int k = 0; k < n; ++k) d.vec[k] += s.vec[k];   // gain.c:69-79
+		return true;
+	case Kind::Biquad:
+		for (int k = 0; k < n; ++k) if (d.sel[k] && s.sel[k]) return false;   // biquad.c:344-351
+		for (int k = 0; k < n; ++k) if (s.sel[k]) { d.sel[k] = 1; d.bq[k] = s.bq[k]; }
+		return true;
+	case Kind::Delay:
+		for (int k = 0; k < n; ++k) d.delay[k] += s.delay[k];   // delay.c:127-141
+		return true;
+	default:
+		return false;
+	}
+}
+
+}  // namespace dspamd

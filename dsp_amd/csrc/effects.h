@@ -1,0 +1,74 @@
+// effects.h -- host-side description of one effect (what the reference keeps in e->data) and the
+// init-time parsers that produce it.  No device code here: a Spec is plain data that the pipeline
+// compiler (engine.cpp) turns into fused GPU stages.
+#pragma once
+#include <array>
+#include <memory>
+#include <string>
+#include <vector>
+#include "dsp_effect_abi.h"
+#include "host_util.h"
+
+namespace dspamd {
+
+enum class Kind { Gain, Add, Biquad, Remix, Delay, Align, FirDirect, Conv, Resample };
+
+enum ConvMode {
+	CONV_ZERO_LATENCY = 0,   // fir_p (fir_p.c): y[n] = sum h[k] x[n-k], no added latency
+	CONV_LATENCY_LEN = 1,    // fir (fir.c:109-149): same values, `latency` frames late, latency reported to the host
+	CONV_ZITA_EQUIV = 2,     // zita_convolver contract: float32 in / filter / out, `latency` = part_len frames late
+};
+
+struct Spec {
+	Kind kind;
+	std::string name;                        // effect name as the registry knows it (e->name)
+	int fs_in = 0, fs_out = 0, ch_in = 0, ch_out = 0;
+	Selector sel;                            // channels acted on (copy of channel_selector)
+	int flags = 0;                           // EFFECT_FLAG_*
+
+	std::vector<double> vec;                 // Gain/Add: per-channel operand (1.0 / 0.0 where unselected)
+	std::vector<std::array<double, 5>> bq;   // Biquad: c0..c4 per channel (valid where sel)
+	std::vector<Selector> remix;             // Remix: [ch_out] selectors over ch_in
+	std::vector<ssize_t> delay;              // Delay: requested per-channel delay (realised by Align); Align: ring length
+	ssize_t discard = 0;                     // Align: leading frames dropped at end of chain (align.c:53-62)
+
+	std::vector<double> taps;                // FirDirect/Conv: [T][fch] interleaved
+	int fch = 0;
+	ssize_t T = 0, ref = 0, latency = 0;
+	int conv_mode = CONV_ZERO_LATENCY;
+
+	int rs_n = 1, rs_d = 1, rs_m = 0;        // Resample: ratio n/d, prototype order m
+	double rs_fc = 0.0;
+	std::vector<double> rs_proto;            // windowed-sinc prototype s[0..m] at rate max(fs_in, fs_out) * sinc_os
+	int rs_os = 1;
+};
+
+using SpecPtr = std::unique_ptr<Spec>;
+
+// Parsers: argv[0] is the effect name; return nullptr after set_error() on any syntax/range error.
+// *noop is set when the effect is valid but does nothing (host drops it: run == NULL).
+SpecPtr parse_biquad(int effect_number, const stream_info *is, const char *sel, int argc, const char *const *argv, bool *unsupported_reverse);
+SpecPtr parse_gain(int effect_number, const stream_info *is, const char *sel, int argc, const char *const *argv);
+SpecPtr parse_remix(const stream_info *is, const char *sel, int argc, const char *const *argv);
+SpecPtr parse_delay(const stream_info *is, const char *sel, int argc, const char *const *argv, bool *noop);
+SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv);
+SpecPtr parse_zita(const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv);
+SpecPtr parse_hilbert(const stream_info *is, const char *sel, int argc, const char *const *argv);
+SpecPtr parse_resample(const stream_info *is, const char *sel, int argc, const char *const *argv, bool *noop);
+
+SpecPtr make_fir_spec(const char *name, const stream_info *is, const char *sel, const double *filter, int fch, ssize_t T, ssize_t ref, int mode, int force_direct, int part_len);
+SpecPtr make_delay_spec(const char *name, const stream_info *is, const char *sel, ssize_t samples, bool *noop);
+SpecPtr make_align_spec(int fs, int channels, const std::vector<ssize_t> &len, ssize_t discard);
+
+// merge(dest, src): the reference's e->merge callbacks (gain.c:57-79, biquad.c:344-376, delay.c:127-141)
+bool merge_specs(Spec &dest, const Spec &src);
+
+// design helpers (also used by tests through the C API)
+void biquad_normalise(double b0, double b1, double b2, double a0, double a1, double a2, std::array<double, 5> &c);
+void biquad_design(int type, double fs, double arg0, double arg1, double arg2, double arg3, int width_type, std::array<double, 5> &c);
+void hilbert_design(ssize_t taps, double angle_rad, std::vector<double> &h);
+
+const effect_info *registry_lookup(const char *name);
+const effect_info *registry_table(int *n);
+
+}  // namespace dspamd

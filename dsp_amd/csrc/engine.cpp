@@ -1,0 +1,412 @@
+// engine.cpp -- pipeline compiler and the simple stages (cascade, remix, align/delay).
+// The FFT convolution and resample stages live in conv.cpp.
+#include "engine.h"
+#include "stages.h"
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+namespace dspamd {
+
+bool hip_ok(hipError_t e, const char *what)
+{
+	if (e == hipSuccess) return true;
+	set_error("HIP error in %s: %s", what, hipGetErrorString(e));
+	return false;
+}
+
+int device_count()
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+bool DevBuf::alloc(size_t n, bool zero)
+{
+	release();
+	if (n == 0) n = 16;
+	if (!hip_ok(hipMalloc(&p, n), "hipMalloc")) { p = nullptr; return false; }
+	bytes = n;
+	if (zero && !hip_ok(hipMemset(p, 0, n), "hipMemset")) return false;
+	return true;
+}
+
+bool DevBuf::upload(const void *src, size_t n)
+{
+	if (!alloc(n, false)) return false;
+	return hip_ok(hipMemcpy(p, src, n, hipMemcpyHostToDevice), "hipMemcpy H2D");
+}
+
+void DevBuf::release()
+{
+	if (p) (void) hipFree(p);
+	p = nullptr;
+	bytes = 0;
+}
+
+// ------------------------------------------------------------ CascadeStage
+
+static void mat_mul(const long double a[4], const long double b[4], long double r[4])
+{
+	r[0] = a[0]*b[0] + a[1]*b[2];
+	r[1] = a[0]*b[1] + a[1]*b[3];
+	r[2] = a[2]*b[0] + a[3]*b[2];
+	r[3] = a[2]*b[1] + a[3]*b[3];
+}
+
+static void fill_biquad_op(OpDesc &od, const std::array<double, 5> &c)
+{
+	od.kind = OP_BIQUAD;
+	for (int i = 0; i < 5; ++i) od.c[i] = c[i];
+	// A = [[-c3, 1], [-c4, 0]]; powers by repeated squaring in extended precision
+	long double A[4] = { -(long double) c[3], 1.0L, -(long double) c[4], 0.0L };
+	long double Pk[4] = { A[0], A[1], A[2], A[3] };
+	for (int k = 0; k < CASCADE_NPOW; ++k) {
+		for (int q = 0; q < 4; ++q) od.P[k][q] = (double) Pk[q];
+		long double sq[4];
+		mat_mul(Pk, Pk, sq);
+		memcpy(Pk, sq, sizeof(sq));
+	}
+	// h[i] = first row of A^i
+	long double row[2] = { 1.0L, 0.0L };
+	for (int i = 0; i < CASCADE_L; ++i) {
+		od.h[i][0] = (double) row[0];
+		od.h[i][1] = (double) row[1];
+		const long double n0 = row[0]*A[0] + row[1]*A[2], n1 = row[0]*A[1] + row[1]*A[3];
+		row[0] = n0;
+		row[1] = n1;
+	}
+}
+
+void CascadeStage::add(const Spec &sp)
+{
+	std::vector<OpDesc> col(ch_in);
+	for (int k = 0; k < ch_in; ++k) {
+		OpDesc &od = col[k];
+		memset(&od, 0, sizeof(od));
+		if (sp.kind == Kind::Gain) { od.kind = OP_MUL; od.g = sp.vec[k]; }
+		else if (sp.kind == Kind::Add) { od.kind = OP_ADD; od.g = sp.vec[k]; }
+		else if (sp.sel[k]) fill_biquad_op(od, sp.bq[k]);
+		else od.kind = OP_SKIP;
+	}
+	cols.push_back(std::move(col));
+	names.push_back(sp.name);
+}
+
+bool CascadeStage::finalize()
+{
+	n_ops = (int) cols.size();
+	std::vector<OpDesc> host((size_t) ch_in * n_ops);
+	for (int c = 0; c < ch_in; ++c)
+		for (int j = 0; j < n_ops; ++j)
+			host[(size_t) c * n_ops + j] = cols[j][c];
+	if (!ops.upload(host.data(), host.size() * sizeof(OpDesc))) return false;
+	if (!state.alloc((size_t) S * ch_in * n_ops * 2 * sizeof(double))) return false;
+	Cg = (ch_in <= 16) ? ch_in : 8;
+	return true;
+}
+
+std::string CascadeStage::describe() const
+{
+	std::ostringstream o;
+	o << "cascade[";
+	for (size_t i = 0; i < names.size(); ++i) o << (i ? " " : "") << names[i];
+	o << "; Cg=" << Cg << (ring.base ? (write_interleaved ? "; +ring" : "; ->ring") : "") << "]";
+	return o.str();
+}
+
+ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	CascadeParams p;
+	p.in = in; p.out = out;
+	p.in_stride_frames = in_stride; p.out_stride_frames = out_stride;
+	p.frames = frames;
+	p.C = ch_in; p.cg0 = 0; p.Cg = Cg;
+	p.n_ops = n_ops;
+	p.ops = ops.as<OpDesc>();
+	p.state = state.as<double>();
+	p.ring = ring;
+	p.write_interleaved = write_interleaved;
+	launch_cascade(p, S, st);
+	if (ring.base) ring.pos = (ring.pos + frames) & ring.mask;
+	return frames;
+}
+
+void CascadeStage::reset(hipStream_t st)
+{
+	(void) hipMemsetAsync(state.p, 0, state.bytes, st);
+}
+
+// -------------------------------------------------------------- RemixStage
+
+bool RemixStage::init(const Spec &sp)
+{
+	max_n = 1;
+	for (auto &r : sp.remix) max_n = std::max(max_n, num_set(r));
+	std::vector<int> idx((size_t) ch_out * max_n, -1);
+	for (int k = 0; k < ch_out; ++k) {
+		int n = 0;
+		for (int j = 0; j < ch_in; ++j) if (sp.remix[k][j]) idx[(size_t) k * max_n + n++] = j;
+	}
+	return d_idx.upload(idx.data(), idx.size() * sizeof(int));
+}
+
+ssize_t RemixStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	RemixParams p{ in, out, in_stride, out_stride, frames, ch_in, ch_out, d_idx.as<int>(), max_n };
+	launch_remix(p, S, st);
+	return frames;
+}
+
+// -------------------------------------------------------------- DelayStage
+
+bool DelayStage::init(const Spec &sp)
+{
+	len = sp.delay;
+	discard = sp.discard;
+	remaining_discard = discard;
+	std::vector<long> l(ch_in), off(ch_in);
+	ring_per_stream = 0;
+	max_len = 0;
+	for (int k = 0; k < ch_in; ++k) {
+		l[k] = (long) len[k];
+		off[k] = ring_per_stream;
+		ring_per_stream += l[k];
+		max_len = std::max(max_len, l[k]);
+	}
+	if (!d_len.upload(l.data(), l.size() * sizeof(long))) return false;
+	if (!d_off.upload(off.data(), off.size() * sizeof(long))) return false;
+	// two copies (read / write) per stream, see delay_kernel
+	return ring.alloc((size_t) 2 * S * std::max<long>(ring_per_stream, 1) * sizeof(double));
+}
+
+std::string DelayStage::describe() const
+{
+	std::ostringstream o;
+	o << "align[max_len=" << max_len << " discard=" << discard << "]";
+	return o.str();
+}
+
+void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream);
+
+ssize_t DelayStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	const long half = (long) S * std::max<long>(ring_per_stream, 1);
+	DelayParams p;
+	p.in = in; p.out = out;
+	p.in_stride_frames = in_stride; p.out_stride_frames = out_stride;
+	p.frames = frames;
+	p.C = ch_in;
+	p.len = d_len.as<long>();
+	p.ring_off = d_off.as<long>();
+	p.ring = ring.as<double>() + (size_t) (phase ? half : 0);
+	p.ring_per_stream = ring_per_stream;
+	p.pos = pos;
+	const long skip = std::min<long>(remaining_discard, frames);
+	launch_delay_ex(p, phase ? -half : half, skip, max_len, S, st);
+	phase ^= 1;
+	pos += frames;
+	remaining_discard -= skip;
+	return frames - skip;
+}
+
+void DelayStage::reset(hipStream_t st)
+{
+	(void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
+	pos = 0;
+	phase = 0;
+	remaining_discard = discard;
+}
+
+// ---------------------------------------------------------------- Pipeline
+
+Pipeline::~Pipeline() {}
+
+std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &specs, int fs, int channels, int n_streams, ssize_t max_frames)
+{
+	std::unique_ptr<Pipeline> pl(new Pipeline);
+	pl->S = n_streams;
+	pl->fs_in = fs;
+	pl->ch_in = channels;
+	pl->max_frames = max_frames;
+	int cur_fs = fs, cur_ch = channels;
+	CascadeStage *casc = nullptr;
+	auto flush = [&]() -> bool {
+		if (!casc) return true;
+		const bool ok = casc->finalize();
+		casc = nullptr;
+		return ok;
+	};
+	auto base = [&](Stage *s, const Spec &sp) {
+		s->S = n_streams;
+		s->fs_in = sp.fs_in; s->fs_out = sp.fs_out;
+		s->ch_in = sp.ch_in; s->ch_out = sp.ch_out;
+	};
+	ssize_t frames_here = max_frames;   // worst-case frames entering the next stage
+	for (const Spec *sp : specs) {
+		if (sp->fs_in != cur_fs || sp->ch_in != cur_ch) {
+			set_error("pipeline: BUG: stream format mismatch at %s (%d ch @ %d vs %d ch @ %d)", sp->name.c_str(), sp->ch_in, sp->fs_in, cur_ch, cur_fs);
+			return nullptr;
+		}
+		switch (sp->kind) {
+		case Kind::Gain: case Kind::Add: case Kind::Biquad:
+			if (!casc) {
+				casc = new CascadeStage;
+				base(casc, *sp);
+				pl->stages.emplace_back(casc);
+			}
+			casc->add(*sp);
+			break;
+		case Kind::Delay:
+			break;   // realised by Align (delay.c:142-147, 195-202)
+		case Kind::Remix: {
+			if (!flush()) return nullptr;
+			RemixStage *r = new RemixStage;
+			base(r, *sp);
+			pl->stages.emplace_back(r);
+			if (!r->init(*sp)) return nullptr;
+			break;
+		}
+		case Kind::Align: {
+			if (!flush()) return nullptr;
+			DelayStage *d = new DelayStage;
+			base(d, *sp);
+			pl->stages.emplace_back(d);
+			if (!d->init(*sp)) return nullptr;
+			break;
+		}
+		case Kind::FirDirect: case Kind::Conv: case Kind::Resample: {
+			CascadeStage *feeder = casc;
+			if (!flush()) return nullptr;
+			Stage *s = make_conv_stage(*sp, n_streams, frames_here, feeder);
+			if (!s) return nullptr;
+			base(s, *sp);
+			pl->stages.emplace_back(s);
+			break;
+		}
+		}
+		cur_fs = sp->fs_out;
+		cur_ch = sp->ch_out;
+		if (!pl->stages.empty()) frames_here = pl->stages.back()->max_out_frames(frames_here);
+	}
+	if (!flush()) return nullptr;
+	pl->fs_out = cur_fs;
+	pl->ch_out = cur_ch;
+	// ping-pong scratch sized for the widest intermediate
+	ssize_t fr = max_frames;
+	size_t worst = 0;
+	long worst_frames = max_frames;
+	int worst_ch = channels;
+	for (auto &s : pl->stages) {
+		fr = s->max_out_frames(fr);
+		worst_frames = std::max<long>(worst_frames, fr);
+		worst_ch = std::max(worst_ch, s->ch_out);
+	}
+	worst = (size_t) n_streams * worst_frames * worst_ch * sizeof(double);
+	if (pl->stages.size() > 1) {
+		for (int i = 0; i < 2; ++i) {
+			if (!pl->tmp[i].alloc(worst, false)) return nullptr;
+			pl->tmp_stride[i] = worst_frames;
+		}
+	}
+	pl->tmp_ch = worst_ch;
+	return pl;
+}
+
+ssize_t Pipeline::max_out_frames(ssize_t in_frames) const
+{
+	ssize_t f = in_frames;
+	for (auto &s : stages) f = s->max_out_frames(f);
+	return f;
+}
+
+ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st)
+{
+	if (frames > max_frames) { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return -1; }
+	if (out_stride <= 0) out_stride = max_out_frames(frames);
+	if (frames <= 0) return 0;
+	if (stages.empty()) {
+		launch_copy_slab(d_in, frames, d_out, out_stride, frames, 0, ch_in, S, st);
+		return frames;
+	}
+	const double *cur = d_in;
+	long cur_stride = frames;
+	ssize_t F = frames;
+	int which = 0;
+	for (size_t i = 0; i < stages.size(); ++i) {
+		Stage *s = stages[i].get();
+		const bool last = (i + 1 == stages.size());
+		double *dst;
+		long dst_stride;
+		if (last) { dst = d_out; dst_stride = out_stride; }
+		else if (s->in_place_ok() && cur != d_in) { dst = const_cast<double *>(cur); dst_stride = cur_stride; }
+		else {
+			dst = tmp[which].as<double>();
+			// slabs are re-strided per stage: [S][tmp_frames][ch_out] always fits the allocation
+			dst_stride = (long) (tmp[which].bytes / sizeof(double) / S / s->ch_out);
+			which ^= 1;
+		}
+		F = s->run(cur, cur_stride, F, dst, dst_stride, st);
+		if (F < 0) return F;
+		cur = dst;
+		cur_stride = dst_stride;
+		if (F == 0) {
+			// nothing came out (latency still filling): downstream stages see no frames this call
+			return 0;
+		}
+	}
+	return F;
+}
+
+ssize_t Pipeline::drain2(ssize_t block_frames, double *d_out, long out_stride, hipStream_t st)
+{
+	// mirror of effects_chain.c:1199-1217: give each stage with a drain2 a turn, feed what comes out to the rest
+	while (drain_stage < (int) stages.size()) {
+		Stage *s = stages[drain_stage].get();
+		const bool last = (drain_stage + 1 == (int) stages.size());
+		double *dst = last ? d_out : tmp[0].as<double>();
+		long dst_stride = last ? out_stride : (long) (tmp[0].bytes / sizeof(double) / S / s->ch_out);
+		ssize_t F = s->drain2(block_frames, dst, dst_stride, st);
+		if (F < 0) { ++drain_stage; continue; }
+		const double *cur = dst;
+		long cur_stride = dst_stride;
+		int which = 1;
+		for (size_t i = drain_stage + 1; i < stages.size() && F > 0; ++i) {
+			Stage *n = stages[i].get();
+			const bool nlast = (i + 1 == stages.size());
+			double *d2 = nlast ? d_out : tmp[which].as<double>();
+			long d2_stride = nlast ? out_stride : (long) (tmp[which].bytes / sizeof(double) / S / n->ch_out);
+			which ^= 1;
+			F = n->run(cur, cur_stride, F, d2, d2_stride, st);
+			cur = d2;
+			cur_stride = d2_stride;
+		}
+		return F;
+	}
+	return -1;
+}
+
+void Pipeline::reset(hipStream_t st)
+{
+	for (auto &s : stages) s->reset(st);
+	drain_stage = 0;
+}
+
+std::string Pipeline::plan() const
+{
+	std::ostringstream o;
+	o << "S=" << S << " " << ch_in << "ch@" << fs_in << " :";
+	for (auto &s : stages) o << " " << s->describe();
+	o << " : " << ch_out << "ch@" << fs_out;
+	return o.str();
+}
+
+size_t Pipeline::device_bytes() const
+{
+	size_t b = tmp[0].bytes + tmp[1].bytes;
+	for (auto &s : stages) b += s->device_bytes();
+	return b;
+}
+
+}  // namespace dspamd

@@ -1,0 +1,82 @@
+// engine.h -- the device pipeline: a chain of Specs compiled into fused GPU stages that process a
+// batch of S independent streams whose buffers ([stream][frame][channel] fp64) live in HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <vector>
+#include "effects.h"
+#include "kparams.h"
+
+namespace dspamd {
+
+bool hip_ok(hipError_t e, const char *what);   // logs + set_error on failure
+int device_count();
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t bytes = 0;
+	DevBuf() = default;
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
+	~DevBuf() { release(); }
+	bool alloc(size_t n, bool zero = true);
+	bool upload(const void *src, size_t n);    // alloc + H2D (synchronous)
+	void release();
+	template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// One fused device stage.  in/out are [S][stride][C] slabs; a stage may be run in place when
+// in_place_ok() (out == in, same stride).
+class Stage {
+public:
+	int S = 1, fs_in = 0, fs_out = 0, ch_in = 0, ch_out = 0;
+	virtual ~Stage() {}
+	virtual const char *type() const = 0;
+	virtual std::string describe() const = 0;
+	virtual bool in_place_ok() const { return false; }
+	virtual ssize_t max_out_frames(ssize_t in_frames) const { return in_frames; }
+	// returns frames produced per stream (>= 0) or < 0 on error
+	virtual ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) = 0;
+	// second-phase drain for stages that hold frames back (resample drain2); -1 = nothing (left)
+	virtual ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) { (void) max_frames; (void) out; (void) out_stride; (void) st; return -1; }
+	virtual void reset(hipStream_t st) = 0;
+	virtual size_t device_bytes() const { return 0; }
+};
+
+class ConvStage;
+
+class Pipeline {
+public:
+	// specs are borrowed for the duration of the call only
+	static std::unique_ptr<Pipeline> compile(const std::vector<const Spec *> &specs, int fs, int channels, int n_streams, ssize_t max_frames);
+	~Pipeline();
+	int S, fs_in, ch_in, fs_out, ch_out;
+	ssize_t max_frames;
+	ssize_t max_out_frames(ssize_t in_frames) const;
+	ssize_t run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st);
+	ssize_t drain2(ssize_t block_frames, double *d_out, long out_stride, hipStream_t st);   // rate-changer flush
+	void reset(hipStream_t st);
+	std::string plan() const;
+	int n_stages() const { return (int) stages.size(); }
+	size_t device_bytes() const;
+private:
+	Pipeline() {}
+	std::vector<std::unique_ptr<Stage>> stages;
+	DevBuf tmp[2];
+	long tmp_stride[2] = { 0, 0 };   // frames
+	int tmp_ch = 0;
+	int drain_stage = 0;
+};
+
+// kernel launchers (kernels_*.hip)
+size_t cascade_lds_bytes(int Cg, int n_ops);
+void launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream);
+void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream);
+void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream);
+void launch_copy_slab(const double *in, long in_stride, double *out, long out_stride, long frames, long skip, int C, int n_streams, hipStream_t stream);
+void launch_sgen_sine(double *buf, int n_streams, long frames, int channels, int fs, double freq0, double dfreq, long pos0, hipStream_t stream);
+void launch_digest(const double *buf, int n_streams, long frames, long stride, int channels, double *out, hipStream_t stream);
+void launch_copy_probe(const void *src, void *dst, size_t bytes, hipStream_t stream);
+
+}  // namespace dspamd

@@ -1,0 +1,194 @@
+// kernels_cascade.hip -- fused gain/add/biquad cascade as a block-parallel state-space recurrence.
+//
+// Replaces, for a whole batch of streams in one launch, the reference's per-effect passes
+//   gain_effect_run / add_effect_run        gain.c:25-43
+//   biquad_effect_run{,_all} + biquad()     biquad.c:296-315, biquad.h:76-92
+// (the reference never merges biquads that act on the same channel, biquad.c:344-351, so a chain of
+// 10 biquads is 10 full passes over the block there; here it is one read and one write).
+//
+// Math.  One TDF-II section with x = (m0, m1):
+//     r[n] = c0 s[n] + m0[n],   x[n+1] = A x[n] + B s[n],   A = [[-c3, 1], [-c4, 0]]
+// A wave owns 64*L consecutive samples of one channel, lane l owning samples [lL, lL+L):
+//   1. every lane runs the recurrence from ZERO state over its L samples (registers only);
+//   2. the lane end-states b_l are combined with a 6-step Kogge-Stone scan over the wave using the
+//      constant matrices A^(L 2^k) (the carried state enters through lane 0: b_0 += A^L x_in);
+//   3. every lane adds the zero-input response of its true incoming state: r[i] += (A^i x_l)[0].
+// Sections run back to back on the register-resident samples; the state leaving lane 63 is the state
+// carried to the next tile / next run() call, exactly the reference's (m0, m1).
+// Blocks whose length is not a multiple of 64*L finish with L = 1 steps (64 samples per wave step,
+// cut at any sample), so consecutive calls of ANY size form one stream.
+//
+// Layout: workgroup = (stream, channel group); the [frames][C] slab of the stream is read coalesced,
+// transposed through LDS (row stride padded so that both the transposing ds_write_b64 and the per-lane
+// ds_read_b64 are bank-conflict free), results go back the same way and/or into the planar ring that
+// feeds the FFT convolver.
+#include <hip/hip_runtime.h>
+#include "kparams.h"
+
+namespace dspamd {
+
+constexpr int L16 = CASCADE_L;
+// per-channel LDS row: 64 lanes x (16 + 1 pad) doubles, + 2 so that rows of different channels land on
+// different bank pairs for the transposing store (see DESIGN.md "cascade kernel")
+constexpr int CH_STRIDE = 64 * (L16 + 1) + 2;
+
+__device__ __forceinline__ int lds_index(int t) { return t + (t >> 4); }
+
+template <int L, int LOG2L>
+__device__ __forceinline__ void run_ops(double (&v)[L], const OpDesc *__restrict__ ops, int n_ops,
+                                        double *st /* LDS [n_ops][2] */, int lane, int last_lane)
+{
+	for (int j = 0; j < n_ops; ++j) {
+		const OpDesc *od = ops + j;
+		const int kind = od->kind;
+		if (kind == OP_MUL) {
+			const double g = od->g;
+#pragma unroll
+			for (int i = 0; i < L; ++i) v[i] = __dmul_rn(v[i], g);
+		}
+		else if (kind == OP_ADD) {
+			const double g = od->g;
+#pragma unroll
+			for (int i = 0; i < L; ++i) v[i] = __dadd_rn(v[i], g);
+		}
+		else if (kind == OP_BIQUAD) {
+			const double c0 = od->c[0], c1 = od->c[1], c2 = od->c[2], nc3 = -od->c[3], nc4 = -od->c[4];
+			double m0 = 0.0, m1 = 0.0;
+#pragma unroll
+			for (int i = 0; i < L; ++i) {
+				const double s = v[i];
+				const double r = fma(c0, s, m0);
+				m0 = fma(nc3, r, fma(c1, s, m1));
+				m1 = fma(nc4, r, c2 * s);
+				v[i] = r;
+			}
+			const double xin0 = st[2*j], xin1 = st[2*j + 1];
+			if (lane == 0) {  // the carried state rides through lane 0's L samples
+				const double *PL = od->P[LOG2L];
+				m0 += PL[0] * xin0 + PL[1] * xin1;
+				m1 += PL[2] * xin0 + PL[3] * xin1;
+			}
+#pragma unroll
+			for (int k = 0; k < 6; ++k) {
+				const double *Pk = od->P[LOG2L + k];
+				const double t0 = __shfl_up(m0, 1u << k, 64);
+				const double t1 = __shfl_up(m1, 1u << k, 64);
+				if (lane >= (1 << k)) {
+					m0 += Pk[0] * t0 + Pk[1] * t1;
+					m1 += Pk[2] * t0 + Pk[3] * t1;
+				}
+			}
+			double x0 = __shfl_up(m0, 1, 64), x1 = __shfl_up(m1, 1, 64);
+			if (lane == 0) { x0 = xin0; x1 = xin1; }
+#pragma unroll
+			for (int i = 0; i < L; ++i)
+				v[i] += od->h[i][0] * x0 + od->h[i][1] * x1;
+			// state after the last valid lane's samples = the reference's (m0, m1) at that point
+			const double e0 = __shfl(m0, last_lane, 64), e1 = __shfl(m1, last_lane, 64);
+			if (lane == 0) { st[2*j] = e0; st[2*j + 1] = e1; }
+		}
+	}
+}
+
+__global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) double smem[];
+	const int s = blockIdx.x;
+	const int c0 = p.cg0 + blockIdx.y * p.Cg;
+	const int cgn = min(p.Cg, p.C - c0);
+	const int tid = threadIdx.x, nth = blockDim.x;
+	const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+	double *tile = smem;                               // [cgn][CH_STRIDE]
+	double *st = smem + (size_t) p.Cg * CH_STRIDE;     // [cgn][n_ops][2]
+
+	int cgp = 1, cgs = 0;                              // next power of two >= cgn
+	while (cgp < cgn) { cgp <<= 1; ++cgs; }
+
+	const int n_st = cgn * p.n_ops * 2;
+	double *gstate = p.state + ((size_t) s * p.C + c0) * p.n_ops * 2;
+	for (int i = tid; i < n_st; i += nth) st[i] = gstate[i];
+	__syncthreads();
+
+	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	const long n_full = p.frames / CASCADE_TILE;
+	const int rem = (int) (p.frames - n_full * CASCADE_TILE);
+
+	for (long tl = 0; tl <= n_full; ++tl) {
+		const long t0 = tl * CASCADE_TILE;
+		const int nfr = (tl < n_full) ? CASCADE_TILE : rem;
+		if (nfr == 0) break;
+		// ---- coalesced load, transposed into LDS ----
+		for (int e = tid; e < (nfr << cgs); e += nth) {
+			const int t = e >> cgs, cc = e & (cgp - 1);
+			if (cc < cgn)
+				tile[cc * CH_STRIDE + lds_index(t)] = in[(t0 + t) * p.C + c0 + cc];
+		}
+		__syncthreads();
+		// ---- recurrences: one wave per channel at a time ----
+		for (int cc = wave; cc < cgn; cc += nw) {
+			const OpDesc *ops = p.ops + (size_t) __builtin_amdgcn_readfirstlane(c0 + cc) * p.n_ops;
+			double *row = tile + cc * CH_STRIDE;
+			double *cst = st + cc * p.n_ops * 2;
+			if (nfr == CASCADE_TILE) {
+				double v[L16];
+#pragma unroll
+				for (int i = 0; i < L16; ++i) v[i] = row[lane * (L16 + 1) + i];
+				run_ops<L16, 4>(v, ops, p.n_ops, cst, lane, 63);
+#pragma unroll
+				for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
+			}
+			else {
+				for (int t1 = 0; t1 < nfr; t1 += 64) {
+					const int t = t1 + lane;
+					const int nvalid = min(64, nfr - t1);
+					double v[1];
+					v[0] = (t < nfr) ? row[lds_index(t)] : 0.0;
+					run_ops<1, 0>(v, ops, p.n_ops, cst, lane, nvalid - 1);
+					if (t < nfr) row[lds_index(t)] = v[0];
+				}
+			}
+		}
+		__syncthreads();
+		// ---- store ----
+		if (p.write_interleaved) {
+			for (int e = tid; e < (nfr << cgs); e += nth) {
+				const int t = e >> cgs, cc = e & (cgp - 1);
+				if (cc < cgn)
+					out[(t0 + t) * p.C + c0 + cc] = tile[cc * CH_STRIDE + lds_index(t)];
+			}
+		}
+		if (p.ring.base) {
+			for (int cc = 0; cc < cgn; ++cc) {
+				const int r = p.ring.row_of_channel[c0 + cc];
+				if (r < 0) continue;
+				double *dst = p.ring.base + ((size_t) s * p.ring.rows_per_stream + r) * p.ring.row_stride;
+				for (int t = tid; t < nfr; t += nth)
+					dst[(p.ring.pos + t0 + t) & p.ring.mask] = tile[cc * CH_STRIDE + lds_index(t)];
+			}
+		}
+		__syncthreads();
+	}
+	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
+}
+
+size_t cascade_lds_bytes(int Cg, int n_ops)
+{
+	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2) * sizeof(double);
+}
+
+void launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	const int n_groups = (p.C - p.cg0 + p.Cg - 1) / p.Cg;
+	const int waves = p.Cg < 8 ? (p.Cg < 1 ? 1 : p.Cg) : 8;
+	dim3 grid(n_streams, n_groups), block(64 * waves);
+	const size_t lds = cascade_lds_bytes(p.Cg, p.n_ops);
+	static size_t lds_granted = 0;   // LDS above 64 KiB must be requested once per process
+	if (lds > lds_granted) {
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		lds_granted = lds;
+	}
+	hipLaunchKernelGGL(cascade_kernel, grid, block, lds, stream, p);
+}
+
+}  // namespace dspamd

@@ -1,0 +1,187 @@
+// kernels_pointwise.hip -- the bit-exact class (remix, integer delay / align, slab copy) and the device-side
+// bench endpoints (sgen sine source, digest sink, copy probe).
+//
+//   remix_kernel  : remix_effect_run_{1a,4,generic}   remix.c:39-101  (ascending-input-channel sums from 0.0)
+//   delay_kernel  : align_channel_run                 align.c:35-44   (per-channel delay of len frames, state carried)
+//   sgen_kernel   : sgen_run_generator (sine)         sgen.c:55-67
+//   digest_kernel : the `stats` quantities            stats.c:47-76
+// All arithmetic that must match the CPU bit for bit uses the explicitly rounded intrinsics
+// (__dadd_rn / __dmul_rn) so that the compiler can never contract it into an FMA.
+#include <hip/hip_runtime.h>
+#include "kparams.h"
+
+namespace dspamd {
+
+__global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
+{
+	const int s = blockIdx.y;
+	const long n = p.frames * p.Cout;
+	const double *in = p.in + (size_t) s * p.in_stride_frames * p.Cin;
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.Cout;
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
+		const long t = e / p.Cout;
+		const int k = (int) (e - t * p.Cout);
+		const int *idx = p.idx + (size_t) k * p.max_n;
+		const double *fr = in + t * p.Cin;
+		double acc = 0.0;
+		for (int j = 0; j < p.max_n; ++j) {
+			const int c = idx[j];
+			if (c < 0) break;
+			acc = __dadd_rn(acc, fr[c]);
+		}
+		out[e] = acc;
+	}
+}
+
+void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream)
+{
+	const long n = p.frames * p.Cout;
+	if (n <= 0) return;
+	long blocks = (n + 255) / 256;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(remix_kernel, dim3((unsigned) blocks, n_streams), dim3(256), 0, stream, p);
+}
+
+// out[t] = x[t - len]; the ring holds the last len input frames.  ring is double-buffered by the host
+// (read `ring`, write `ring + ring_alt_off`) so that no slot is read and written by different threads.
+struct DelayKArgs {
+	DelayParams p;
+	long ring_alt_off;   // offset (doubles) from the read ring to the write ring
+	long skip;           // leading output frames dropped (end-of-chain discard, align.c:53-62)
+	long max_len;
+};
+
+__global__ __launch_bounds__(256) void delay_kernel(DelayKArgs a)
+{
+	const DelayParams &p = a.p;
+	const int s = blockIdx.y;
+	const long span = (p.frames > a.max_len) ? p.frames : a.max_len;
+	const long n = span * p.C;
+	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	const double *rd = p.ring + (size_t) s * p.ring_per_stream;
+	double *wr = p.ring + (size_t) s * p.ring_per_stream + a.ring_alt_off;
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
+		const long t = e / p.C;
+		const int c = (int) (e - t * p.C);
+		const long len = p.len[c];
+		if (t < p.frames) {
+			double v;
+			if (len == 0) v = in[t * p.C + c];
+			else if (t >= len) v = in[(t - len) * p.C + c];
+			else v = rd[p.ring_off[c] + (p.pos + t) % len];
+			if (t >= a.skip) out[(t - a.skip) * p.C + c] = v;
+		}
+		if (len > 0 && t < span) {
+			if (t < p.frames) {
+				if (t >= p.frames - len) wr[p.ring_off[c] + (p.pos + t) % len] = in[t * p.C + c];
+			}
+			else if (t < len) {   // slot not overwritten this block: carry it over
+				const long slot = (p.pos + t) % len;
+				wr[p.ring_off[c] + slot] = rd[p.ring_off[c] + slot];
+			}
+		}
+	}
+}
+
+void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream)
+{
+	DelayKArgs a{ p, ring_alt_off, skip, max_len };
+	const long span = (p.frames > max_len) ? p.frames : max_len;
+	const long n = span * p.C;
+	if (n <= 0) return;
+	long blocks = (n + 255) / 256;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(delay_kernel, dim3((unsigned) blocks, n_streams), dim3(256), 0, stream, a);
+}
+
+__global__ __launch_bounds__(256) void copy_slab_kernel(const double *in, long in_stride, double *out, long out_stride, long frames, long skip, int C)
+{
+	const int s = blockIdx.y;
+	const double *src = in + ((size_t) s * in_stride + skip) * C;
+	double *dst = out + (size_t) s * out_stride * C;
+	const long n = frames * C;
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x)
+		dst[e] = src[e];
+}
+
+void launch_copy_slab(const double *in, long in_stride, double *out, long out_stride, long frames, long skip, int C, int n_streams, hipStream_t stream)
+{
+	const long n = frames * C;
+	if (n <= 0) return;
+	long blocks = (n + 255) / 256;
+	if (blocks > 4096) blocks = 4096;
+	hipLaunchKernelGGL(copy_slab_kernel, dim3((unsigned) blocks, n_streams), dim3(256), 0, stream, in, in_stride, out, out_stride, frames, skip, C);
+}
+
+// stream s: sin(2 pi f_s t), t = (pos0 + frame) / fs, the same value on every channel (sgen.c:55-67).
+// Device libm differs from the host's by ulps: this source is for throughput runs; parity runs feed
+// byte-identical host-generated input to both sides.
+__global__ __launch_bounds__(256) void sgen_kernel(double *buf, long frames, int C, int fs, double freq0, double dfreq, long pos0)
+{
+	const int s = blockIdx.y;
+	const double w = (freq0 + s * dfreq) * (2.0 * M_PI);
+	double *dst = buf + (size_t) s * frames * C;
+	const long n = frames * C;
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
+		const long t = e / C;
+		dst[e] = sin(w * ((double) (pos0 + t) / fs));
+	}
+}
+
+void launch_sgen_sine(double *buf, int n_streams, long frames, int channels, int fs, double freq0, double dfreq, long pos0, hipStream_t stream)
+{
+	const long n = frames * channels;
+	if (n <= 0) return;
+	long blocks = (n + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(sgen_kernel, dim3((unsigned) blocks, n_streams), dim3(256), 0, stream, buf, frames, channels, fs, freq0, dfreq, pos0);
+}
+
+// per stream: sum, sum of squares, peak |x|  ->  out[s][3]   (one workgroup per stream; deterministic order)
+__global__ __launch_bounds__(256) void digest_kernel(const double *buf, long frames, long stride, int C, double *out)
+{
+	__shared__ double sh[3][256];
+	const int s = blockIdx.x;
+	const double *src = buf + (size_t) s * stride * C;
+	const long n = frames * C;
+	double a = 0.0, b = 0.0, m = 0.0;
+	for (long e = threadIdx.x; e < n; e += blockDim.x) {
+		const double v = src[e];
+		a += v;
+		b += v * v;
+		m = fmax(m, fabs(v));
+	}
+	sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = m;
+	__syncthreads();
+	for (int k = 128; k > 0; k >>= 1) {
+		if ((int) threadIdx.x < k) {
+			sh[0][threadIdx.x] += sh[0][threadIdx.x + k];
+			sh[1][threadIdx.x] += sh[1][threadIdx.x + k];
+			sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + k]);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) { out[3*s] = sh[0][0]; out[3*s + 1] = sh[1][0]; out[3*s + 2] = sh[2][0]; }
+}
+
+void launch_digest(const double *buf, int n_streams, long frames, long stride, int channels, double *out, hipStream_t stream)
+{
+	hipLaunchKernelGGL(digest_kernel, dim3(n_streams), dim3(256), 0, stream, buf, frames, stride, channels, out);
+}
+
+// 16 B per lane streaming copy: the measured HBM ceiling quoted next to the 8 TB/s spec
+__global__ __launch_bounds__(256) void copy_probe_kernel(const double2 *src, double2 *dst, size_t n)
+{
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+		dst[i] = src[i];
+}
+
+void launch_copy_probe(const void *src, void *dst, size_t bytes, hipStream_t stream)
+{
+	const size_t n = bytes / 16;
+	if (!n) return;
+	hipLaunchKernelGGL(copy_probe_kernel, dim3(2048), dim3(256), 0, stream, (const double2 *) src, (double2 *) dst, n);
+}
+
+}  // namespace dspamd

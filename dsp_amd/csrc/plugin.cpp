@@ -1,0 +1,373 @@
+// plugin.cpp -- the reference's plugin surface (effect.h:24-59) implemented over the device pipeline.
+//
+// Every *_effect_init() below has the reference's name and signature (include/dsp_effect_abi.h), parses its
+// argv exactly like the reference effect it replaces, and returns a calloc'd `struct effect` whose callbacks
+// drive HIP kernels.  run() works on the host's interleaved fp64 buffers (one PCIe round trip per call: this
+// is the compatibility path; throughput work goes through the device-resident batch API, capi.cpp).
+#include "plugin.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace dspamd {
+
+static std::once_flag g_dev_once;
+
+static void select_device_once()
+{
+	std::call_once(g_dev_once, [] {
+		const char *d = getenv("DSP_AMD_DEVICE");
+		if (d) (void) hipSetDevice(atoi(d));
+	});
+}
+
+Node *node_of(struct effect *e)
+{
+	if (!e || !e->data) return nullptr;
+	Node *n = static_cast<Node *>(e->data);
+	return (n->magic == NODE_MAGIC) ? n : nullptr;
+}
+
+static bool ensure_pipe(struct effect *e, Node *n)
+{
+	if (n->pipe) return true;
+	select_device_once();
+	if (device_count() < 1) {
+		set_error("%s: error: no HIP device available (the GPU backend has no CPU fallback)", e->name);
+		return false;
+	}
+	const ssize_t cap = 1 << 16;
+	std::vector<const Spec *> specs{ n->spec.get() };
+	n->pipe = Pipeline::compile(specs, n->spec->fs_in, n->spec->ch_in, 1, cap);
+	if (!n->pipe) return false;
+	n->pipe_frames = cap;
+	n->out_cap_frames = n->pipe->max_out_frames(cap);
+	if (!n->d_in.alloc((size_t) cap * n->spec->ch_in * sizeof(double), false)) return false;
+	if (!n->d_out.alloc((size_t) n->out_cap_frames * n->spec->ch_out * sizeof(double), false)) return false;
+	return true;
+}
+
+static bool spec_in_place(const Spec &s)
+{
+	return s.kind != Kind::Remix && s.kind != Kind::Resample;
+}
+
+static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, sample_t *obuf)
+{
+	Node *n = node_of(e);
+	if (!n || !ensure_pipe(e, n)) {
+		// no error channel in run() (effect.h:47): degrade to silence of the right shape and keep logging
+		const ssize_t f = *frames;
+		memset(obuf, 0, (size_t) f * e->ostream.channels * sizeof(sample_t));
+		return obuf;
+	}
+	const Spec &sp = *n->spec;
+	sample_t *dst = spec_in_place(sp) ? ibuf : obuf;
+	ssize_t done = 0, produced = 0;
+	const ssize_t total = *frames;
+	while (done < total) {
+		const ssize_t nb = std::min<ssize_t>(total - done, n->pipe_frames);
+		if (!hip_ok(hipMemcpy(n->d_in.p, ibuf + done * sp.ch_in, (size_t) nb * sp.ch_in * sizeof(double), hipMemcpyHostToDevice), "H2D")) break;
+		const ssize_t f = n->pipe->run(n->d_in.as<double>(), nb, n->d_out.as<double>(), n->out_cap_frames, nullptr);
+		if (f < 0) break;
+		if (f > 0 && !hip_ok(hipMemcpy(dst + produced * sp.ch_out, n->d_out.p, (size_t) f * sp.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H")) break;
+		produced += f;
+		done += nb;
+	}
+	*frames = produced;
+	return dst;
+}
+
+static sample_t *plugin_run_noop(struct effect *, ssize_t *, sample_t *ibuf, sample_t *)
+{
+	return ibuf;   // delay.c:98-101: integer delays are realised by the host's align effect
+}
+
+static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1, sample_t *buf2)
+{
+	Node *n = node_of(e);
+	if (!n || !n->pipe) { *frames = -1; return buf1; }
+	const Spec &sp = *n->spec;
+	const ssize_t want = std::min<ssize_t>(*frames, n->pipe_frames);
+	const ssize_t f = n->pipe->drain2(want, n->d_out.as<double>(), n->out_cap_frames, nullptr);
+	if (f < 0) { *frames = -1; return buf1; }
+	if (f > 0) (void) hip_ok(hipMemcpy(buf2, n->d_out.p, (size_t) f * sp.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+	*frames = f;
+	return buf2;
+}
+
+static void plugin_reset(struct effect *e)
+{
+	Node *n = node_of(e);
+	if (n && n->pipe) {
+		n->pipe->reset(nullptr);
+		(void) hipStreamSynchronize(nullptr);
+	}
+}
+
+static void plugin_destroy(struct effect *e)
+{
+	Node *n = node_of(e);
+	if (n) {
+		(void) hipDeviceSynchronize();
+		delete n;
+	}
+	e->data = nullptr;
+	free(e->channel_selector);
+	e->channel_selector = nullptr;
+}
+
+static int plugin_merge(struct effect *dest, struct effect *src)
+{
+	if (dest->merge != src->merge) return 0;
+	Node *d = node_of(dest), *s = node_of(src);
+	if (!d || !s || d->pipe || s->pipe) return 0;   // merge may only happen before the first run()
+	if (!merge_specs(*d->spec, *s->spec)) return 0;
+	if (d->spec->kind == Kind::Biquad)
+		memcpy(dest->channel_selector, d->spec->sel.data(), d->spec->sel.size());
+	return 1;
+}
+
+static void plugin_drain_samples(struct effect *e, ssize_t *samples)
+{
+	Node *n = node_of(e);
+	if (!n) return;
+	const Spec &sp = *n->spec;
+	for (int k = 0; k < sp.ch_out; ++k) {
+		if (sp.kind == Kind::Align) samples[k] += sp.delay[k];                                  // align.c:77-82
+		else if (sp.sel[k]) samples[k] += sp.latency + sp.T - 1;                                // fir.c:180-187, fir_p.c:235-240
+	}
+}
+
+static void plugin_channel_offsets(struct effect *e, ssize_t *latency, ssize_t *req_delay)
+{
+	Node *n = node_of(e);
+	if (!n) return;
+	const Spec &sp = *n->spec;
+	for (int k = 0; k < sp.ch_in; ++k) {
+		if (sp.kind == Kind::Delay) req_delay[k] += sp.delay[k];                                // delay.c:142-147
+		else if (sp.sel[k]) { latency[k] += sp.latency; req_delay[k] -= sp.ref; }               // fir.c:208-217
+	}
+}
+
+static void plugin_channel_deps(struct effect *e, char **deps)
+{
+	Node *n = node_of(e);
+	if (!n) return;
+	for (int k = 0; k < n->spec->ch_out; ++k)
+		memcpy(deps[k], n->spec->remix[k].data(), n->spec->ch_in);                              // remix.c:116-121
+}
+
+static void plugin_plot(struct effect *e, int i)
+{
+	Node *n = node_of(e);
+	if (!n) return;
+	const Spec &sp = *n->spec;
+	for (int k = 0; k < sp.ch_out; ++k) {
+		if (sp.kind == Kind::Biquad && sp.sel[k])   // biquad.h:94-95, biquad.c:325-336
+			printf("H%d_%d(w)=(abs(w)<=pi)?(%.15e+%.15e*exp(-j*w)+%.15e*exp(-2.0*j*w))/(1.0+%.15e*exp(-j*w)+%.15e*exp(-2.0*j*w)):0/0\n",
+				k, i, sp.bq[k][0], sp.bq[k][1], sp.bq[k][2], sp.bq[k][3], sp.bq[k][4]);
+		else if (sp.kind == Kind::Gain) printf("H%d_%d(w)=%.15e\n", k, i, sp.vec[k]);           // gain.c:45-50
+		else if (sp.kind == Kind::Delay) printf("H%d_%d(w)=exp(-j*w*%zd)\n", k, i, sp.delay[k]);
+		else printf("H%d_%d(w)=1.0\n", k, i);
+	}
+}
+
+struct effect *make_effect(SpecPtr spec, bool noop)
+{
+	struct effect *e = static_cast<struct effect *>(calloc(1, sizeof(struct effect)));
+	if (!e) { set_error("out of memory"); return nullptr; }
+	Node *n = new Node;
+	const Spec &sp = *spec;
+	e->istream.fs = sp.fs_in; e->istream.channels = sp.ch_in;
+	e->ostream.fs = sp.fs_out; e->ostream.channels = sp.ch_out;
+	e->channel_selector = static_cast<char *>(calloc(sp.ch_in ? sp.ch_in : 1, 1));
+	if (e->channel_selector) memcpy(e->channel_selector, sp.sel.data(), sp.sel.size());
+	e->flags = sp.flags;
+	e->destroy = plugin_destroy;
+	e->data = n;
+	if (!noop) {
+		e->run = (sp.kind == Kind::Delay) ? plugin_run_noop : plugin_run;
+		e->reset = plugin_reset;
+		switch (sp.kind) {
+		case Kind::Gain: case Kind::Add: e->merge = plugin_merge; e->plot = plugin_plot; break;
+		case Kind::Biquad: e->merge = plugin_merge; e->plot = plugin_plot; break;
+		case Kind::Delay: e->merge = plugin_merge; e->plot = plugin_plot; e->channel_offsets = plugin_channel_offsets; break;
+		case Kind::Align: e->drain_samples = plugin_drain_samples; e->plot = plugin_plot; break;
+		case Kind::Remix: e->channel_deps = plugin_channel_deps; break;
+		case Kind::FirDirect: case Kind::Conv:
+			e->drain_samples = plugin_drain_samples;
+			e->channel_offsets = plugin_channel_offsets;
+			break;
+		case Kind::Resample: e->drain2 = plugin_drain2; break;
+		}
+	}
+	n->spec = std::move(spec);
+	e->name = n->spec->name.c_str();
+	return e;
+}
+
+struct effect *make_align_effect(int fs, int channels, const std::vector<ssize_t> &len, ssize_t discard)
+{
+	return make_effect(make_align_spec(fs, channels, len, discard), false);
+}
+
+}  // namespace dspamd
+
+// ------------------------------------------------------------------ exported entry points
+
+using namespace dspamd;
+
+extern "C" {
+
+struct effect *biquad_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) dir;
+	bool rev = false;
+	SpecPtr s = parse_biquad(ei->effect_number, is, sel, argc, argv, &rev);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *gain_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) dir;
+	SpecPtr s = parse_gain(ei->effect_number, is, sel, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *remix_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) ei; (void) dir;
+	SpecPtr s = parse_remix(is, sel, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *delay_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) ei; (void) dir;
+	bool noop = false;
+	SpecPtr s = parse_delay(is, sel, argc, argv, &noop);
+	return s ? make_effect(std::move(s), noop) : nullptr;
+}
+
+struct effect *delay_effect_init_int(const char *name, const struct stream_info *is, const char *sel, ssize_t samples_int)
+{
+	bool noop = false;
+	SpecPtr s = make_delay_spec(name, is, sel, samples_int, &noop);
+	return s ? make_effect(std::move(s), noop) : nullptr;
+}
+
+struct effect *fir_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	SpecPtr s = parse_fir(ei->name, false, is, sel, dir, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *fir_p_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	SpecPtr s = parse_fir(ei->name, true, is, sel, dir, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *zita_convolver_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) ei;
+	SpecPtr s = parse_zita(is, sel, dir, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *hilbert_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) ei; (void) dir;
+	SpecPtr s = parse_hilbert(is, sel, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *resample_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) ei; (void) dir;
+	bool noop = false;
+	SpecPtr s = parse_resample(is, sel, argc, argv, &noop);
+	return s ? make_effect(std::move(s), noop) : nullptr;
+}
+
+struct effect *fir_effect_init_with_filter(const struct effect_info *ei, const struct stream_info *is, const char *sel, sample_t *filter_data,
+	int filter_channels, ssize_t filter_frames, ssize_t ref, int force_direct)
+{
+	SpecPtr s = make_fir_spec(ei->name, is, sel, filter_data, filter_channels, filter_frames, ref, CONV_LATENCY_LEN, force_direct, 0);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *fir_p_effect_init_with_filter(const struct effect_info *ei, const struct stream_info *is, const char *sel, sample_t *filter_data,
+	int filter_channels, ssize_t filter_frames, ssize_t ref, int max_part_len)
+{
+	(void) max_part_len;
+	SpecPtr s = make_fir_spec(ei->name, is, sel, filter_data, filter_channels, filter_frames, ref, CONV_ZERO_LATENCY, 0, 0);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *zita_convolver_effect_init_with_filter(const struct effect_info *ei, const struct stream_info *is, const char *sel, sample_t *filter_data,
+	int filter_channels, ssize_t filter_frames, ssize_t ref, int min_part_len, int max_part_len)
+{
+	(void) max_part_len;
+	SpecPtr s = make_fir_spec(ei->name, is, sel, filter_data, filter_channels, filter_frames, ref, CONV_ZITA_EQUIV, 0, min_part_len);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ registry (mirror of effect.c:46-76 for these effects)
+
+namespace dspamd {
+
+#define FIR_OPTS "[-a[offset[s|m|S]]] [input_options]"
+#define FIR_FILTER "[file:][~/]filter_path|coefs:list[/list...]"
+
+static const effect_info g_effects[] = {
+	{ "lowpass_1",          "[-r[thresh]] f0[k]",                             biquad_effect_init, DSPAMD_BIQUAD_LOWPASS_1 },
+	{ "highpass_1",         "[-r[thresh]] f0[k]",                             biquad_effect_init, DSPAMD_BIQUAD_HIGHPASS_1 },
+	{ "allpass_1",          "[-r[thresh]] f0[k]",                             biquad_effect_init, DSPAMD_BIQUAD_ALLPASS_1 },
+	{ "lowshelf_1",         "[-r[thresh]] f0[k] gain",                        biquad_effect_init, DSPAMD_BIQUAD_LOWSHELF_1 },
+	{ "highshelf_1",        "[-r[thresh]] f0[k] gain",                        biquad_effect_init, DSPAMD_BIQUAD_HIGHSHELF_1 },
+	{ "lowpass_1p",         "[-r[thresh]] f0[k]",                             biquad_effect_init, DSPAMD_BIQUAD_LOWPASS_1P },
+	{ "lowpass",            "[-r[thresh]] f0[k] width[q|o|h|k]",              biquad_effect_init, DSPAMD_BIQUAD_LOWPASS },
+	{ "highpass",           "[-r[thresh]] f0[k] width[q|o|h|k]",              biquad_effect_init, DSPAMD_BIQUAD_HIGHPASS },
+	{ "bandpass_skirt",     "[-r[thresh]] f0[k] width[q|o|h|k]",              biquad_effect_init, DSPAMD_BIQUAD_BANDPASS_SKIRT },
+	{ "bandpass_peak",      "[-r[thresh]] f0[k] width[q|o|h|k]",              biquad_effect_init, DSPAMD_BIQUAD_BANDPASS_PEAK },
+	{ "notch",              "[-r[thresh]] f0[k] width[q|o|h|k]",              biquad_effect_init, DSPAMD_BIQUAD_NOTCH },
+	{ "allpass",            "[-r[thresh]] f0[k] width[q|o|h|k]",              biquad_effect_init, DSPAMD_BIQUAD_ALLPASS },
+	{ "eq",                 "[-r[thresh]] f0[k] width[q|o|h|k] gain",         biquad_effect_init, DSPAMD_BIQUAD_PEAK },
+	{ "lowshelf",           "[-r[thresh]] f0[k] width[q|s|d|o|h|k] gain",     biquad_effect_init, DSPAMD_BIQUAD_LOWSHELF },
+	{ "highshelf",          "[-r[thresh]] f0[k] width[q|s|d|o|h|k] gain",     biquad_effect_init, DSPAMD_BIQUAD_HIGHSHELF },
+	{ "lowpass_transform",  "[-r[thresh]] fz[k] width_z[q] fp[k] width_p[q]", biquad_effect_init, DSPAMD_BIQUAD_LOWPASS_TRANSFORM },
+	{ "highpass_transform", "[-r[thresh]] fz[k] width_z[q] fp[k] width_p[q]", biquad_effect_init, DSPAMD_BIQUAD_HIGHPASS_TRANSFORM },
+	{ "linkwitz_transform", "[-r[thresh]] fz[k] width_z[q] fp[k] width_p[q]", biquad_effect_init, DSPAMD_BIQUAD_HIGHPASS_TRANSFORM },
+	{ "deemph",             "[-r[thresh]]",                                   biquad_effect_init, DSPAMD_BIQUAD_DEEMPH },
+	{ "biquad",             "[-r[thresh]] b0 b1 b2 a0 a1 a2",                 biquad_effect_init, DSPAMD_BIQUAD_BIQUAD },
+	{ "gain",               "gain_dB",                                        gain_effect_init, DSPAMD_GAIN_GAIN },
+	{ "mult",               "multiplier",                                     gain_effect_init, DSPAMD_GAIN_MULT },
+	{ "add",                "value",                                          gain_effect_init, DSPAMD_GAIN_ADD },
+	{ "remix",              "channel_selector|. ...",                         remix_effect_init, 0 },
+	{ "delay",              "[-f[order]] [-m|M depth[s|m|S|%]] [-b bw[k]] [-q quality] delay[s|m|S]", delay_effect_init, 0 },
+	{ "resample",           "[bandwidth] fs[k]|x{mult}|/{div}",                        resample_effect_init, 0 },
+	{ "fir",                FIR_OPTS " " FIR_FILTER,                          fir_effect_init, 0 },
+	{ "fir_p",              FIR_OPTS " [max_part_len] " FIR_FILTER,           fir_p_effect_init, 0 },
+	{ "zita_convolver",     FIR_OPTS " [min_part_len [max_part_len]] " FIR_FILTER, zita_convolver_effect_init, 0 },
+	{ "hilbert",            "[-pzc] [-a angle] taps",                         hilbert_effect_init, 0 },
+};
+
+const effect_info *registry_table(int *n)
+{
+	*n = (int) (sizeof(g_effects) / sizeof(g_effects[0]));
+	return g_effects;
+}
+
+const effect_info *registry_lookup(const char *name)
+{
+	for (const effect_info &ei : g_effects)
+		if (strcmp(ei.name, name) == 0) return &ei;
+	return nullptr;
+}
+
+}  // namespace dspamd

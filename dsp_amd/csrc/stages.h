@@ -1,0 +1,62 @@
+// stages.h -- concrete Stage classes
+#pragma once
+#include "engine.h"
+
+namespace dspamd {
+
+// gain / add / biquad sections on the same stream format, fused into one launch
+class CascadeStage : public Stage {
+public:
+	void add(const Spec &sp);
+	bool finalize();
+	const char *type() const override { return "cascade"; }
+	std::string describe() const override;
+	bool in_place_ok() const override { return true; }
+	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
+	void reset(hipStream_t st) override;
+	size_t device_bytes() const override { return ops.bytes + state.bytes; }
+	// optional planar destination owned by the following FFT convolver
+	PlanarRing ring = { nullptr, 0, 0, 0, nullptr, 0 };
+	int write_interleaved = 1;
+	int n_ops = 0, Cg = 1;
+private:
+	std::vector<std::vector<OpDesc>> cols;   // [op][channel]
+	std::vector<std::string> names;
+	DevBuf ops, state;
+};
+
+class RemixStage : public Stage {
+public:
+	bool init(const Spec &sp);
+	const char *type() const override { return "remix"; }
+	std::string describe() const override { return "remix[" + std::to_string(ch_in) + "->" + std::to_string(ch_out) + "]"; }
+	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
+	void reset(hipStream_t) override {}
+	size_t device_bytes() const override { return d_idx.bytes; }
+private:
+	DevBuf d_idx;
+	int max_n = 1;
+};
+
+// integer per-channel delay with carried state + end-of-chain discard (the reference's `align`, align.c)
+class DelayStage : public Stage {
+public:
+	bool init(const Spec &sp);
+	const char *type() const override { return "align"; }
+	std::string describe() const override;
+	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
+	void reset(hipStream_t st) override;
+	size_t device_bytes() const override { return ring.bytes; }
+private:
+	std::vector<ssize_t> len;
+	ssize_t discard = 0, remaining_discard = 0;
+	long ring_per_stream = 0, max_len = 0, pos = 0;
+	int phase = 0;
+	DevBuf d_len, d_off, ring;
+};
+
+// conv.cpp: FirDirect / Conv / Resample.  `feeder` (may be null) is the cascade stage immediately before,
+// which can write straight into the convolver's planar ring instead of an interleaved slab.
+Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder);
+
+}  // namespace dspamd

@@ -1,0 +1,100 @@
+/*
+ * include/dsp_amd.h -- the drop-in boundary, part 2: stand-alone host and
+ * device-resident batch entry points of libdsp_amd.so.
+ *
+ * Part 1 (dsp_effect_abi.h) is the plugin surface the reference's host binds.
+ * This header is what a host WITHOUT the reference's chain runtime binds
+ * (ctypes / cgo / JNI): the same life-cycle as effects_chain.h:40-53, plus a
+ * batch axis ("S independent streams", which the reference can only express as
+ * S processes) whose buffers live in HBM.
+ *
+ * All functions: plain C types, no torch / HIP types.  Device pointers are
+ * passed as void* (hipMalloc'd or torch tensor.data_ptr()), streams as void*
+ * (hipStream_t, e.g. torch.cuda.current_stream().cuda_stream; NULL = default).
+ * Errors: functions returning pointers return NULL, functions returning
+ * ssize_t/int return a negative value; dspamd_last_error() gives the message.
+ * There is NO CPU fallback: without a usable HIP device every compute entry
+ * point fails loudly.
+ */
+#ifndef DSP_AMD_H
+#define DSP_AMD_H
+
+#include <sys/types.h>
+#include "dsp_effect_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *dspamd_version(void);
+const char *dspamd_last_error(void);
+/* number of visible HIP devices (0 if none); never touches oracle or CPU paths */
+int dspamd_device_count(void);
+/* bind the calling process to a device (one process per GPU); returns 0 on success */
+int dspamd_set_device(int device);
+/* LL_* of dsp.h:25-32 (0 silent .. 4 verbose); default 1 (errors) */
+void dspamd_set_loglevel(int level);
+
+/* registry lookup -- mirror of get_effect_info(), effect.c:69-76, for the effects this library provides */
+const struct effect_info *dspamd_get_effect_info(const char *name);
+
+/* ---- stand-alone chain on HOST buffers (one stream; mirror of effects_chain.h:40-53) ---- */
+typedef struct dspamd_chain dspamd_chain;
+
+/* build_effects_chain_from_string() + optimise/prepare/align/drain accounting (effects_chain.c:934-969) */
+dspamd_chain *dspamd_chain_build(const char *chain_str, int fs, int channels, const char *dir, int *out_fs, int *out_channels);
+/* run_effects_chain(), effects_chain.c:1058: interleaved fp64 frames in, frames out (may differ); returns frames written or <0 */
+ssize_t dspamd_chain_run(dspamd_chain *, const double *in, ssize_t frames, double *out, ssize_t out_capacity_frames);
+/* drain_effects_chain(), effects_chain.c:1186: returns frames written, or -1 when dry */
+ssize_t dspamd_chain_drain(dspamd_chain *, ssize_t block_frames, double *out, ssize_t out_capacity_frames);
+/* get_effects_chain_max_out_frames(), effects_chain.c:1015-1020 */
+ssize_t dspamd_chain_max_out_frames(dspamd_chain *, ssize_t in_frames);
+ssize_t dspamd_chain_drain_frames(dspamd_chain *);   /* chain->drain_frames, effects_chain.c:877-923 */
+void dspamd_chain_reset(dspamd_chain *);             /* reset_effects_chain(), effects_chain.c:1091 */
+void dspamd_chain_destroy(dspamd_chain *);           /* destroy_effects_chain(), effects_chain.c:1220 */
+int dspamd_chain_n_effects(dspamd_chain *);
+const char *dspamd_chain_effect_name(dspamd_chain *, int i);
+
+/* ---- device-resident batch: S independent streams x C channels, buffers in HBM ---- */
+typedef struct dspamd_batch dspamd_batch;
+
+/*
+ * Every stream runs the same chain (filters are shared, state is per stream).
+ * Layout of every device buffer: [stream][frame][channel] fp64, i.e. each
+ * stream's slab is exactly what the reference's run() would be handed
+ * (dsp.h:42, effects_chain.c:1044-1056).
+ * max_frames: the largest `frames` that will be passed to dspamd_batch_run.
+ */
+dspamd_batch *dspamd_batch_create(const char *chain_str, int fs, int channels, int n_streams, ssize_t max_frames, const char *dir);
+int dspamd_batch_out_fs(dspamd_batch *);
+int dspamd_batch_out_channels(dspamd_batch *);
+ssize_t dspamd_batch_max_out_frames(dspamd_batch *, ssize_t in_frames);
+ssize_t dspamd_batch_drain_frames(dspamd_batch *);
+/*
+ * One block for all streams, asynchronously on `stream`; no host sync, no
+ * allocation, graph-capturable.  d_in: [S][frames][C_in]; d_out: [S][out_stride_frames][C_out]
+ * (out_stride_frames >= returned frame count; pass 0 for "= max_out_frames(frames)").
+ * Returns frames produced per stream, or <0.
+ */
+ssize_t dspamd_batch_run(dspamd_batch *, const void *d_in, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream);
+/* end of stream: push zeros / flush rate changers; returns frames produced, -1 when dry */
+ssize_t dspamd_batch_drain(dspamd_batch *, ssize_t block_frames, void *d_out, ssize_t out_stride_frames, void *stream);
+void dspamd_batch_reset(dspamd_batch *, void *stream);
+void dspamd_batch_destroy(dspamd_batch *);
+/* introspection for tests / DESIGN.md: human-readable stage plan ("cascade[gain+10 biquad] -> conv[N=131072 ...]") */
+const char *dspamd_batch_plan(dspamd_batch *);
+/* names + stream of the kernels the batch launches per run (for HIP-event timing on the right stream) */
+int dspamd_batch_n_stages(dspamd_batch *);
+
+/* ---- device-side bench endpoints (sgen.c:55-67 / null.c:31-34 equivalents) ---- */
+/* stream s, frame t (absolute position pos0+t), every channel: sin(2 pi (freq0 + s*dfreq) * (pos0+t)/fs) */
+int dspamd_sgen_sine(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double dfreq, ssize_t pos0, void *stream);
+/* per-stream digests like stats.c:47-76: sum, sum of squares, peak -> d_out[S][3] */
+int dspamd_digest(const void *d_buf, int n_streams, ssize_t frames, ssize_t stride_frames, int channels, void *d_out, void *stream);
+/* plain device copy kernel: measured HBM ceiling next to the 8 TB/s spec (bytes must be a multiple of 16) */
+int dspamd_copy_probe(const void *d_src, void *d_dst, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
