@@ -1,0 +1,63 @@
+// fft_params.h -- launch parameters of the FFT convolver kernels (kernels_fft.hip) shared with conv.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dspamd {
+
+constexpr int FFT_LOG2_N2 = 9;          // contiguous (row) dimension of the four-step decomposition: 512 points
+constexpr int FFT_MIN_LOG2_N1 = 3, FFT_MAX_LOG2_N1 = 10;
+constexpr int FIR_DIRECT_MAX = 32;      // fir_p.c:34 DIRECT_LEN
+
+struct ConvParams {
+	int log2N1, log2_lo;
+	long N, N1, N2;
+	// input window: z[n] = ring[row][(win_base + n) & ring_mask] for n < valid, else 0
+	const double *ring;
+	long ring_row_stride, ring_mask, win_base, valid;
+	const long *pair_rows;              // [n_pairs][2] absolute ring rows (or -1 = silent half)
+	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
+	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
+	double2 *W;                         // [pairs in chunk][N] work spectrum / time buffer
+	const double2 *tw_n1, *tw_n2;       // exp(-2 pi i k / N1), exp(-2 pi i k / N2)
+	const double2 *tw_hi, *tw_lo;       // w_N^(hi << log2_lo), w_N^lo
+	const double2 *H;                   // [n_filters][N] filter spectra in [k1][k2] order, pre-scaled by 1/N
+	double2 *Hout;                      // mode 1 of conv_row
+	double h_scale;
+	// output (K3)
+	double *out;
+	long out_stride_frames, out_frame0, out_frames, first_n;
+	int C, pairs_per_stream;
+	long stream0;
+	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)
+	int round_f32;
+};
+
+struct DeintParams {
+	const double *in;
+	double *out;                        // pass-through destination for unselected channels (may be null)
+	long in_stride_frames, out_stride_frames, frames;
+	int C;
+	const int *row_of_channel;          // [C] ring row within the stream, or -1
+	int rows_per_stream;
+	double *ring;
+	long ring_row_stride, ring_mask, pos;
+	int round_f32;
+};
+
+struct FirDirectParams {
+	const double *in;
+	double *out;
+	long in_stride_frames, out_stride_frames, frames;
+	int C, T;
+	const int *filter_of_channel;       // [C] filter index or -1 (pass through)
+	const double *taps;                 // [n_filters][FIR_DIRECT_MAX]
+	const double *hist_rd;              // [S][C][FIR_DIRECT_MAX]  x[-(q+1)]
+	double *hist_wr;
+};
+
+void launch_conv_col(const ConvParams &p, bool inverse, int grid_y, hipStream_t st);
+void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st);
+void launch_deinterleave(const DeintParams &p, int n_streams, hipStream_t st);
+void launch_fir_direct(const FirDirectParams &p, int n_streams, hipStream_t st);
+
+}  // namespace dspamd

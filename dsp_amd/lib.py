@@ -58,6 +58,24 @@ API_SYMBOLS = [
 ]
 
 
+def _preload_hip_runtime():
+    """libdsp_amd.so carries no DT_NEEDED on a particular libamdhip64: a process must hold exactly ONE
+    HIP runtime (a second one cannot open the GPU), and torch -- our plumbing for device memory,
+    streams and RCCL -- bundles its own.  So: make torch's runtime global, fall back to /opt/rocm."""
+    candidates = []
+    try:
+        import torch
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:  # torch absent: a plain C host would link -lamdhip64 itself
+        pass
+    candidates += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so")]
+    for c in candidates:
+        if os.path.exists(c):
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return c
+    raise LibraryMissing("no libamdhip64.so found (torch/lib or $ROCM_PATH/lib)")
+
+
 def load_library():
     global _LIB
     if _LIB is not None:
@@ -66,6 +84,7 @@ def load_library():
     if not os.path.exists(path):
         raise LibraryMissing(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(hipcc --offload-arch=gfx950).  dsp_amd has no CPU fallback.")
+    _preload_hip_runtime()
     L = C.CDLL(path)
     vp, cp, i = C.c_void_p, C.c_char_p, C.c_int
     sig = {
