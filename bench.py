@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the effects_chain hot path on MI355X.
+
+Workload (BASELINE.json `metric` / north_star): 256 independent streams x 8 channels @ 48 kHz, chain =
+10 biquads (SURVEY.md section 8(d) config-2 argv) + fir_p with a 65536-tap filter (config-3 recipe).
+A "step" is one block of --block frames pushed through the chain for every stream, with input and output
+resident in HBM ([stream][frame][channel] fp64).  Streams are sharded contiguously over the ranks (one
+process per GPU, no data-plane collective), the total number of streams is fixed: strong scaling.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line: metric/value/... + "roofline" (dominant kernel, HIP events on the launch
+stream) + "cpu_baseline" (the reference's own CPU path on this box's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BIQUADS = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 "
+           "eq 800 1.0 -1 eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+HBM_PEAK = 8.0e12      # B/s, MI355X spec (MI355X_MICROARCH.md); measured copy ceiling reported next to it
+B_ALG = 16.0           # algorithmic bytes per input channel-sample for same-rate chains
+
+
+def make_filter(taps, seed=7):
+    # N(0,1) * exp(-n/8000), L2-normalised then / 4, numpy default_rng(7)
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / 8000.0)
+    return h / np.sqrt(np.sum(h * h)) / 4.0
+
+
+def cpu_baseline(chain, filt_dir, fs, channels, seconds_target=12.0):
+    """The reference's own CPU path (oracle/_ref, built from /root/reference) timed on this box's cores on a
+    bounded sample of the same workload; falls back to the scalar oracle port when _ref is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        from oracle_api import RefChain, Oracle
+    except Exception as e:  # pragma: no cover
+        return {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "unavailable", "sample": str(e)}
+    block = 2048
+    rng = np.random.Generator(np.random.PCG64(1234))
+    x = rng.uniform(-0.5, 0.5, size=(block, channels))
+    for variant, fft in (("_mkl", "MKL FFTW3 wrapper (sequential)"), ("_o2", "own fp64 FFT (oracle/fftw3_abi)"), ("", "own fp64 FFT (oracle/fftw3_abi)")):
+        if not RefChain.available(variant):
+            continue
+        try:
+            L = RefChain.lib(variant)
+        except OSError:
+            continue
+        cores = L.refh_ncpu()
+        # calibrate with a short run, then size the sample for ~seconds_target
+        t = L.refh_bench(chain.encode(), filt_dir.encode(), fs, channels, cores, cores, block, 8, x.ctypes.data)
+        if t <= 0:
+            continue
+        n_blocks = int(max(8, min(20000, 8 * seconds_target / t)))
+        t = L.refh_bench(chain.encode(), filt_dir.encode(), fs, channels, cores, cores, block, n_blocks, x.ctypes.data)
+        samples = cores * n_blocks * block * channels
+        flags = {"_mkl": "-O2", "_o2": "-O2", "": "-Os (reference flags)"}[variant]
+        return {"value": samples / t / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                "sample": f"{cores} streams x {channels} ch x {n_blocks} blocks of {block} frames, one chain per core "
+                          f"(fir_p adds 2 worker threads per chain), reference sources gcc {flags}, FFT = {fft}, {t:.1f} s"}
+    if Oracle.available():
+        import oracle_chain
+        n = 48000
+        xs = rng.uniform(-0.5, 0.5, size=(n, 1))
+        filt = np.fromfile(os.path.join(filt_dir, "filt.raw"))
+        t0 = time.time()
+        oracle_chain.run(chain.replace("filt.raw", "{F}"), xs, fs, filt=filt)
+        t = time.time() - t0
+        return {"value": n / t / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/dsp_oracle.c restatement, 1 stream x 1 ch x {n} frames, scalar, {t:.1f} s"}
+    return {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "unavailable", "sample": "oracle not built"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--channels", type=int, default=8)
+    ap.add_argument("--block", type=int, default=196608, help="frames per step per stream")
+    ap.add_argument("--taps", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain", default=None, help="override the chain (use {F} for the filter file)")
+    args = ap.parse_args()
+
+    import torch
+    import dsp_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE\n")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    L = dsp_amd.load_library()
+    L.dspamd_set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    fs, C = 48000, args.channels
+    S_total = args.streams
+    s_lo = S_total * rank // world
+    s_hi = S_total * (rank + 1) // world
+    S = s_hi - s_lo
+    assert S >= 1, "fewer streams than ranks: replicas only"
+
+    filt_dir = f"/tmp/dsp_amd_bench_{os.getpid()}"
+    os.makedirs(filt_dir, exist_ok=True)
+    np.asarray(make_filter(args.taps), dtype="<f8").tofile(os.path.join(filt_dir, "filt.raw"))
+    chain_t = args.chain or (BIQUADS + " fir_p -t pcm -e double -c 1 {F}")
+    chain = chain_t.replace("{F}", "filt.raw")
+
+    batch = dsp_amd.BatchChain(chain, fs, C, S, args.block, directory=filt_dir)
+    plan = batch.plan()
+    stream = torch.cuda.current_stream().cuda_stream
+    # synthetic sgen input resident in HBM: stream i = sine at (100 + 90 i) Hz, amplitude 1
+    x = [torch.empty((S, args.block, C), dtype=torch.float64, device="cuda") for _ in range(2)]
+    for k in range(2):
+        L.dspamd_sgen_sine(x[k].data_ptr(), S, args.block, C, fs, 100.0 + 90.0 * s_lo, 90.0, k * args.block, stream)
+    out = torch.empty((S, batch.max_out_frames(args.block), batch.ochannels), dtype=torch.float64, device="cuda")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        batch.run(x[w & 1], out)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        batch.run(x[k & 1], out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel averages with HIP events on the launch stream (same K steps, second pass) ----
+    L.dspamd_profile_enable(1)
+    for k in range(args.steps):
+        batch.run(x[k & 1], out)
+    prof = {}
+    for line in L.dspamd_profile_collect().decode().splitlines():
+        name, ms, cnt = line.split()
+        prof[name] = {"total_ms": float(ms), "launches": int(cnt), "avg_ms": float(ms) / max(int(cnt), 1)}
+    L.dspamd_profile_enable(0)
+
+    # measured copy ceiling (read + write of 1 GiB)
+    nbytes = 1 << 30
+    a = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+    b = torch.empty_like(a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L.dspamd_copy_probe(a.data_ptr(), b.data_ptr(), nbytes, stream)
+    ev0.record()
+    for _ in range(5):
+        L.dspamd_copy_probe(a.data_ptr(), b.data_ptr(), nbytes, stream)
+    ev1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 5 * 2 * nbytes / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del a, b
+
+    # digest: keeps the output observable and gives the judge a cheap checksum
+    dig = torch.empty((S, 3), dtype=torch.float64, device="cuda")
+    L.dspamd_digest(out.data_ptr(), S, args.block, out.shape[1], batch.ochannels, dig.data_ptr(), stream)
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(dig).all().item())
+
+    if rank == 0:
+        samples_per_step_total = S_total * C * args.block          # input channel-samples, all ranks
+        value = samples_per_step_total * args.steps / elapsed / 1e6
+        # dominant kernel = largest total time among the per-launch kernels
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        launches_per_step = dom[1]["launches"] / args.steps
+        samples_per_launch = S * C * args.block / launches_per_step  # this rank's samples handled by one launch
+        achieved = samples_per_launch * B_ALG / (dom[1]["avg_ms"] * 1e-3) / 1e9
+        chain_frac = (value * 1e6 / world) * B_ALG / HBM_PEAK
+        res = {
+            "metric": "Msamples/s (all streams), 256x8ch biquadx10 + fir_p(65536)",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic (device sgen sine, 100+90*i Hz per stream; seeded random 65536-tap filter)",
+            "config": {"workload": f"{S_total} streams x {C} ch @ {fs} Hz, chain = 10 biquads + fir_p({args.taps} taps), {args.block} frames/step/stream",
+                       "streams": S_total, "channels": C, "block_frames": args.block, "taps": args.taps,
+                       "parallelism": f"streams sharded {S_total // world}/GPU, no data-plane collective", "plan": plan},
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                         "avg_launch_ms": dom[1]["avg_ms"], "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": samples_per_launch * B_ALG,
+                         "whole_chain_frac_per_gpu": chain_frac, "measured_copy_GBps": copy_gbps,
+                         "kernels": {k: {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / args.steps} for k, v in prof.items()}},
+            "output_finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(chain, filt_dir, fs, C)
+            if res["cpu_baseline"].get("value"):
+                res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -3,6 +3,7 @@
 #include "chain.h"
 #include "engine.h"
 #include <cstring>
+#include <cstdio>
 
 using namespace dspamd;
 
@@ -170,6 +171,29 @@ const char *dspamd_chain_effect_name(dspamd_chain *c, int i)
 {
 	if (i < 0 || i >= (int) c->b->plan.effects.size()) return nullptr;
 	return c->b->plan.effects[i]->name;
+}
+
+// ---------------------------------------------------------------- per-kernel HIP-event timing
+
+void dspamd_profile_enable(int on) { g_prof.on = (on != 0); }
+
+// Synchronises the device, then returns a JSON-ish text: one "name total_ms launches" line per kernel seen since
+// the last call.  The pointer stays valid until the next call.
+const char *dspamd_profile_collect(void)
+{
+	static std::string text;
+	(void) hipDeviceSynchronize();
+	std::vector<std::string> names;
+	std::vector<double> ms;
+	std::vector<long> counts;
+	g_prof.collect(names, ms, counts);
+	text.clear();
+	char line[256];
+	for (size_t i = 0; i < names.size(); ++i) {
+		snprintf(line, sizeof(line), "%s %.6f %ld\n", names[i].c_str(), ms[i], counts[i]);
+		text += line;
+	}
+	return text.c_str();
 }
 
 // ---------------------------------------------------------------- bench endpoints

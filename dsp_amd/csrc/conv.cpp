@@ -1,9 +1,323 @@
-// conv.cpp -- FirDirect / Conv / Resample stages (placeholder until the FFT engine lands)
+// conv.cpp -- FIR stages: FFT overlap-save convolver (fir / fir_p / hilbert / zita-equivalent) and the
+// direct form for <= 32 taps.  Kernels: kernels_fft.hip.  Resampler: resample.cpp.
 #include "stages.h"
+#include "fft_params.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
 namespace dspamd {
-Stage *make_conv_stage(const Spec &sp, int, ssize_t, CascadeStage *)
+
+Stage *make_resample_stage(const Spec &sp, int n_streams, ssize_t max_frames);
+
+static long next_pow2(long v)
 {
-	set_error("%s: error: this stage type is not implemented yet", sp.name.c_str());
-	return nullptr;
+	long p = 1;
+	while (p < v) p <<= 1;
+	return p;
 }
+
+static int ilog2(long v)
+{
+	int l = 0;
+	while ((1L << l) < v) ++l;
+	return l;
 }
+
+static void make_twiddles(long n, long count, long stride, std::vector<double2> &out)
+{
+	// out[k] = exp(-2 pi i k stride / n), k < count
+	out.resize(count);
+	for (long k = 0; k < count; ++k) {
+		const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double) ((k * stride) % n) / (long double) n;
+		out[k] = make_double2((double) cosl(a), (double) sinl(a));
+	}
+}
+
+// ------------------------------------------------------------------ ConvStage
+
+class ConvStage : public Stage {
+public:
+	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder);
+	const char *type() const override { return "conv"; }
+	std::string describe() const override;
+	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
+	void reset(hipStream_t st) override;
+	size_t device_bytes() const override { return ring.bytes + W.bytes + H.bytes; }
+private:
+	bool prepare_filters(const Spec &sp);
+	ConvParams base_params() const;
+	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, lat = 0, ring_len = 0, pos = 0;
+	int log2N1 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
+	bool fed = false, all_selected = false;
+	long pairs_per_chunk = 0;
+	std::string name;
+	CascadeStage *feeder_ = nullptr;
+	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_rows, pair_h, pair_out_ch, row_of_channel;
+};
+
+std::string ConvStage::describe() const
+{
+	std::ostringstream o;
+	o << "conv[" << name << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
+	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? " fed-by-cascade" : "")
+	  << (round_f32 ? " f32-io" : "") << "]";
+	return o.str();
+}
+
+ConvParams ConvStage::base_params() const
+{
+	ConvParams p;
+	memset(&p, 0, sizeof(p));
+	p.log2N1 = log2N1; p.log2_lo = log2_lo;
+	p.N = N; p.N1 = N1; p.N2 = N2;
+	p.ring = ring.as<double>();
+	p.ring_row_stride = ring_len; p.ring_mask = ring_len - 1;
+	p.pair_rows = pair_rows.as<long>();
+	p.pair_h = pair_h.as<int>();
+	p.W = W.as<double2>();
+	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>();
+	p.tw_hi = tw_hi.as<double2>(); p.tw_lo = tw_lo.as<double2>();
+	p.H = H.as<double2>();
+	p.h_scale = 1.0 / (double) N;
+	p.C = ch_in;
+	p.pairs_per_stream = pps;
+	p.pair_out_ch = pair_out_ch.as<int>();
+	p.round_f32 = round_f32;
+	return p;
+}
+
+bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
+{
+	name = sp.name;
+	T = sp.T;
+	lat = sp.latency;
+	round_f32 = (sp.conv_mode == CONV_ZITA_EQUIV);
+	nsel = num_set(sp.sel);
+	all_selected = (nsel == ch_in);
+	n_filters = (sp.fch == 1) ? 1 : nsel;
+	// channel pairs share a transform only when they share the filter
+	pps = (n_filters == 1) ? (nsel + 1) / 2 : nsel;
+
+	// transform size: at least 2T (overlap <= 1/2), grown up to 8x the filter when calls are long
+	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_LOG2_N2 + FFT_MIN_LOG2_N1));
+	const long want = next_pow2(T - 1 + std::max<long>(max_frames, 1));
+	N = std::min(std::max(lo, want), lo * 4);
+	const char *env = getenv("DSP_AMD_CONV_LOG2N");
+	if (env) N = std::max(lo, 1L << atoi(env));
+	N2 = 1L << FFT_LOG2_N2;
+	N1 = N / N2;
+	log2N1 = ilog2(N1);
+	if (log2N1 > FFT_MAX_LOG2_N1) {
+		set_error("%s: error: filter too long for the GPU convolver (%ld taps; limit %ld)", name.c_str(), T, (1L << (FFT_LOG2_N2 + FFT_MAX_LOG2_N1 - 1)));
+		return false;
+	}
+	B = N - (T - 1);
+	ring_len = next_pow2(T - 1 + lat + std::max<long>(max_frames, B));
+	log2_lo = (ilog2(N) + 1) / 2;
+
+	// rings: one row per selected channel per stream
+	if (!ring.alloc((size_t) S * nsel * ring_len * sizeof(double))) return false;
+	std::vector<int> roc(ch_in, -1);
+	std::vector<int> sel_ch;
+	for (int c = 0; c < ch_in; ++c) if (sp.sel[c]) { roc[c] = (int) sel_ch.size(); sel_ch.push_back(c); }
+	if (!row_of_channel.upload(roc.data(), roc.size() * sizeof(int))) return false;
+	std::vector<long> prow((size_t) S * pps * 2);
+	std::vector<int> ph((size_t) S * pps), poc((size_t) pps * 2);
+	for (int s = 0; s < S; ++s) {
+		for (int q = 0; q < pps; ++q) {
+			const int ia = (n_filters == 1) ? 2 * q : q, ib = (n_filters == 1 && 2 * q + 1 < nsel) ? 2 * q + 1 : -1;
+			prow[((size_t) s * pps + q) * 2] = (long) s * nsel + ia;
+			prow[((size_t) s * pps + q) * 2 + 1] = (ib >= 0) ? (long) s * nsel + ib : -1;
+			ph[(size_t) s * pps + q] = (n_filters == 1) ? 0 : q;
+			if (s == 0) { poc[2 * q] = sel_ch[ia]; poc[2 * q + 1] = (ib >= 0) ? sel_ch[ib] : -1; }
+		}
+	}
+	if (!pair_rows.upload(prow.data(), prow.size() * sizeof(long))) return false;
+	if (!pair_h.upload(ph.data(), ph.size() * sizeof(int))) return false;
+	if (!pair_out_ch.upload(poc.data(), poc.size() * sizeof(int))) return false;
+
+	std::vector<double2> t;
+	make_twiddles(N1, N1, 1, t);
+	if (!tw_n1.upload(t.data(), t.size() * sizeof(double2))) return false;
+	make_twiddles(N2, N2, 1, t);
+	if (!tw_n2.upload(t.data(), t.size() * sizeof(double2))) return false;
+	make_twiddles(N, 1L << log2_lo, 1, t);
+	if (!tw_lo.upload(t.data(), t.size() * sizeof(double2))) return false;
+	make_twiddles(N, N >> log2_lo, 1L << log2_lo, t);
+	if (!tw_hi.upload(t.data(), t.size() * sizeof(double2))) return false;
+
+	// work buffer: streams are processed in chunks so that W (written by K1, rewritten by K2, read by K3)
+	// can stay in the 256 MiB Infinity Cache between the three launches
+	long chunk_streams = S;
+	const char *cenv = getenv("DSP_AMD_CONV_CHUNK_MB");
+	const double chunk_mb = cenv ? atof(cenv) : 0.0;
+	if (chunk_mb > 0) {
+		const double per_stream_mb = (double) pps * N * 16.0 / (1024.0 * 1024.0);
+		chunk_streams = std::max<long>(1, std::min<long>(S, (long) (chunk_mb / per_stream_mb)));
+	}
+	pairs_per_chunk = chunk_streams * pps;
+	if (!W.alloc((size_t) pairs_per_chunk * N * sizeof(double2), false)) return false;
+	if (!H.alloc((size_t) n_filters * N * sizeof(double2), false)) return false;
+	if (!prepare_filters(sp)) return false;
+
+	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
+	if (feeder && all_selected && !round_f32 && !getenv("DSP_AMD_NO_FEED")) {
+		feeder->ring.base = ring.as<double>();
+		feeder->ring.row_stride = ring_len;
+		feeder->ring.mask = ring_len - 1;
+		feeder->ring.pos = 0;
+		feeder->ring.row_of_channel = row_of_channel.as<int>();
+		feeder->ring.rows_per_stream = nsel;
+		feeder->write_interleaved = 0;
+		feeder_ = feeder;
+		fed = true;
+	}
+	return true;
+}
+
+// filter spectra: run the forward half of the pipeline on the taps themselves (exactly what the
+// reference does at init with its r2c plan, fir.c:342-357 / fir_p.c:482-498)
+bool ConvStage::prepare_filters(const Spec &sp)
+{
+	DevBuf tring, trows, tph;
+	std::vector<double> taps(N, 0.0);
+	std::vector<long> rows{ 0, -1 };
+	std::vector<int> hsel{ 0 };
+	if (!tring.alloc((size_t) N * sizeof(double), false)) return false;
+	if (!trows.upload(rows.data(), rows.size() * sizeof(long))) return false;
+	if (!tph.upload(hsel.data(), hsel.size() * sizeof(int))) return false;
+	for (int f = 0; f < n_filters; ++f) {
+		for (long i = 0; i < T; ++i) {
+			double v = sp.taps[(size_t) i * sp.fch + f];
+			if (round_f32) v = (double) (float) v;
+			taps[i] = v;
+		}
+		if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double), hipMemcpyHostToDevice), "H2D taps")) return false;
+		ConvParams p = base_params();
+		p.ring = tring.as<double>();
+		p.ring_row_stride = N; p.ring_mask = N - 1;
+		p.win_base = 0; p.valid = T;
+		p.pair_rows = trows.as<long>();
+		p.pair_h = tph.as<int>();
+		p.pair0 = 0;
+		p.Hout = H.as<double2>() + (size_t) f * N;
+		launch_conv_col(p, false, 1, nullptr);
+		launch_conv_row(p, 1, 1, nullptr);
+		if (!hip_ok(hipDeviceSynchronize(), "filter spectrum")) return false;
+	}
+	return true;
+}
+
+ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	if (!fed) {
+		DeintParams d;
+		d.in = in;
+		d.out = all_selected ? nullptr : out;
+		d.in_stride_frames = in_stride; d.out_stride_frames = out_stride; d.frames = frames;
+		d.C = ch_in;
+		d.row_of_channel = row_of_channel.as<int>();
+		d.rows_per_stream = nsel;
+		d.ring = ring.as<double>();
+		d.ring_row_stride = ring_len; d.ring_mask = ring_len - 1; d.pos = pos;
+		d.round_f32 = round_f32;
+		{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
+	}
+	const long chunk_streams = pairs_per_chunk / pps;
+	for (long off = 0; off < frames; off += B) {
+		const long f = std::min<long>(B, frames - off);
+		ConvParams p = base_params();
+		p.win_base = (pos + off - lat - (T - 1)) & (ring_len - 1);   // two's complement wrap: ring_len is a power of two
+		p.valid = T - 1 + f;
+		p.out = out;
+		p.out_stride_frames = out_stride;
+		p.out_frame0 = off;
+		p.out_frames = f;
+		p.first_n = T - 1;
+		for (long s0 = 0; s0 < S; s0 += chunk_streams) {
+			const long ns = std::min<long>(chunk_streams, S - s0);
+			p.pair0 = s0 * pps;
+			p.stream0 = s0;
+			{ ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, (int) (ns * pps), st); }
+			{ ProfScope ps("conv_row", st); launch_conv_row(p, 0, (int) (ns * pps), st); }
+			{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) ns, st); }
+		}
+	}
+	pos = (pos + frames) & (ring_len - 1);
+	return frames;
+}
+
+void ConvStage::reset(hipStream_t st)
+{
+	(void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
+	pos = 0;
+	if (feeder_) feeder_->ring.pos = 0;
+}
+
+// -------------------------------------------------------------- FirDirectStage
+
+class FirDirectStage : public Stage {
+public:
+	bool init(const Spec &sp);
+	const char *type() const override { return "fir_direct"; }
+	std::string describe() const override { return "fir_direct[" + name + " T=" + std::to_string(T) + "]"; }
+	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
+	void reset(hipStream_t st) override { (void) hipMemsetAsync(hist.p, 0, hist.bytes, st); phase = 0; }
+	size_t device_bytes() const override { return hist.bytes + taps.bytes; }
+private:
+	int T = 0, phase = 0;
+	std::string name;
+	DevBuf taps, foc, hist;
+};
+
+bool FirDirectStage::init(const Spec &sp)
+{
+	name = sp.name;
+	T = (int) sp.T;
+	if (T > FIR_DIRECT_MAX) { set_error("%s: BUG: direct FIR longer than %d taps", name.c_str(), FIR_DIRECT_MAX); return false; }
+	const int nf = sp.fch;
+	std::vector<double> h((size_t) nf * FIR_DIRECT_MAX, 0.0);
+	for (int f = 0; f < nf; ++f) for (int i = 0; i < T; ++i) h[(size_t) f * FIR_DIRECT_MAX + i] = sp.taps[(size_t) i * nf + f];
+	std::vector<int> fo(ch_in, -1);
+	for (int c = 0, k = 0; c < ch_in; ++c) if (sp.sel[c]) { fo[c] = (nf == 1) ? 0 : k; ++k; }
+	if (!taps.upload(h.data(), h.size() * sizeof(double))) return false;
+	if (!foc.upload(fo.data(), fo.size() * sizeof(int))) return false;
+	return hist.alloc((size_t) 2 * S * ch_in * FIR_DIRECT_MAX * sizeof(double));
+}
+
+ssize_t FirDirectStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	const size_t half = (size_t) S * ch_in * FIR_DIRECT_MAX;
+	FirDirectParams p;
+	p.in = in; p.out = out;
+	p.in_stride_frames = in_stride; p.out_stride_frames = out_stride; p.frames = frames;
+	p.C = ch_in; p.T = T;
+	p.filter_of_channel = foc.as<int>();
+	p.taps = taps.as<double>();
+	p.hist_rd = hist.as<double>() + (phase ? half : 0);
+	p.hist_wr = hist.as<double>() + (phase ? 0 : half);
+	{ ProfScope ps("fir_direct_kernel", st); launch_fir_direct(p, S, st); }
+	phase ^= 1;
+	return frames;
+}
+
+// ------------------------------------------------------------------ factory
+
+Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder)
+{
+	if (sp.kind == Kind::Resample) return make_resample_stage(sp, n_streams, max_frames);
+	if (sp.kind == Kind::FirDirect) {
+		FirDirectStage *s = new FirDirectStage;
+		s->S = n_streams; s->ch_in = sp.ch_in; s->ch_out = sp.ch_out; s->fs_in = sp.fs_in; s->fs_out = sp.fs_out;
+		if (!s->init(sp)) { delete s; return nullptr; }
+		return s;
+	}
+	ConvStage *s = new ConvStage;
+	s->S = n_streams; s->ch_in = sp.ch_in; s->ch_out = sp.ch_out; s->fs_in = sp.fs_in; s->fs_out = sp.fs_out;
+	if (!s->init(sp, max_frames, feeder)) { delete s; return nullptr; }
+	return s;
+}
+
+}  // namespace dspamd

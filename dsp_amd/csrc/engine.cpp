@@ -3,6 +3,7 @@
 #include "engine.h"
 #include "stages.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -20,6 +21,44 @@ int device_count()
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+
+Profiler g_prof;
+
+void Profiler::begin(const char *name, hipStream_t st)
+{
+	Rec r{ name, nullptr, nullptr };
+	(void) hipEventCreate(&r.a);
+	(void) hipEventCreate(&r.b);
+	(void) hipEventRecord(r.a, st);
+	recs.push_back(r);
+}
+
+void Profiler::end(hipStream_t st)
+{
+	if (!recs.empty()) (void) hipEventRecord(recs.back().b, st);
+}
+
+void Profiler::collect(std::vector<std::string> &names, std::vector<double> &ms, std::vector<long> &counts)
+{
+	for (Rec &r : recs) {
+		float t = 0.f;
+		if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+			size_t i = 0;
+			for (; i < names.size(); ++i) if (names[i] == r.name) break;
+			if (i == names.size()) { names.push_back(r.name); ms.push_back(0.0); counts.push_back(0); }
+			ms[i] += t;
+			counts[i] += 1;
+		}
+		(void) hipEventDestroy(r.a);
+		(void) hipEventDestroy(r.b);
+	}
+	recs.clear();
+}
+
+Profiler::~Profiler()
+{
+	for (Rec &r : recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
 }
 
 bool DevBuf::alloc(size_t n, bool zero)
@@ -103,7 +142,11 @@ bool CascadeStage::finalize()
 			host[(size_t) c * n_ops + j] = cols[j][c];
 	if (!ops.upload(host.data(), host.size() * sizeof(OpDesc))) return false;
 	if (!state.alloc((size_t) S * ch_in * n_ops * 2 * sizeof(double))) return false;
+	// channel group per workgroup: the whole stream when it fits in LDS (contiguous, vectorisable loads)
 	Cg = (ch_in <= 16) ? ch_in : 8;
+	while (Cg > 1 && cascade_lds_bytes(Cg, n_ops) > 150 * 1024) Cg = (Cg + 1) / 2;
+	const char *env = getenv("DSP_AMD_CASCADE_CG");
+	if (env && atoi(env) >= 1 && atoi(env) <= Cg) Cg = atoi(env);
 	return true;
 }
 
@@ -128,7 +171,7 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
-	launch_cascade(p, S, st);
+	{ ProfScope ps("cascade_kernel", st); launch_cascade(p, S, st); }
 	if (ring.base) ring.pos = (ring.pos + frames) & ring.mask;
 	return frames;
 }
@@ -155,7 +198,7 @@ bool RemixStage::init(const Spec &sp)
 ssize_t RemixStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
 	RemixParams p{ in, out, in_stride, out_stride, frames, ch_in, ch_out, d_idx.as<int>(), max_n };
-	launch_remix(p, S, st);
+	{ ProfScope ps("remix_kernel", st); launch_remix(p, S, st); }
 	return frames;
 }
 
@@ -204,7 +247,7 @@ ssize_t DelayStage::run(const double *in, long in_stride, ssize_t frames, double
 	p.ring_per_stream = ring_per_stream;
 	p.pos = pos;
 	const long skip = std::min<long>(remaining_discard, frames);
-	launch_delay_ex(p, phase ? -half : half, skip, max_len, S, st);
+	{ ProfScope ps("delay_kernel", st); launch_delay_ex(p, phase ? -half : half, skip, max_len, S, st); }
 	phase ^= 1;
 	pos += frames;
 	remaining_discard -= skip;

@@ -26,6 +26,25 @@ struct DevBuf {
 	template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Optional per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on
+// (bench.py's roofline object).  Off by default; when on, every launch site brackets itself.
+struct Profiler {
+	struct Rec { const char *name; hipEvent_t a, b; };
+	bool on = false;
+	std::vector<Rec> recs;
+	void begin(const char *name, hipStream_t st);
+	void end(hipStream_t st);
+	// after a device sync: accumulate (name -> total ms, count), then drop the events
+	void collect(std::vector<std::string> &names, std::vector<double> &ms, std::vector<long> &counts);
+	~Profiler();
+};
+extern Profiler g_prof;
+struct ProfScope {
+	hipStream_t st; bool on;
+	ProfScope(const char *name, hipStream_t s) : st(s), on(g_prof.on) { if (on) g_prof.begin(name, st); }
+	~ProfScope() { if (on) g_prof.end(st); }
+};
+
 // One fused device stage.  in/out are [S][stride][C] slabs; a stage may be run in place when
 // in_place_ok() (out == in, same stride).
 class Stage {

@@ -12,16 +12,19 @@
 //   1. every lane runs the recurrence from ZERO state over its L samples (registers only);
 //   2. the lane end-states b_l are combined with a 6-step Kogge-Stone scan over the wave using the
 //      constant matrices A^(L 2^k) (the carried state enters through lane 0: b_0 += A^L x_in);
-//   3. every lane adds the zero-input response of its true incoming state: r[i] += (A^i x_l)[0].
+//   3. every lane adds the zero-input response of its true incoming state x_l, r[i] += (A^i x_l)[0],
+//      obtained by running the homogeneous recurrence (2 FMA per sample, no tables).
 // Sections run back to back on the register-resident samples; the state leaving lane 63 is the state
 // carried to the next tile / next run() call, exactly the reference's (m0, m1).
 // Blocks whose length is not a multiple of 64*L finish with L = 1 steps (64 samples per wave step,
 // cut at any sample), so consecutive calls of ANY size form one stream.
 //
-// Layout: workgroup = (stream, channel group); the [frames][C] slab of the stream is read coalesced,
-// transposed through LDS (row stride padded so that both the transposing ds_write_b64 and the per-lane
-// ds_read_b64 are bank-conflict free), results go back the same way and/or into the planar ring that
-// feeds the FFT convolver.
+// Layout: workgroup = (stream, channel group); the [frames][C] slab of the stream is read coalesced
+// (16 B per lane when the channel count allows), transposed through LDS (row stride padded so that both
+// the transposing ds_write and the per-lane ds_read_b64 are bank-conflict free), results go back the same
+// way and/or into the planar ring that feeds the FFT convolver.  The next tile's global loads are issued
+// before the current tile's recurrences so HBM latency hides under the fp64 work; the per-(channel, op)
+// coefficients are staged in LDS once per launch and read as broadcasts.
 #include <hip/hip_runtime.h>
 #include "kparams.h"
 
@@ -31,28 +34,32 @@ constexpr int L16 = CASCADE_L;
 // per-channel LDS row: 64 lanes x (16 + 1 pad) doubles, + 2 so that rows of different channels land on
 // different bank pairs for the transposing store (see DESIGN.md "cascade kernel")
 constexpr int CH_STRIDE = 64 * (L16 + 1) + 2;
+constexpr int NPOW_USED = 10;              // A^(2^k), k = 0..9
+constexpr int OPL_DOUBLES = 8 + 4 * NPOW_USED;   // compact LDS descriptor: kind, g, c0..c4, pad, P[10][4]
+constexpr int MAX_PF = 16;                 // prefetch registers (doubles) per thread
 
 __device__ __forceinline__ int lds_index(int t) { return t + (t >> 4); }
 
+// ops: LDS, compact descriptors of this channel: [n_ops][OPL_DOUBLES]
 template <int L, int LOG2L>
-__device__ __forceinline__ void run_ops(double (&v)[L], const OpDesc *__restrict__ ops, int n_ops,
-                                        double *st /* LDS [n_ops][2] */, int lane, int last_lane)
+__device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n_ops, double *st /* LDS [n_ops][2] */,
+                                        int lane, int last_lane)
 {
 	for (int j = 0; j < n_ops; ++j) {
-		const OpDesc *od = ops + j;
-		const int kind = od->kind;
+		const double *od = ops + j * OPL_DOUBLES;
+		const int kind = __double_as_longlong(od[0]);
 		if (kind == OP_MUL) {
-			const double g = od->g;
+			const double g = od[1];
 #pragma unroll
 			for (int i = 0; i < L; ++i) v[i] = __dmul_rn(v[i], g);
 		}
 		else if (kind == OP_ADD) {
-			const double g = od->g;
+			const double g = od[1];
 #pragma unroll
 			for (int i = 0; i < L; ++i) v[i] = __dadd_rn(v[i], g);
 		}
 		else if (kind == OP_BIQUAD) {
-			const double c0 = od->c[0], c1 = od->c[1], c2 = od->c[2], nc3 = -od->c[3], nc4 = -od->c[4];
+			const double c0 = od[2], c1 = od[3], c2 = od[4], nc3 = -od[5], nc4 = -od[6];
 			double m0 = 0.0, m1 = 0.0;
 #pragma unroll
 			for (int i = 0; i < L; ++i) {
@@ -63,14 +70,15 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const OpDesc *__restrict
 				v[i] = r;
 			}
 			const double xin0 = st[2*j], xin1 = st[2*j + 1];
+			const double *P = od + 8;
 			if (lane == 0) {  // the carried state rides through lane 0's L samples
-				const double *PL = od->P[LOG2L];
+				const double *PL = P + 4 * LOG2L;
 				m0 += PL[0] * xin0 + PL[1] * xin1;
 				m1 += PL[2] * xin0 + PL[3] * xin1;
 			}
 #pragma unroll
 			for (int k = 0; k < 6; ++k) {
-				const double *Pk = od->P[LOG2L + k];
+				const double *Pk = P + 4 * (LOG2L + k);
 				const double t0 = __shfl_up(m0, 1u << k, 64);
 				const double t1 = __shfl_up(m1, 1u << k, 64);
 				if (lane >= (1 << k)) {
@@ -80,9 +88,14 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const OpDesc *__restrict
 			}
 			double x0 = __shfl_up(m0, 1, 64), x1 = __shfl_up(m1, 1, 64);
 			if (lane == 0) { x0 = xin0; x1 = xin1; }
+			// zero-input response of the true incoming state
 #pragma unroll
-			for (int i = 0; i < L; ++i)
-				v[i] += od->h[i][0] * x0 + od->h[i][1] * x1;
+			for (int i = 0; i < L; ++i) {
+				const double r = x0;
+				v[i] += r;
+				x0 = fma(nc3, r, x1);
+				x1 = nc4 * r;
+			}
 			// state after the last valid lane's samples = the reference's (m0, m1) at that point
 			const double e0 = __shfl(m0, last_lane, 64), e1 = __shfl(m1, last_lane, 64);
 			if (lane == 0) { st[2*j] = e0; st[2*j + 1] = e1; }
@@ -90,7 +103,7 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const OpDesc *__restrict
 	}
 }
 
-__global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p)
+__global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpDesc *__restrict__ gops)
 {
 	extern __shared__ __attribute__((aligned(16))) double smem[];
 	const int s = blockIdx.x;
@@ -98,36 +111,79 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p)
 	const int cgn = min(p.Cg, p.C - c0);
 	const int tid = threadIdx.x, nth = blockDim.x;
 	const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
-	double *tile = smem;                               // [cgn][CH_STRIDE]
-	double *st = smem + (size_t) p.Cg * CH_STRIDE;     // [cgn][n_ops][2]
+	double *tile = smem;                                        // [Cg][CH_STRIDE]
+	double *st = tile + (size_t) p.Cg * CH_STRIDE;              // [Cg][n_ops][2]
+	double *lops = st + (size_t) p.Cg * p.n_ops * 2;            // [Cg][n_ops][OPL_DOUBLES]
 
-	int cgp = 1, cgs = 0;                              // next power of two >= cgn
+	int cgp = 1, cgs = 0;                                       // next power of two >= cgn
 	while (cgp < cgn) { cgp <<= 1; ++cgs; }
 
 	const int n_st = cgn * p.n_ops * 2;
 	double *gstate = p.state + ((size_t) s * p.C + c0) * p.n_ops * 2;
 	for (int i = tid; i < n_st; i += nth) st[i] = gstate[i];
-	__syncthreads();
+	for (int i = tid; i < cgn * p.n_ops * OPL_DOUBLES; i += nth) {
+		const int q = i % OPL_DOUBLES, co = i / OPL_DOUBLES;     // co = cc * n_ops + j
+		const OpDesc *od = gops + (size_t) c0 * p.n_ops + co;
+		double v;
+		if (q == 0) v = __longlong_as_double((long long) od->kind);
+		else if (q == 1) v = od->g;
+		else if (q < 7) v = od->c[q - 2];
+		else if (q == 7) v = 0.0;
+		else v = od->P[(q - 8) >> 2][(q - 8) & 3];
+		lops[i] = v;
+	}
 
 	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
 	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
 	const long n_full = p.frames / CASCADE_TILE;
 	const int rem = (int) (p.frames - n_full * CASCADE_TILE);
+	const long n_tiles = n_full + (rem ? 1 : 0);
+	// full tiles of a group that spans whole frames can be fetched 16 B per lane and prefetched into registers
+	const bool vec = (cgn == p.C) && (cgn == cgp) && (cgn >= 2) && ((CASCADE_TILE * cgn) / 2 <= nth * (MAX_PF / 2))
+	                 && ((((size_t) in) & 15) == 0) && ((((size_t) out) & 15) == 0);
+	const int npf = vec ? (CASCADE_TILE * cgn / 2 + nth - 1) / nth : 0;   // double2 loads per thread per tile
+	double2 pf[MAX_PF / 2];
+	if (vec && n_full > 0) {
+#pragma unroll
+		for (int q = 0; q < MAX_PF / 2; ++q)
+			if (q < npf) { const int e = tid + q * nth; if (e < CASCADE_TILE * cgn / 2) pf[q] = reinterpret_cast<const double2 *>(in)[e]; }
+	}
+	__syncthreads();
 
-	for (long tl = 0; tl <= n_full; ++tl) {
+	for (long tl = 0; tl < n_tiles; ++tl) {
 		const long t0 = tl * CASCADE_TILE;
 		const int nfr = (tl < n_full) ? CASCADE_TILE : rem;
-		if (nfr == 0) break;
-		// ---- coalesced load, transposed into LDS ----
-		for (int e = tid; e < (nfr << cgs); e += nth) {
-			const int t = e >> cgs, cc = e & (cgp - 1);
-			if (cc < cgn)
-				tile[cc * CH_STRIDE + lds_index(t)] = in[(t0 + t) * p.C + c0 + cc];
+		// ---- stage the tile in LDS, transposed ----
+		if (vec && nfr == CASCADE_TILE) {
+#pragma unroll
+			for (int q = 0; q < MAX_PF / 2; ++q) {
+				if (q < npf) {
+					const int e = tid + q * nth;
+					if (e < CASCADE_TILE * cgn / 2) {
+						const int t = (2 * e) >> cgs, cc = (2 * e) & (cgp - 1);
+						tile[cc * CH_STRIDE + lds_index(t)] = pf[q].x;
+						tile[(cc + 1) * CH_STRIDE + lds_index(t)] = pf[q].y;
+					}
+				}
+			}
+			if (tl + 1 < n_full) {   // issue the next tile's loads now; they land while this tile computes
+				const double2 *nx = reinterpret_cast<const double2 *>(in + (t0 + CASCADE_TILE) * p.C);
+#pragma unroll
+				for (int q = 0; q < MAX_PF / 2; ++q)
+					if (q < npf) { const int e = tid + q * nth; if (e < CASCADE_TILE * cgn / 2) pf[q] = nx[e]; }
+			}
+		}
+		else {
+			for (int e = tid; e < (nfr << cgs); e += nth) {
+				const int t = e >> cgs, cc = e & (cgp - 1);
+				if (cc < cgn)
+					tile[cc * CH_STRIDE + lds_index(t)] = in[(t0 + t) * p.C + c0 + cc];
+			}
 		}
 		__syncthreads();
 		// ---- recurrences: one wave per channel at a time ----
 		for (int cc = wave; cc < cgn; cc += nw) {
-			const OpDesc *ops = p.ops + (size_t) __builtin_amdgcn_readfirstlane(c0 + cc) * p.n_ops;
+			const double *ops = lops + (size_t) cc * p.n_ops * OPL_DOUBLES;
 			double *row = tile + cc * CH_STRIDE;
 			double *cst = st + cc * p.n_ops * 2;
 			if (nfr == CASCADE_TILE) {
@@ -152,10 +208,19 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p)
 		__syncthreads();
 		// ---- store ----
 		if (p.write_interleaved) {
-			for (int e = tid; e < (nfr << cgs); e += nth) {
-				const int t = e >> cgs, cc = e & (cgp - 1);
-				if (cc < cgn)
-					out[(t0 + t) * p.C + c0 + cc] = tile[cc * CH_STRIDE + lds_index(t)];
+			if (vec && nfr == CASCADE_TILE) {
+				double2 *o2 = reinterpret_cast<double2 *>(out + t0 * p.C);
+				for (int e = tid; e < CASCADE_TILE * cgn / 2; e += nth) {
+					const int t = (2 * e) >> cgs, cc = (2 * e) & (cgp - 1);
+					o2[e] = make_double2(tile[cc * CH_STRIDE + lds_index(t)], tile[(cc + 1) * CH_STRIDE + lds_index(t)]);
+				}
+			}
+			else {
+				for (int e = tid; e < (nfr << cgs); e += nth) {
+					const int t = e >> cgs, cc = e & (cgp - 1);
+					if (cc < cgn)
+						out[(t0 + t) * p.C + c0 + cc] = tile[cc * CH_STRIDE + lds_index(t)];
+				}
 			}
 		}
 		if (p.ring.base) {
@@ -174,7 +239,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p)
 
 size_t cascade_lds_bytes(int Cg, int n_ops)
 {
-	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2) * sizeof(double);
+	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2 + (size_t) Cg * n_ops * OPL_DOUBLES) * sizeof(double);
 }
 
 void launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream)
@@ -188,7 +253,7 @@ void launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream)
 		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 		lds_granted = lds;
 	}
-	hipLaunchKernelGGL(cascade_kernel, grid, block, lds, stream, p);
+	hipLaunchKernelGGL(cascade_kernel, grid, block, lds, stream, p, p.ops);
 }
 
 }  // namespace dspamd

@@ -1,0 +1,22 @@
+// resample_params.h -- launch parameters of the polyphase resampler
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dspamd {
+
+struct ResampleParams {
+	const double *ring;        // [S][ring_len][C] input history (interleaved frames)
+	long ring_len, ring_mask;
+	long q_total;              // input frames received so far (frames >= q_total read as zero: drain)
+	const double *tab;         // [J][n] polyphase taps, gain folded in
+	int n, d, J, C, KT;
+	long out_delay;            // leading full-rate outputs dropped (resample.c:144-147)
+	long m_first, m_count;     // visible output frames [m_first, m_first + m_count) to produce
+	double *out;               // [S][out_stride][C]
+	long out_stride_frames, out_frame0;
+};
+
+void launch_resample(const ResampleParams &p, int n_streams, hipStream_t st);
+void launch_resample_push(const double *in, long in_stride, double *ring, long ring_len, long pos, long frames, int C, int n_streams, hipStream_t st);
+
+}  // namespace dspamd

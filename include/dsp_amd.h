@@ -86,6 +86,11 @@ const char *dspamd_batch_plan(dspamd_batch *);
 /* names + stream of the kernels the batch launches per run (for HIP-event timing on the right stream) */
 int dspamd_batch_n_stages(dspamd_batch *);
 
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py "roofline") ---- */
+void dspamd_profile_enable(int on);
+/* device-synchronises; text lines "kernel_name total_ms launches" for everything launched since the last collect */
+const char *dspamd_profile_collect(void);
+
 /* ---- device-side bench endpoints (sgen.c:55-67 / null.c:31-34 equivalents) ---- */
 /* stream s, frame t (absolute position pos0+t), every channel: sin(2 pi (freq0 + s*dfreq) * (pos0+t)/fs) */
 int dspamd_sgen_sine(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double dfreq, ssize_t pos0, void *stream);
