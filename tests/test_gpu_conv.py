@@ -1,0 +1,208 @@
+"""GPU parity for the FIR family (fir / fir_p / hilbert / zita-equivalent) and resample beyond the golden
+cases: long filters, batches of streams, per-channel filters, channel subsets, arbitrary call sizes, and
+size-independent properties at the benchmark's full filter length."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_api import Oracle, RefChain, rms
+import oracle_chain
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def noise(frames, ch, seed, amp=0.5):
+    return np.random.Generator(np.random.PCG64(seed)).uniform(-amp, amp, size=(frames, ch))
+
+
+def make_filter(n, seed=7, decay=8000.0):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n) * np.exp(-np.arange(n) / decay)
+    return h / np.sqrt(np.sum(h * h)) / 4.0
+
+
+def write(tmp_path, h, name="f.raw"):
+    p = os.path.join(str(tmp_path), name)
+    np.asarray(h, dtype="<f8").tofile(p)
+    return p
+
+
+def fftconv(x, h):
+    """independent fp64 oracle (scipy), SURVEY.md section 4 item 2"""
+    from scipy.signal import fftconvolve
+    return np.stack([fftconvolve(x[:, k], h if h.ndim == 1 else h[:, k]) for k in range(x.shape[1])], axis=1)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import dsp_amd
+    assert dsp_amd.load_library().dspamd_device_count() >= 1
+    return dsp_amd
+
+
+@pytest.mark.parametrize("taps,block", [(33, 100), (2049, 777), (65536, 2048), (65536, 50000), (131072, 65536)])
+def test_fir_p_long_filters(amd, tmp_path, taps, block):
+    h = make_filter(taps)
+    x = noise(taps // 2 + 3 * block + 17, 3, 31)   # odd channel count: one half-empty pair
+    y = amd.EffectsChain(f"fir_p -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, 3).process(x, block=block)
+    ref = fftconv(x, h)
+    assert y.shape == ref.shape            # N + T - 1 frames after drain (fir_p.c:235-240)
+    assert rms(y - ref) < TOL, rms(y - ref)
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_fir_p_65536_vs_real_reference(amd, tmp_path):
+    h = make_filter(65536)
+    p = write(tmp_path, h)
+    x = noise(30000, 2, 32)
+    chain = f"fir_p -t pcm -e double -c 1 {p}"
+    ref = RefChain(chain, 48000, 2).process(x, block=2048)
+    y = amd.EffectsChain(chain, 48000, 2).process(x, block=2048)
+    assert y.shape == ref.shape and rms(y - ref) < TOL
+
+
+def test_per_channel_filters_and_subset(amd, tmp_path):
+    # 2-channel filter applied to channels 1 and 3 of 4 (fir.c:342-357 mapping order); others pass through untouched
+    h = np.stack([make_filter(3000, 1, 400.0), make_filter(3000, 2, 700.0)], axis=1)
+    p = write(tmp_path, h.reshape(-1))
+    x = noise(8000, 4, 33)
+    chain = f":1,3 fir_p -t pcm -e double -c 2 {p}"
+    y = amd.EffectsChain(chain, 48000, 4).process(x, block=1500)
+    xpad = np.vstack([x, np.zeros((2999, 4))])
+    ref = xpad.copy()
+    ref[:, 1] = fftconv(x[:, 1:2], h[:, 0])[:, 0]
+    ref[:, 3] = fftconv(x[:, 3:4], h[:, 1])[:, 0]
+    assert y.shape == ref.shape
+    assert np.array_equal(y[:, [0, 2]], ref[:, [0, 2]])      # untouched channels are bit-identical
+    assert rms(y - ref) < TOL
+
+
+@pytest.mark.parametrize("taps", [17, 100, 5000])
+def test_fir_latency_semantics(amd, tmp_path, taps):
+    # `fir` = same values as fir_p, delayed by next_fast_fftw_len(taps) frames which the host's end-of-chain
+    # align discards (fir.c:208-217, align.c:147-152): the CLI-visible stream equals plain convolution
+    h = make_filter(taps, 4, taps / 6.0)
+    x = noise(7000, 2, 34)
+    ec = amd.EffectsChain(f"fir -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, 2)
+    assert "align" in ec.effect_names()
+    y = ec.process(x, block=900)
+    ref = fftconv(x, h)
+    assert y.shape == ref.shape and rms(y - ref) < TOL
+    if RefChain.available():
+        r = RefChain(f"fir -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, 2)
+        assert r.effect_names() == ec.effect_names()
+        assert r.drain_frames() == ec.drain_frames()
+
+
+def test_fir_align_option(amd, tmp_path):
+    # -a: the filter's peak becomes time zero (fir_util.c:187-205), reported as a negative requested delay.
+    # On all channels that only moves the chain's zero reference; on a subset the OTHER channels get delayed
+    # by an auto-inserted align (README.md:364-366, effects_chain.c:727-875).
+    h = np.zeros(401); h[200] = 0.5; h[190] = 0.1; h[260] = -0.2
+    x = noise(3000, 2, 35)
+    f = write(tmp_path, h)
+    full = fftconv(x, h)
+    y = amd.EffectsChain(f"fir_p -a -t pcm -e double -c 1 {f}", 48000, 2).process(x, block=512)
+    assert rms(y - full) < TOL
+    ec = amd.EffectsChain(f":0 fir_p -a -t pcm -e double -c 1 {f}", 48000, 2)
+    assert ec.effect_names() == ["fir_p", "align"]
+    y = ec.process(x, block=512)
+    assert rms(y[:3000, 0] - full[:3000, 0]) < TOL               # filtered channel: as is
+    assert np.array_equal(y[200:3200, 1], x[:3000, 1])           # the other channel waits 200 frames
+    if RefChain.available():
+        for chain in (f"fir_p -a -t pcm -e double -c 1 {f}", f":0 fir_p -a -t pcm -e double -c 1 {f}", f":1 fir -a50S -t pcm -e double -c 1 {f}"):
+            ref = RefChain(chain, 48000, 2).process(x, block=512)
+            y = amd.EffectsChain(chain, 48000, 2).process(x, block=512)
+            assert y.shape == ref.shape and rms(y - ref) < TOL, chain
+
+
+def test_hilbert_variants(amd):
+    x = noise(6000, 2, 36)
+    for opts in ("-p 255", "255", "-p -c 1023", "-a 45 -p 511"):
+        chain = f"hilbert {opts}"
+        y = amd.EffectsChain(chain, 48000, 2).process(x, block=1000)
+        if RefChain.available():
+            ref = RefChain(chain, 48000, 2).process(x, block=1000)
+            assert y.shape == ref.shape and rms(y - ref) < TOL, opts
+
+
+def test_zita_equivalent_contract(amd, tmp_path):
+    # zita-convolver is absent (parity unpinned): check the restated contract -- float32 in/filter/out and
+    # min_part_len frames of latency removed by the host (zita_convolver.cpp:36-61, 93-113)
+    h = make_filter(2000, 5, 300.0)
+    x = noise(5000, 2, 37)
+    ec = amd.EffectsChain(f"zita_convolver -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, 2)
+    y = ec.process(x, block=700)
+    ref = fftconv(x.astype(np.float32).astype(np.float64), h.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+    assert y.shape == ref.shape
+    assert np.array_equal(y, y.astype(np.float32).astype(np.float64))     # output is float32-representable
+    assert np.abs(y - ref).max() < 2e-7                                    # one float32 ulp at |y| < 1
+    orc = Oracle.per_channel("zita_equiv", h, np.vstack([x, np.zeros((2063, 2))]), 64)[64:]
+    assert np.abs(y - orc).max() < 2e-7
+
+
+@pytest.mark.parametrize("fs_in,fs_out,block", [(48000, 96000, 1), (48000, 96000, 4096), (96000, 48000, 333), (44100, 48000, 1000),
+                                                (48000, 44100, 2048), (48000, 32000, 777), (32000, 48000, 100), (48000, 192000, 500)])
+def test_resample_ratios_and_call_sizes(amd, fs_in, fs_out, block):
+    n = 700 if block == 1 else 9000
+    x = noise(n, 2, 38, 0.4)
+    y = amd.EffectsChain(f"resample {fs_out}", fs_in, 2).process(x, block=block)
+    ref = Oracle.resample(x, fs_in, fs_out, block=1000)
+    assert y.shape == ref.shape, (y.shape, ref.shape)   # total length ceil(N n / d)
+    assert rms(y - ref) < 1e-11, rms(y - ref)
+
+
+def test_config4_chain_batch(amd, tmp_path):
+    """BASELINE config 4 (biquad x10 + fir_p(65536) + resample 48k->96k) on a small batch, every stream
+    checked against the real reference (or the oracle)."""
+    import torch
+    biq = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 "
+           "eq 800 1.0 -1 eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    h = make_filter(65536)
+    p = write(tmp_path, h)
+    chain = f"{biq} fir_p -t pcm -e double -c 1 {p} resample 96k"
+    S, C, N = 3, 8, 20000
+    x = np.stack([noise(N, C, 200 + s, 0.3) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, 8192)
+    y = b.process(torch.from_numpy(x).cuda(), 8192).cpu().numpy()
+    assert y.shape[1] == 2 * (N + 65535)
+    for s in range(S):
+        if RefChain.available():
+            ref = RefChain(chain, 48000, C).process(x[s], block=4096)
+        else:
+            ref, _ = oracle_chain.run(chain.replace(p, "{F}"), x[s], 48000, filt=h)
+        assert ref.shape == y[s].shape
+        assert rms(ref - y[s]) < 1e-11, rms(ref - y[s])
+
+
+def test_full_size_properties(amd, tmp_path):
+    """At the benchmark's sizes the oracle is too slow; use size-independent properties instead:
+    impulse response reproduces the taps, linearity, and block-size invariance of the device-resident path."""
+    import torch
+    taps = 65536
+    h = make_filter(taps)
+    p = write(tmp_path, h)
+    chain = f"fir_p -t pcm -e double -c 1 {p}"
+    S, C = 4, 8
+    N = 3 * 65536
+    b = amd.BatchChain(chain, 48000, C, S, 196608)
+    x = torch.zeros((S, N, C), dtype=torch.float64, device="cuda")
+    x[:, 5, :] = 1.0
+    y = b.run(x)
+    ir = y[0, 5:5 + taps, 3].cpu().numpy()
+    assert np.abs(ir - h).max() < 1e-15                      # delta in -> taps out
+    assert float(y[:, :5, :].abs().max()) < 1e-18
+    # linearity + block-size invariance: (a x1 + b x2) in 3 blocks == a y1 + b y2 computed in 1 block
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    x1 = torch.rand((S, N, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    x2 = torch.rand((S, N, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    b.reset(); y1 = b.run(x1).clone()
+    b.reset(); y2 = b.run(x2).clone()
+    b3 = amd.BatchChain(chain, 48000, C, S, 65536)
+    xm = 0.25 * x1 - 1.5 * x2
+    parts = [b3.run(xm[:, k:k + 65536, :].contiguous()).clone() for k in range(0, N, 65536)]
+    ym = torch.cat(parts, dim=1)
+    err = (ym - (0.25 * y1 - 1.5 * y2)).pow(2).mean().sqrt().item()
+    assert err < 1e-13, err

@@ -1,0 +1,77 @@
+"""Drop-in check: the UNMODIFIED reference host (CLI + chain runtime + registry, compiled by oracle/Makefile
+from /root/reference into oracle/_ref/dsp_gpu) linked against libdsp_amd.so, run side by side with the stock
+reference CLI (oracle/_ref/dsp_ref) on the same files.  Exercises the plugin ABI end to end: init / merge /
+channel_offsets / drain_samples / run / drain2 / plot / destroy as the reference host calls them."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_api import REF_DIR, rms
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not (os.path.exists(os.path.join(REF_DIR, "dsp_gpu")) and os.path.exists(os.path.join(REF_DIR, "dsp_ref"))),
+                                 reason="oracle/_ref/dsp_gpu or dsp_ref not built")]
+
+REF = os.path.join(REF_DIR, "dsp_ref")
+GPU = os.path.join(REF_DIR, "dsp_gpu")
+BIQ = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 "
+       "eq 800 1.0 -1 eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+
+
+def run_cli(exe, args, **kw):
+    r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, **kw)
+    assert r.returncode == 0, f"{exe} {' '.join(args)}\n{r.stderr[-2000:]}"
+    return r
+
+
+def both(tmp_path, in_args, chain, channels_out):
+    outs = []
+    for exe, tag in ((REF, "ref"), (GPU, "gpu")):
+        o = os.path.join(str(tmp_path), f"out_{tag}.raw")
+        run_cli(exe, ["-q"] + in_args + ["-o", "-t", "pcm", "-e", "double", o] + chain.split())
+        outs.append(np.fromfile(o).reshape(-1, channels_out))
+    return outs
+
+
+def test_config1_sgen_cli(tmp_path):
+    # BASELINE config 1: sgen sine 48 kHz 2 ch -> gain -6 -> lowpass 1k 0.707
+    ref, gpu = both(tmp_path, ["-t", "sgen", "-r", "48k", "-c", "2", "sine+1"], "gain -6 lowpass 1k 0.707", 2)
+    assert ref.shape == gpu.shape == (48000, 2)
+    assert rms(ref - gpu) < 1e-13
+
+
+def test_file_chain_cli(tmp_path):
+    rng = np.random.Generator(np.random.PCG64(77))
+    x = rng.uniform(-0.3, 0.3, size=(30000, 2))
+    xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
+    h = rng.standard_normal(5000) * np.exp(-np.arange(5000) / 600.0); h = h / np.sqrt(np.sum(h * h)) / 4
+    hf = os.path.join(str(tmp_path), "h.raw"); h.astype("<f8").tofile(hf)
+    in_args = ["-t", "pcm", "-e", "double", "-r", "48k", "-c", "2", xin]
+    for chain, och, tol in [
+        (f"gain -3 {BIQ}", 2, 1e-12),
+        (f"{BIQ} fir_p -t pcm -e double -c 1 {hf} resample 96k", 2, 1e-11),
+        (f"fir -t pcm -e double -c 1 {hf} :0 delay 11S : remix 0,1 1 0", 3, 1e-12),
+        ("hilbert -p 1023 :1 gain -2 : resample 44.1k", 2, 1e-11),
+    ]:
+        ref, gpu = both(tmp_path, in_args, chain, och)
+        assert ref.shape == gpu.shape, (chain, ref.shape, gpu.shape)
+        assert rms(ref - gpu) < tol, (chain, rms(ref - gpu))
+
+
+def test_bit_exact_class_cli(tmp_path):
+    rng = np.random.Generator(np.random.PCG64(78))
+    x = rng.uniform(-0.3, 0.3, size=(5000, 4))
+    xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
+    ref, gpu = both(tmp_path, ["-t", "pcm", "-e", "double", "-r", "48k", "-c", "4", xin],
+                    "gain -6 :1,3 mult 0.3 : add 0.001 remix 0,1 2 . 1,2,3 :0 delay 37S", 4)
+    assert ref.shape == gpu.shape and np.array_equal(ref, gpu)
+
+
+def test_plot_coefficients_identical():
+    # `dsp -p` prints every biquad with %.15e (biquad.h:94-95): a coefficient known-answer test through the CLI
+    args = ["-p", "-r", "48k", "-c", "1", "-n"] + "gain -6 lowpass 1k 0.707 eq 400 2.0 1.5 highshelf 8k 6d -3 linkwitz_transform 80 0.9 40 0.5".split()
+    a = run_cli(REF, args).stdout
+    b = run_cli(GPU, args).stdout
+    assert "H0_1(w)=" in a and a == b
