@@ -106,22 +106,21 @@ def main():
     torch.cuda.set_device(local_rank)
     L = dsp_amd.load_library()
     L.dspamd_set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from dsp_amd.shard import Job, stream_range
+    job = Job(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL over xGMI on ROCm
 
     fs, C = 48000, args.channels
     S_total = args.streams
-    s_lo = S_total * rank // world
-    s_hi = S_total * (rank + 1) // world
+    s_lo, s_hi = stream_range(S_total, rank, world)
     S = s_hi - s_lo
     assert S >= 1, "fewer streams than ranks: replicas only"
 
     filt_dir = f"/tmp/dsp_amd_bench_{os.getpid()}"
     os.makedirs(filt_dir, exist_ok=True)
-    np.asarray(make_filter(args.taps), dtype="<f8").tofile(os.path.join(filt_dir, "filt.raw"))
     chain_t = args.chain or (BIQUADS + " fir_p -t pcm -e double -c 1 {F}")
+    # setup broadcast (the only payload that ever crosses xGMI besides digests and timings): chain text + taps
+    chain_t, taps = job.broadcast_setup(chain_t, make_filter(args.taps) if rank == 0 else None)
+    np.asarray(taps, dtype="<f8").tofile(os.path.join(filt_dir, "filt.raw"))
     chain = chain_t.replace("{F}", "filt.raw")
 
     batch = dsp_amd.BatchChain(chain, fs, C, S, args.block, directory=filt_dir)
@@ -135,8 +134,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        job.barrier()
         torch.cuda.synchronize()
 
     for w in range(args.warmup):
@@ -146,11 +144,7 @@ def main():
     for k in range(args.steps):
         batch.run(x[k & 1], out)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = job.max_time(time.perf_counter() - t0)
 
     # ---- per-kernel averages with HIP events on the launch stream (same K steps, second pass) ----
     L.dspamd_profile_enable(1)
@@ -180,7 +174,10 @@ def main():
     dig = torch.empty((S, 3), dtype=torch.float64, device="cuda")
     L.dspamd_digest(out.data_ptr(), S, args.block, out.shape[1], batch.ochannels, dig.data_ptr(), stream)
     torch.cuda.synchronize()
+    dig = job.gather_digests(dig, S_total)       # [S_total, 3]: sum, sum of squares, peak per stream
     finite = bool(torch.isfinite(dig).all().item())
+    total_streams = job.sum_count(S)
+    assert total_streams == S_total
 
     if rank == 0:
         samples_per_step_total = S_total * C * args.block          # input channel-samples, all ranks
@@ -206,6 +203,7 @@ def main():
                          "whole_chain_frac_per_gpu": chain_frac, "measured_copy_GBps": copy_gbps,
                          "kernels": {k: {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / args.steps} for k, v in prof.items()}},
             "output_finite": finite,
+            "digest": {"streams": int(dig.shape[0]), "sum_of_squares": float(dig[:, 1].sum().item()), "peak": float(dig[:, 2].max().item())},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(chain, filt_dir, fs, C)
@@ -214,8 +212,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if dist is not None:
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":
