@@ -49,7 +49,7 @@ private:
 	bool prepare_filters(const Spec &sp);
 	ConvParams base_params() const;
 	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, lat = 0, ring_len = 0, pos = 0;
-	int log2N1 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
+	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
 	bool fed = false, all_selected = false;
 	long pairs_per_chunk = 0;
 	std::string name;
@@ -70,7 +70,7 @@ ConvParams ConvStage::base_params() const
 {
 	ConvParams p;
 	memset(&p, 0, sizeof(p));
-	p.log2N1 = log2N1; p.log2_lo = log2_lo;
+	p.log2N1 = log2N1; p.log2N2 = log2N2; p.log2_lo = log2_lo;
 	p.N = N; p.N1 = N1; p.N2 = N2;
 	p.ring = ring.as<double>();
 	p.ring_row_stride = ring_len; p.ring_mask = ring_len - 1;
@@ -101,16 +101,20 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	pps = (n_filters == 1) ? (nsel + 1) / 2 : nsel;
 
 	// transform size: at least 2T (overlap <= 1/2), grown up to 8x the filter when calls are long
-	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_LOG2_N2 + FFT_MIN_LOG2_N1));
+	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	const long want = next_pow2(T - 1 + std::max<long>(max_frames, 1));
 	N = std::min(std::max(lo, want), lo * 4);
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
 	if (env) N = std::max(lo, 1L << atoi(env));
-	N2 = 1L << FFT_LOG2_N2;
-	N1 = N / N2;
+	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
+	// N = N1 x N2: columns (strided) at most 256 points so that a 16-wide column tile is 64 KiB of LDS,
+	// rows (contiguous) 512..2048 points
+	N1 = std::min<long>(1L << FFT_MAX_LOG2_N1, N >> FFT_MIN_LOG2_N2);
+	N2 = N / N1;
 	log2N1 = ilog2(N1);
-	if (log2N1 > FFT_MAX_LOG2_N1) {
-		set_error("%s: error: filter too long for the GPU convolver (%ld taps; limit %ld)", name.c_str(), T, (1L << (FFT_LOG2_N2 + FFT_MAX_LOG2_N1 - 1)));
+	log2N2 = ilog2(N2);
+	if (log2N2 > FFT_MAX_LOG2_N2) {
+		set_error("%s: error: filter too long for the GPU convolver (%ld taps; limit %ld)", name.c_str(), T, (1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1 - 1)));
 		return false;
 	}
 	B = N - (T - 1);
@@ -240,9 +244,10 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 			const long ns = std::min<long>(chunk_streams, S - s0);
 			p.pair0 = s0 * pps;
 			p.stream0 = s0;
+			p.n_streams_launch = ns;
 			{ ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, (int) (ns * pps), st); }
 			{ ProfScope ps("conv_row", st); launch_conv_row(p, 0, (int) (ns * pps), st); }
-			{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) ns, st); }
+			{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) (ns * pps), st); }
 		}
 	}
 	pos = (pos + frames) & (ring_len - 1);

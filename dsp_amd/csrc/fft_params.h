@@ -4,12 +4,12 @@
 
 namespace dspamd {
 
-constexpr int FFT_LOG2_N2 = 9;          // contiguous (row) dimension of the four-step decomposition: 512 points
-constexpr int FFT_MIN_LOG2_N1 = 3, FFT_MAX_LOG2_N1 = 10;
+constexpr int FFT_MIN_LOG2_N2 = 9, FFT_MAX_LOG2_N2 = 11;   // contiguous (row) dimension: 512 .. 2048 points
+constexpr int FFT_MIN_LOG2_N1 = 3, FFT_MAX_LOG2_N1 = 8;    // strided (column) dimension: 8 .. 256 points
 constexpr int FIR_DIRECT_MAX = 32;      // fir_p.c:34 DIRECT_LEN
 
 struct ConvParams {
-	int log2N1, log2_lo;
+	int log2N1, log2N2, log2_lo;
 	long N, N1, N2;
 	// input window: z[n] = ring[row][(win_base + n) & ring_mask] for n < valid, else 0
 	const double *ring;
@@ -27,7 +27,7 @@ struct ConvParams {
 	double *out;
 	long out_stride_frames, out_frame0, out_frames, first_n;
 	int C, pairs_per_stream;
-	long stream0;
+	long stream0, n_streams_launch;
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)
 	int round_f32;
 };

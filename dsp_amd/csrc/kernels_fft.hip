@@ -18,9 +18,11 @@
 //      K3 conv_col_inv : IFFT over k1, scatter the valid outputs to the interleaved slab
 //  * Everything fp64 (the reference is fp64 end to end); twiddles come from tables built in extended
 //    precision on the host, the big inter-pass twiddle w_N^(n2 k1) from a two-level table (one complex
-//    multiply) so that no 2 MB table is streamed.
-//  * LDS-resident Stockham radix-4 passes (radix-2 tail), 64-wide waves, 16-byte ds accesses; column
-//    tiles are 16 points wide so every global access is a 256 B run.
+//    multiply) so that no multi-megabyte table is streamed.
+//  * LDS-resident Stockham passes, radix 8 in registers (radix 4 / 2 for the remainder, done first where its
+//    twiddles are trivial), 64-wide waves, 16-byte ds accesses; row tiles are padded by one point per 16 so that
+//    the strided Stockham stores are bank-conflict free; column tiles are 16 points wide so every global access
+//    is a 256 B run; global loads are issued in register batches ahead of the LDS stores.
 #include <hip/hip_runtime.h>
 #include "kparams.h"
 #include "fft_params.h"
@@ -33,92 +35,108 @@ __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x *
 __device__ __forceinline__ cplx cmulc(cplx a, cplx b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV> __device__ __forceinline__ cplx mul_mi(cplx a) { return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
 
 constexpr int NT = 256;   // threads per workgroup in all FFT kernels
 
-// In-LDS Stockham FFT of BATCH sequences of N = 2^LOG2N points.
-//   ROWS = true : sequence b is contiguous:      element (b, i) at b*N + i
-//   ROWS = false: sequences are interleaved:     element (b, i) at i*BATCH + b   (column tiles)
-// tw[m] = exp(-2 pi i m / N).  INV = true computes the unnormalised inverse.  All threads of the
-// workgroup must call it; it begins and ends with the data visible to every thread.
+// ---- in-register DFTs, natural-order output ----
+template <bool INV> __device__ __forceinline__ void dft2(cplx &a, cplx &b)
+{
+	const cplx s = cadd(a, b), d = csub(a, b);
+	a = s; b = d;
+}
+
+template <bool INV> __device__ __forceinline__ void dft4(cplx &c0, cplx &c1, cplx &c2, cplx &c3)
+{
+	const cplx s02 = cadd(c0, c2), d02 = csub(c0, c2), s13 = cadd(c1, c3), d13 = mul_mi<INV>(csub(c1, c3));
+	c0 = cadd(s02, s13); c1 = cadd(d02, d13); c2 = csub(s02, s13); c3 = csub(d02, d13);
+}
+
+template <bool INV> __device__ __forceinline__ void dft8(cplx (&v)[8])
+{
+	constexpr double h = 0.70710678118654752440;
+	cplx a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
+	cplx b0 = csub(v[0], v[4]), b1 = csub(v[1], v[5]), b2 = csub(v[2], v[6]), b3 = csub(v[3], v[7]);
+	// b_i *= w8^i,  w8 = exp(-+ i pi/4)
+	b1 = INV ? make_double2((b1.x - b1.y) * h, (b1.x + b1.y) * h) : make_double2((b1.x + b1.y) * h, (b1.y - b1.x) * h);
+	b2 = mul_mi<INV>(b2);
+	b3 = INV ? make_double2(-(b3.x + b3.y) * h, (b3.x - b3.y) * h) : make_double2((b3.y - b3.x) * h, -(b3.x + b3.y) * h);
+	dft4<INV>(a0, a1, a2, a3);
+	dft4<INV>(b0, b1, b2, b3);
+	v[0] = a0; v[1] = b0; v[2] = a1; v[3] = b1; v[4] = a2; v[5] = b2; v[6] = a3; v[7] = b3;
+}
+
+template <int R, bool INV> __device__ __forceinline__ void dftR(cplx (&v)[R])
+{
+	if constexpr (R == 8) dft8<INV>(v);
+	else if constexpr (R == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
+	else dft2<INV>(v[0], v[1]);
+}
+
+// LDS addressing.  ROWS: sequence b contiguous, one pad point per 16 (bank-conflict-free Stockham stores).
+// !ROWS: sequences interleaved, element (b, i) at i*BATCH + b (column tiles; BATCH*16 B contiguous per i).
+template <int LOG2N, int BATCH, bool ROWS> struct LdsMap {
+	static constexpr int N = 1 << LOG2N;
+	static constexpr int ROW_PITCH = N + (N >> 4);
+	static constexpr int SIZE = ROWS ? BATCH * ROW_PITCH : BATCH * N;
+	__device__ static __forceinline__ int at(int b, int i) { return ROWS ? b * ROW_PITCH + i + (i >> 4) : i * BATCH + b; }
+};
+
+// one Stockham pass of radix R with accumulated stride Ns
+template <int LOG2N, int BATCH, bool ROWS, bool INV, int R>
+__device__ __forceinline__ void fft_pass(cplx *data, const cplx *tw, int tid, int Ns)
+{
+	using M = LdsMap<LOG2N, BATCH, ROWS>;
+	constexpr int N = 1 << LOG2N;
+	constexpr int NR = N / R;
+	constexpr int TOT = NR * BATCH;
+	constexpr int BPT = (TOT + NT - 1) / NT;
+	cplx v[BPT][R];
+#pragma unroll
+	for (int q = 0; q < BPT; ++q) {
+		const int e = tid + q * NT;
+		if (e < TOT) {
+			const int j = ROWS ? e % NR : e / BATCH, b = ROWS ? e / NR : e % BATCH;
+#pragma unroll
+			for (int r = 0; r < R; ++r) v[q][r] = data[M::at(b, j + r * NR)];
+		}
+	}
+	__syncthreads();
+	const int step = N / (R * Ns);
+#pragma unroll
+	for (int q = 0; q < BPT; ++q) {
+		const int e = tid + q * NT;
+		if (e < TOT) {
+			const int j = ROWS ? e % NR : e / BATCH, b = ROWS ? e / NR : e % BATCH;
+			const int k = j & (Ns - 1);
+			if (Ns > 1) {
+#pragma unroll
+				for (int r = 1; r < R; ++r) {
+					const cplx w = tw[r * k * step];
+					v[q][r] = INV ? cmulc(v[q][r], w) : cmul(v[q][r], w);
+				}
+			}
+			dftR<R, INV>(v[q]);
+			const int j0 = (j - k) * R + k;
+#pragma unroll
+			for (int r = 0; r < R; ++r) data[M::at(b, j0 + r * Ns)] = v[q][r];
+		}
+	}
+	__syncthreads();
+}
+
+// In-LDS Stockham FFT of BATCH sequences of N = 2^LOG2N points; tw[m] = exp(-2 pi i m / N).
+// INV computes the unnormalised inverse.  All threads of the workgroup must call it; the data must be
+// visible to every thread on entry (barrier by the caller) and is visible on exit.
 template <int LOG2N, int BATCH, bool ROWS, bool INV>
 __device__ __forceinline__ void fft_lds(cplx *data, const cplx *tw, int tid)
 {
-	constexpr int N = 1 << LOG2N;
-	auto at = [](int b, int i) { return ROWS ? b * N + i : i * BATCH + b; };
 	int Ns = 1;
-	// ---- radix-4 passes ----
-	constexpr int N4 = N / 4;
-	constexpr int TOT4 = (N4 > 0 ? N4 : 1) * BATCH;
-	constexpr int BPT4 = (TOT4 + NT - 1) / NT;
+	if constexpr (LOG2N % 3 == 1) { fft_pass<LOG2N, BATCH, ROWS, INV, 2>(data, tw, tid, Ns); Ns *= 2; }
+	if constexpr (LOG2N % 3 == 2) { fft_pass<LOG2N, BATCH, ROWS, INV, 4>(data, tw, tid, Ns); Ns *= 4; }
 #pragma unroll 1
-	for (int p = 0; p + 2 <= LOG2N; p += 2) {
-		cplx v[BPT4][4];
-#pragma unroll
-		for (int q = 0; q < BPT4; ++q) {
-			const int e = tid + q * NT;
-			if (e < TOT4) {
-				const int j = ROWS ? e % N4 : e / BATCH, b = ROWS ? e / N4 : e % BATCH;
-#pragma unroll
-				for (int r = 0; r < 4; ++r) v[q][r] = data[at(b, j + r * N4)];
-			}
-		}
-		__syncthreads();
-		const int step = N / (4 * Ns);
-#pragma unroll
-		for (int q = 0; q < BPT4; ++q) {
-			const int e = tid + q * NT;
-			if (e < TOT4) {
-				const int j = ROWS ? e % N4 : e / BATCH, b = ROWS ? e / N4 : e % BATCH;
-				const int k = j & (Ns - 1);
-				cplx a0 = v[q][0], a1, a2, a3;
-				if (INV) { a1 = cmulc(v[q][1], tw[k * step]); a2 = cmulc(v[q][2], tw[2 * k * step]); a3 = cmulc(v[q][3], tw[3 * k * step]); }
-				else { a1 = cmul(v[q][1], tw[k * step]); a2 = cmul(v[q][2], tw[2 * k * step]); a3 = cmul(v[q][3], tw[3 * k * step]); }
-				const cplx s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
-				// forward: -i * d13 ; inverse: +i * d13
-				const cplx jd = INV ? make_double2(-d13.y, d13.x) : make_double2(d13.y, -d13.x);
-				const int j0 = ((j - k) << 2) + k;
-				data[at(b, j0)] = cadd(s02, s13);
-				data[at(b, j0 + Ns)] = cadd(d02, jd);
-				data[at(b, j0 + 2 * Ns)] = csub(s02, s13);
-				data[at(b, j0 + 3 * Ns)] = csub(d02, jd);
-			}
-		}
-		__syncthreads();
-		Ns <<= 2;
-	}
-	// ---- radix-2 tail ----
-	if (LOG2N & 1) {
-		constexpr int N2_ = N / 2;
-		constexpr int TOT2 = N2_ * BATCH;
-		constexpr int BPT2 = (TOT2 + NT - 1) / NT;
-		cplx v[BPT2][2];
-#pragma unroll
-		for (int q = 0; q < BPT2; ++q) {
-			const int e = tid + q * NT;
-			if (e < TOT2) {
-				const int j = ROWS ? e % N2_ : e / BATCH, b = ROWS ? e / N2_ : e % BATCH;
-				v[q][0] = data[at(b, j)];
-				v[q][1] = data[at(b, j + N2_)];
-			}
-		}
-		__syncthreads();
-		const int step = N / (2 * Ns);
-#pragma unroll
-		for (int q = 0; q < BPT2; ++q) {
-			const int e = tid + q * NT;
-			if (e < TOT2) {
-				const int j = ROWS ? e % N2_ : e / BATCH, b = ROWS ? e / N2_ : e % BATCH;
-				const int k = j & (Ns - 1);
-				const cplx a0 = v[q][0];
-				const cplx a1 = INV ? cmulc(v[q][1], tw[k * step]) : cmul(v[q][1], tw[k * step]);
-				const int j0 = ((j - k) << 1) + k;
-				data[at(b, j0)] = cadd(a0, a1);
-				data[at(b, j0 + Ns)] = csub(a0, a1);
-			}
-		}
-		__syncthreads();
-	}
+	for (int p = 0; p < LOG2N / 3; ++p) { fft_pass<LOG2N, BATCH, ROWS, INV, 8>(data, tw, tid, Ns); Ns *= 8; }
 }
 
 // w_N^m from the two-level table: m = hi * 2^log2_lo + lo
@@ -131,7 +149,8 @@ __device__ __forceinline__ cplx big_twiddle(const ConvParams &p, long m)
 
 template <int LOG2N1> struct ColCfg {
 	static constexpr int N1 = 1 << LOG2N1;
-	static constexpr int TW = (LOG2N1 <= 9) ? 16 : 8;       // column tile width (points of n2)
+	static constexpr int TW = 16;                                     // column tile width (points of n2): 256 B runs
+	static constexpr int EPT = (N1 * TW) / NT > 0 ? (N1 * TW) / NT : 1;   // points per thread
 	static constexpr size_t LDS = ((size_t) N1 * TW + N1) * sizeof(cplx);
 };
 
@@ -140,7 +159,7 @@ template <int LOG2N1>
 __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 {
 	using Cfg = ColCfg<LOG2N1>;
-	constexpr int N1 = Cfg::N1, TW = Cfg::TW;
+	constexpr int N1 = Cfg::N1, TW = Cfg::TW, EPT = Cfg::EPT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);
 	cplx *tw = data + N1 * TW;
@@ -151,20 +170,32 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 	const long ra = p.pair_rows[2 * pair], rb = p.pair_rows[2 * pair + 1];
 	const double *rowa = (ra >= 0) ? p.ring + ra * p.ring_row_stride : nullptr;
 	const double *rowb = (rb >= 0) ? p.ring + rb * p.ring_row_stride : nullptr;
-	for (int e = tid; e < N1 * TW; e += NT) {
-		const int n1 = e / TW, t = e % TW;
-		const long n = (long) n1 * p.N2 + n2_0 + t;
-		double re = 0.0, im = 0.0;
-		if (n < p.valid) {
-			const long ri = (p.win_base + n) & p.ring_mask;
-			if (rowa) re = rowa[ri];
-			if (rowb) im = rowb[ri];
+	constexpr int BATCHL = EPT < 8 ? EPT : 8;
+#pragma unroll 1
+	for (int q0 = 0; q0 < EPT; q0 += BATCHL) {
+		double re[BATCHL], im[BATCHL];
+#pragma unroll
+		for (int q = 0; q < BATCHL; ++q) {   // issue all loads of the batch before any LDS store
+			const int e = tid + (q0 + q) * NT;
+			const int n1 = e / TW, t = e % TW;
+			const long n = (long) n1 * p.N2 + n2_0 + t;
+			re[q] = 0.0; im[q] = 0.0;
+			if (e < N1 * TW && n < p.valid) {
+				const long ri = (p.win_base + n) & p.ring_mask;
+				if (rowa) re[q] = rowa[ri];
+				if (rowb) im[q] = rowb[ri];
+			}
 		}
-		data[e] = make_double2(re, im);
+#pragma unroll
+		for (int q = 0; q < BATCHL; ++q) {
+			const int e = tid + (q0 + q) * NT;
+			if (e < N1 * TW) data[e] = make_double2(re[q], im[q]);
+		}
 	}
 	__syncthreads();
 	fft_lds<LOG2N1, TW, false, false>(data, tw, tid);
 	cplx *W = p.W + (pair - p.pair0) * p.N;
+#pragma unroll 4
 	for (int e = tid; e < N1 * TW; e += NT) {
 		const int k1 = e / TW, t = e % TW;
 		const long n2 = n2_0 + t;
@@ -174,38 +205,61 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 }
 
 // K3: W[pair][k1][n2] --IFFT over k1--> y[n1 N2 + n2]; valid outputs scattered into the interleaved slab.
-// One workgroup walks all pairs of its stream for one column tile, so that the 16-byte pieces it writes
-// into each 64-byte frame are merged in L2 before they reach HBM.
+// blockIdx.x enumerates (tile, stream, pair-in-stream) so that the workgroups writing the 16-byte pieces of the
+// same 64-byte frames are dispatched back to back on the SAME XCD (block b runs on XCD b % 8): their partial
+// writes then meet in that XCD's L2 instead of reaching HBM as separate 32-byte sectors.
 template <int LOG2N1>
 __global__ __launch_bounds__(NT) void conv_col_inv(ConvParams p)
 {
 	using Cfg = ColCfg<LOG2N1>;
-	constexpr int N1 = Cfg::N1, TW = Cfg::TW;
+	constexpr int N1 = Cfg::N1, TW = Cfg::TW, EPT = Cfg::EPT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);
 	cplx *tw = data + N1 * TW;
 	const int tid = threadIdx.x;
-	const long n2_0 = (long) blockIdx.x * TW;
-	const long s = p.stream0 + blockIdx.y;
+	// decode: linear id L = (g_hi * pps + q) * 8 + x, group g = g_hi * 8 + x, group -> (stream-in-chunk, tile)
+	const long L = blockIdx.x;
+	const int x = (int) (L & 7);
+	const long r = L >> 3;
+	const int q = (int) (r % p.pairs_per_stream);
+	const long g = (r / p.pairs_per_stream) * 8 + x;
+	const long n_tiles = p.N2 / TW;
+	if (g >= n_tiles * p.n_streams_launch) return;
+	const long tile = g % n_tiles;
+	const long s = p.stream0 + g / n_tiles;
+	const long n2_0 = tile * TW;
 	for (int i = tid; i < N1; i += NT) tw[i] = p.tw_n1[i];
-	double *out = p.out + ((size_t) s * p.out_stride_frames + p.out_frame0) * p.C;
-	for (int q = 0; q < p.pairs_per_stream; ++q) {
-		const long pair = s * p.pairs_per_stream + q;
-		const cplx *W = p.W + (pair - p.pair0) * p.N;
-		__syncthreads();
-		for (int e = tid; e < N1 * TW; e += NT) {
-			const int k1 = e / TW, t = e % TW;
-			data[e] = W[(long) k1 * p.N2 + n2_0 + t];
+	const long pair = s * p.pairs_per_stream + q;
+	const cplx *W = p.W + (pair - p.pair0) * p.N;
+	constexpr int BATCHL = EPT < 8 ? EPT : 8;
+#pragma unroll 1
+	for (int q0 = 0; q0 < EPT; q0 += BATCHL) {
+		cplx v[BATCHL];
+#pragma unroll
+		for (int qq = 0; qq < BATCHL; ++qq) {
+			const int e = tid + (q0 + qq) * NT;
+			if (e < N1 * TW) v[qq] = W[(long) (e / TW) * p.N2 + n2_0 + (e % TW)];
 		}
-		__syncthreads();
-		fft_lds<LOG2N1, TW, false, true>(data, tw, tid);
-		const int cha = p.pair_out_ch[2 * q], chb = p.pair_out_ch[2 * q + 1];
-		for (int e = tid; e < N1 * TW; e += NT) {
-			const int n1 = e / TW, t = e % TW;
-			const long f = (long) n1 * p.N2 + n2_0 + t - p.first_n;
-			if (f >= 0 && f < p.out_frames) {
-				cplx v = data[e];
-				if (p.round_f32) { v.x = (double) (float) v.x; v.y = (double) (float) v.y; }
+#pragma unroll
+		for (int qq = 0; qq < BATCHL; ++qq) {
+			const int e = tid + (q0 + qq) * NT;
+			if (e < N1 * TW) data[e] = v[qq];
+		}
+	}
+	__syncthreads();
+	fft_lds<LOG2N1, TW, false, true>(data, tw, tid);
+	double *out = p.out + ((size_t) s * p.out_stride_frames + p.out_frame0) * p.C;
+	const int cha = p.pair_out_ch[2 * q], chb = p.pair_out_ch[2 * q + 1];
+	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
+#pragma unroll 4
+	for (int e = tid; e < N1 * TW; e += NT) {
+		const int n1 = e / TW, t = e % TW;
+		const long f = (long) n1 * p.N2 + n2_0 + t - p.first_n;
+		if (f >= 0 && f < p.out_frames) {
+			cplx v = data[e];
+			if (p.round_f32) { v.x = (double) (float) v.x; v.y = (double) (float) v.y; }
+			if (wide) *reinterpret_cast<cplx *>(out + f * p.C + cha) = v;
+			else {
 				if (cha >= 0) out[f * p.C + cha] = v.x;
 				if (chb >= 0) out[f * p.C + chb] = v.y;
 			}
@@ -213,40 +267,70 @@ __global__ __launch_bounds__(NT) void conv_col_inv(ConvParams p)
 	}
 }
 
-constexpr int ROW_LOG2 = FFT_LOG2_N2;
-constexpr int ROW_N = 1 << ROW_LOG2;
-constexpr int ROWS_PER_WG = 4;
+// rows per workgroup so that a workgroup holds ~2048 points
+template <int LOG2N2> struct RowCfg {
+	static constexpr int N2 = 1 << LOG2N2;
+	static constexpr int RPW = (2048 / N2) > 0 ? 2048 / N2 : 1;
+	using M = LdsMap<LOG2N2, RPW, true>;
+	static constexpr size_t LDS = ((size_t) M::SIZE + N2) * sizeof(cplx);
+	static constexpr int EPT = RPW * N2 / NT;
+};
 
 // K2: per row k1: FFT over n2, multiply by the filter spectrum (already scaled by 1/N), IFFT over k2,
-// conjugate twiddle.  mode 1: spectrum only (filter preparation): write scale * FFT to p.Hout.
-template <int MODE>
+// conjugate twiddle.  MODE 1: spectrum only (filter preparation): write scale * FFT to p.Hout.
+template <int LOG2N2, int MODE>
 __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 {
+	using Cfg = RowCfg<LOG2N2>;
+	using M = typename Cfg::M;
+	constexpr int N2 = Cfg::N2, RPW = Cfg::RPW, EPT = Cfg::EPT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *tw = data + ROWS_PER_WG * ROW_N;
+	cplx *tw = data + M::SIZE;
 	const int tid = threadIdx.x;
-	const long k1_0 = (long) blockIdx.x * ROWS_PER_WG;
+	const long k1_0 = (long) blockIdx.x * RPW;
 	const long pair = p.pair0 + blockIdx.y;
-	cplx *W = p.W + (pair - p.pair0) * p.N + k1_0 * ROW_N;
-	for (int i = tid; i < ROW_N; i += NT) tw[i] = p.tw_n2[i];
-	for (int e = tid; e < ROWS_PER_WG * ROW_N; e += NT) data[e] = W[e];
+	cplx *W = p.W + (pair - p.pair0) * p.N + k1_0 * N2;
+	for (int i = tid; i < N2; i += NT) tw[i] = p.tw_n2[i];
+	{
+		cplx v[EPT];
+#pragma unroll
+		for (int q = 0; q < EPT; ++q) v[q] = W[tid + q * NT];
+#pragma unroll
+		for (int q = 0; q < EPT; ++q) { const int e = tid + q * NT; data[M::at(e / N2, e % N2)] = v[q]; }
+	}
 	__syncthreads();
-	fft_lds<ROW_LOG2, ROWS_PER_WG, true, false>(data, tw, tid);
+	fft_lds<LOG2N2, RPW, true, false>(data, tw, tid);
 	if (MODE == 1) {
-		cplx *H = p.Hout + k1_0 * ROW_N;
-		for (int e = tid; e < ROWS_PER_WG * ROW_N; e += NT)
-			H[e] = make_double2(data[e].x * p.h_scale, data[e].y * p.h_scale);
+		cplx *H = p.Hout + k1_0 * N2;
+#pragma unroll
+		for (int q = 0; q < EPT; ++q) {
+			const int e = tid + q * NT;
+			const cplx d = data[M::at(e / N2, e % N2)];
+			H[e] = make_double2(d.x * p.h_scale, d.y * p.h_scale);
+		}
 		return;
 	}
-	const cplx *H = p.H + p.pair_h[pair] * p.N + k1_0 * ROW_N;
-	for (int e = tid; e < ROWS_PER_WG * ROW_N; e += NT) data[e] = cmul(data[e], H[e]);
+	const cplx *H = p.H + p.pair_h[pair] * p.N + k1_0 * N2;
+	{
+		cplx h[EPT];
+#pragma unroll
+		for (int q = 0; q < EPT; ++q) h[q] = H[tid + q * NT];
+#pragma unroll
+		for (int q = 0; q < EPT; ++q) {
+			const int e = tid + q * NT;
+			const int a = M::at(e / N2, e % N2);
+			data[a] = cmul(data[a], h[q]);
+		}
+	}
 	__syncthreads();
-	fft_lds<ROW_LOG2, ROWS_PER_WG, true, true>(data, tw, tid);
-	for (int e = tid; e < ROWS_PER_WG * ROW_N; e += NT) {
-		const long k1 = k1_0 + e / ROW_N, n2 = e % ROW_N;
+	fft_lds<LOG2N2, RPW, true, true>(data, tw, tid);
+#pragma unroll
+	for (int q = 0; q < EPT; ++q) {
+		const int e = tid + q * NT;
+		const long k1 = k1_0 + e / N2, n2 = e % N2;
 		const cplx w = big_twiddle(p, (n2 * k1) & (p.N - 1));
-		W[e] = cmulc(data[e], w);
+		W[e] = cmulc(data[M::at(e / N2, e % N2)], w);
 	}
 }
 
@@ -313,7 +397,7 @@ __global__ __launch_bounds__(NT) void fir_direct_kernel(FirDirectParams p)
 
 // ------------------------------------------------------------------ launchers
 
-template <int L> static void launch_col(const ConvParams &p, bool inverse, int grid_y, hipStream_t st)
+template <int L> static void launch_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t st)
 {
 	using Cfg = ColCfg<L>;
 	static bool attr_set[2] = { false, false };
@@ -322,32 +406,49 @@ template <int L> static void launch_col(const ConvParams &p, bool inverse, int g
 		(void) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Cfg::LDS);
 		attr_set[inverse] = true;
 	}
-	dim3 grid((unsigned) (p.N2 / Cfg::TW), grid_y), block(NT);
-	if (inverse) hipLaunchKernelGGL(conv_col_inv<L>, grid, block, Cfg::LDS, st, p);
-	else hipLaunchKernelGGL(conv_col_fwd<L>, grid, block, Cfg::LDS, st, p);
+	if (inverse) {
+		const long groups = (p.N2 / Cfg::TW) * p.n_streams_launch;
+		const long blocks = ((groups + 7) / 8) * 8 * p.pairs_per_stream;
+		hipLaunchKernelGGL(conv_col_inv<L>, dim3((unsigned) blocks), dim3(NT), Cfg::LDS, st, p);
+	}
+	else hipLaunchKernelGGL(conv_col_fwd<L>, dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
 }
 
-void launch_conv_col(const ConvParams &p, bool inverse, int grid_y, hipStream_t st)
+void launch_conv_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t st)
 {
 	switch (p.log2N1) {
-	case 3: launch_col<3>(p, inverse, grid_y, st); break;
-	case 4: launch_col<4>(p, inverse, grid_y, st); break;
-	case 5: launch_col<5>(p, inverse, grid_y, st); break;
-	case 6: launch_col<6>(p, inverse, grid_y, st); break;
-	case 7: launch_col<7>(p, inverse, grid_y, st); break;
-	case 8: launch_col<8>(p, inverse, grid_y, st); break;
-	case 9: launch_col<9>(p, inverse, grid_y, st); break;
-	case 10: launch_col<10>(p, inverse, grid_y, st); break;
+	case 3: launch_col<3>(p, inverse, n_pairs, st); break;
+	case 4: launch_col<4>(p, inverse, n_pairs, st); break;
+	case 5: launch_col<5>(p, inverse, n_pairs, st); break;
+	case 6: launch_col<6>(p, inverse, n_pairs, st); break;
+	case 7: launch_col<7>(p, inverse, n_pairs, st); break;
+	case 8: launch_col<8>(p, inverse, n_pairs, st); break;
 	default: break;
 	}
 }
 
+template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
+{
+	using Cfg = RowCfg<L2>;
+	static bool attr_set[2] = { false, false };
+	if (!attr_set[mode]) {
+		const void *fn = mode ? (const void *) conv_row<L2, 1> : (const void *) conv_row<L2, 0>;
+		(void) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Cfg::LDS);
+		attr_set[mode] = true;
+	}
+	dim3 grid((unsigned) (p.N1 / Cfg::RPW), n_pairs), block(NT);
+	if (mode == 1) hipLaunchKernelGGL((conv_row<L2, 1>), grid, block, Cfg::LDS, st, p);
+	else hipLaunchKernelGGL((conv_row<L2, 0>), grid, block, Cfg::LDS, st, p);
+}
+
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	const size_t lds = ((size_t) ROWS_PER_WG * ROW_N + ROW_N) * sizeof(cplx);
-	dim3 grid((unsigned) (p.N1 / ROWS_PER_WG), n_pairs), block(NT);
-	if (mode == 1) hipLaunchKernelGGL(conv_row<1>, grid, block, lds, st, p);
-	else hipLaunchKernelGGL(conv_row<0>, grid, block, lds, st, p);
+	switch (p.log2N2) {
+	case 9: launch_row<9>(p, mode, n_pairs, st); break;
+	case 10: launch_row<10>(p, mode, n_pairs, st); break;
+	case 11: launch_row<11>(p, mode, n_pairs, st); break;
+	default: break;
+	}
 }
 
 void launch_deinterleave(const DeintParams &p, int n_streams, hipStream_t st)
