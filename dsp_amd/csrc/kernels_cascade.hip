@@ -40,11 +40,45 @@ constexpr int MAX_PF = 16;                 // prefetch registers (doubles) per t
 
 __device__ __forceinline__ int lds_index(int t) { return t + (t >> 4); }
 
+// ---- cross-lane helpers: DPP moves of fp64 values (two 32-bit DPP ops), no LDS traffic ----
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+	// bound_ctrl = true: lanes whose source is outside the row / wave read 0.0
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xf, 0xf, true);
+	return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+	const long long b = __double_as_longlong(v);
+	const int lo = __builtin_amdgcn_readlane((int) (b & 0xffffffffLL), lane);
+	const int hi = __builtin_amdgcn_readlane((int) (b >> 32), lane);
+	return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_WAVE_SHR1 = 0x138;
+
+// inclusive scan WITHIN each 16-lane row of the affine recurrence x <- P x + b (P constant, given as powers
+// P^(2^k) at Pw[4k..4k+3], k = 0..3): m_l = sum_{j <= l, same row} P^(l-j) b_j
+__device__ __forceinline__ void row_scan(double &m0, double &m1, const double (&Pw)[16])
+{
+	double t0, t1;
+	t0 = dpp_f64<DPP_ROW_SHR1>(m0); t1 = dpp_f64<DPP_ROW_SHR1>(m1);
+	m0 += Pw[0] * t0 + Pw[1] * t1; m1 += Pw[2] * t0 + Pw[3] * t1;
+	t0 = dpp_f64<DPP_ROW_SHR2>(m0); t1 = dpp_f64<DPP_ROW_SHR2>(m1);
+	m0 += Pw[4] * t0 + Pw[5] * t1; m1 += Pw[6] * t0 + Pw[7] * t1;
+	t0 = dpp_f64<DPP_ROW_SHR4>(m0); t1 = dpp_f64<DPP_ROW_SHR4>(m1);
+	m0 += Pw[8] * t0 + Pw[9] * t1; m1 += Pw[10] * t0 + Pw[11] * t1;
+	t0 = dpp_f64<DPP_ROW_SHR8>(m0); t1 = dpp_f64<DPP_ROW_SHR8>(m1);
+	m0 += Pw[12] * t0 + Pw[13] * t1; m1 += Pw[14] * t0 + Pw[15] * t1;
+}
+
 // ops: LDS, compact descriptors of this channel: [n_ops][OPL_DOUBLES]
 template <int L, int LOG2L>
 __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n_ops, double *st /* LDS [n_ops][2] */,
                                         int lane, int last_lane)
 {
+	const int row = lane >> 4;
 	for (int j = 0; j < n_ops; ++j) {
 		const double *od = ops + j * OPL_DOUBLES;
 		const int kind = __double_as_longlong(od[0]);
@@ -59,7 +93,14 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n
 			for (int i = 0; i < L; ++i) v[i] = __dadd_rn(v[i], g);
 		}
 		else if (kind == OP_BIQUAD) {
+			// all constants of the section up front: their LDS latency hides under the recurrence below
 			const double c0 = od[2], c1 = od[3], c2 = od[4], nc3 = -od[5], nc4 = -od[6];
+			const double xin0 = st[2*j], xin1 = st[2*j + 1];
+			double Pw[16], P16[4];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) Pw[i] = od[8 + 4 * LOG2L + i];          // P^(L), P^(2L), P^(4L), P^(8L)
+#pragma unroll
+			for (int i = 0; i < 4; ++i) P16[i] = od[8 + 4 * (LOG2L + 4) + i];    // P^(16L): one whole row
 			double m0 = 0.0, m1 = 0.0;
 #pragma unroll
 			for (int i = 0; i < L; ++i) {
@@ -69,24 +110,26 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n
 				m1 = fma(nc4, r, c2 * s);
 				v[i] = r;
 			}
-			const double xin0 = st[2*j], xin1 = st[2*j + 1];
-			const double *P = od + 8;
 			if (lane == 0) {  // the carried state rides through lane 0's L samples
-				const double *PL = P + 4 * LOG2L;
-				m0 += PL[0] * xin0 + PL[1] * xin1;
-				m1 += PL[2] * xin0 + PL[3] * xin1;
+				m0 += Pw[0] * xin0 + Pw[1] * xin1;
+				m1 += Pw[2] * xin0 + Pw[3] * xin1;
 			}
-#pragma unroll
-			for (int k = 0; k < 6; ++k) {
-				const double *Pk = P + 4 * (LOG2L + k);
-				const double t0 = __shfl_up(m0, 1u << k, 64);
-				const double t1 = __shfl_up(m1, 1u << k, 64);
-				if (lane >= (1 << k)) {
-					m0 += Pk[0] * t0 + Pk[1] * t1;
-					m1 += Pk[2] * t0 + Pk[3] * t1;
-				}
-			}
-			double x0 = __shfl_up(m0, 1, 64), x1 = __shfl_up(m1, 1, 64);
+			// pass 1: per-row inclusive scans; row totals sit in lanes 15, 31, 47, 63
+			row_scan(m0, m1, Pw);
+			const double T00 = readlane_f64(m0, 15), T01 = readlane_f64(m1, 15);
+			const double T10 = readlane_f64(m0, 31), T11 = readlane_f64(m1, 31);
+			const double T20 = readlane_f64(m0, 47), T21 = readlane_f64(m1, 47);
+			// true states at the row boundaries: E_r = P^(16L) E_(r-1) + T_r
+			const double E10 = P16[0] * T00 + P16[1] * T01 + T10, E11 = P16[2] * T00 + P16[3] * T01 + T11;
+			const double E20 = P16[0] * E10 + P16[1] * E11 + T20, E21 = P16[2] * E10 + P16[3] * E11 + T21;
+			// pass 2: carry c_r = E_(r-1) enters each row at its first lane as P^L c_r and is spread by the same scan
+			const double cr0 = (row == 1) ? T00 : (row == 2) ? E10 : E20;
+			const double cr1 = (row == 1) ? T01 : (row == 2) ? E11 : E21;
+			double u0 = 0.0, u1 = 0.0;
+			if (row > 0 && (lane & 15) == 0) { u0 = Pw[0] * cr0 + Pw[1] * cr1; u1 = Pw[2] * cr0 + Pw[3] * cr1; }
+			row_scan(u0, u1, Pw);
+			m0 += u0; m1 += u1;                                  // (m0, m1) = true state after this lane's samples
+			double x0 = dpp_f64<DPP_WAVE_SHR1>(m0), x1 = dpp_f64<DPP_WAVE_SHR1>(m1);
 			if (lane == 0) { x0 = xin0; x1 = xin1; }
 			// zero-input response of the true incoming state
 #pragma unroll
@@ -97,7 +140,7 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n
 				x1 = nc4 * r;
 			}
 			// state after the last valid lane's samples = the reference's (m0, m1) at that point
-			const double e0 = __shfl(m0, last_lane, 64), e1 = __shfl(m1, last_lane, 64);
+			const double e0 = readlane_f64(m0, last_lane), e1 = readlane_f64(m1, last_lane);
 			if (lane == 0) { st[2*j] = e0; st[2*j + 1] = e1; }
 		}
 	}
@@ -141,6 +184,8 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 	// full tiles of a group that spans whole frames can be fetched 16 B per lane and prefetched into registers
 	const bool vec = (cgn == p.C) && (cgn == cgp) && (cgn >= 2) && ((CASCADE_TILE * cgn) / 2 <= nth * (MAX_PF / 2))
 	                 && ((((size_t) in) & 15) == 0) && ((((size_t) out) & 15) == 0);
+	// ring-only output whose position keeps 16-sample groups contiguous and 16-byte aligned
+	const bool ring_direct = p.ring.base && !p.write_interleaved && ((p.ring.pos & 15) == 0) && (p.ring.mask >= CASCADE_TILE - 1);
 	const int npf = vec ? (CASCADE_TILE * cgn / 2 + nth - 1) / nth : 0;   // double2 loads per thread per tile
 	double2 pf[MAX_PF / 2];
 	if (vec && n_full > 0) {
@@ -191,8 +236,21 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 #pragma unroll
 				for (int i = 0; i < L16; ++i) v[i] = row[lane * (L16 + 1) + i];
 				run_ops<L16, 4>(v, ops, p.n_ops, cst, lane, 63);
+				if (ring_direct) {
+					// planar destination: this lane's 16 samples are 128 contiguous bytes of the channel's ring row,
+					// stored straight from registers (no LDS transpose, no barrier on the way out)
+					const int r = p.ring.row_of_channel[c0 + cc];
+					if (r >= 0) {
+						double *dst = p.ring.base + ((size_t) s * p.ring.rows_per_stream + r) * p.ring.row_stride
+						              + ((p.ring.pos + t0 + lane * L16) & p.ring.mask);
 #pragma unroll
-				for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
+						for (int i = 0; i < L16; i += 2) *reinterpret_cast<double2 *>(dst + i) = make_double2(v[i], v[i + 1]);
+					}
+				}
+				else {
+#pragma unroll
+					for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
+				}
 			}
 			else {
 				for (int t1 = 0; t1 < nfr; t1 += 64) {
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 				}
 			}
 		}
-		if (p.ring.base) {
+		if (p.ring.base && !(ring_direct && nfr == CASCADE_TILE)) {
 			for (int cc = 0; cc < cgn; ++cc) {
 				const int r = p.ring.row_of_channel[c0 + cc];
 				if (r < 0) continue;
