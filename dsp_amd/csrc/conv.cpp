@@ -48,13 +48,13 @@ public:
 private:
 	bool prepare_filters(const Spec &sp);
 	ConvParams base_params() const;
-	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, lat = 0, ring_len = 0, pos = 0;
+	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, first_n = 0, lat = 0, ring_len = 0, pos = 0;
 	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
 	bool fed = false, all_selected = false;
 	long pairs_per_chunk = 0;
 	std::string name;
 	CascadeStage *feeder_ = nullptr;
-	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_rows, pair_h, pair_out_ch, row_of_channel;
+	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_h, pair_out_ch, slot_of_channel;
 };
 
 std::string ConvStage::describe() const
@@ -72,9 +72,8 @@ ConvParams ConvStage::base_params() const
 	memset(&p, 0, sizeof(p));
 	p.log2N1 = log2N1; p.log2N2 = log2N2; p.log2_lo = log2_lo;
 	p.N = N; p.N1 = N1; p.N2 = N2;
-	p.ring = ring.as<double>();
+	p.ring = ring.as<double2>();
 	p.ring_row_stride = ring_len; p.ring_mask = ring_len - 1;
-	p.pair_rows = pair_rows.as<long>();
 	p.pair_h = pair_h.as<int>();
 	p.W = W.as<double2>();
 	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>();
@@ -100,15 +99,15 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	// channel pairs share a transform only when they share the filter
 	pps = (n_filters == 1) ? (nsel + 1) / 2 : nsel;
 
-	// transform size: at least 2T (overlap <= 1/2), grown up to 8x the filter when calls are long
+	// transform size: at least 2T (overlap <= 1/2), grown up to 16x the filter when calls are long
+	// (valid fraction (N - T + 1) / N: 1/2 at 2T, 15/16 at 16T)
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
-	const long want = next_pow2(T - 1 + std::max<long>(max_frames, 1));
-	N = std::min(std::max(lo, want), lo * 4);
+	const long want = next_pow2(((T + 6) & ~7L) + std::max<long>(max_frames, 1));
+	N = std::min(std::max(lo, want), lo * 8);
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
 	if (env) N = std::max(lo, 1L << atoi(env));
 	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
-	// N = N1 x N2: columns (strided) at most 256 points so that a 16-wide column tile is 64 KiB of LDS,
-	// rows (contiguous) 512..2048 points
+	// N = N1 x N2: columns (strided) 16..256 points (one LDS exchange), rows (contiguous) 512..4096 points
 	N1 = std::min<long>(1L << FFT_MAX_LOG2_N1, N >> FFT_MIN_LOG2_N2);
 	N2 = N / N1;
 	log2N1 = ilog2(N1);
@@ -117,28 +116,28 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 		set_error("%s: error: filter too long for the GPU convolver (%ld taps; limit %ld)", name.c_str(), T, (1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1 - 1)));
 		return false;
 	}
-	B = N - (T - 1);
-	ring_len = next_pow2(T - 1 + lat + std::max<long>(max_frames, B));
+	// The window starts up to 7 samples earlier than overlap-save needs, so that the first valid output index
+	// (first_n) and the hop are multiples of 8: K3's runs of 8 frames then start on 512-byte boundaries of the slab.
+	first_n = (T - 1 + 7) & ~7L;
+	B = (N - first_n) & ~7L;
+	ring_len = next_pow2(first_n + lat + std::max<long>(max_frames, B));
 	log2_lo = (ilog2(N) + 1) / 2;
 
-	// rings: one row per selected channel per stream
-	if (!ring.alloc((size_t) S * nsel * ring_len * sizeof(double))) return false;
-	std::vector<int> roc(ch_in, -1);
+	// rings: one row of complex samples (x_a[n], x_b[n]) per channel pair per stream -- the sequence K1 transforms
+	if (!ring.alloc((size_t) S * pps * ring_len * sizeof(double2))) return false;
+	std::vector<int> soc(ch_in, -1);
 	std::vector<int> sel_ch;
-	for (int c = 0; c < ch_in; ++c) if (sp.sel[c]) { roc[c] = (int) sel_ch.size(); sel_ch.push_back(c); }
-	if (!row_of_channel.upload(roc.data(), roc.size() * sizeof(int))) return false;
-	std::vector<long> prow((size_t) S * pps * 2);
+	for (int c = 0; c < ch_in; ++c) if (sp.sel[c]) sel_ch.push_back(c);
 	std::vector<int> ph((size_t) S * pps), poc((size_t) pps * 2);
-	for (int s = 0; s < S; ++s) {
-		for (int q = 0; q < pps; ++q) {
-			const int ia = (n_filters == 1) ? 2 * q : q, ib = (n_filters == 1 && 2 * q + 1 < nsel) ? 2 * q + 1 : -1;
-			prow[((size_t) s * pps + q) * 2] = (long) s * nsel + ia;
-			prow[((size_t) s * pps + q) * 2 + 1] = (ib >= 0) ? (long) s * nsel + ib : -1;
-			ph[(size_t) s * pps + q] = (n_filters == 1) ? 0 : q;
-			if (s == 0) { poc[2 * q] = sel_ch[ia]; poc[2 * q + 1] = (ib >= 0) ? sel_ch[ib] : -1; }
-		}
+	for (int q = 0; q < pps; ++q) {
+		const int ia = (n_filters == 1) ? 2 * q : q, ib = (n_filters == 1 && 2 * q + 1 < nsel) ? 2 * q + 1 : -1;
+		poc[2 * q] = sel_ch[ia];
+		poc[2 * q + 1] = (ib >= 0) ? sel_ch[ib] : -1;
+		soc[sel_ch[ia]] = 2 * q;
+		if (ib >= 0) soc[sel_ch[ib]] = 2 * q + 1;
+		for (int s = 0; s < S; ++s) ph[(size_t) s * pps + q] = (n_filters == 1) ? 0 : q;
 	}
-	if (!pair_rows.upload(prow.data(), prow.size() * sizeof(long))) return false;
+	if (!slot_of_channel.upload(soc.data(), soc.size() * sizeof(int))) return false;
 	if (!pair_h.upload(ph.data(), ph.size() * sizeof(int))) return false;
 	if (!pair_out_ch.upload(poc.data(), poc.size() * sizeof(int))) return false;
 
@@ -167,13 +166,13 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	if (!prepare_filters(sp)) return false;
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
-	if (feeder && all_selected && !round_f32 && !getenv("DSP_AMD_NO_FEED")) {
+	if (feeder && all_selected && !round_f32 && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
 		feeder->ring.base = ring.as<double>();
 		feeder->ring.row_stride = ring_len;
 		feeder->ring.mask = ring_len - 1;
 		feeder->ring.pos = 0;
-		feeder->ring.row_of_channel = row_of_channel.as<int>();
-		feeder->ring.rows_per_stream = nsel;
+		feeder->ring.pair_ch = pair_out_ch.as<int>();
+		feeder->ring.rows_per_stream = pps;
 		feeder->write_interleaved = 0;
 		feeder_ = feeder;
 		fed = true;
@@ -185,25 +184,22 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 // reference does at init with its r2c plan, fir.c:342-357 / fir_p.c:482-498)
 bool ConvStage::prepare_filters(const Spec &sp)
 {
-	DevBuf tring, trows, tph;
-	std::vector<double> taps(N, 0.0);
-	std::vector<long> rows{ 0, -1 };
+	DevBuf tring, tph;
+	std::vector<double2> taps(N, make_double2(0.0, 0.0));
 	std::vector<int> hsel{ 0 };
-	if (!tring.alloc((size_t) N * sizeof(double), false)) return false;
-	if (!trows.upload(rows.data(), rows.size() * sizeof(long))) return false;
+	if (!tring.alloc((size_t) N * sizeof(double2), false)) return false;
 	if (!tph.upload(hsel.data(), hsel.size() * sizeof(int))) return false;
 	for (int f = 0; f < n_filters; ++f) {
 		for (long i = 0; i < T; ++i) {
 			double v = sp.taps[(size_t) i * sp.fch + f];
 			if (round_f32) v = (double) (float) v;
-			taps[i] = v;
+			taps[i].x = v;
 		}
-		if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double), hipMemcpyHostToDevice), "H2D taps")) return false;
+		if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double2), hipMemcpyHostToDevice), "H2D taps")) return false;
 		ConvParams p = base_params();
-		p.ring = tring.as<double>();
+		p.ring = tring.as<double2>();
 		p.ring_row_stride = N; p.ring_mask = N - 1;
 		p.win_base = 0; p.valid = T;
-		p.pair_rows = trows.as<long>();
 		p.pair_h = tph.as<int>();
 		p.pair0 = 0;
 		p.Hout = H.as<double2>() + (size_t) f * N;
@@ -222,9 +218,9 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 		d.out = all_selected ? nullptr : out;
 		d.in_stride_frames = in_stride; d.out_stride_frames = out_stride; d.frames = frames;
 		d.C = ch_in;
-		d.row_of_channel = row_of_channel.as<int>();
-		d.rows_per_stream = nsel;
-		d.ring = ring.as<double>();
+		d.slot_of_channel = slot_of_channel.as<int>();
+		d.rows_per_stream = pps;
+		d.ring = ring.as<double2>();
 		d.ring_row_stride = ring_len; d.ring_mask = ring_len - 1; d.pos = pos;
 		d.round_f32 = round_f32;
 		{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
@@ -233,13 +229,13 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 	for (long off = 0; off < frames; off += B) {
 		const long f = std::min<long>(B, frames - off);
 		ConvParams p = base_params();
-		p.win_base = (pos + off - lat - (T - 1)) & (ring_len - 1);   // two's complement wrap: ring_len is a power of two
-		p.valid = T - 1 + f;
+		p.win_base = (pos + off - lat - first_n) & (ring_len - 1);   // two's complement wrap: ring_len is a power of two
+		p.first_n = first_n;
+		p.valid = first_n + f;
 		p.out = out;
 		p.out_stride_frames = out_stride;
 		p.out_frame0 = off;
 		p.out_frames = f;
-		p.first_n = T - 1;
 		for (long s0 = 0; s0 < S; s0 += chunk_streams) {
 			const long ns = std::min<long>(chunk_streams, S - s0);
 			p.pair0 = s0 * pps;

@@ -4,17 +4,17 @@
 
 namespace dspamd {
 
-constexpr int FFT_MIN_LOG2_N2 = 9, FFT_MAX_LOG2_N2 = 11;   // contiguous (row) dimension: 512 .. 2048 points
-constexpr int FFT_MIN_LOG2_N1 = 3, FFT_MAX_LOG2_N1 = 8;    // strided (column) dimension: 8 .. 256 points
+constexpr int FFT_MIN_LOG2_N2 = 9, FFT_MAX_LOG2_N2 = 12;   // contiguous (row) dimension: 512 .. 4096 points = 16 * 16 * {2, 4, 8, 16}
+constexpr int FFT_MIN_LOG2_N1 = 4, FFT_MAX_LOG2_N1 = 8;    // strided (column) dimension: 16 .. 256 points = 16 * {1, 2, 4, 8, 16}
 constexpr int FIR_DIRECT_MAX = 32;      // fir_p.c:34 DIRECT_LEN
 
 struct ConvParams {
 	int log2N1, log2N2, log2_lo;
 	long N, N1, N2;
-	// input window: z[n] = ring[row][(win_base + n) & ring_mask] for n < valid, else 0
-	const double *ring;
+	// input window of pair r: z[n] = ring[r * ring_row_stride + ((win_base + n) & ring_mask)] for n < valid, else 0.
+	// The ring holds the complex sequence itself: (first channel of the pair, second channel or 0.0) per frame.
+	const double2 *ring;
 	long ring_row_stride, ring_mask, win_base, valid;
-	const long *pair_rows;              // [n_pairs][2] absolute ring rows (or -1 = silent half)
 	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
 	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
 	double2 *W;                         // [pairs in chunk][N] work spectrum / time buffer
@@ -37,9 +37,9 @@ struct DeintParams {
 	double *out;                        // pass-through destination for unselected channels (may be null)
 	long in_stride_frames, out_stride_frames, frames;
 	int C;
-	const int *row_of_channel;          // [C] ring row within the stream, or -1
-	int rows_per_stream;
-	double *ring;
+	const int *slot_of_channel;         // [C] 2 * (pair within the stream) + (0 = re, 1 = im), or -1 (not convolved)
+	int rows_per_stream;                // pairs per stream
+	double2 *ring;
 	long ring_row_stride, ring_mask, pos;
 	int round_f32;
 };

@@ -22,7 +22,7 @@
 // Layout: workgroup = (stream, channel group); the [frames][C] slab of the stream is read coalesced
 // (16 B per lane when the channel count allows), transposed through LDS (row stride padded so that both
 // the transposing ds_write and the per-lane ds_read_b64 are bank-conflict free), results go back the same
-// way and/or into the planar ring that feeds the FFT convolver.  The next tile's global loads are issued
+// way and/or into the pair ring that feeds the FFT convolver.  The next tile's global loads are issued
 // before the current tile's recurrences so HBM latency hides under the fp64 work; the per-(channel, op)
 // coefficients are staged in LDS once per launch and read as broadcasts.
 #include <hip/hip_runtime.h>
@@ -184,8 +184,6 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 	// full tiles of a group that spans whole frames can be fetched 16 B per lane and prefetched into registers
 	const bool vec = (cgn == p.C) && (cgn == cgp) && (cgn >= 2) && ((CASCADE_TILE * cgn) / 2 <= nth * (MAX_PF / 2))
 	                 && ((((size_t) in) & 15) == 0) && ((((size_t) out) & 15) == 0);
-	// ring-only output whose position keeps 16-sample groups contiguous and 16-byte aligned
-	const bool ring_direct = p.ring.base && !p.write_interleaved && ((p.ring.pos & 15) == 0) && (p.ring.mask >= CASCADE_TILE - 1);
 	const int npf = vec ? (CASCADE_TILE * cgn / 2 + nth - 1) / nth : 0;   // double2 loads per thread per tile
 	double2 pf[MAX_PF / 2];
 	if (vec && n_full > 0) {
@@ -236,21 +234,8 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 #pragma unroll
 				for (int i = 0; i < L16; ++i) v[i] = row[lane * (L16 + 1) + i];
 				run_ops<L16, 4>(v, ops, p.n_ops, cst, lane, 63);
-				if (ring_direct) {
-					// planar destination: this lane's 16 samples are 128 contiguous bytes of the channel's ring row,
-					// stored straight from registers (no LDS transpose, no barrier on the way out)
-					const int r = p.ring.row_of_channel[c0 + cc];
-					if (r >= 0) {
-						double *dst = p.ring.base + ((size_t) s * p.ring.rows_per_stream + r) * p.ring.row_stride
-						              + ((p.ring.pos + t0 + lane * L16) & p.ring.mask);
 #pragma unroll
-						for (int i = 0; i < L16; i += 2) *reinterpret_cast<double2 *>(dst + i) = make_double2(v[i], v[i + 1]);
-					}
-				}
-				else {
-#pragma unroll
-					for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
-				}
+				for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
 			}
 			else {
 				for (int t1 = 0; t1 < nfr; t1 += 64) {
@@ -281,13 +266,17 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 				}
 			}
 		}
-		if (p.ring.base && !(ring_direct && nfr == CASCADE_TILE)) {
-			for (int cc = 0; cc < cgn; ++cc) {
-				const int r = p.ring.row_of_channel[c0 + cc];
-				if (r < 0) continue;
-				double *dst = p.ring.base + ((size_t) s * p.ring.rows_per_stream + r) * p.ring.row_stride;
-				for (int t = tid; t < nfr; t += nth)
-					dst[(p.ring.pos + t0 + t) & p.ring.mask] = tile[cc * CH_STRIDE + lds_index(t)];
+		if (p.ring.base) {
+			// the convolver's ring: one 16-byte element (x_a[n], x_b[n]) per frame and channel pair, consecutive lanes =
+			// consecutive frames (the workgroup holds every channel of the stream: the feeder requires Cg == C)
+			for (int q = 0; q < p.ring.rows_per_stream; ++q) {
+				const int ca = p.ring.pair_ch[2 * q] - c0, cb = p.ring.pair_ch[2 * q + 1] - c0;
+				double2 *dst = reinterpret_cast<double2 *>(p.ring.base) + ((size_t) s * p.ring.rows_per_stream + q) * p.ring.row_stride;
+				for (int t = tid; t < nfr; t += nth) {
+					const int li = lds_index(t);
+					dst[(p.ring.pos + t0 + t) & p.ring.mask] =
+						make_double2((ca >= 0 && ca < cgn) ? tile[ca * CH_STRIDE + li] : 0.0, (cb >= 0 && cb < cgn) ? tile[cb * CH_STRIDE + li] : 0.0);
+				}
 			}
 		}
 		__syncthreads();

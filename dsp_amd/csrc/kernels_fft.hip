@@ -17,12 +17,16 @@
 //      K2 conv_row     : FFT over n2 (contiguous), x H, IFFT over k2, conj twiddle         -> W (in place)
 //      K3 conv_col_inv : IFFT over k1, scatter the valid outputs to the interleaved slab
 //  * Everything fp64 (the reference is fp64 end to end); twiddles come from tables built in extended
-//    precision on the host, the big inter-pass twiddle w_N^(n2 k1) from a two-level table (one complex
-//    multiply) so that no multi-megabyte table is streamed.
-//  * LDS-resident Stockham passes, radix 8 in registers (radix 4 / 2 for the remainder, done first where its
-//    twiddles are trivial), 64-wide waves, 16-byte ds accesses; row tiles are padded by one point per 16 so that
-//    the strided Stockham stores are bank-conflict free; column tiles are 16 points wide so every global access
-//    is a 256 B run; global loads are issued in register batches ahead of the LDS stores.
+//    precision on the host; large twiddles are the product of two table entries (one complex multiply),
+//    so no multi-megabyte table is streamed and no power recurrences lose bits.
+//  * Register-resident Stockham: every thread owns 16 points of a sequence (positions j + P m, P = N/16) and every
+//    pass is radix 16 (or 16/R butterflies of radix R for the last factor), so
+//      - the first pass runs on the registers the global loads landed in and the last pass feeds the global
+//        stores (and, in K2, the H multiply and the first inverse pass) without touching LDS;
+//      - LDS only carries the exchanges BETWEEN passes: one round trip for a 256-point column FFT, two for a
+//        row FFT of up to 4096 points (a 64-wide wave owns a whole 1024-point row: no workgroup barriers);
+//      - every global access is a 16-byte lane access in runs of >= 128 B; K3 gathers the pairs of a stream in
+//        one workgroup so that whole 64-byte frames leave in 512-byte runs.
 #include <hip/hip_runtime.h>
 #include "kparams.h"
 #include "fft_params.h"
@@ -37,16 +41,15 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x +
 __device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
 // multiply by -i (forward) or +i (inverse)
 template <bool INV> __device__ __forceinline__ cplx mul_mi(cplx a) { return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
-
-constexpr int NT = 256;   // threads per workgroup in all FFT kernels
-
-// ---- in-register DFTs, natural-order output ----
-template <bool INV> __device__ __forceinline__ void dft2(cplx &a, cplx &b)
+// multiply by the constant (wr - i wi) (forward) or its conjugate (inverse)
+template <bool INV> __device__ __forceinline__ cplx mul_w(cplx a, double wr, double wi)
 {
-	const cplx s = cadd(a, b), d = csub(a, b);
-	a = s; b = d;
+	return INV ? make_double2(a.x * wr - a.y * wi, a.y * wr + a.x * wi) : make_double2(a.x * wr + a.y * wi, a.y * wr - a.x * wi);
 }
 
+constexpr int NT = 256;   // threads per workgroup (conv_col_inv with 4 pairs per workgroup uses 2 * NT)
+
+// ---- in-register DFTs, natural-order output ----
 template <bool INV> __device__ __forceinline__ void dft4(cplx &c0, cplx &c1, cplx &c2, cplx &c3)
 {
 	const cplx s02 = cadd(c0, c2), d02 = csub(c0, c2), s13 = cadd(c1, c3), d13 = mul_mi<INV>(csub(c1, c3));
@@ -67,76 +70,99 @@ template <bool INV> __device__ __forceinline__ void dft8(cplx (&v)[8])
 	v[0] = a0; v[1] = b0; v[2] = a1; v[3] = b1; v[4] = a2; v[5] = b2; v[6] = a3; v[7] = b3;
 }
 
+// 16 = 4 x 4: input index n = n1 + 4 n2, output index k = k2 + 4 k1;
+//   A[n1][k2] = sum_n2 x[n1 + 4 n2] w4^(n2 k2),   X[k2 + 4 k1] = sum_n1 (A[n1][k2] w16^(n1 k2)) w4^(n1 k1)
+template <bool INV> __device__ __forceinline__ void dft16(cplx (&u)[16])
+{
+	constexpr double c = 0.92387953251128675613, s = 0.38268343236508977173, h = 0.70710678118654752440;
+	cplx a[4][4];
+#pragma unroll
+	for (int n1 = 0; n1 < 4; ++n1) {
+		cplx t0 = u[n1], t1 = u[n1 + 4], t2 = u[n1 + 8], t3 = u[n1 + 12];
+		dft4<INV>(t0, t1, t2, t3);
+		a[n1][0] = t0; a[n1][1] = t1; a[n1][2] = t2; a[n1][3] = t3;
+	}
+	// w16^1 = (c, -s)  w16^2 = (h, -h)  w16^3 = (s, -c)  w16^4 = -i  w16^6 = (-h, -h)  w16^9 = (-c, s)
+	a[1][1] = mul_w<INV>(a[1][1], c, s);
+	a[1][2] = INV ? make_double2((a[1][2].x - a[1][2].y) * h, (a[1][2].x + a[1][2].y) * h) : make_double2((a[1][2].x + a[1][2].y) * h, (a[1][2].y - a[1][2].x) * h);
+	a[1][3] = mul_w<INV>(a[1][3], s, c);
+	a[2][1] = INV ? make_double2((a[2][1].x - a[2][1].y) * h, (a[2][1].x + a[2][1].y) * h) : make_double2((a[2][1].x + a[2][1].y) * h, (a[2][1].y - a[2][1].x) * h);
+	a[2][2] = mul_mi<INV>(a[2][2]);
+	a[2][3] = INV ? make_double2(-(a[2][3].x + a[2][3].y) * h, (a[2][3].x - a[2][3].y) * h) : make_double2((a[2][3].y - a[2][3].x) * h, -(a[2][3].x + a[2][3].y) * h);
+	a[3][1] = mul_w<INV>(a[3][1], s, c);
+	a[3][2] = INV ? make_double2(-(a[3][2].x + a[3][2].y) * h, (a[3][2].x - a[3][2].y) * h) : make_double2((a[3][2].y - a[3][2].x) * h, -(a[3][2].x + a[3][2].y) * h);
+	a[3][3] = mul_w<INV>(a[3][3], -c, -s);
+#pragma unroll
+	for (int k2 = 0; k2 < 4; ++k2) {
+		cplx t0 = a[0][k2], t1 = a[1][k2], t2 = a[2][k2], t3 = a[3][k2];
+		dft4<INV>(t0, t1, t2, t3);
+		u[k2] = t0; u[k2 + 4] = t1; u[k2 + 8] = t2; u[k2 + 12] = t3;
+	}
+}
+
 template <int R, bool INV> __device__ __forceinline__ void dftR(cplx (&v)[R])
 {
-	if constexpr (R == 8) dft8<INV>(v);
+	if constexpr (R == 16) dft16<INV>(v);
+	else if constexpr (R == 8) dft8<INV>(v);
 	else if constexpr (R == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
-	else dft2<INV>(v[0], v[1]);
+	else if constexpr (R == 2) { const cplx s = cadd(v[0], v[1]), d = csub(v[0], v[1]); v[0] = s; v[1] = d; }
 }
 
-// LDS addressing.  ROWS: sequence b contiguous, one pad point per 16 (bank-conflict-free Stockham stores).
-// !ROWS: sequences interleaved, element (b, i) at i*BATCH + b (column tiles; BATCH*16 B contiguous per i).
-template <int LOG2N, int BATCH, bool ROWS> struct LdsMap {
-	static constexpr int N = 1 << LOG2N;
-	static constexpr int ROW_PITCH = N + (N >> 4);
-	static constexpr int SIZE = ROWS ? BATCH * ROW_PITCH : BATCH * N;
-	__device__ static __forceinline__ int at(int b, int i) { return ROWS ? b * ROW_PITCH + i + (i >> 4) : i * BATCH + b; }
+// Twiddle providers (LDS tables).  get<M>(e) = exp(-2 pi i e / M).
+struct TwCol {            // sequence length NSEQ <= 256: one table of W_NSEQ; the only twiddled pass has M == NSEQ
+	const cplx *t;
+	template <int M> __device__ __forceinline__ cplx get(int e) const { return t[e]; }
+};
+template <int NSEQ> struct TwRow {   // rows: W_256 direct, W_NSEQ as hi[e >> 6] * lo[e & 63]
+	const cplx *t256, *lo, *hi;
+	template <int M> __device__ __forceinline__ cplx get(int e) const
+	{
+		if constexpr (M == NSEQ && NSEQ > 256) return cmul(hi[e >> 6], lo[e & 63]);
+		else return t256[e * (256 / M)];
+	}
 };
 
-// one Stockham pass of radix R with accumulated stride Ns
-template <int LOG2N, int BATCH, bool ROWS, bool INV, int R>
-__device__ __forceinline__ void fft_pass(cplx *data, const cplx *tw, int tid, int Ns)
+// One Stockham pass on the 16 register-resident points of a thread.  v[m] <-> position j + P m of the sequence
+// (P = N / 16); the pass runs 16 / R butterflies b = j + P q of radix R, whose inputs b + (N / R) r are exactly
+// v[q + (16 / R) r] in EVERY pass.  Outputs go to LDS at the Stockham positions, or -- in the last pass, where they
+// coincide with the input positions -- stay in v.
+template <int LOG2N, int R, int NS, bool INV, bool LAST, class Map, class Tw, class T>
+__device__ __forceinline__ void pass16(cplx (&v)[16], int j, T *lds, const Map &map, const Tw &tw)
 {
-	using M = LdsMap<LOG2N, BATCH, ROWS>;
-	constexpr int N = 1 << LOG2N;
-	constexpr int NR = N / R;
-	constexpr int TOT = NR * BATCH;
-	constexpr int BPT = (TOT + NT - 1) / NT;
-	cplx v[BPT][R];
+	constexpr int N = 1 << LOG2N, P = N / 16, Q = 16 / R;
 #pragma unroll
-	for (int q = 0; q < BPT; ++q) {
-		const int e = tid + q * NT;
-		if (e < TOT) {
-			const int j = ROWS ? e % NR : e / BATCH, b = ROWS ? e / NR : e % BATCH;
+	for (int q = 0; q < Q; ++q) {
+		const int b = j + P * q;
+		const int k = b & (NS - 1);
+		cplx u[R];
 #pragma unroll
-			for (int r = 0; r < R; ++r) v[q][r] = data[M::at(b, j + r * NR)];
-		}
-	}
-	__syncthreads();
-	const int step = N / (R * Ns);
+		for (int r = 0; r < R; ++r) u[r] = v[q + Q * r];
+		if constexpr (NS > 1) {
 #pragma unroll
-	for (int q = 0; q < BPT; ++q) {
-		const int e = tid + q * NT;
-		if (e < TOT) {
-			const int j = ROWS ? e % NR : e / BATCH, b = ROWS ? e / NR : e % BATCH;
-			const int k = j & (Ns - 1);
-			if (Ns > 1) {
-#pragma unroll
-				for (int r = 1; r < R; ++r) {
-					const cplx w = tw[r * k * step];
-					v[q][r] = INV ? cmulc(v[q][r], w) : cmul(v[q][r], w);
-				}
+			for (int r = 1; r < R; ++r) {
+				const cplx w = tw.template get<R * NS>(r * k);
+				u[r] = INV ? cmulc(u[r], w) : cmul(u[r], w);
 			}
-			dftR<R, INV>(v[q]);
-			const int j0 = (j - k) * R + k;
+		}
+		dftR<R, INV>(u);
+		if constexpr (LAST) {
 #pragma unroll
-			for (int r = 0; r < R; ++r) data[M::at(b, j0 + r * Ns)] = v[q][r];
+			for (int r = 0; r < R; ++r) v[q + Q * r] = u[r];
+		}
+		else {
+			const int j0 = (b - k) * R + k;
+#pragma unroll
+			for (int r = 0; r < R; ++r) map.store(lds, j0 + NS * r, u[r]);
 		}
 	}
-	__syncthreads();
 }
 
-// In-LDS Stockham FFT of BATCH sequences of N = 2^LOG2N points; tw[m] = exp(-2 pi i m / N).
-// INV computes the unnormalised inverse.  All threads of the workgroup must call it; the data must be
-// visible to every thread on entry (barrier by the caller) and is visible on exit.
-template <int LOG2N, int BATCH, bool ROWS, bool INV>
-__device__ __forceinline__ void fft_lds(cplx *data, const cplx *tw, int tid)
+template <int LOG2N, class Map, class T>
+__device__ __forceinline__ void gather16(cplx (&v)[16], int j, const T *lds, const Map &map)
 {
-	int Ns = 1;
-	if constexpr (LOG2N % 3 == 1) { fft_pass<LOG2N, BATCH, ROWS, INV, 2>(data, tw, tid, Ns); Ns *= 2; }
-	if constexpr (LOG2N % 3 == 2) { fft_pass<LOG2N, BATCH, ROWS, INV, 4>(data, tw, tid, Ns); Ns *= 4; }
-#pragma unroll 1
-	for (int p = 0; p < LOG2N / 3; ++p) { fft_pass<LOG2N, BATCH, ROWS, INV, 8>(data, tw, tid, Ns); Ns *= 8; }
+	constexpr int P = (1 << LOG2N) / 16;
+#pragma unroll
+	for (int m = 0; m < 16; ++m) map.load(lds, j + P * m, v[m]);
 }
 
 // w_N^m from the two-level table: m = hi * 2^log2_lo + lo
@@ -147,134 +173,198 @@ __device__ __forceinline__ cplx big_twiddle(const ConvParams &p, long m)
 	return cmul(a, b);
 }
 
-template <int LOG2N1> struct ColCfg {
-	static constexpr int N1 = 1 << LOG2N1;
-	static constexpr int TW = 16;                                     // column tile width (points of n2): 256 B runs
-	static constexpr int EPT = (N1 * TW) / NT > 0 ? (N1 * TW) / NT : 1;   // points per thread
-	static constexpr size_t LDS = ((size_t) N1 * TW + N1) * sizeof(cplx);
+// ------------------------------------------------------------------ column kernels (K1, K3)
+//
+// A workgroup owns PPS pairs x TW adjacent columns; thread (q, t, j) owns the points n1 = j + P m of column t of
+// pair q.  LDS element (q, pos, t) sits at q * QS + pos * TW + t (QS padded so that the PPS lanes of one frame hit
+// different banks).  With SPLIT the real and imaginary parts make separate 8-byte round trips through one
+// half-size buffer (4 pairs x 256 x 8 points would not leave room for two workgroups per CU otherwise).
+template <int LOG2N1, int PPS> struct ColCfg {
+	static constexpr int N1 = 1 << LOG2N1, P = N1 / 16;
+	static constexpr int THREADS = (PPS == 4) ? 2 * NT : NT;
+	static constexpr int TW = THREADS / (P * PPS);
+	static constexpr bool SPLIT = (PPS == 4);
+	static constexpr int QS = N1 * TW + (PPS == 4 ? 4 : PPS == 2 ? 8 : 0);
+	static constexpr size_t LDS = (LOG2N1 > 4 ? (size_t) PPS * QS * (SPLIT ? sizeof(double) : sizeof(cplx)) : 0) + (size_t) N1 * sizeof(cplx);
 };
 
-// K1: z (two planar real rings -> one complex sequence) --FFT over n1--> twiddle --> W[pair][k1][n2]
+template <int TW> struct ColMap {           // full complex elements
+	int base;                                // q * QS + t
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + pos * TW] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + pos * TW]; }
+};
+template <int TW, int PART> struct ColMapHalf {   // one component per round trip
+	int base;
+	__device__ __forceinline__ void store(double *lds, int pos, cplx v) const { lds[base + pos * TW] = PART ? v.y : v.x; }
+	__device__ __forceinline__ void load(const double *lds, int pos, cplx &v) const { if (PART) v.y = lds[base + pos * TW]; else v.x = lds[base + pos * TW]; }
+};
+
+// the LDS exchange between the two passes of a column FFT: v (pass-1 outputs, Stockham positions) -> v (pass-2 inputs)
+template <int LOG2N1, int PPS, bool INV, class Tw>
+__device__ __forceinline__ void col_fft(cplx (&v)[16], int q, int t, int j, unsigned char *smem, const Tw &tw)
+{
+	using Cfg = ColCfg<LOG2N1, PPS>;
+	constexpr int N1 = Cfg::N1, TW = Cfg::TW, R2 = N1 / 16;
+	if constexpr (LOG2N1 == 4) {
+		pass16<4, 16, 1, INV, true>(v, j, (cplx *) nullptr, ColMap<TW>{ 0 }, tw);
+	}
+	else if constexpr (!Cfg::SPLIT) {
+		cplx *lds = reinterpret_cast<cplx *>(smem);
+		const ColMap<TW> map{ q * Cfg::QS + t };
+		pass16<LOG2N1, 16, 1, INV, false>(v, j, lds, map, tw);
+		__syncthreads();
+		gather16<LOG2N1>(v, j, lds, map);
+		pass16<LOG2N1, R2, 16, INV, true>(v, j, lds, map, tw);
+	}
+	else {
+		double *lds = reinterpret_cast<double *>(smem);
+		const ColMapHalf<TW, 0> map_re{ q * Cfg::QS + t };
+		const ColMapHalf<TW, 1> map_im{ q * Cfg::QS + t };
+		// pass 1 once, into a scratch copy that both half exchanges read
+		cplx u[16];
+#pragma unroll
+		for (int m = 0; m < 16; ++m) u[m] = v[m];
+		pass16<LOG2N1, 16, 1, INV, true>(u, j, lds, map_re, tw);     // LAST: results stay in u (u[r] <-> Stockham position 16 j + r)
+		constexpr int P = N1 / 16;
+#pragma unroll
+		for (int r = 0; r < 16; ++r) lds[map_re.base + (16 * j + r) * TW] = u[r].x;
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m].x = lds[map_re.base + (j + P * m) * TW];
+		__syncthreads();
+#pragma unroll
+		for (int r = 0; r < 16; ++r) lds[map_im.base + (16 * j + r) * TW] = u[r].y;
+		__syncthreads();
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m].y = lds[map_im.base + (j + P * m) * TW];
+		pass16<LOG2N1, R2, 16, INV, true>(v, j, lds, map_re, tw);
+	}
+}
+
+// K1: z (the pair's ring row: complex samples) --FFT over n1--> twiddle --> W[pair][k1][n2]
 template <int LOG2N1>
 __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 {
-	using Cfg = ColCfg<LOG2N1>;
-	constexpr int N1 = Cfg::N1, TW = Cfg::TW, EPT = Cfg::EPT;
+	using Cfg = ColCfg<LOG2N1, 1>;
+	constexpr int N1 = Cfg::N1, TW = Cfg::TW, P = Cfg::P;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *tw = data + N1 * TW;
+	cplx *twt = reinterpret_cast<cplx *>(smem_raw + Cfg::LDS - (size_t) N1 * sizeof(cplx));
 	const int tid = threadIdx.x;
-	const long n2_0 = (long) blockIdx.x * TW;
+	const int t = tid % TW, j = tid / TW;
+	const long n2 = (long) blockIdx.x * TW + t;
 	const long pair = p.pair0 + blockIdx.y;
-	for (int i = tid; i < N1; i += NT) tw[i] = p.tw_n1[i];
-	const long ra = p.pair_rows[2 * pair], rb = p.pair_rows[2 * pair + 1];
-	const double *rowa = (ra >= 0) ? p.ring + ra * p.ring_row_stride : nullptr;
-	const double *rowb = (rb >= 0) ? p.ring + rb * p.ring_row_stride : nullptr;
-	constexpr int BATCHL = EPT < 8 ? EPT : 8;
-#pragma unroll 1
-	for (int q0 = 0; q0 < EPT; q0 += BATCHL) {
-		double re[BATCHL], im[BATCHL];
+	for (int i = tid; i < N1; i += NT) twt[i] = p.tw_n1[i];
+	const cplx *src = p.ring + pair * p.ring_row_stride;
+	cplx v[16];
 #pragma unroll
-		for (int q = 0; q < BATCHL; ++q) {   // issue all loads of the batch before any LDS store
-			const int e = tid + (q0 + q) * NT;
-			const int n1 = e / TW, t = e % TW;
-			const long n = (long) n1 * p.N2 + n2_0 + t;
-			re[q] = 0.0; im[q] = 0.0;
-			if (e < N1 * TW && n < p.valid) {
-				const long ri = (p.win_base + n) & p.ring_mask;
-				if (rowa) re[q] = rowa[ri];
-				if (rowb) im[q] = rowb[ri];
-			}
-		}
-#pragma unroll
-		for (int q = 0; q < BATCHL; ++q) {
-			const int e = tid + (q0 + q) * NT;
-			if (e < N1 * TW) data[e] = make_double2(re[q], im[q]);
-		}
+	for (int m = 0; m < 16; ++m) {
+		const long n = (long) (j + P * m) * p.N2 + n2;
+		v[m] = (n < p.valid) ? src[(p.win_base + n) & p.ring_mask] : make_double2(0.0, 0.0);
 	}
-	__syncthreads();
-	fft_lds<LOG2N1, TW, false, false>(data, tw, tid);
+	__syncthreads();   // twiddle table visible
+	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });
 	cplx *W = p.W + (pair - p.pair0) * p.N;
-#pragma unroll 4
-	for (int e = tid; e < N1 * TW; e += NT) {
-		const int k1 = e / TW, t = e % TW;
-		const long n2 = n2_0 + t;
+#pragma unroll
+	for (int m = 0; m < 16; ++m) {
+		const long k1 = j + P * m;
 		const cplx w = big_twiddle(p, (n2 * k1) & (p.N - 1));
-		W[(long) k1 * p.N2 + n2] = cmul(data[e], w);
+		W[k1 * p.N2 + n2] = cmul(v[m], w);
 	}
 }
 
 // K3: W[pair][k1][n2] --IFFT over k1--> y[n1 N2 + n2]; valid outputs scattered into the interleaved slab.
-// blockIdx.x enumerates (tile, stream, pair-in-stream) so that the workgroups writing the 16-byte pieces of the
-// same 64-byte frames are dispatched back to back on the SAME XCD (block b runs on XCD b % 8): their partial
-// writes then meet in that XCD's L2 instead of reaching HBM as separate 32-byte sectors.
-template <int LOG2N1>
-__global__ __launch_bounds__(NT) void conv_col_inv(ConvParams p)
+// blockIdx.y = stream * groups + group; the workgroup holds PPS pairs of that stream, lanes ordered pair-fastest so
+// that the 16-byte (re, im) = (channel 2q, 2q+1) pieces of one frame leave from adjacent lanes.
+template <int LOG2N1, int PPS>
+__global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(ConvParams p)
 {
-	using Cfg = ColCfg<LOG2N1>;
-	constexpr int N1 = Cfg::N1, TW = Cfg::TW, EPT = Cfg::EPT;
+	using Cfg = ColCfg<LOG2N1, PPS>;
+	constexpr int N1 = Cfg::N1, TW = Cfg::TW, P = Cfg::P, THREADS = Cfg::THREADS;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *tw = data + N1 * TW;
+	cplx *twt = reinterpret_cast<cplx *>(smem_raw + Cfg::LDS - (size_t) N1 * sizeof(cplx));
 	const int tid = threadIdx.x;
-	// decode: linear id L = (g_hi * pps + q) * 8 + x, group g = g_hi * 8 + x, group -> (stream-in-chunk, tile)
-	const long L = blockIdx.x;
-	const int x = (int) (L & 7);
-	const long r = L >> 3;
-	const int q = (int) (r % p.pairs_per_stream);
-	const long g = (r / p.pairs_per_stream) * 8 + x;
-	const long n_tiles = p.N2 / TW;
-	if (g >= n_tiles * p.n_streams_launch) return;
-	const long tile = g % n_tiles;
-	const long s = p.stream0 + g / n_tiles;
-	const long n2_0 = tile * TW;
-	for (int i = tid; i < N1; i += NT) tw[i] = p.tw_n1[i];
-	const long pair = s * p.pairs_per_stream + q;
-	const cplx *W = p.W + (pair - p.pair0) * p.N;
-	constexpr int BATCHL = EPT < 8 ? EPT : 8;
-#pragma unroll 1
-	for (int q0 = 0; q0 < EPT; q0 += BATCHL) {
-		cplx v[BATCHL];
+	const int q = tid % PPS, t = (tid / PPS) % TW, j = tid / (PPS * TW);
+	const int groups = (p.pairs_per_stream + PPS - 1) / PPS;
+	const long s = p.stream0 + blockIdx.y / groups;
+	const int qs = (int) (blockIdx.y % groups) * PPS + q;          // pair within the stream
+	const bool active = qs < p.pairs_per_stream;
+	const long n2 = (long) blockIdx.x * TW + t;
+	for (int i = tid; i < N1; i += THREADS) twt[i] = p.tw_n1[i];
+	cplx v[16];
+	if (active) {
+		const cplx *W = p.W + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
 #pragma unroll
-		for (int qq = 0; qq < BATCHL; ++qq) {
-			const int e = tid + (q0 + qq) * NT;
-			if (e < N1 * TW) v[qq] = W[(long) (e / TW) * p.N2 + n2_0 + (e % TW)];
-		}
+		for (int m = 0; m < 16; ++m) v[m] = W[(long) (j + P * m) * p.N2];
+	}
+	else {
 #pragma unroll
-		for (int qq = 0; qq < BATCHL; ++qq) {
-			const int e = tid + (q0 + qq) * NT;
-			if (e < N1 * TW) data[e] = v[qq];
-		}
+		for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
 	}
 	__syncthreads();
-	fft_lds<LOG2N1, TW, false, true>(data, tw, tid);
+	col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
+	if (!active) return;
 	double *out = p.out + ((size_t) s * p.out_stride_frames + p.out_frame0) * p.C;
-	const int cha = p.pair_out_ch[2 * q], chb = p.pair_out_ch[2 * q + 1];
+	const int cha = p.pair_out_ch[2 * qs], chb = p.pair_out_ch[2 * qs + 1];
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
-#pragma unroll 4
-	for (int e = tid; e < N1 * TW; e += NT) {
-		const int n1 = e / TW, t = e % TW;
-		const long f = (long) n1 * p.N2 + n2_0 + t - p.first_n;
+#pragma unroll
+	for (int m = 0; m < 16; ++m) {
+		const long f = (long) (j + P * m) * p.N2 + n2 - p.first_n;
 		if (f >= 0 && f < p.out_frames) {
-			cplx v = data[e];
-			if (p.round_f32) { v.x = (double) (float) v.x; v.y = (double) (float) v.y; }
-			if (wide) *reinterpret_cast<cplx *>(out + f * p.C + cha) = v;
+			cplx y = v[m];
+			if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+			if (wide) *reinterpret_cast<cplx *>(out + f * p.C + cha) = y;
 			else {
-				if (cha >= 0) out[f * p.C + cha] = v.x;
-				if (chb >= 0) out[f * p.C + chb] = v.y;
+				if (cha >= 0) out[f * p.C + cha] = y.x;
+				if (chb >= 0) out[f * p.C + chb] = y.y;
 			}
 		}
 	}
 }
 
-// rows per workgroup so that a workgroup holds ~2048 points
+// ------------------------------------------------------------------ row kernel (K2)
+//
+// Rows of N2 = 16 * 16 * R3 points, P = N2 / 16 threads per row, 4096 / N2 rows per workgroup.  Padded LDS rows
+// (one point per 16) keep the strided Stockham stores conflict-free.  A row of <= 1024 points belongs to a single
+// wave, which then needs no workgroup barrier between passes.
 template <int LOG2N2> struct RowCfg {
-	static constexpr int N2 = 1 << LOG2N2;
-	static constexpr int RPW = (2048 / N2) > 0 ? 2048 / N2 : 1;
-	using M = LdsMap<LOG2N2, RPW, true>;
-	static constexpr size_t LDS = ((size_t) M::SIZE + N2) * sizeof(cplx);
-	static constexpr int EPT = RPW * N2 / NT;
+	static constexpr int N2 = 1 << LOG2N2, P = N2 / 16, RPW = NT / P, R3 = N2 / 256;
+	static constexpr int PITCH = N2 + N2 / 16;
+	static constexpr int NTW = 256 + 64 + 64;
+	static constexpr size_t LDS = ((size_t) RPW * PITCH + NTW) * sizeof(cplx);
+	static constexpr bool WAVE_LOCAL = (P <= 64);
 };
+
+struct RowMap {
+	int base;                                // row * PITCH
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + pos + (pos >> 4)] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + pos + (pos >> 4)]; }
+};
+
+template <bool WAVE_LOCAL> __device__ __forceinline__ void row_sync()
+{
+	if constexpr (WAVE_LOCAL) {
+		// same-wave LDS traffic is processed in order; only the compiler must not move accesses across this point
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	else __syncthreads();
+}
+
+template <int LOG2N2, bool INV, class Tw>
+__device__ __forceinline__ void row_fft(cplx (&v)[16], int j, cplx *lds, const RowMap &map, const Tw &tw)
+{
+	using Cfg = RowCfg<LOG2N2>;
+	constexpr bool WL = Cfg::WAVE_LOCAL;
+	pass16<LOG2N2, 16, 1, INV, false>(v, j, lds, map, tw);
+	row_sync<WL>();
+	gather16<LOG2N2>(v, j, lds, map);
+	row_sync<WL>();
+	pass16<LOG2N2, 16, 16, INV, false>(v, j, lds, map, tw);
+	row_sync<WL>();
+	gather16<LOG2N2>(v, j, lds, map);
+	pass16<LOG2N2, Cfg::R3, 256, INV, true>(v, j, lds, map, tw);
+}
 
 // K2: per row k1: FFT over n2, multiply by the filter spectrum (already scaled by 1/N), IFFT over k2,
 // conjugate twiddle.  MODE 1: spectrum only (filter preparation): write scale * FFT to p.Hout.
@@ -282,73 +372,67 @@ template <int LOG2N2, int MODE>
 __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 {
 	using Cfg = RowCfg<LOG2N2>;
-	using M = typename Cfg::M;
-	constexpr int N2 = Cfg::N2, RPW = Cfg::RPW, EPT = Cfg::EPT;
+	constexpr int N2 = Cfg::N2, P = Cfg::P, RPW = Cfg::RPW;
+	constexpr bool WL = Cfg::WAVE_LOCAL;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *tw = data + M::SIZE;
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + 256, *thi = tlo + 64;
 	const int tid = threadIdx.x;
-	const long k1_0 = (long) blockIdx.x * RPW;
+	const int rw = tid / P, j = tid % P;
+	const long k1 = (long) blockIdx.x * RPW + rw;
 	const long pair = p.pair0 + blockIdx.y;
-	cplx *W = p.W + (pair - p.pair0) * p.N + k1_0 * N2;
-	for (int i = tid; i < N2; i += NT) tw[i] = p.tw_n2[i];
-	{
-		cplx v[EPT];
+	cplx *W = p.W + (pair - p.pair0) * p.N + k1 * N2 + j;
+	cplx v[16];
 #pragma unroll
-		for (int q = 0; q < EPT; ++q) v[q] = W[tid + q * NT];
-#pragma unroll
-		for (int q = 0; q < EPT; ++q) { const int e = tid + q * NT; data[M::at(e / N2, e % N2)] = v[q]; }
-	}
+	for (int m = 0; m < 16; ++m) v[m] = W[P * m];
+	t256[tid] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) tlo[tid] = p.tw_n2[tid];
+	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
 	__syncthreads();
-	fft_lds<LOG2N2, RPW, true, false>(data, tw, tid);
+	const TwRow<N2> tw{ t256, tlo, thi };
+	const RowMap map{ rw * Cfg::PITCH };
+	row_fft<LOG2N2, false>(v, j, data, map, tw);
 	if (MODE == 1) {
-		cplx *H = p.Hout + k1_0 * N2;
+		cplx *H = p.Hout + k1 * N2 + j;
 #pragma unroll
-		for (int q = 0; q < EPT; ++q) {
-			const int e = tid + q * NT;
-			const cplx d = data[M::at(e / N2, e % N2)];
-			H[e] = make_double2(d.x * p.h_scale, d.y * p.h_scale);
-		}
+		for (int m = 0; m < 16; ++m) H[P * m] = make_double2(v[m].x * p.h_scale, v[m].y * p.h_scale);
 		return;
 	}
-	const cplx *H = p.H + p.pair_h[pair] * p.N + k1_0 * N2;
 	{
-		cplx h[EPT];
+		const cplx *H = p.H + p.pair_h[pair] * p.N + k1 * N2 + j;
+		cplx h[16];
 #pragma unroll
-		for (int q = 0; q < EPT; ++q) h[q] = H[tid + q * NT];
+		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
 #pragma unroll
-		for (int q = 0; q < EPT; ++q) {
-			const int e = tid + q * NT;
-			const int a = M::at(e / N2, e % N2);
-			data[a] = cmul(data[a], h[q]);
-		}
+		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], h[m]);
 	}
-	__syncthreads();
-	fft_lds<LOG2N2, RPW, true, true>(data, tw, tid);
+	row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
+	row_fft<LOG2N2, true>(v, j, data, map, tw);
 #pragma unroll
-	for (int q = 0; q < EPT; ++q) {
-		const int e = tid + q * NT;
-		const long k1 = k1_0 + e / N2, n2 = e % N2;
+	for (int m = 0; m < 16; ++m) {
+		const long n2 = j + P * m;
 		const cplx w = big_twiddle(p, (n2 * k1) & (p.N - 1));
-		W[e] = cmulc(data[M::at(e / N2, e % N2)], w);
+		W[P * m] = cmulc(v[m], w);
 	}
 }
 
-// interleaved slab -> planar rings for the selected channels (+ pass-through of the others to `out`)
+// interleaved slab -> pair rings for the selected channels (+ pass-through of the others to `out`).
+// Adjacent lanes hold adjacent channels of a frame, so the two 8-byte halves of a ring element leave together.
 __global__ __launch_bounds__(NT) void conv_deinterleave(DeintParams p)
 {
 	const int s = blockIdx.y;
 	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
 	double *out = p.out ? p.out + (size_t) s * p.out_stride_frames * p.C : nullptr;
+	double *ring = reinterpret_cast<double *>(p.ring);
 	const long n = p.frames * p.C;
 	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
 		const long t = e / p.C;
 		const int c = (int) (e - t * p.C);
-		const int r = p.row_of_channel[c];
+		const int slot = p.slot_of_channel[c];
 		double v = in[e];
-		if (r >= 0) {
+		if (slot >= 0) {
 			if (p.round_f32) v = (double) (float) v;
-			p.ring[((size_t) s * p.rows_per_stream + r) * p.ring_row_stride + ((p.pos + t) & p.ring_mask)] = v;
+			ring[2 * (((size_t) s * p.rows_per_stream + (slot >> 1)) * p.ring_row_stride + ((p.pos + t) & p.ring_mask)) + (slot & 1)] = v;
 		}
 		else if (out) out[e] = v;
 	}
@@ -397,32 +481,43 @@ __global__ __launch_bounds__(NT) void fir_direct_kernel(FirDirectParams p)
 
 // ------------------------------------------------------------------ launchers
 
-template <int L> static void launch_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t st)
+template <class K> static void grant_lds(K kernel, size_t bytes)
 {
-	using Cfg = ColCfg<L>;
-	static bool attr_set[2] = { false, false };
-	const void *fn = inverse ? (const void *) conv_col_inv<L> : (const void *) conv_col_fwd<L>;
-	if (!attr_set[inverse]) {
-		(void) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Cfg::LDS);
-		attr_set[inverse] = true;
-	}
-	if (inverse) {
-		const long groups = (p.N2 / Cfg::TW) * p.n_streams_launch;
-		const long blocks = ((groups + 7) / 8) * 8 * p.pairs_per_stream;
-		hipLaunchKernelGGL(conv_col_inv<L>, dim3((unsigned) blocks), dim3(NT), Cfg::LDS, st, p);
-	}
-	else hipLaunchKernelGGL(conv_col_fwd<L>, dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
+	(void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+}
+
+template <int L> static void launch_col_fwd(const ConvParams &p, int n_pairs, hipStream_t st)
+{
+	using Cfg = ColCfg<L, 1>;
+	static bool granted = false;
+	if (!granted) { grant_lds(conv_col_fwd<L>, Cfg::LDS); granted = true; }
+	hipLaunchKernelGGL(conv_col_fwd<L>, dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
+}
+
+template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hipStream_t st)
+{
+	using Cfg = ColCfg<L, PPS>;
+	static bool granted = false;
+	if (!granted) { grant_lds(conv_col_inv<L, PPS>, Cfg::LDS); granted = true; }
+	const int groups = (p.pairs_per_stream + PPS - 1) / PPS;
+	hipLaunchKernelGGL((conv_col_inv<L, PPS>), dim3((unsigned) (p.N2 / Cfg::TW), (unsigned) (p.n_streams_launch * groups)), dim3(Cfg::THREADS), Cfg::LDS, st, p);
+}
+
+template <int L> static void launch_col_inv(const ConvParams &p, hipStream_t st)
+{
+	if (p.pairs_per_stream >= 3) launch_col_inv_pps<L, 4>(p, st);
+	else if (p.pairs_per_stream == 2) launch_col_inv_pps<L, 2>(p, st);
+	else launch_col_inv_pps<L, 1>(p, st);
 }
 
 void launch_conv_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t st)
 {
 	switch (p.log2N1) {
-	case 3: launch_col<3>(p, inverse, n_pairs, st); break;
-	case 4: launch_col<4>(p, inverse, n_pairs, st); break;
-	case 5: launch_col<5>(p, inverse, n_pairs, st); break;
-	case 6: launch_col<6>(p, inverse, n_pairs, st); break;
-	case 7: launch_col<7>(p, inverse, n_pairs, st); break;
-	case 8: launch_col<8>(p, inverse, n_pairs, st); break;
+	case 4: if (inverse) launch_col_inv<4>(p, st); else launch_col_fwd<4>(p, n_pairs, st); break;
+	case 5: if (inverse) launch_col_inv<5>(p, st); else launch_col_fwd<5>(p, n_pairs, st); break;
+	case 6: if (inverse) launch_col_inv<6>(p, st); else launch_col_fwd<6>(p, n_pairs, st); break;
+	case 7: if (inverse) launch_col_inv<7>(p, st); else launch_col_fwd<7>(p, n_pairs, st); break;
+	case 8: if (inverse) launch_col_inv<8>(p, st); else launch_col_fwd<8>(p, n_pairs, st); break;
 	default: break;
 	}
 }
@@ -430,11 +525,10 @@ void launch_conv_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t
 template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
 	using Cfg = RowCfg<L2>;
-	static bool attr_set[2] = { false, false };
-	if (!attr_set[mode]) {
-		const void *fn = mode ? (const void *) conv_row<L2, 1> : (const void *) conv_row<L2, 0>;
-		(void) hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) Cfg::LDS);
-		attr_set[mode] = true;
+	static bool granted[2] = { false, false };
+	if (!granted[mode]) {
+		if (mode) grant_lds(conv_row<L2, 1>, Cfg::LDS); else grant_lds(conv_row<L2, 0>, Cfg::LDS);
+		granted[mode] = true;
 	}
 	dim3 grid((unsigned) (p.N1 / Cfg::RPW), n_pairs), block(NT);
 	if (mode == 1) hipLaunchKernelGGL((conv_row<L2, 1>), grid, block, Cfg::LDS, st, p);
@@ -447,6 +541,7 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 	case 9: launch_row<9>(p, mode, n_pairs, st); break;
 	case 10: launch_row<10>(p, mode, n_pairs, st); break;
 	case 11: launch_row<11>(p, mode, n_pairs, st); break;
+	case 12: launch_row<12>(p, mode, n_pairs, st); break;
 	default: break;
 	}
 }

@@ -24,14 +24,15 @@ struct alignas(16) OpDesc {
 	double h[CASCADE_L][2];              // first row of A^i, i = 0..L-1: zero-input response to the carried state
 };
 
-// A planar ring (one row per channel) that a kernel may write instead of / read as the interleaved block.
+// The FFT convolver's input ring (one row per channel PAIR, 16-byte elements (x_a[n], x_b[n]) = the complex
+// sequence the convolver transforms) that the cascade kernel may write instead of the interleaved block.
 struct PlanarRing {
-	double *base;                        // row r starts at base + r * row_stride
-	long row_stride;                     // doubles
+	double *base;                        // row r starts at base + 2 * r * row_stride (doubles)
+	long row_stride;                     // elements (16 B) per row
 	long mask;                           // ring length - 1 (power of two)
 	long pos;                            // ring index of frame 0 of this block
-	const int *row_of_channel;           // [C] -> row within the stream's group, or -1 (not routed)
-	int rows_per_stream;
+	const int *pair_ch;                  // [rows_per_stream][2] channel feeding re / im (or -1: written as 0.0)
+	int rows_per_stream;                 // pairs per stream
 };
 
 struct CascadeParams {

@@ -193,7 +193,7 @@ def test_full_size_properties(amd, tmp_path):
     y = b.run(x)
     ir = y[0, 5:5 + taps, 3].cpu().numpy()
     assert np.abs(ir - h).max() < 1e-15                      # delta in -> taps out
-    assert float(y[:, :5, :].abs().max()) < 1e-18
+    assert float(y[:, :5, :].abs().max()) < 1e-17
     # linearity + block-size invariance: (a x1 + b x2) in 3 blocks == a y1 + b y2 computed in 1 block
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     x1 = torch.rand((S, N, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
