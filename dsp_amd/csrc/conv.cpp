@@ -173,6 +173,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 		feeder->ring.pos = 0;
 		feeder->ring.pair_ch = pair_out_ch.as<int>();
 		feeder->ring.rows_per_stream = pps;
+		feeder->ring.consecutive_pairs = (n_filters == 1 && (ch_in % 2) == 0) ? 1 : 0;
 		feeder->write_interleaved = 0;
 		feeder_ = feeder;
 		fed = true;

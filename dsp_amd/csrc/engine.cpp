@@ -141,6 +141,33 @@ bool CascadeStage::finalize()
 		for (int j = 0; j < n_ops; ++j)
 			host[(size_t) c * n_ops + j] = cols[j][c];
 	if (!ops.upload(host.data(), host.size() * sizeof(OpDesc))) return false;
+	// tables of the fast kernel: wave-uniform constants (scalar loads) and per-lane carry matrices
+	{
+		std::vector<double> tab((size_t) ch_in * n_ops * FOP_DOUBLES, 0.0), q((size_t) ch_in * n_ops * FQ_DOUBLES, 0.0);
+		int lg = 0;
+		while ((1 << lg) < CASCADE_L) ++lg;
+		for (size_t e = 0; e < host.size(); ++e) {
+			const OpDesc &od = host[e];
+			double *d = &tab[e * FOP_DOUBLES];
+			long long kind = od.kind;
+			memcpy(&d[0], &kind, sizeof(kind));
+			d[1] = od.g;
+			for (int i = 0; i < 5; ++i) d[2 + i] = od.c[i];
+			if (od.kind != OP_BIQUAD) continue;
+			for (int k = 0; k < 5; ++k) for (int i = 0; i < 4; ++i) d[FOP_PW + 4 * k + i] = od.P[lg + k][i];
+			// Q[i] = (A^L)^(i+1) in extended precision
+			long double A[4] = { -(long double) od.c[3], 1.0L, -(long double) od.c[4], 0.0L }, AL[4] = { 1.0L, 0.0L, 0.0L, 1.0L }, t[4];
+			for (int i = 0; i < CASCADE_L; ++i) { mat_mul(AL, A, t); memcpy(AL, t, sizeof(t)); }
+			long double Q[4] = { AL[0], AL[1], AL[2], AL[3] };
+			for (int i = 0; i < 16; ++i) {
+				for (int k = 0; k < 4; ++k) q[e * FQ_DOUBLES + 4 * i + k] = (double) Q[k];
+				mat_mul(Q, AL, t);
+				memcpy(Q, t, sizeof(t));
+			}
+		}
+		if (!fops.upload(tab.data(), tab.size() * sizeof(double))) return false;
+		if (!fq.upload(q.data(), q.size() * sizeof(double))) return false;
+	}
 	if (!state.alloc((size_t) S * ch_in * n_ops * 2 * sizeof(double))) return false;
 	// channel group per workgroup: the whole stream when it fits in LDS (contiguous, vectorisable loads)
 	Cg = (ch_in <= 16) ? ch_in : 8;
@@ -168,9 +195,12 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.C = ch_in; p.cg0 = 0; p.Cg = Cg;
 	p.n_ops = n_ops;
 	p.ops = ops.as<OpDesc>();
+	p.fops = fops.as<double>();
+	p.fq = fq.as<double>();
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
+	{ static const char *dbg = getenv("DSP_AMD_CASCADE_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
 	{ ProfScope ps("cascade_kernel", st); launch_cascade(p, S, st); }
 	if (ring.base) ring.pos = (ring.pos + frames) & ring.mask;
 	return frames;

@@ -26,6 +26,8 @@
 // before the current tile's recurrences so HBM latency hides under the fp64 work; the per-(channel, op)
 // coefficients are staged in LDS once per launch and read as broadcasts.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include "kparams.h"
 
 namespace dspamd {
@@ -73,14 +75,15 @@ __device__ __forceinline__ void row_scan(double &m0, double &m1, const double (&
 	m0 += Pw[12] * t0 + Pw[13] * t1; m1 += Pw[14] * t0 + Pw[15] * t1;
 }
 
-// ops: LDS, compact descriptors of this channel: [n_ops][OPL_DOUBLES]
-template <int L, int LOG2L>
+// ops: LDS descriptors of this channel: [n_ops][OPD] doubles = kind, g, c0..c4, pad, then matrices; the five
+// matrices P^(L), P^(2L), P^(4L), P^(8L), P^(16L) start at od[PW_OFF]
+template <int L, int OPD, int PW_OFF>
 __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n_ops, double *st /* LDS [n_ops][2] */,
                                         int lane, int last_lane)
 {
 	const int row = lane >> 4;
 	for (int j = 0; j < n_ops; ++j) {
-		const double *od = ops + j * OPL_DOUBLES;
+		const double *od = ops + j * OPD;
 		const int kind = __double_as_longlong(od[0]);
 		if (kind == OP_MUL) {
 			const double g = od[1];
@@ -98,9 +101,9 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n
 			const double xin0 = st[2*j], xin1 = st[2*j + 1];
 			double Pw[16], P16[4];
 #pragma unroll
-			for (int i = 0; i < 16; ++i) Pw[i] = od[8 + 4 * LOG2L + i];          // P^(L), P^(2L), P^(4L), P^(8L)
+			for (int i = 0; i < 16; ++i) Pw[i] = od[PW_OFF + i];          // P^(L), P^(2L), P^(4L), P^(8L)
 #pragma unroll
-			for (int i = 0; i < 4; ++i) P16[i] = od[8 + 4 * (LOG2L + 4) + i];    // P^(16L): one whole row
+			for (int i = 0; i < 4; ++i) P16[i] = od[PW_OFF + 16 + i];    // P^(16L): one whole row
 			double m0 = 0.0, m1 = 0.0;
 #pragma unroll
 			for (int i = 0; i < L; ++i) {
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 				double v[L16];
 #pragma unroll
 				for (int i = 0; i < L16; ++i) v[i] = row[lane * (L16 + 1) + i];
-				run_ops<L16, 4>(v, ops, p.n_ops, cst, lane, 63);
+				run_ops<L16, OPL_DOUBLES, 8 + 4 * 4>(v, ops, p.n_ops, cst, lane, 63);
 #pragma unroll
 				for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
 			}
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 					const int nvalid = min(64, nfr - t1);
 					double v[1];
 					v[0] = (t < nfr) ? row[lds_index(t)] : 0.0;
-					run_ops<1, 0>(v, ops, p.n_ops, cst, lane, nvalid - 1);
+					run_ops<1, OPL_DOUBLES, 8>(v, ops, p.n_ops, cst, lane, nvalid - 1);
 					if (t < nfr) row[lds_index(t)] = v[0];
 				}
 			}
@@ -284,13 +287,278 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast path: whole tiles of 64 * L frames (L = CASCADE_L = 16), CG channels (CG even) per workgroup, one wave
+// per channel.
+//
+// Per tile the workgroup runs two phases separated by LDS-only barriers:
+//   I/O     every thread owns K = L / 2 slots (frame t, channel pair cp) of the LDS tile: it reads the finished
+//           results of the previous tile out of its slots, drops the prefetched inputs of this tile into the same
+//           slots, sends the results to HBM (interleaved slab and / or the convolver's pair ring -- both are
+//           16-byte (c, c+1) elements, i.e. exactly a slot) and issues the loads of the next tile.
+//   compute each wave reads its channel's row (L samples per lane), runs all sections, writes the row back.
+// Loads and stores are asynchronous across the compute phase (lds_barrier does not drain vmcnt): HBM traffic and
+// the fp64 recurrences overlap.  With only two waves per SIMD (one wave per channel is all the parallelism a
+// recurrence offers) the compute phase is latency-bound unless nothing waits on memory, so
+//   * the wave-uniform constants of a section come through SCALAR loads into SGPRs (no LDS round trips, no VGPRs),
+//     the next section's recurrence coefficients one section ahead;
+//   * the second scan of the generic kernel is replaced by one 2x2 product with a per-lane matrix
+//     Q[lane % 16] = P^(L (lane % 16 + 1)) (LDS table, requested before the recurrence that hides its latency);
+//   * the zero-input response of a lane's incoming state (2 FMA + 1 MUL per sample, no constants but the pole
+//     coefficients) is fused into the NEXT section's recurrence loop, whose dependent chain it fills.
+template <int CG> struct FastCfg {
+	static constexpr int L = CASCADE_L, TILE = 64 * L, NTH = 64 * CG, K = L / 2, HP = CG / 2;
+	static constexpr int CHS = 64 * (L + 1) + 16 / CG;      // row stride: rows of the CG / 2 pairs on distinct bank groups
+};
+
+// zero-input response still to be added to v: r[i] = x0, (x0, x1) <- (nc3 x0 + x1, nc4 x0); all zero = nothing pending
+struct PendingFix { double x0, x1, nc3, nc4; };
+
+template <int L>
+__device__ __forceinline__ void apply_fix(double (&v)[L], PendingFix f)
+{
+#pragma unroll
+	for (int i = 0; i < L; ++i) {
+		const double r = f.x0;
+		v[i] += r;
+		f.x0 = fma(f.nc3, r, f.x1);
+		f.x1 = f.nc4 * r;
+	}
+}
+
+// first 64 bytes of an op's constants: what the recurrence loop needs, fetched one op ahead
+struct OpHead { long long kind; double g, c0, c1, c2, c3, c4, pad; };
+
+__device__ __forceinline__ OpHead load_head(const double *__restrict__ od)
+{
+	OpHead h;
+	h.kind = __double_as_longlong(od[0]); h.g = od[1]; h.c0 = od[2]; h.c1 = od[3]; h.c2 = od[4]; h.c3 = od[5]; h.c4 = od[6]; h.pad = 0.0;
+	return h;
+}
+
+// cf: this channel's [n_ops][FOP_DOUBLES] constants in global memory (uniform address -> scalar loads);
+// q: LDS [n_ops][FQ_DOUBLES]; st: LDS [n_ops][2]
+template <int L>
+__device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__restrict__ cf, const double *q, int n_ops, double *st, int lane)
+{
+	const int row = lane >> 4;
+	PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
+	OpHead cur = load_head(cf);
+	for (int j = 0; j < n_ops; ++j) {
+		const double *__restrict__ od = cf + j * FOP_DOUBLES;
+		// next op's head: in flight during this op
+		const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : j) * FOP_DOUBLES);
+		if (cur.kind == OP_BIQUAD) {
+			// requested now, consumed after the recurrence that hides their latency
+			double Pw[16], P16[4];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];
+#pragma unroll
+			for (int i = 0; i < 4; ++i) P16[i] = od[FOP_P16 + i];
+			const double2 qa = *reinterpret_cast<const double2 *>(q + j * FQ_DOUBLES + 4 * (lane & 15));
+			const double2 qb = *reinterpret_cast<const double2 *>(q + j * FQ_DOUBLES + 4 * (lane & 15) + 2);
+			const double2 xin = *reinterpret_cast<const double2 *>(st + 2 * j);
+			__builtin_amdgcn_sched_barrier(0);
+			const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, nc3 = -cur.c3, nc4 = -cur.c4;
+			double m0 = 0.0, m1 = 0.0;
+			{
+				// zero-state recurrence of this section on (previous section's output + its pending zero-input response)
+				double x0 = fix.x0, x1 = fix.x1;
+#pragma unroll
+				for (int i = 0; i < L; ++i) {
+					const double s = v[i] + x0;
+					const double t = fix.nc4 * x0;
+					x0 = fma(fix.nc3, x0, x1);
+					x1 = t;
+					const double r = fma(c0, s, m0);
+					m0 = fma(nc3, r, fma(c1, s, m1));
+					m1 = fma(nc4, r, c2 * s);
+					v[i] = r;
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			// within-row inclusive scan of the zero-state end states; row totals in lanes 15, 31, 47
+			row_scan(m0, m1, Pw);
+			const double T00 = readlane_f64(m0, 15), T01 = readlane_f64(m1, 15);
+			const double T10 = readlane_f64(m0, 31), T11 = readlane_f64(m1, 31);
+			const double T20 = readlane_f64(m0, 47), T21 = readlane_f64(m1, 47);
+			// true state at the end of each row: E_(-1) = carried state, E_r = P^(16L) E_(r-1) + T_r
+			const double E00 = fma(P16[0], xin.x, fma(P16[1], xin.y, T00)), E01 = fma(P16[2], xin.x, fma(P16[3], xin.y, T01));
+			const double E10 = fma(P16[0], E00, fma(P16[1], E01, T10)), E11 = fma(P16[2], E00, fma(P16[3], E01, T11));
+			const double E20 = fma(P16[0], E10, fma(P16[1], E11, T20)), E21 = fma(P16[2], E10, fma(P16[3], E11, T21));
+			const double cr0 = (row == 0) ? xin.x : (row == 1) ? E00 : (row == 2) ? E10 : E20;
+			const double cr1 = (row == 0) ? xin.y : (row == 1) ? E01 : (row == 2) ? E11 : E21;
+			m0 = fma(qa.x, cr0, fma(qa.y, cr1, m0));        // true state after this lane's samples
+			m1 = fma(qb.x, cr0, fma(qb.y, cr1, m1));
+			double x0 = dpp_f64<DPP_WAVE_SHR1>(m0), x1 = dpp_f64<DPP_WAVE_SHR1>(m1);
+			if (lane == 0) { x0 = xin.x; x1 = xin.y; }
+			fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
+			// state after the last lane's samples = the reference's (m0, m1) at that point
+			if (lane == 63) *reinterpret_cast<double2 *>(st + 2 * j) = make_double2(m0, m1);
+		}
+		else if (cur.kind == OP_MUL || cur.kind == OP_ADD) {
+			apply_fix<L>(v, fix);
+			fix.x0 = 0.0; fix.x1 = 0.0; fix.nc3 = 0.0; fix.nc4 = 0.0;
+			const double g = cur.g;
+			if (cur.kind == OP_MUL) {
+#pragma unroll
+				for (int i = 0; i < L; ++i) v[i] = __dmul_rn(v[i], g);
+			}
+			else {
+#pragma unroll
+				for (int i = 0; i < L; ++i) v[i] = __dadd_rn(v[i], g);
+			}
+		}
+		cur = nxt;
+	}
+	apply_fix<L>(v, fix);
+}
+
+template <int CG>
+__global__ __launch_bounds__(64 * CG) void cascade_fast(CascadeParams p, const double *__restrict__ fops)
+{
+	using Cfg = FastCfg<CG>;
+	constexpr int L = Cfg::L, TILE = Cfg::TILE, NTH = Cfg::NTH, K = Cfg::K, HP = Cfg::HP, CHS = Cfg::CHS;
+	extern __shared__ __attribute__((aligned(16))) double smem[];
+	const int s = blockIdx.x;
+	const int c0 = p.cg0 + blockIdx.y * CG;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	double *tile = smem;                                        // [CG][CHS]
+	double *st = tile + (size_t) CG * CHS;                      // [CG][n_ops][2]
+	double *qt = st + (size_t) CG * p.n_ops * 2;                // [CG][n_ops][FQ_DOUBLES]
+
+	const int n_st = CG * p.n_ops * 2;
+	double *gstate = p.state + ((size_t) s * p.C + c0) * p.n_ops * 2;
+	for (int i = tid; i < n_st; i += NTH) st[i] = gstate[i];
+	for (int i = tid; i < CG * p.n_ops * FQ_DOUBLES; i += NTH) qt[i] = p.fq[(size_t) c0 * p.n_ops * FQ_DOUBLES + i];
+
+	const long n_full = p.frames / TILE;
+	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C + c0;
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.C + c0;
+	// slot k of this thread: frame t_k = (tid + k NTH) / HP, pair cp (HP divides NTH: one cp per thread)
+	const int cp = tid % HP;
+	double2 *ring = p.ring.base ? reinterpret_cast<double2 *>(p.ring.base) + ((size_t) s * p.ring.rows_per_stream + (c0 >> 1) + cp) * p.ring.row_stride : nullptr;
+	int tk[K], la[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		tk[k] = (tid + k * NTH) / HP;
+		la[k] = (2 * cp) * CHS + tk[k] + tk[k] / L;
+	}
+	double2 pf[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k) pf[k] = *reinterpret_cast<const double2 *>(in + (size_t) tk[k] * p.C + 2 * cp);
+	const double *__restrict__ cf = fops + (size_t) (c0 + wave) * p.n_ops * FOP_DOUBLES;
+	const double *wq = qt + (size_t) wave * p.n_ops * FQ_DOUBLES;
+	double *row = tile + wave * CHS;
+	double *cst = st + wave * p.n_ops * 2;
+	__syncthreads();
+
+	for (long tl = 0; tl <= n_full; ++tl) {
+		// ---- I/O phase ----
+		double2 r[K];
+		if (tl > 0) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) r[k] = make_double2(tile[la[k]], tile[la[k] + CHS]);
+		}
+		if (tl < n_full) {
+#pragma unroll
+			for (int k = 0; k < K; ++k) { tile[la[k]] = pf[k].x; tile[la[k] + CHS] = pf[k].y; }
+		}
+		if (tl > 0 && !(p.debug & 1)) {
+			const long t0 = (tl - 1) * TILE;
+			if (p.write_interleaved) {
+#pragma unroll
+				for (int k = 0; k < K; ++k) *reinterpret_cast<double2 *>(out + (size_t) (t0 + tk[k]) * p.C + 2 * cp) = r[k];
+			}
+			if (ring) {
+#pragma unroll
+				for (int k = 0; k < K; ++k) ring[(p.ring.pos + t0 + tk[k]) & p.ring.mask] = r[k];
+			}
+		}
+		if (tl + 1 < n_full && !(p.debug & 2)) {
+			const double *nx = in + (size_t) (tl + 1) * TILE * p.C;
+#pragma unroll
+			for (int k = 0; k < K; ++k) pf[k] = *reinterpret_cast<const double2 *>(nx + (size_t) tk[k] * p.C + 2 * cp);
+		}
+		if (tl == n_full) break;
+		lds_barrier();
+		// ---- compute phase: wave = channel ----
+		{
+			double v[L];
+#pragma unroll
+			for (int i = 0; i < L; ++i) v[i] = row[lane * (L + 1) + i];
+			run_ops_fast<L>(v, cf, wq, p.n_ops, cst, lane);
+#pragma unroll
+			for (int i = 0; i < L; ++i) row[lane * (L + 1) + i] = v[i];
+		}
+		lds_barrier();
+	}
+	for (int i = tid; i < n_st; i += NTH) gstate[i] = st[i];
+}
+
+template <int CG> static size_t fast_lds_bytes(int n_ops)
+{
+	using Cfg = FastCfg<CG>;
+	return ((size_t) CG * Cfg::CHS + (size_t) CG * n_ops * 2 + (size_t) CG * n_ops * FQ_DOUBLES) * sizeof(double);
+}
+
+template <int CG> static bool try_launch_fast(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	const size_t lds = fast_lds_bytes<CG>(p.n_ops);
+	if (lds > 160 * 1024) return false;
+	static size_t granted = 0;
+	if (lds > granted) {
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_fast<CG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		granted = lds;
+	}
+	dim3 grid(n_streams, p.C / CG), block(64 * CG);
+	hipLaunchKernelGGL((cascade_fast<CG>), grid, block, lds, stream, p, p.fops);
+	return true;
+}
+
+// 0 = not eligible; otherwise the number of leading frames the fast kernel took
+static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	static int cfg_cg = -1;
+	if (cfg_cg < 0) {
+		const char *e = getenv("DSP_AMD_CASCADE_FAST");     // channels per workgroup (8, 4, 2) or 0 to disable
+		cfg_cg = e ? atoi(e) : 8;
+	}
+	if (cfg_cg == 0 || (p.C & 1) || p.cg0 != 0 || !p.fops) return 0;
+	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
+	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
+	const long n_full = p.frames / CASCADE_TILE;
+	if (n_full < 1) return 0;
+	// the widest channel group that divides C and whose tables fit in LDS
+	for (int cg = cfg_cg; cg >= 2; cg >>= 1) {
+		if (p.C % cg) continue;
+		bool ok = false;
+		if (cg == 8) ok = try_launch_fast<8>(p, n_streams, stream);
+		else if (cg == 4) ok = try_launch_fast<4>(p, n_streams, stream);
+		else if (cg == 2) ok = try_launch_fast<2>(p, n_streams, stream);
+		if (ok) return n_full * CASCADE_TILE;
+	}
+	return 0;
+}
+
 size_t cascade_lds_bytes(int Cg, int n_ops)
 {
 	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2 + (size_t) Cg * n_ops * OPL_DOUBLES) * sizeof(double);
 }
 
-void launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream)
+void launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
 {
+	CascadeParams p = p0;
+	const long done = launch_cascade_fast(p0, n_streams, stream);
+	if (done > 0) {
+		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block
+		if (done == p0.frames) return;
+		p.in = p0.in + (size_t) done * p0.C;
+		p.out = p0.out + (size_t) done * p0.C;
+		p.frames = p0.frames - done;
+		if (p.ring.base) p.ring.pos = (p0.ring.pos + done) & p0.ring.mask;
+	}
 	const int n_groups = (p.C - p.cg0 + p.Cg - 1) / p.Cg;
 	const int waves = p.Cg < 8 ? (p.Cg < 1 ? 1 : p.Cg) : 8;
 	dim3 grid(n_streams, n_groups), block(64 * waves);

@@ -212,7 +212,7 @@ __device__ __forceinline__ void col_fft(cplx (&v)[16], int q, int t, int j, unsi
 		cplx *lds = reinterpret_cast<cplx *>(smem);
 		const ColMap<TW> map{ q * Cfg::QS + t };
 		pass16<LOG2N1, 16, 1, INV, false>(v, j, lds, map, tw);
-		__syncthreads();
+		lds_barrier();
 		gather16<LOG2N1>(v, j, lds, map);
 		pass16<LOG2N1, R2, 16, INV, true>(v, j, lds, map, tw);
 	}
@@ -228,13 +228,13 @@ __device__ __forceinline__ void col_fft(cplx (&v)[16], int q, int t, int j, unsi
 		constexpr int P = N1 / 16;
 #pragma unroll
 		for (int r = 0; r < 16; ++r) lds[map_re.base + (16 * j + r) * TW] = u[r].x;
-		__syncthreads();
+		lds_barrier();
 #pragma unroll
 		for (int m = 0; m < 16; ++m) v[m].x = lds[map_re.base + (j + P * m) * TW];
-		__syncthreads();
+		lds_barrier();
 #pragma unroll
 		for (int r = 0; r < 16; ++r) lds[map_im.base + (16 * j + r) * TW] = u[r].y;
-		__syncthreads();
+		lds_barrier();
 #pragma unroll
 		for (int m = 0; m < 16; ++m) v[m].y = lds[map_im.base + (j + P * m) * TW];
 		pass16<LOG2N1, R2, 16, INV, true>(v, j, lds, map_re, tw);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 		const long n = (long) (j + P * m) * p.N2 + n2;
 		v[m] = (n < p.valid) ? src[(p.win_base + n) & p.ring_mask] : make_double2(0.0, 0.0);
 	}
-	__syncthreads();   // twiddle table visible
+	lds_barrier();   // twiddle table visible (the data loads stay in flight)
 	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });
 	cplx *W = p.W + (pair - p.pair0) * p.N;
 #pragma unroll
@@ -300,7 +300,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 #pragma unroll
 		for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
 	}
-	__syncthreads();
+	lds_barrier();
 	col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
 	if (!active) return;
 	double *out = p.out + ((size_t) s * p.out_stride_frames + p.out_frame0) * p.C;
@@ -348,7 +348,7 @@ template <bool WAVE_LOCAL> __device__ __forceinline__ void row_sync()
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
-	else __syncthreads();
+	else lds_barrier();
 }
 
 template <int LOG2N2, bool INV, class Tw>
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	t256[tid] = p.tw_n2[tid * (N2 / 256)];
 	if (tid < 64) tlo[tid] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
-	__syncthreads();
+	lds_barrier();
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	row_fft<LOG2N2, false>(v, j, data, map, tw);

@@ -24,6 +24,14 @@ struct alignas(16) OpDesc {
 	double h[CASCADE_L][2];              // first row of A^i, i = 0..L-1: zero-input response to the carried state
 };
 
+// Tables of the fast cascade kernel (kernels_cascade.hip, cascade_fast), per (channel, op), L = CASCADE_L:
+//   fops [C][n_ops][FOP_DOUBLES]  wave-uniform constants, fetched with SCALAR loads (they live in SGPRs):
+//        [0] kind (int64 bits)  [1] g  [2..6] c0..c4  [7] pad
+//        [8..23] P^(L), P^(2L), P^(4L), P^(8L)  (row scan steps)   [24..27] P^(16L)  (row -> row carry)   [28..31] pad
+//   fq   [C][n_ops][16][4]        Q[i] = P^(L (i + 1)): carry of the previous row's end state to lane i of a row
+// with P = A = [[-c3, 1], [-c4, 0]].
+constexpr int FOP_DOUBLES = 32, FOP_PW = 8, FOP_P16 = 24, FQ_DOUBLES = 64;
+
 // The FFT convolver's input ring (one row per channel PAIR, 16-byte elements (x_a[n], x_b[n]) = the complex
 // sequence the convolver transforms) that the cascade kernel may write instead of the interleaved block.
 struct PlanarRing {
@@ -33,6 +41,7 @@ struct PlanarRing {
 	long pos;                            // ring index of frame 0 of this block
 	const int *pair_ch;                  // [rows_per_stream][2] channel feeding re / im (or -1: written as 0.0)
 	int rows_per_stream;                 // pairs per stream
+	int consecutive_pairs;               // pair q = channels (2q, 2q+1) for every q
 };
 
 struct CascadeParams {
@@ -44,9 +53,12 @@ struct CascadeParams {
 	int cg0, Cg;                         // channel group handled by blockIdx.y: [cg0 + y*Cg, ...)
 	int n_ops;
 	const OpDesc *ops;                   // [C][n_ops]
+	const double *fops;                  // [C][n_ops][FOP_DOUBLES] fast-kernel constants (scalar loads)
+	const double *fq;                    // [C][n_ops][FQ_DOUBLES] per-lane carry matrices
 	double *state;                       // [S][C][n_ops][2]
 	PlanarRing ring;                     // optional second destination (ring.base != nullptr)
 	int write_interleaved;               // 0: only the ring is written
+	int debug;                           // experiment switches (DSP_AMD_CASCADE_DEBUG): 1 = no stores, 2 = no reloads
 };
 
 // ---- pointwise kernels ----
@@ -74,5 +86,17 @@ struct ConvGeom {
 	int log2N, log2N1, log2N2;           // N = N1 * N2 complex points
 	long N, N1, N2;
 };
+
+#ifdef __HIPCC__
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)), which would serialise prefetches and fire-and-forget stores with the
+// compute phase they are meant to overlap.
+__device__ __forceinline__ void lds_barrier()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#endif
 
 }  // namespace dspamd

@@ -14,15 +14,15 @@ public:
 	bool in_place_ok() const override { return true; }
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
-	size_t device_bytes() const override { return ops.bytes + state.bytes; }
+	size_t device_bytes() const override { return ops.bytes + state.bytes + fops.bytes + fq.bytes; }
 	// optional planar destination owned by the following FFT convolver
-	PlanarRing ring = { nullptr, 0, 0, 0, nullptr, 0 };
+	PlanarRing ring = { nullptr, 0, 0, 0, nullptr, 0, 0 };
 	int write_interleaved = 1;
 	int n_ops = 0, Cg = 1;
 private:
 	std::vector<std::vector<OpDesc>> cols;   // [op][channel]
 	std::vector<std::string> names;
-	DevBuf ops, state;
+	DevBuf ops, state, fops, fq;
 };
 
 class RemixStage : public Stage {
