@@ -52,6 +52,10 @@ private:
 	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
 	bool fed = false, all_selected = false;
 	long pairs_per_chunk = 0;
+	int n_sub = 1;                       // chunks in flight on separate HIP streams (each with its own W)
+	std::vector<hipStream_t> sub;
+	std::vector<hipEvent_t> sub_done;
+	hipEvent_t ev_start = nullptr;
 	std::string name;
 	CascadeStage *feeder_ = nullptr;
 	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_h, pair_out_ch, slot_of_channel;
@@ -161,7 +165,17 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 		chunk_streams = std::max<long>(1, std::min<long>(S, (long) (chunk_mb / per_stream_mb)));
 	}
 	pairs_per_chunk = chunk_streams * pps;
-	if (!W.alloc((size_t) pairs_per_chunk * N * sizeof(double2), false)) return false;
+	const char *senv = getenv("DSP_AMD_CONV_SUBSTREAMS");
+	n_sub = (senv && chunk_streams < S) ? std::max(1, std::min(8, atoi(senv))) : 1;
+	if (!W.alloc((size_t) n_sub * pairs_per_chunk * N * sizeof(double2), false)) return false;
+	if (n_sub > 1) {
+		sub.resize(n_sub); sub_done.resize(n_sub);
+		for (int k = 0; k < n_sub; ++k) {
+			if (!hip_ok(hipStreamCreateWithFlags(&sub[k], hipStreamNonBlocking), "hipStreamCreate")) return false;
+			if (!hip_ok(hipEventCreateWithFlags(&sub_done[k], hipEventDisableTiming), "hipEventCreate")) return false;
+		}
+		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
+	}
 	if (!H.alloc((size_t) n_filters * N * sizeof(double2), false)) return false;
 	if (!prepare_filters(sp)) return false;
 
@@ -237,6 +251,26 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 		p.out_stride_frames = out_stride;
 		p.out_frame0 = off;
 		p.out_frames = f;
+		if (n_sub > 1) {
+			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
+			// every chunk's W is small enough to live in the Infinity Cache between its three launches
+			(void) hipEventRecord(ev_start, st);
+			for (int k = 0; k < n_sub; ++k) (void) hipStreamWaitEvent(sub[k], ev_start, 0);
+			long c = 0;
+			for (long s0 = 0; s0 < S; s0 += chunk_streams, ++c) {
+				const long ns = std::min<long>(chunk_streams, S - s0);
+				const int k = (int) (c % n_sub);
+				p.pair0 = s0 * pps;
+				p.stream0 = s0;
+				p.n_streams_launch = ns;
+				p.W = W.as<double2>() + (size_t) k * pairs_per_chunk * N;
+				launch_conv_col(p, false, (int) (ns * pps), sub[k]);
+				launch_conv_row(p, 0, (int) (ns * pps), sub[k]);
+				launch_conv_col(p, true, (int) (ns * pps), sub[k]);
+			}
+			for (int k = 0; k < n_sub; ++k) { (void) hipEventRecord(sub_done[k], sub[k]); (void) hipStreamWaitEvent(st, sub_done[k], 0); }
+			continue;
+		}
 		for (long s0 = 0; s0 < S; s0 += chunk_streams) {
 			const long ns = std::min<long>(chunk_streams, S - s0);
 			p.pair0 = s0 * pps;

@@ -28,6 +28,7 @@
 //      - every global access is a 16-byte lane access in runs of >= 128 B; K3 gathers the pairs of a stream in
 //        one workgroup so that whole 64-byte frames leave in 512-byte runs.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kparams.h"
 #include "fft_params.h"
 
@@ -241,7 +242,7 @@ __device__ __forceinline__ void col_fft(cplx (&v)[16], int q, int t, int j, unsi
 	}
 }
 
-// K1: z (the pair's ring row: complex samples) --FFT over n1--> twiddle --> W[pair][k1][n2]
+// K1: z (the pair's ring row: complex samples) --FFT over n1--> W[pair][k1][n2]
 template <int LOG2N1>
 __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 {
@@ -263,13 +264,10 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 	}
 	lds_barrier();   // twiddle table visible (the data loads stay in flight)
 	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });
+	// the inter-pass twiddle w_N^(n2 k1) is applied by K2 when it reads the row (per row it is a geometric sequence in n2)
 	cplx *W = p.W + (pair - p.pair0) * p.N;
 #pragma unroll
-	for (int m = 0; m < 16; ++m) {
-		const long k1 = j + P * m;
-		const cplx w = big_twiddle(p, (n2 * k1) & (p.N - 1));
-		W[k1 * p.N2 + n2] = cmul(v[m], w);
-	}
+	for (int m = 0; m < 16; ++m) W[(long) (j + P * m) * p.N2 + n2] = v[m];
 }
 
 // K3: W[pair][k1][n2] --IFFT over k1--> y[n1 N2 + n2]; valid outputs scattered into the interleaved slab.
@@ -329,7 +327,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 template <int LOG2N2> struct RowCfg {
 	static constexpr int N2 = 1 << LOG2N2, P = N2 / 16, RPW = NT / P, R3 = N2 / 256;
 	static constexpr int PITCH = N2 + N2 / 16;
-	static constexpr int NTW = 256 + 64 + 64;
+	static constexpr int NTW = 256 + 64 + 64 + RPW * 16;   // W_256, W_N2 lo / hi, per-row inter-pass twiddle steps
 	static constexpr size_t LDS = ((size_t) RPW * PITCH + NTW) * sizeof(cplx);
 	static constexpr bool WAVE_LOCAL = (P <= 64);
 };
@@ -366,6 +364,17 @@ __device__ __forceinline__ void row_fft(cplx (&v)[16], int j, cplx *lds, const R
 	pass16<LOG2N2, Cfg::R3, 256, INV, true>(v, j, lds, map, tw);
 }
 
+// The inter-pass twiddle of row k1 at position n2 = j0 + off_q:  w_N^(k1 n2) = w_N^(k1 j0) * w_N^(k1 off_q).
+// The second factor is the same for every thread of the row: lanes 0..15 of each wave fetch the 16 steps into LDS
+// once, so a thread pays one table lookup (two gathered loads) instead of sixteen.  The first 16 threads of a row
+// compute its steps
+// (the caller's next workgroup barrier publishes them)
+template <class OffFn>
+__device__ __forceinline__ void row_twiddle_steps(const ConvParams &p, long k1, int j, cplx *steps, OffFn off)
+{
+	if (j < 16) steps[j] = big_twiddle(p, (k1 * off(j)) & (p.N - 1));
+}
+
 // K2: per row k1: FFT over n2, multiply by the filter spectrum (already scaled by 1/N), IFFT over k2,
 // conjugate twiddle.  MODE 1: spectrum only (filter preparation): write scale * FFT to p.Hout.
 template <int LOG2N2, int MODE>
@@ -388,7 +397,12 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	t256[tid] = p.tw_n2[tid * (N2 / 256)];
 	if (tid < 64) tlo[tid] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
+	cplx *steps = thi + 64 + rw * 16;
+	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
+	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
 	lds_barrier();
+#pragma unroll
+	for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], cmul(twb, steps[m]));
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	row_fft<LOG2N2, false>(v, j, data, map, tw);
@@ -409,10 +423,102 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
 	row_fft<LOG2N2, true>(v, j, data, map, tw);
 #pragma unroll
+	for (int m = 0; m < 16; ++m) W[P * m] = cmulc(v[m], cmul(twb, steps[m]));
+}
+
+// K2 for rows of N2 = WV * 1024 points (WV = 2, 4): the row FFT is itself split 4-step style so that all but one
+// exchange per direction stay inside a wave.  With n2 = a + 1024 b and k2 = WV ka + kb:
+//   forward   Z_kb[a] = w_N2^(a kb) sum_b x[a + 1024 b] w_WV^(b kb)      radix-WV butterflies on registers (a thread
+//                                                                        loads its own WV blocks), then ONE
+//                                                                        cross-wave exchange: wave kb collects Z_kb
+//             X[WV ka + kb] = sum_a Z_kb[a] w_1024^(a ka)                1024-point FFT inside wave kb (no barriers)
+//   multiply by H, which filter preparation (MODE 1) stores in this kernel's own (kb, ka) order
+//   inverse   the mirror image: 1024-point IFFT inside the wave, conj twiddle, ONE cross-wave exchange, radix-WV
+//             butterflies, y[a + 1024 b] leaves in contiguous runs.
+// Two workgroup barriers per row instead of the seven of the generic 3-pass kernel.
+template <int WV, int MODE>
+__global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
+{
+	using C10 = RowCfg<10>;
+	constexpr int N2 = 1024 * WV, AV = 16 / WV, TR = 64 * WV, ROWS = 4 / WV, PITCH = C10::PITCH;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	cplx *data = reinterpret_cast<cplx *>(smem_raw);                 // [4 sub-rows][PITCH]
+	cplx *t256 = data + 4 * PITCH, *tlo = t256 + 256, *thi = tlo + 64, *t1lo = thi + 64, *t1hi = t1lo + 64;
+	const int tid = threadIdx.x;
+	const int lane = tid & 63, wq = tid >> 6;                        // wq: wave of the workgroup = sub-row buffer
+	const int rw = wq / WV, w = wq % WV, tr = w * 64 + lane;
+	const long k1 = (long) blockIdx.x * ROWS + rw;
+	const long pair = p.pair0 + blockIdx.y;
+	cplx *W = p.W + (pair - p.pair0) * p.N + k1 * N2;
+	cplx v[16];
+#pragma unroll
+	for (int i = 0; i < AV; ++i)
+#pragma unroll
+		for (int b = 0; b < WV; ++b) v[i * WV + b] = W[tr + TR * i + 1024 * b];
+	// tables: W_256, W_N2 two-level (cross-wave twiddles), W_1024 two-level (in-wave FFT)
+	t256[tid] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) { tlo[tid] = p.tw_n2[tid]; t1lo[tid] = p.tw_n2[tid * WV]; }
+	else if (tid < 128) { thi[tid - 64] = (tid - 64 < N2 / 64) ? p.tw_n2[(tid - 64) * 64] : make_double2(0.0, 0.0); }
+	else if (tid < 144) t1hi[tid - 128] = p.tw_n2[(tid - 128) * 64 * WV];
+	cplx *steps = t1hi + 64 + rw * 16;
+	row_twiddle_steps(p, k1, tr, steps, [](int q) { return (long) TR * (q / WV) + 1024L * (q % WV); });
+	const cplx twb = big_twiddle(p, (k1 * tr) & (p.N - 1));
+	lds_barrier();
+#pragma unroll
+	for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(twb, steps[q]));
+	const TwRow<1024> tw1{ t256, t1lo, t1hi };
+	const int rbase = rw * WV * PITCH;
+	const RowMap mymap{ wq * PITCH };
+	// ---- forward: radix-WV over the blocks, twiddle, hand Z_kb to wave kb ----
+#pragma unroll
+	for (int i = 0; i < AV; ++i) {
+		cplx u[WV];
+#pragma unroll
+		for (int b = 0; b < WV; ++b) u[b] = v[i * WV + b];
+		dftR<WV, false>(u);
+		const int a = tr + TR * i;
+#pragma unroll
+		for (int kb = 0; kb < WV; ++kb) {
+			if (kb > 0) { const int e = a * kb; u[kb] = cmul(u[kb], cmul(thi[e >> 6], tlo[e & 63])); }
+			RowMap{ rbase + kb * PITCH }.store(data, a, u[kb]);
+		}
+	}
+	lds_barrier();
+	gather16<10>(v, lane, data, mymap);
+	row_sync<true>();
+	row_fft<10, false>(v, lane, data, mymap, tw1);
+	if (MODE == 1) {
+		cplx *H = p.Hout + k1 * N2 + w * 1024 + lane;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) H[64 * m] = make_double2(v[m].x * p.h_scale, v[m].y * p.h_scale);
+		return;
+	}
+	{
+		const cplx *H = p.H + p.pair_h[pair] * p.N + k1 * N2 + w * 1024 + lane;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], H[64 * m]);
+	}
+	// ---- inverse ----
+	row_sync<true>();
+	row_fft<10, true>(v, lane, data, mymap, tw1);
+	row_sync<true>();
+#pragma unroll
 	for (int m = 0; m < 16; ++m) {
-		const long n2 = j + P * m;
-		const cplx w = big_twiddle(p, (n2 * k1) & (p.N - 1));
-		W[P * m] = cmulc(v[m], w);
+		const int a = lane + 64 * m;
+		cplx z = v[m];
+		if (w > 0) { const int e = a * w; z = cmulc(z, cmul(thi[e >> 6], tlo[e & 63])); }
+		mymap.store(data, a, z);
+	}
+	lds_barrier();
+#pragma unroll
+	for (int i = 0; i < AV; ++i) {
+		const int a = tr + TR * i;
+		cplx u[WV];
+#pragma unroll
+		for (int kb = 0; kb < WV; ++kb) RowMap{ rbase + kb * PITCH }.load(data, a, u[kb]);
+		dftR<WV, true>(u);
+#pragma unroll
+		for (int b = 0; b < WV; ++b) W[a + 1024 * b] = cmulc(u[b], cmul(twb, steps[i * WV + b]));
 	}
 }
 
@@ -535,8 +641,25 @@ template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pa
 	else hipLaunchKernelGGL((conv_row<L2, 0>), grid, block, Cfg::LDS, st, p);
 }
 
+template <int WV> static void launch_row_big(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
+{
+	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + 256 + 4 * 64 + 4 * 16) * sizeof(cplx);
+	static bool granted[2] = { false, false };
+	if (!granted[mode]) {
+		if (mode) grant_lds(conv_row_big<WV, 1>, LDS); else grant_lds(conv_row_big<WV, 0>, LDS);
+		granted[mode] = true;
+	}
+	dim3 grid((unsigned) (p.N1 / (4 / WV)), n_pairs), block(NT);
+	if (mode == 1) hipLaunchKernelGGL((conv_row_big<WV, 1>), grid, block, LDS, st, p);
+	else hipLaunchKernelGGL((conv_row_big<WV, 0>), grid, block, LDS, st, p);
+}
+
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
+	static int big = -1;
+	if (big < 0) { const char *e = getenv("DSP_AMD_ROW_BIG"); big = e ? atoi(e) : 1; }
+	if (big && p.log2N2 == 11) { launch_row_big<2>(p, mode, n_pairs, st); return; }
+	if (big > 1 && p.log2N2 == 12) { launch_row_big<4>(p, mode, n_pairs, st); return; }   // measured: the 3-pass kernel is ahead at 4096
 	switch (p.log2N2) {
 	case 9: launch_row<9>(p, mode, n_pairs, st); break;
 	case 10: launch_row<10>(p, mode, n_pairs, st); break;

@@ -206,3 +206,18 @@ def test_full_size_properties(amd, tmp_path):
     ym = torch.cat(parts, dim=1)
     err = (ym - (0.25 * y1 - 1.5 * y2)).pow(2).mean().sqrt().item()
     assert err < 1e-13, err
+
+
+@pytest.mark.parametrize("log2n", [13, 14, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("channels", [1, 3, 4, 8])
+def test_every_transform_geometry(amd, tmp_path, monkeypatch, log2n, channels):
+    # force each N = N1 x N2 geometry of the FFT convolver (16..256 columns x 512..4096 rows, including the
+    # wave-local big-row kernel at 2048 / 4096) and each pairs-per-workgroup variant of K3 (1, 2, 4 pairs)
+    monkeypatch.setenv("DSP_AMD_CONV_LOG2N", str(log2n))
+    taps = 3001
+    h = make_filter(taps, 5, 300.0)
+    x = noise(9000, channels, 40 + log2n)
+    y = amd.EffectsChain(f"fir_p -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, channels).process(x, block=2500)
+    ref = fftconv(x, h)
+    assert y.shape == ref.shape
+    assert rms(y - ref) < TOL, rms(y - ref)
