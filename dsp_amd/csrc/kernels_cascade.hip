@@ -445,55 +445,76 @@ __global__ __launch_bounds__(64 * CG) void cascade_fast(CascadeParams p, const d
 		tk[k] = (tid + k * NTH) / HP;
 		la[k] = (2 * cp) * CHS + tk[k] + tk[k] / L;
 	}
-	double2 pf[K];
+	// ring-only output: results leave in row order instead -- slot (pair (tid + k NTH) / TILE, frame (tid + k NTH) % TILE),
+	// so that one store instruction of the workgroup covers NTH consecutive 16-byte elements of ONE ring row (the
+	// (t, cp) order above would interleave the rows of the HP pairs lane by lane).  Costs one extra LDS barrier.
+	const bool ring_rows = ring && !p.write_interleaved;
+	double2 *ring0 = p.ring.base ? reinterpret_cast<double2 *>(p.ring.base) + ((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride : nullptr;
+	int lb[K];
 #pragma unroll
-	for (int k = 0; k < K; ++k) pf[k] = *reinterpret_cast<const double2 *>(in + (size_t) tk[k] * p.C + 2 * cp);
+	for (int k = 0; k < K; ++k) {
+		const int e = tid + k * NTH, tb = e % TILE;
+		lb[k] = (2 * (e / TILE)) * CHS + tb + tb / L;
+	}
+	double2 pf0[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k) pf0[k] = *reinterpret_cast<const double2 *>(in + (size_t) tk[k] * p.C + 2 * cp);
 	const double *__restrict__ cf = fops + (size_t) (c0 + wave) * p.n_ops * FOP_DOUBLES;
 	const double *wq = qt + (size_t) wave * p.n_ops * FQ_DOUBLES;
 	double *row = tile + wave * CHS;
 	double *cst = st + wave * p.n_ops * 2;
 	__syncthreads();
 
-	for (long tl = 0; tl <= n_full; ++tl) {
-		// ---- I/O phase ----
-		double2 r[K];
-		if (tl > 0) {
-#pragma unroll
-			for (int k = 0; k < K; ++k) r[k] = make_double2(tile[la[k]], tile[la[k] + CHS]);
-		}
-		if (tl < n_full) {
-#pragma unroll
-			for (int k = 0; k < K; ++k) { tile[la[k]] = pf[k].x; tile[la[k] + CHS] = pf[k].y; }
-		}
-		if (tl > 0 && !(p.debug & 1)) {
-			const long t0 = (tl - 1) * TILE;
-			if (p.write_interleaved) {
-#pragma unroll
-				for (int k = 0; k < K; ++k) *reinterpret_cast<double2 *>(out + (size_t) (t0 + tk[k]) * p.C + 2 * cp) = r[k];
-			}
-			if (ring) {
-#pragma unroll
-				for (int k = 0; k < K; ++k) ring[(p.ring.pos + t0 + tk[k]) & p.ring.mask] = r[k];
-			}
-		}
-		if (tl + 1 < n_full && !(p.debug & 2)) {
-			const double *nx = in + (size_t) (tl + 1) * TILE * p.C;
-#pragma unroll
-			for (int k = 0; k < K; ++k) pf[k] = *reinterpret_cast<const double2 *>(nx + (size_t) tk[k] * p.C + 2 * cp);
-		}
-		if (tl == n_full) break;
-		lds_barrier();
-		// ---- compute phase: wave = channel ----
-		{
-			double v[L];
-#pragma unroll
-			for (int i = 0; i < L; ++i) v[i] = row[lane * (L + 1) + i];
-			run_ops_fast<L>(v, cf, wq, p.n_ops, cst, lane);
-#pragma unroll
-			for (int i = 0; i < L; ++i) row[lane * (L + 1) + i] = v[i];
-		}
-		lds_barrier();
+	// one tile step: I/O phase (results of tile tl-1 out, inputs of tile tl in from PF, loads of tile tl+1 into PF),
+	// then the compute phase on tile tl.  (Two tiles of loads in flight were measured: no gain, 32 more VGPRs.)
+#define CASCADE_FAST_STEP(PF)                                                                                              \
+	{                                                                                                                      \
+		double2 r[K];                                                                                                      \
+		if (tl > 0) {                                                                                                      \
+			if (ring_rows) {                                                                                               \
+				_Pragma("unroll") for (int k = 0; k < K; ++k) r[k] = make_double2(tile[lb[k]], tile[lb[k] + CHS]);        \
+				lds_barrier();   /* other threads' slots were read: they may be overwritten now */                        \
+			}                                                                                                              \
+			else {                                                                                                         \
+				_Pragma("unroll") for (int k = 0; k < K; ++k) r[k] = make_double2(tile[la[k]], tile[la[k] + CHS]);        \
+			}                                                                                                              \
+		}                                                                                                                  \
+		if (tl < n_full) {                                                                                                 \
+			_Pragma("unroll") for (int k = 0; k < K; ++k) { tile[la[k]] = PF[k].x; tile[la[k] + CHS] = PF[k].y; }        \
+		}                                                                                                                  \
+		if (tl > 0 && !(p.debug & 1)) {                                                                                    \
+			const long t0 = (tl - 1) * TILE;                                                                               \
+			if (p.write_interleaved) {                                                                                     \
+				_Pragma("unroll") for (int k = 0; k < K; ++k)                                                             \
+					*reinterpret_cast<double2 *>(out + (size_t) (t0 + tk[k]) * p.C + 2 * cp) = r[k];                      \
+			}                                                                                                              \
+			if (ring_rows) {                                                                                               \
+				_Pragma("unroll") for (int k = 0; k < K; ++k)                                                             \
+					ring0[(size_t) ((tid + k * NTH) / TILE) * p.ring.row_stride + ((p.ring.pos + t0 + (tid + k * NTH) % TILE) & p.ring.mask)] = r[k]; \
+			}                                                                                                              \
+			else if (ring) {                                                                                               \
+				_Pragma("unroll") for (int k = 0; k < K; ++k) ring[(p.ring.pos + t0 + tk[k]) & p.ring.mask] = r[k];      \
+			}                                                                                                              \
+		}                                                                                                                  \
+		if (tl + 1 < n_full && !(p.debug & 2)) {                                                                           \
+			const double *nx = in + (size_t) (tl + 1) * TILE * p.C;                                                        \
+			_Pragma("unroll") for (int k = 0; k < K; ++k)                                                                 \
+				PF[k] = *reinterpret_cast<const double2 *>(nx + (size_t) tk[k] * p.C + 2 * cp);                           \
+		}                                                                                                                  \
+		if (tl == n_full) break;                                                                                           \
+		lds_barrier();                                                                                                     \
+		{                                                                                                                  \
+			double v[L];                                                                                                   \
+			_Pragma("unroll") for (int i = 0; i < L; ++i) v[i] = row[lane * (L + 1) + i];                                 \
+			run_ops_fast<L>(v, cf, wq, p.n_ops, cst, lane);                                                                \
+			_Pragma("unroll") for (int i = 0; i < L; ++i) row[lane * (L + 1) + i] = v[i];                                 \
+		}                                                                                                                  \
+		lds_barrier();                                                                                                     \
 	}
+	for (long tl = 0; ; ++tl) {
+		CASCADE_FAST_STEP(pf0)
+	}
+#undef CASCADE_FAST_STEP
 	for (int i = tid; i < n_st; i += NTH) gstate[i] = st[i];
 }
 
@@ -520,11 +541,15 @@ template <int CG> static bool try_launch_fast(const CascadeParams &p, int n_stre
 // 0 = not eligible; otherwise the number of leading frames the fast kernel took
 static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
-	static int cfg_cg = -1;
-	if (cfg_cg < 0) {
+	static int env_cg = -2;
+	if (env_cg == -2) {
 		const char *e = getenv("DSP_AMD_CASCADE_FAST");     // channels per workgroup (8, 4, 2) or 0 to disable
-		cfg_cg = e ? atoi(e) : 8;
+		env_cg = e ? atoi(e) : -1;
 	}
+	// measured on MI355X (256 x 8 ch, 10 sections): whole frames per workgroup (8 channels) win when the interleaved
+	// slab is written (2.4 vs 3.8 ms); half frames (two independent workgroups per stream) win when only the
+	// convolver's ring rows are written (2.45 vs 2.57 ms)
+	const int cfg_cg = (env_cg >= 0) ? env_cg : ((p.ring.base && !p.write_interleaved) ? 4 : 8);
 	if (cfg_cg == 0 || (p.C & 1) || p.cg0 != 0 || !p.fops) return 0;
 	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
 	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
