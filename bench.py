@@ -37,6 +37,25 @@ def make_filter(taps, seed=7):
     return h / np.sqrt(np.sum(h * h)) / 4.0
 
 
+def measured_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_traffic.json, produced by
+    scripts/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command).
+    bench.py cannot run a PMC pass on itself; the figure is only reported when the summary was taken on the same
+    workload (streams x channels x block x taps), otherwise null."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload_key") != workload_key or kernel not in d.get("kernels", {}):
+            continue
+        k = d["kernels"][kernel]
+        return k["traffic"], {"file": os.path.relpath(f, ROOT), "fetch_raw": k["fetch_raw"], "fetch_corrected": k["fetch_corrected"],
+                              "write": k["write"], "bytes_the_kernel_is_designed_to_move": k["algorithmic_bytes_of_kernel"]}
+    return None, None
+
+
 def cpu_baseline(chain, filt_dir, fs, channels, seconds_target=12.0):
     """The reference's own CPU path (oracle/_ref, built from /root/reference) timed on this box's cores on a
     bounded sample of the same workload; falls back to the scalar oracle port when _ref is absent."""
@@ -188,6 +207,9 @@ def main():
         samples_per_launch = S * C * args.block / launches_per_step  # this rank's samples handled by one launch
         achieved = samples_per_launch * B_ALG / (dom[1]["avg_ms"] * 1e-3) / 1e9
         chain_frac = (value * 1e6 / world) * B_ALG / HBM_PEAK
+        traffic, traffic_src = (None, None)
+        if args.chain is None:
+            traffic, traffic_src = measured_traffic(dom[0], f"{S}x{C}x{args.block}x{args.taps}")
         res = {
             "metric": "Msamples/s (all streams), 256x8ch biquadx10 + fir_p(65536)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,7 +219,7 @@ def main():
                        "streams": S_total, "channels": C, "block_frames": args.block, "taps": args.taps,
                        "parallelism": f"streams sharded {S_total // world}/GPU, no data-plane collective", "plan": plan},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": None,
+                         "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom[1]["avg_ms"], "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": samples_per_launch * B_ALG,
                          "whole_chain_frac_per_gpu": chain_frac, "measured_copy_GBps": copy_gbps,
