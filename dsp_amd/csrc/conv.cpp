@@ -43,10 +43,21 @@ public:
 	const char *type() const override { return "conv"; }
 	std::string describe() const override;
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
+	ssize_t max_out_frames(ssize_t in_frames) const override { return ((long long) in_frames * up + down - 1) / down; }
+	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
 	size_t device_bytes() const override { return ring.bytes + W.bytes + H.bytes; }
 private:
 	bool prepare_filters(const Spec &sp);
+	void push(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st);
+	void convolve(long q_lo, long q_hi, long k_origin, long out_count, double *out, long out_stride, hipStream_t st);
+	ssize_t emit(long count, double *out, long out_stride, hipStream_t st);
+	// integer-ratio resampling = nph = up filters (the polyphase branches) on the same input, outputs interleaved in
+	// time (up > 1), or one filter whose output is kept every down-th frame (down > 1); see resample.cpp for the maths
+	int up = 1, down = 1, nph = 1;
+	bool resampler = false;
+	long out_delay = 0, q_total = 0, emitted = 0, q_abs = 0;   // q_abs: absolute input index of the next frame (plain conv)
+	std::vector<double> rs_tab;
 	ConvParams base_params() const;
 	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, first_n = 0, lat = 0, ring_len = 0, pos = 0;
 	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
@@ -64,7 +75,9 @@ private:
 std::string ConvStage::describe() const
 {
 	std::ostringstream o;
-	o << "conv[" << name << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
+	o << (resampler ? "fft-resample[" : "conv[") << name;
+	if (resampler) o << " " << fs_in << "->" << fs_out << " " << up << "/" << down << " delay=" << out_delay;
+	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? " fed-by-cascade" : "")
 	  << (round_f32 ? " f32-io" : "") << "]";
 	return o.str();
@@ -88,6 +101,8 @@ ConvParams ConvStage::base_params() const
 	p.pairs_per_stream = pps;
 	p.pair_out_ch = pair_out_ch.as<int>();
 	p.round_f32 = round_f32;
+	p.nph = nph; p.up = up; p.down = down;
+	p.phase_stride = pairs_per_chunk * N;
 	return p;
 }
 
@@ -100,6 +115,16 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	nsel = num_set(sp.sel);
 	all_selected = (nsel == ch_in);
 	n_filters = (sp.fch == 1) ? 1 : nsel;
+	if (sp.kind == Kind::Resample) {
+		// resample acts on every channel whatever the selector says (README.md:389-391)
+		resampler = true;
+		up = sp.rs_n; down = sp.rs_d; nph = up;
+		int J = 0;
+		resample_polyphase_table(sp, &J, &out_delay, rs_tab);
+		T = J;
+		lat = 0;
+		nsel = ch_in; all_selected = true; n_filters = 1;
+	}
 	// channel pairs share a transform only when they share the filter
 	pps = (n_filters == 1) ? (nsel + 1) / 2 : nsel;
 
@@ -107,7 +132,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	// (valid fraction (N - T + 1) / N: 1/2 at 2T, 15/16 at 16T)
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	const long want = next_pow2(((T + 6) & ~7L) + std::max<long>(max_frames, 1));
-	N = std::min(std::max(lo, want), lo * 8);
+	N = std::min(std::max(lo, want), std::max(lo * 8, resampler ? (1L << 16) : 0L));
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
 	if (env) N = std::max(lo, 1L << atoi(env));
 	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
@@ -131,7 +156,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	if (!ring.alloc((size_t) S * pps * ring_len * sizeof(double2))) return false;
 	std::vector<int> soc(ch_in, -1);
 	std::vector<int> sel_ch;
-	for (int c = 0; c < ch_in; ++c) if (sp.sel[c]) sel_ch.push_back(c);
+	for (int c = 0; c < ch_in; ++c) if (resampler || sp.sel[c]) sel_ch.push_back(c);
 	std::vector<int> ph((size_t) S * pps), poc((size_t) pps * 2);
 	for (int q = 0; q < pps; ++q) {
 		const int ia = (n_filters == 1) ? 2 * q : q, ib = (n_filters == 1 && 2 * q + 1 < nsel) ? 2 * q + 1 : -1;
@@ -167,7 +192,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	pairs_per_chunk = chunk_streams * pps;
 	const char *senv = getenv("DSP_AMD_CONV_SUBSTREAMS");
 	n_sub = (senv && chunk_streams < S) ? std::max(1, std::min(8, atoi(senv))) : 1;
-	if (!W.alloc((size_t) n_sub * pairs_per_chunk * N * sizeof(double2), false)) return false;
+	if (nph > 1) n_sub = 1;
+	if (!W.alloc((size_t) n_sub * nph * pairs_per_chunk * N * sizeof(double2), false)) return false;
 	if (n_sub > 1) {
 		sub.resize(n_sub); sub_done.resize(n_sub);
 		for (int k = 0; k < n_sub; ++k) {
@@ -176,11 +202,11 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 		}
 		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
 	}
-	if (!H.alloc((size_t) n_filters * N * sizeof(double2), false)) return false;
+	if (!H.alloc((size_t) n_filters * nph * N * sizeof(double2), false)) return false;
 	if (!prepare_filters(sp)) return false;
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
-	if (feeder && all_selected && !round_f32 && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
+	if (feeder && all_selected && !round_f32 && !resampler && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
 		feeder->ring.base = ring.as<double>();
 		feeder->ring.row_stride = ring_len;
 		feeder->ring.mask = ring_len - 1;
@@ -204,9 +230,9 @@ bool ConvStage::prepare_filters(const Spec &sp)
 	std::vector<int> hsel{ 0 };
 	if (!tring.alloc((size_t) N * sizeof(double2), false)) return false;
 	if (!tph.upload(hsel.data(), hsel.size() * sizeof(int))) return false;
-	for (int f = 0; f < n_filters; ++f) {
+	for (int f = 0; f < n_filters * nph; ++f) {
 		for (long i = 0; i < T; ++i) {
-			double v = sp.taps[(size_t) i * sp.fch + f];
+			double v = resampler ? rs_tab[(size_t) i * up + f] : sp.taps[(size_t) i * sp.fch + f];
 			if (round_f32) v = (double) (float) v;
 			taps[i].x = v;
 		}
@@ -218,6 +244,7 @@ bool ConvStage::prepare_filters(const Spec &sp)
 		p.pair_h = tph.as<int>();
 		p.pair0 = 0;
 		p.Hout = H.as<double2>() + (size_t) f * N;
+		p.nph = nph;   // selects the row kernel whose order H is stored in
 		launch_conv_col(p, false, 1, nullptr);
 		launch_conv_row(p, 1, 1, nullptr);
 		if (!hip_ok(hipDeviceSynchronize(), "filter spectrum")) return false;
@@ -225,32 +252,40 @@ bool ConvStage::prepare_filters(const Spec &sp)
 	return true;
 }
 
-ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+void ConvStage::push(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
-	if (!fed) {
-		DeintParams d;
-		d.in = in;
-		d.out = all_selected ? nullptr : out;
-		d.in_stride_frames = in_stride; d.out_stride_frames = out_stride; d.frames = frames;
-		d.C = ch_in;
-		d.slot_of_channel = slot_of_channel.as<int>();
-		d.rows_per_stream = pps;
-		d.ring = ring.as<double2>();
-		d.ring_row_stride = ring_len; d.ring_mask = ring_len - 1; d.pos = pos;
-		d.round_f32 = round_f32;
-		{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
-	}
+	DeintParams d;
+	d.in = in;
+	d.out = all_selected ? nullptr : out;
+	d.in_stride_frames = in_stride; d.out_stride_frames = out_stride; d.frames = frames;
+	d.C = ch_in;
+	d.slot_of_channel = slot_of_channel.as<int>();
+	d.rows_per_stream = pps;
+	d.ring = ring.as<double2>();
+	d.ring_row_stride = ring_len; d.ring_mask = ring_len - 1; d.pos = pos;
+	d.round_f32 = round_f32;
+	{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
+}
+
+// Convolution outputs at the absolute input indices q_lo .. q_hi (the ring holds input index q at q & mask; indices
+// at or beyond q_end read as zero: the drain), mapped to output frames by (up, down, k_origin): see fft_params.h.
+void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, double *out, long out_stride, hipStream_t st)
+{
 	const long chunk_streams = pairs_per_chunk / pps;
-	for (long off = 0; off < frames; off += B) {
-		const long f = std::min<long>(B, frames - off);
+	const long q_end = resampler ? q_total : q_hi + 1;
+	for (long q_blk = q_lo; q_blk <= q_hi; q_blk += B) {
+		const long f = std::min<long>(B, q_hi - q_blk + 1);
 		ConvParams p = base_params();
-		p.win_base = (pos + off - lat - first_n) & (ring_len - 1);   // two's complement wrap: ring_len is a power of two
+		p.win_base = (q_blk - lat - first_n) & (ring_len - 1);   // two's complement wrap: ring_len is a power of two
 		p.first_n = first_n;
-		p.valid = first_n + f;
+		p.valid = std::max<long>(0, std::min<long>(first_n + f, first_n + q_end - q_blk));
 		p.out = out;
 		p.out_stride_frames = out_stride;
-		p.out_frame0 = off;
-		p.out_frames = f;
+		p.in_count = f;
+		p.q_blk = q_blk;
+		p.k_origin = k_origin;
+		p.out_count = out_count;
+		const int row_mode = (nph > 1) ? 2 : 0;
 		if (n_sub > 1) {
 			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
 			// every chunk's W is small enough to live in the Infinity Cache between its three launches
@@ -265,7 +300,7 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 				p.n_streams_launch = ns;
 				p.W = W.as<double2>() + (size_t) k * pairs_per_chunk * N;
 				launch_conv_col(p, false, (int) (ns * pps), sub[k]);
-				launch_conv_row(p, 0, (int) (ns * pps), sub[k]);
+				launch_conv_row(p, row_mode, (int) (ns * pps), sub[k]);
 				launch_conv_col(p, true, (int) (ns * pps), sub[k]);
 			}
 			for (int k = 0; k < n_sub; ++k) { (void) hipEventRecord(sub_done[k], sub[k]); (void) hipStreamWaitEvent(st, sub_done[k], 0); }
@@ -277,18 +312,54 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 			p.stream0 = s0;
 			p.n_streams_launch = ns;
 			{ ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, (int) (ns * pps), st); }
-			{ ProfScope ps("conv_row", st); launch_conv_row(p, 0, (int) (ns * pps), st); }
+			{ ProfScope ps("conv_row", st); launch_conv_row(p, row_mode, (int) (ns * pps), st); }
 			{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) (ns * pps), st); }
 		}
 	}
+}
+
+// resampler: visible output frames [emitted, emitted + count) = full-rate indices k' = emitted + out_delay + ...,
+// each the convolution at input index floor(k' down / up)
+ssize_t ConvStage::emit(long count, double *out, long out_stride, hipStream_t st)
+{
+	if (count <= 0) return 0;
+	const long kp0 = emitted + out_delay, kp1 = kp0 + count;
+	convolve((kp0 * down) / up, ((kp1 - 1) * down) / up, kp0, count, out, out_stride, st);
+	emitted += count;
+	return count;
+}
+
+ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	if (!fed) push(in, in_stride, frames, out, out_stride, st);
+	if (resampler) {
+		pos = (pos + frames) & (ring_len - 1);
+		q_total += frames;
+		// full-rate outputs k with floor(k down / up) < q_total are computable: k < ceil(q_total up / down)
+		const long avail = std::max<long>(0, max_out_frames(q_total) - out_delay) - emitted;
+		return emit(std::min<long>(avail, max_out_frames(frames)), out, out_stride, st);
+	}
+	// plain convolution: output frame m of this call = convolution at ring index pos + m
+	convolve(q_abs, q_abs + frames - 1, q_abs, frames, out, out_stride, st);
+	q_abs += frames;
 	pos = (pos + frames) & (ring_len - 1);
 	return frames;
+}
+
+ssize_t ConvStage::drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st)
+{
+	if (!resampler) return -1;
+	// total output length is ceil(N up / down) (resample.c:163-188): the tail is computed against zero input
+	const long left = max_out_frames(q_total) - emitted;
+	if (q_total == 0 || left <= 0) return -1;
+	return emit(std::min<long>(left, std::max<long>(max_out_frames(max_frames), 1)), out, out_stride, st);
 }
 
 void ConvStage::reset(hipStream_t st)
 {
 	(void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
 	pos = 0;
+	q_total = emitted = q_abs = 0;
 	if (feeder_) feeder_->ring.pos = 0;
 }
 
@@ -343,7 +414,10 @@ ssize_t FirDirectStage::run(const double *in, long in_stride, ssize_t frames, do
 
 Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder)
 {
-	if (sp.kind == Kind::Resample) return make_resample_stage(sp, n_streams, max_frames);
+	// integer ratios ride the FFT convolver (one forward transform, one inverse per polyphase branch); general n/d
+	// stays on the polyphase dot-product kernel
+	if (sp.kind == Kind::Resample && !((sp.rs_n == 1 || sp.rs_d == 1) && sp.rs_n <= 8 && sp.rs_d <= 8 && !getenv("DSP_AMD_RESAMPLE_DIRECT")))
+		return make_resample_stage(sp, n_streams, max_frames);
 	if (sp.kind == Kind::FirDirect) {
 		FirDirectStage *s = new FirDirectStage;
 		s->S = n_streams; s->ch_in = sp.ch_in; s->ch_out = sp.ch_out; s->fs_in = sp.fs_in; s->fs_out = sp.fs_out;

@@ -23,9 +23,13 @@ struct ConvParams {
 	const double2 *H;                   // [n_filters][N] filter spectra in [k1][k2] order, pre-scaled by 1/N
 	double2 *Hout;                      // mode 1 of conv_row
 	double h_scale;
-	// output (K3)
+	// output (K3).  Window sample first_n + f (0 <= f < in_count) is the convolution at input index q_blk + f; phase ph
+	// of it is output index K = up * (q_blk + f) + ph, written -- when down divides K -- to frame K / down - k_origin
+	// (if inside [0, out_count)).  Plain convolution: nph = up = down = 1, q_blk = 0, k_origin = -(first frame of the block).
 	double *out;
-	long out_stride_frames, out_frame0, out_frames, first_n;
+	long out_stride_frames, first_n, in_count, out_count, q_blk, k_origin;
+	int nph, up, down;                  // nph phases: filter spectrum (pair_h * nph + ph), W + ph * phase_stride
+	long phase_stride;
 	int C, pairs_per_stream;
 	long stream0, n_streams_launch;
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)

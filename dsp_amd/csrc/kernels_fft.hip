@@ -288,32 +288,38 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	const bool active = qs < p.pairs_per_stream;
 	const long n2 = (long) blockIdx.x * TW + t;
 	for (int i = tid; i < N1; i += THREADS) twt[i] = p.tw_n1[i];
-	cplx v[16];
-	if (active) {
-		const cplx *W = p.W + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
-#pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = W[(long) (j + P * m) * p.N2];
-	}
-	else {
-#pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
-	}
 	lds_barrier();
-	col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
-	if (!active) return;
-	double *out = p.out + ((size_t) s * p.out_stride_frames + p.out_frame0) * p.C;
-	const int cha = p.pair_out_ch[2 * qs], chb = p.pair_out_ch[2 * qs + 1];
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	const int cha = active ? p.pair_out_ch[2 * qs] : -1, chb = active ? p.pair_out_ch[2 * qs + 1] : -1;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
+	for (int ph = 0; ph < p.nph; ++ph) {
+		cplx v[16];
+		if (active) {
+			const cplx *W = p.W + ph * p.phase_stride + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
 #pragma unroll
-	for (int m = 0; m < 16; ++m) {
-		const long f = (long) (j + P * m) * p.N2 + n2 - p.first_n;
-		if (f >= 0 && f < p.out_frames) {
+			for (int m = 0; m < 16; ++m) v[m] = W[(long) (j + P * m) * p.N2];
+		}
+		else {
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
+		}
+		if (ph > 0) lds_barrier();   // the previous phase's exchange has been read by everyone
+		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
+		if (!active) continue;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			const long f = (long) (j + P * m) * p.N2 + n2 - p.first_n;
+			if (f < 0 || f >= p.in_count) continue;
+			long mo = p.up * (p.q_blk + f) + ph;
+			if (p.down > 1) { if (mo % p.down) continue; mo /= p.down; }
+			mo -= p.k_origin;
+			if (mo < 0 || mo >= p.out_count) continue;
 			cplx y = v[m];
 			if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
-			if (wide) *reinterpret_cast<cplx *>(out + f * p.C + cha) = y;
+			if (wide) *reinterpret_cast<cplx *>(out + mo * p.C + cha) = y;
 			else {
-				if (cha >= 0) out[f * p.C + cha] = y.x;
-				if (chb >= 0) out[f * p.C + chb] = y.y;
+				if (cha >= 0) out[mo * p.C + cha] = y.x;
+				if (chb >= 0) out[mo * p.C + chb] = y.y;
 			}
 		}
 	}
@@ -410,6 +416,22 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 		cplx *H = p.Hout + k1 * N2 + j;
 #pragma unroll
 		for (int m = 0; m < 16; ++m) H[P * m] = make_double2(v[m].x * p.h_scale, v[m].y * p.h_scale);
+		return;
+	}
+	if (MODE == 2) {
+		// several filters on the same input (the phases of an integer-ratio resampler): one forward transform, one
+		// multiply + inverse transform per phase, each into its own W
+		for (int ph = 0; ph < p.nph; ++ph) {
+			const cplx *H = p.H + ((long) p.pair_h[pair] * p.nph + ph) * p.N + k1 * N2 + j;
+			cplx u[16];
+#pragma unroll
+			for (int m = 0; m < 16; ++m) u[m] = cmul(v[m], H[P * m]);
+			row_sync<WL>();
+			row_fft<LOG2N2, true>(u, j, data, map, tw);
+			cplx *Wp = W + ph * p.phase_stride;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) Wp[P * m] = cmulc(u[m], cmul(twb, steps[m]));
+		}
 		return;
 	}
 	{
@@ -631,13 +653,14 @@ void launch_conv_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t
 template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
 	using Cfg = RowCfg<L2>;
-	static bool granted[2] = { false, false };
+	static bool granted[3] = { false, false, false };
 	if (!granted[mode]) {
-		if (mode) grant_lds(conv_row<L2, 1>, Cfg::LDS); else grant_lds(conv_row<L2, 0>, Cfg::LDS);
+		if (mode == 1) grant_lds(conv_row<L2, 1>, Cfg::LDS); else if (mode == 2) grant_lds(conv_row<L2, 2>, Cfg::LDS); else grant_lds(conv_row<L2, 0>, Cfg::LDS);
 		granted[mode] = true;
 	}
 	dim3 grid((unsigned) (p.N1 / Cfg::RPW), n_pairs), block(NT);
 	if (mode == 1) hipLaunchKernelGGL((conv_row<L2, 1>), grid, block, Cfg::LDS, st, p);
+	else if (mode == 2) hipLaunchKernelGGL((conv_row<L2, 2>), grid, block, Cfg::LDS, st, p);
 	else hipLaunchKernelGGL((conv_row<L2, 0>), grid, block, Cfg::LDS, st, p);
 }
 
@@ -656,8 +679,11 @@ template <int WV> static void launch_row_big(const ConvParams &p, int mode, int 
 
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	static int big = -1;
-	if (big < 0) { const char *e = getenv("DSP_AMD_ROW_BIG"); big = e ? atoi(e) : 1; }
+	static int big_env = -1;
+	if (big_env < 0) { const char *e = getenv("DSP_AMD_ROW_BIG"); big_env = e ? atoi(e) : 1; }
+	int big = big_env;
+	// (H is stored in the row kernel's own order: a multi-phase plan uses the generic kernel for preparation too)
+	if (p.nph > 1) big = 0;
 	if (big && p.log2N2 == 11) { launch_row_big<2>(p, mode, n_pairs, st); return; }
 	if (big > 1 && p.log2N2 == 12) { launch_row_big<4>(p, mode, n_pairs, st); return; }   // measured: the 3-pass kernel is ahead at 4096
 	switch (p.log2N2) {

@@ -48,20 +48,20 @@ static double albrecht(double x)
 	return w;
 }
 
-bool ResampleStage::init(const Spec &sp, ssize_t max_frames)
+// tab[j][p] = A s_a((p + j n) os / min(n, d)), j < J, p < n: the polyphase taps of resample.c's frequency-domain
+// resampler restated in the time domain; *out_delay as resample.c:312-316
+void resample_polyphase_table(const Spec &sp, int *J_out, long *out_delay, std::vector<double> &t)
 {
-	n = sp.rs_n;
-	d = sp.rs_d;
+	const int n = sp.rs_n, d = sp.rs_d;
 	const int m = sp.rs_m, os = sp.rs_os;
 	const int mn = std::min(n, d);
 	const int max_rate = std::max(sp.fs_in, sp.fs_out);
 	const double fc_os = sp.rs_fc / os;
 	const long m_os = (long) (m + 1) * os - 1;
-	// resample.c:312-316
-	out_delay = (sp.fs_out == max_rate) ? m / 2 : lround(m / 2 * ((double) n / d));
+	*out_delay = (sp.fs_out == max_rate) ? m / 2 : lround(m / 2 * ((double) n / d));
 	const double A = (double) os * max_rate / sp.fs_in;
-	J = (int) ceil((double) m_os * mn / ((double) os * n)) + 1;
-	std::vector<double> t((size_t) J * n, 0.0);
+	const int J = (int) ceil((double) m_os * mn / ((double) os * n)) + 1;
+	t.assign((size_t) J * n, 0.0);
 	for (int j = 0; j < J; ++j) {
 		for (int p = 0; p < n; ++p) {
 			const double u = ((double) p + (double) j * n) * os / mn;
@@ -70,6 +70,15 @@ bool ResampleStage::init(const Spec &sp, ssize_t max_frames)
 			t[(size_t) j * n + p] = A * sinc * albrecht(u / m_os);
 		}
 	}
+	*J_out = J;
+}
+
+bool ResampleStage::init(const Spec &sp, ssize_t max_frames)
+{
+	n = sp.rs_n;
+	d = sp.rs_d;
+	std::vector<double> t;
+	resample_polyphase_table(sp, &J, &out_delay, t);
 	if (!tab.upload(t.data(), t.size() * sizeof(double))) return false;
 	long need = (long) J + std::max<long>(max_frames, 1) + (long) KT * d / n + 64;
 	ring_len = 1;

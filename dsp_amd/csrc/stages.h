@@ -55,6 +55,9 @@ private:
 	DevBuf d_len, d_off, ring;
 };
 
+// resample.cpp
+void resample_polyphase_table(const Spec &sp, int *J, long *out_delay, std::vector<double> &tab);
+
 // conv.cpp: FirDirect / Conv / Resample.  `feeder` (may be null) is the cascade stage immediately before,
 // which can write straight into the convolver's planar ring instead of an interleaved slab.
 Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder);

@@ -5,7 +5,7 @@ B20="$B10 $B10"
 run() { python bench.py --steps 10 --warmup 2 --no-cpu-baseline --chain "$1" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']['kernels']; print('   ', {k:round(v['avg_ms']*v['launches_per_step'],3) for k,v in r.items()})"; }
-for dbg in 0 1 2 3; do
+for dbg in ${DBGS:-0 3}; do
   echo "debug=$dbg (1 = no stores, 2 = no reloads)"; export DSP_AMD_CASCADE_DEBUG=$dbg
   for c in "gain -3" "$B1" "$B5" "$B10" "$B20"; do run "$c"; done
 done
