@@ -46,7 +46,7 @@ public:
 	ssize_t max_out_frames(ssize_t in_frames) const override { return ((long long) in_frames * up + down - 1) / down; }
 	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
-	size_t device_bytes() const override { return ring.bytes + W.bytes + H.bytes; }
+	size_t device_bytes() const override { return ring.bytes + W.bytes + H.bytes + H_plain.bytes + tail_z.bytes + tail_scratch.bytes + tail_out.bytes; }
 private:
 	bool prepare_filters(const Spec &sp);
 	void push(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st);
@@ -58,6 +58,18 @@ private:
 	bool resampler = false;
 	long out_delay = 0, q_total = 0, emitted = 0, q_abs = 0;   // q_abs: absolute input index of the next frame (plain conv)
 	std::vector<double> rs_tab;
+	// merged fir_p + resample: the reference's fir_p stops producing when its input stops, so the resampler's drain2
+	// tail sees ZEROS after the last fir_p frame, not the FIR tail the merged filter would add.  The tail is therefore
+	// computed the reference's way: the last J fir_p outputs (plain filter h, H_plain) pushed through a polyphase
+	// resampler of their own, whose drain2 is the tail.
+	bool merged_pre = false;
+	int J_rs = 0;
+	DevBuf H_plain, tail_z, tail_scratch, tail_out;
+	std::unique_ptr<Stage> tail_rs;
+	long tail_frames = -1, tail_served = 0;
+	std::vector<double> pre_taps;
+	bool spectrum_of(const std::vector<double> &taps_1ch, long n_taps, int stride, int offset, double2 *dst, int row_nph);
+	bool compute_tail(hipStream_t st);
 	ConvParams base_params() const;
 	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, first_n = 0, lat = 0, ring_len = 0, pos = 0;
 	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
@@ -122,6 +134,28 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 		int J = 0;
 		resample_polyphase_table(sp, &J, &out_delay, rs_tab);
 		T = J;
+		if (!sp.rs_pre.empty()) {
+			// branch p of the merged stage = pre * h_p
+			const long Tp = (long) sp.rs_pre.size(), Tm = Tp + J - 1;
+			std::vector<double> g((size_t) Tm * up, 0.0);
+			for (int ph = 0; ph < up; ++ph)
+				for (long i = 0; i < Tp; ++i) {
+					const double a = sp.rs_pre[i];
+					if (a == 0.0) continue;
+					for (int j = 0; j < J; ++j) g[(size_t) (i + j) * up + ph] += a * rs_tab[(size_t) j * up + ph];
+				}
+			rs_tab.swap(g);
+			T = Tm;
+			name = sp.rs_pre_name + "+" + sp.name;
+			merged_pre = true;
+			J_rs = J;
+			pre_taps = sp.rs_pre;
+			Spec plain(sp);
+			plain.rs_pre.clear();
+			tail_rs.reset(make_resample_stage(plain, S, J));
+			if (!tail_rs) return false;
+			tail_rs->S = S; tail_rs->ch_in = sp.ch_in; tail_rs->ch_out = sp.ch_out; tail_rs->fs_in = sp.fs_in; tail_rs->fs_out = sp.fs_out;
+		}
 		lat = 0;
 		nsel = ch_in; all_selected = true; n_filters = 1;
 	}
@@ -133,11 +167,26 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	const long want = next_pow2(((T + 6) & ~7L) + std::max<long>(max_frames, 1));
 	N = std::min(std::max(lo, want), std::max(lo * 8, resampler ? (1L << 16) : 0L));
+	{
+		// among the admissible sizes take the cheapest for a call of max_frames: blocks x points x relative cost per
+		// point of the row kernel (measured: 1024-point rows 1.0, 2048 ~1.25, 4096 ~1.3)
+		const long fn = (T - 1 + 7) & ~7L, F = std::max<long>(max_frames, 1), hi = N;
+		double best = 0.0;
+		for (long n = lo; n <= hi; n <<= 1) {
+			const long hop = (n - fn) & ~7L;
+			if (hop <= 0) continue;
+			const long n2 = n / std::min<long>(1L << FFT_MAX_LOG2_N1, ((n >> 10) >= (1L << FFT_MIN_LOG2_N1)) ? (n >> 10) : (n >> FFT_MIN_LOG2_N2));
+			const double c = (n2 >= 4096) ? 1.3 : (n2 >= 2048) ? 1.25 : 1.0;
+			const double cost = (double) ((F + hop - 1) / hop) * (double) n * c;
+			if (best == 0.0 || cost < best) { best = cost; N = n; }
+		}
+	}
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
 	if (env) N = std::max(lo, 1L << atoi(env));
 	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
 	// N = N1 x N2: columns (strided) 16..256 points (one LDS exchange), rows (contiguous) 512..4096 points
-	N1 = std::min<long>(1L << FFT_MAX_LOG2_N1, N >> FFT_MIN_LOG2_N2);
+	// 1024-point rows where possible: one wave owns a row there and K2 needs no workgroup barrier (the best-tuned geometry)
+	N1 = std::min<long>(1L << FFT_MAX_LOG2_N1, ((N >> 10) >= (1L << FFT_MIN_LOG2_N1)) ? (N >> 10) : (N >> FFT_MIN_LOG2_N2));
 	N2 = N / N1;
 	log2N1 = ilog2(N1);
 	log2N2 = ilog2(N2);
@@ -206,7 +255,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	if (!prepare_filters(sp)) return false;
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
-	if (feeder && all_selected && !round_f32 && !resampler && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
+	if (feeder && all_selected && !round_f32 && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
 		feeder->ring.base = ring.as<double>();
 		feeder->ring.row_stride = ring_len;
 		feeder->ring.mask = ring_len - 1;
@@ -223,31 +272,46 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 
 // filter spectra: run the forward half of the pipeline on the taps themselves (exactly what the
 // reference does at init with its r2c plan, fir.c:342-357 / fir_p.c:482-498)
-bool ConvStage::prepare_filters(const Spec &sp)
+bool ConvStage::spectrum_of(const std::vector<double> &src, long n_taps, int stride, int offset, double2 *dst, int row_nph)
 {
 	DevBuf tring, tph;
 	std::vector<double2> taps(N, make_double2(0.0, 0.0));
 	std::vector<int> hsel{ 0 };
 	if (!tring.alloc((size_t) N * sizeof(double2), false)) return false;
 	if (!tph.upload(hsel.data(), hsel.size() * sizeof(int))) return false;
+	for (long i = 0; i < n_taps; ++i) {
+		double v = src[(size_t) i * stride + offset];
+		if (round_f32) v = (double) (float) v;
+		taps[i].x = v;
+	}
+	if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double2), hipMemcpyHostToDevice), "H2D taps")) return false;
+	ConvParams p = base_params();
+	p.ring = tring.as<double2>();
+	p.ring_row_stride = N; p.ring_mask = N - 1;
+	p.win_base = 0; p.valid = n_taps;
+	p.pair_h = tph.as<int>();
+	p.pair0 = 0;
+	p.Hout = dst;
+	p.nph = row_nph;   // selects the row kernel whose order H is stored in
+	launch_conv_col(p, false, 1, nullptr);
+	launch_conv_row(p, 1, 1, nullptr);
+	return hip_ok(hipDeviceSynchronize(), "filter spectrum");
+}
+
+bool ConvStage::prepare_filters(const Spec &sp)
+{
 	for (int f = 0; f < n_filters * nph; ++f) {
-		for (long i = 0; i < T; ++i) {
-			double v = resampler ? rs_tab[(size_t) i * up + f] : sp.taps[(size_t) i * sp.fch + f];
-			if (round_f32) v = (double) (float) v;
-			taps[i].x = v;
-		}
-		if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double2), hipMemcpyHostToDevice), "H2D taps")) return false;
-		ConvParams p = base_params();
-		p.ring = tring.as<double2>();
-		p.ring_row_stride = N; p.ring_mask = N - 1;
-		p.win_base = 0; p.valid = T;
-		p.pair_h = tph.as<int>();
-		p.pair0 = 0;
-		p.Hout = H.as<double2>() + (size_t) f * N;
-		p.nph = nph;   // selects the row kernel whose order H is stored in
-		launch_conv_col(p, false, 1, nullptr);
-		launch_conv_row(p, 1, 1, nullptr);
-		if (!hip_ok(hipDeviceSynchronize(), "filter spectrum")) return false;
+		const bool ok = resampler ? spectrum_of(rs_tab, T, up, f, H.as<double2>() + (size_t) f * N, nph)
+		                          : spectrum_of(sp.taps, T, sp.fch, f, H.as<double2>() + (size_t) f * N, nph);
+		if (!ok) return false;
+	}
+	if (merged_pre) {
+		if (!H_plain.alloc((size_t) N * sizeof(double2), false)) return false;
+		// H_plain is used by the single-phase row kernel (nph = 1 selects it and its H order)
+		if (!spectrum_of(pre_taps, (long) pre_taps.size(), 1, 0, H_plain.as<double2>(), 1)) return false;
+		if (!tail_z.alloc((size_t) S * J_rs * ch_in * sizeof(double))) return false;
+		if (!tail_scratch.alloc((size_t) S * ((size_t) J_rs * up + 8) * ch_in * sizeof(double))) return false;
+		if (!tail_out.alloc((size_t) S * (out_delay + 8) * ch_in * sizeof(double))) return false;
 	}
 	return true;
 }
@@ -352,7 +416,44 @@ ssize_t ConvStage::drain2(ssize_t max_frames, double *out, long out_stride, hipS
 	// total output length is ceil(N up / down) (resample.c:163-188): the tail is computed against zero input
 	const long left = max_out_frames(q_total) - emitted;
 	if (q_total == 0 || left <= 0) return -1;
-	return emit(std::min<long>(left, std::max<long>(max_out_frames(max_frames), 1)), out, out_stride, st);
+	const long count = std::min<long>(left, std::max<long>(max_out_frames(max_frames), 1));
+	if (!merged_pre) return emit(count, out, out_stride, st);
+	if (tail_frames < 0 && !compute_tail(st)) return -1;
+	// serve the precomputed tail
+	const long n = std::min<long>(count, tail_frames - tail_served);
+	if (n <= 0) return -1;
+	launch_copy_slab(tail_out.as<double>() + (size_t) tail_served * ch_in, out_delay + 8, out, out_stride, n, 0, ch_in, S, st);
+	tail_served += n;
+	emitted += n;
+	return n;
+}
+
+// the drain2 tail of a merged fir_p + resample stage, the reference's way (see the member comment)
+bool ConvStage::compute_tail(hipStream_t st)
+{
+	// 1. z = fir_p output at input indices [q_total - J, q_total): plain filter, single phase, into tail_z
+	{
+		const int sv_nph = nph, sv_up = up, sv_down = down;
+		std::swap(H.p, H_plain.p); std::swap(H.bytes, H_plain.bytes);
+		nph = 1; up = 1; down = 1;
+		// inputs at or beyond q_total read as zero, as in the resampler path
+		convolve(q_total - J_rs, q_total - 1, q_total - J_rs, J_rs, tail_z.as<double>(), J_rs, st);
+		nph = sv_nph; up = sv_up; down = sv_down;
+		std::swap(H.p, H_plain.p); std::swap(H.bytes, H_plain.bytes);
+	}
+	// 2. a polyphase resampler of its own over those J frames: its regular output is not needed, its drain2 is the tail
+	tail_rs->reset(st);
+	const long reg = tail_rs->max_out_frames(J_rs);
+	if (tail_rs->run(tail_z.as<double>(), J_rs, J_rs, tail_scratch.as<double>(), reg + 8, st) < 0) return false;
+	tail_frames = 0;
+	for (;;) {
+		const ssize_t got = tail_rs->drain2(J_rs, tail_out.as<double>() + (size_t) tail_frames * ch_in, out_delay + 8, st);
+		if (got <= 0) break;
+		tail_frames += got;
+		if (tail_frames >= out_delay) break;
+	}
+	tail_served = 0;
+	return true;
 }
 
 void ConvStage::reset(hipStream_t st)
@@ -360,6 +461,7 @@ void ConvStage::reset(hipStream_t st)
 	(void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
 	pos = 0;
 	q_total = emitted = q_abs = 0;
+	tail_frames = -1; tail_served = 0;
 	if (feeder_) feeder_->ring.pos = 0;
 }
 

@@ -41,6 +41,8 @@ struct Spec {
 	double rs_fc = 0.0;
 	std::vector<double> rs_proto;            // windowed-sinc prototype s[0..m] at rate max(fs_in, fs_out) * sinc_os
 	int rs_os = 1;
+	std::vector<double> rs_pre;              // Resample: taps of a zero-latency FIR (fir_p) folded in front of the polyphase branches
+	std::string rs_pre_name;
 };
 
 using SpecPtr = std::unique_ptr<Spec>;

@@ -317,7 +317,22 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 		s->ch_in = sp.ch_in; s->ch_out = sp.ch_out;
 	};
 	ssize_t frames_here = max_frames;   // worst-case frames entering the next stage
-	for (const Spec *sp : specs) {
+	std::vector<std::unique_ptr<Spec>> merged;   // specs synthesised here (LTI merges)
+	for (size_t si = 0; si < specs.size(); ++si) {
+		const Spec *sp = specs[si];
+		// fir_p -> integer-ratio resample: two LTI stages on all channels = ONE multi-phase convolution whose branch
+		// filters are h * h_p (one set of FFT passes instead of two, no slab between them)
+		if (sp->kind == Kind::Conv && si + 1 < specs.size() && specs[si + 1]->kind == Kind::Resample && !getenv("DSP_AMD_NO_LTI_MERGE")) {
+			const Spec *rs = specs[si + 1];
+			const bool int_ratio = (rs->rs_n == 1 || rs->rs_d == 1) && rs->rs_n <= 8 && rs->rs_d <= 8;
+			if (int_ratio && sp->conv_mode == CONV_ZERO_LATENCY && sp->latency == 0 && sp->fch == 1 && num_set(sp->sel) == sp->ch_in && sp->ch_in == rs->ch_in) {
+				merged.emplace_back(new Spec(*rs));
+				merged.back()->rs_pre = sp->taps;
+				merged.back()->rs_pre_name = sp->name;
+				sp = merged.back().get();
+				++si;
+			}
+		}
 		if (sp->fs_in != cur_fs || sp->ch_in != cur_ch) {
 			set_error("pipeline: BUG: stream format mismatch at %s (%d ch @ %d vs %d ch @ %d)", sp->name.c_str(), sp->ch_in, sp->fs_in, cur_ch, cur_fs);
 			return nullptr;

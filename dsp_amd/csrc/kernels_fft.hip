@@ -273,7 +273,8 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 // K3: W[pair][k1][n2] --IFFT over k1--> y[n1 N2 + n2]; valid outputs scattered into the interleaved slab.
 // blockIdx.y = stream * groups + group; the workgroup holds PPS pairs of that stream, lanes ordered pair-fastest so
 // that the 16-byte (re, im) = (channel 2q, 2q+1) pieces of one frame leave from adjacent lanes.
-template <int LOG2N1, int PPS>
+// HOLD2: the two interleaved phases of a 2x upsampler -- phase 0 is held in registers and frames 2q, 2q+1 leave together
+template <int LOG2N1, int PPS, bool HOLD2>
 __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(ConvParams p)
 {
 	using Cfg = ColCfg<LOG2N1, PPS>;
@@ -292,6 +293,39 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
 	const int cha = active ? p.pair_out_ch[2 * qs] : -1, chb = active ? p.pair_out_ch[2 * qs + 1] : -1;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
+	if constexpr (HOLD2) {
+		cplx v0[16], v[16];
+		if (active) {
+			const cplx *W = p.W + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v0[m] = W[(long) (j + P * m) * p.N2];
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v[m] = W[p.phase_stride + (long) (j + P * m) * p.N2];
+		}
+		else {
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v0[m] = v[m] = make_double2(0.0, 0.0);
+		}
+		col_fft<LOG2N1, PPS, true>(v0, q, t, j, smem_raw, TwCol{ twt });
+		lds_barrier();
+		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
+		if (!active) return;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			const long f = (long) (j + P * m) * p.N2 + n2 - p.first_n;
+			if (f < 0 || f >= p.in_count) continue;
+			const long mo = 2 * (p.q_blk + f) - p.k_origin;
+			if (wide) {
+				if (mo >= 0 && mo < p.out_count) *reinterpret_cast<cplx *>(out + mo * p.C + cha) = v0[m];
+				if (mo + 1 >= 0 && mo + 1 < p.out_count) *reinterpret_cast<cplx *>(out + (mo + 1) * p.C + cha) = v[m];
+			}
+			else {
+				if (mo >= 0 && mo < p.out_count) { if (cha >= 0) out[mo * p.C + cha] = v0[m].x; if (chb >= 0) out[mo * p.C + chb] = v0[m].y; }
+				if (mo + 1 >= 0 && mo + 1 < p.out_count) { if (cha >= 0) out[(mo + 1) * p.C + cha] = v[m].x; if (chb >= 0) out[(mo + 1) * p.C + chb] = v[m].y; }
+			}
+		}
+		return;
+	}
 	for (int ph = 0; ph < p.nph; ++ph) {
 		cplx v[16];
 		if (active) {
@@ -625,10 +659,18 @@ template <int L> static void launch_col_fwd(const ConvParams &p, int n_pairs, hi
 template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hipStream_t st)
 {
 	using Cfg = ColCfg<L, PPS>;
-	static bool granted = false;
-	if (!granted) { grant_lds(conv_col_inv<L, PPS>, Cfg::LDS); granted = true; }
+	static bool granted[2] = { false, false };
 	const int groups = (p.pairs_per_stream + PPS - 1) / PPS;
-	hipLaunchKernelGGL((conv_col_inv<L, PPS>), dim3((unsigned) (p.N2 / Cfg::TW), (unsigned) (p.n_streams_launch * groups)), dim3(Cfg::THREADS), Cfg::LDS, st, p);
+	const dim3 grid((unsigned) (p.N2 / Cfg::TW), (unsigned) (p.n_streams_launch * groups)), block(Cfg::THREADS);
+	if (PPS == 4 && p.nph == 2 && p.up == 2 && p.down == 1 && !p.round_f32) {
+		if constexpr (PPS == 4) {
+			if (!granted[1]) { grant_lds(conv_col_inv<L, PPS, true>, Cfg::LDS); granted[1] = true; }
+			hipLaunchKernelGGL((conv_col_inv<L, PPS, true>), grid, block, Cfg::LDS, st, p);
+			return;
+		}
+	}
+	if (!granted[0]) { grant_lds(conv_col_inv<L, PPS, false>, Cfg::LDS); granted[0] = true; }
+	hipLaunchKernelGGL((conv_col_inv<L, PPS, false>), grid, block, Cfg::LDS, st, p);
 }
 
 template <int L> static void launch_col_inv(const ConvParams &p, hipStream_t st)
