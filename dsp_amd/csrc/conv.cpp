@@ -39,7 +39,7 @@ static void make_twiddles(long n, long count, long stride, std::vector<double2> 
 
 class ConvStage : public Stage {
 public:
-	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder);
+	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev);
 	const char *type() const override { return "conv"; }
 	std::string describe() const override;
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
@@ -81,6 +81,11 @@ private:
 	hipEvent_t ev_start = nullptr;
 	std::string name;
 	CascadeStage *feeder_ = nullptr;
+	// this stage's K3 writes the next convolver's ring (set by the consumer's init)
+	double2 *feed_ring = nullptr;
+	long feed_stride = 0, feed_mask = 0, feed_pos = 0;
+	int feed_round = 0;
+	ConvStage *feeds = nullptr, *fed_by = nullptr;
 	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_h, pair_out_ch, slot_of_channel;
 };
 
@@ -90,7 +95,7 @@ std::string ConvStage::describe() const
 	o << (resampler ? "fft-resample[" : "conv[") << name;
 	if (resampler) o << " " << fs_in << "->" << fs_out << " " << up << "/" << down << " delay=" << out_delay;
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
-	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? " fed-by-cascade" : "")
+	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
 	  << (round_f32 ? " f32-io" : "") << "]";
 	return o.str();
 }
@@ -115,10 +120,13 @@ ConvParams ConvStage::base_params() const
 	p.round_f32 = round_f32;
 	p.nph = nph; p.up = up; p.down = down;
 	p.phase_stride = pairs_per_chunk * N;
+	p.ring_out = feed_ring;
+	p.ring_out_stride = feed_stride; p.ring_out_mask = feed_mask; p.ring_out_pos = feed_pos;
+	p.ring_out_round_f32 = feed_round;
 	return p;
 }
 
-bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
+bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev)
 {
 	name = sp.name;
 	T = sp.T;
@@ -152,7 +160,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 			pre_taps = sp.rs_pre;
 			Spec plain(sp);
 			plain.rs_pre.clear();
-			tail_rs.reset(make_resample_stage(plain, S, J));
+			tail_rs.reset(make_resample_stage(plain, S, J + 8));
 			if (!tail_rs) return false;
 			tail_rs->S = S; tail_rs->ch_in = sp.ch_in; tail_rs->ch_out = sp.ch_out; tail_rs->fs_in = sp.fs_in; tail_rs->fs_out = sp.fs_out;
 		}
@@ -255,6 +263,20 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder)
 	if (!prepare_filters(sp)) return false;
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
+	// another FFT convolver right before, on the same channel pairs: its K3 writes (re, im) = this ring's elements
+	if (ConvStage *pc = dynamic_cast<ConvStage *>(prev)) {
+		if (all_selected && n_filters == 1 && pc->all_selected && pc->n_filters == 1 && pc->ch_out == ch_in && pc->pps == pps && !pc->feeds
+		    && !pc->merged_pre && !getenv("DSP_AMD_NO_FEED")) {
+			pc->feed_ring = ring.as<double2>();
+			pc->feed_stride = ring_len;
+			pc->feed_mask = ring_len - 1;
+			pc->feed_pos = 0;
+			pc->feed_round = round_f32;
+			pc->feeds = this;
+			fed_by = pc;
+			fed = true;
+		}
+	}
 	if (feeder && all_selected && !round_f32 && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
 		feeder->ring.base = ring.as<double>();
 		feeder->ring.row_stride = ring_len;
@@ -309,8 +331,8 @@ bool ConvStage::prepare_filters(const Spec &sp)
 		if (!H_plain.alloc((size_t) N * sizeof(double2), false)) return false;
 		// H_plain is used by the single-phase row kernel (nph = 1 selects it and its H order)
 		if (!spectrum_of(pre_taps, (long) pre_taps.size(), 1, 0, H_plain.as<double2>(), 1)) return false;
-		if (!tail_z.alloc((size_t) S * J_rs * ch_in * sizeof(double))) return false;
-		if (!tail_scratch.alloc((size_t) S * ((size_t) J_rs * up + 8) * ch_in * sizeof(double))) return false;
+		if (!tail_z.alloc((size_t) S * (J_rs + 8) * ch_in * sizeof(double))) return false;
+		if (!tail_scratch.alloc((size_t) S * ((size_t) (J_rs + 8) * up + 8) * ch_in * sizeof(double))) return false;
 		if (!tail_out.alloc((size_t) S * (out_delay + 8) * ch_in * sizeof(double))) return false;
 	}
 	return true;
@@ -390,6 +412,7 @@ ssize_t ConvStage::emit(long count, double *out, long out_stride, hipStream_t st
 	const long kp0 = emitted + out_delay, kp1 = kp0 + count;
 	convolve((kp0 * down) / up, ((kp1 - 1) * down) / up, kp0, count, out, out_stride, st);
 	emitted += count;
+	feed_pos = (feed_pos + count) & feed_mask;
 	return count;
 }
 
@@ -406,6 +429,7 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 	// plain convolution: output frame m of this call = convolution at ring index pos + m
 	convolve(q_abs, q_abs + frames - 1, q_abs, frames, out, out_stride, st);
 	q_abs += frames;
+	feed_pos = (feed_pos + frames) & feed_mask;
 	pos = (pos + frames) & (ring_len - 1);
 	return frames;
 }
@@ -431,20 +455,23 @@ ssize_t ConvStage::drain2(ssize_t max_frames, double *out, long out_stride, hipS
 // the drain2 tail of a merged fir_p + resample stage, the reference's way (see the member comment)
 bool ConvStage::compute_tail(hipStream_t st)
 {
-	// 1. z = fir_p output at input indices [q_total - J, q_total): plain filter, single phase, into tail_z
+	// 1. z = fir_p output at the last Jt >= J input indices [q_total - Jt, q_total): plain filter, single phase, into
+	//    tail_z.  The helper's stream starts at q_total - Jt: a multiple of `down`, so that its decimation phase is
+	//    the stream's.
+	const long Jt = J_rs + (((q_total - J_rs) % down) + down) % down;
 	{
 		const int sv_nph = nph, sv_up = up, sv_down = down;
 		std::swap(H.p, H_plain.p); std::swap(H.bytes, H_plain.bytes);
 		nph = 1; up = 1; down = 1;
 		// inputs at or beyond q_total read as zero, as in the resampler path
-		convolve(q_total - J_rs, q_total - 1, q_total - J_rs, J_rs, tail_z.as<double>(), J_rs, st);
+		convolve(q_total - Jt, q_total - 1, q_total - Jt, Jt, tail_z.as<double>(), J_rs + 8, st);
 		nph = sv_nph; up = sv_up; down = sv_down;
 		std::swap(H.p, H_plain.p); std::swap(H.bytes, H_plain.bytes);
 	}
-	// 2. a polyphase resampler of its own over those J frames: its regular output is not needed, its drain2 is the tail
+	// 2. a polyphase resampler of its own over those frames: its regular output is not needed, its drain2 is the tail
 	tail_rs->reset(st);
-	const long reg = tail_rs->max_out_frames(J_rs);
-	if (tail_rs->run(tail_z.as<double>(), J_rs, J_rs, tail_scratch.as<double>(), reg + 8, st) < 0) return false;
+	const long reg = tail_rs->max_out_frames(Jt);
+	if (tail_rs->run(tail_z.as<double>(), J_rs + 8, Jt, tail_scratch.as<double>(), reg + 8, st) < 0) return false;
 	tail_frames = 0;
 	for (;;) {
 		const ssize_t got = tail_rs->drain2(J_rs, tail_out.as<double>() + (size_t) tail_frames * ch_in, out_delay + 8, st);
@@ -462,6 +489,7 @@ void ConvStage::reset(hipStream_t st)
 	pos = 0;
 	q_total = emitted = q_abs = 0;
 	tail_frames = -1; tail_served = 0;
+	feed_pos = 0;
 	if (feeder_) feeder_->ring.pos = 0;
 }
 
@@ -514,7 +542,7 @@ ssize_t FirDirectStage::run(const double *in, long in_stride, ssize_t frames, do
 
 // ------------------------------------------------------------------ factory
 
-Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder)
+Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder, Stage *prev)
 {
 	// integer ratios ride the FFT convolver (one forward transform, one inverse per polyphase branch); general n/d
 	// stays on the polyphase dot-product kernel
@@ -528,7 +556,7 @@ Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, Cascad
 	}
 	ConvStage *s = new ConvStage;
 	s->S = n_streams; s->ch_in = sp.ch_in; s->ch_out = sp.ch_out; s->fs_in = sp.fs_in; s->fs_out = sp.fs_out;
-	if (!s->init(sp, max_frames, feeder)) { delete s; return nullptr; }
+	if (!s->init(sp, max_frames, feeder, prev)) { delete s; return nullptr; }
 	return s;
 }
 

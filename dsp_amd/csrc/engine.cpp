@@ -367,7 +367,8 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 		case Kind::FirDirect: case Kind::Conv: case Kind::Resample: {
 			CascadeStage *feeder = casc;
 			if (!flush()) return nullptr;
-			Stage *s = make_conv_stage(*sp, n_streams, frames_here, feeder);
+			Stage *prev = (!feeder && !pl->stages.empty()) ? pl->stages.back().get() : nullptr;
+			Stage *s = make_conv_stage(*sp, n_streams, frames_here, feeder, prev);
 			if (!s) return nullptr;
 			base(s, *sp);
 			pl->stages.emplace_back(s);

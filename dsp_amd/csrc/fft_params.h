@@ -30,6 +30,11 @@ struct ConvParams {
 	long out_stride_frames, first_n, in_count, out_count, q_blk, k_origin;
 	int nph, up, down;                  // nph phases: filter spectrum (pair_h * nph + ph), W + ph * phase_stride
 	long phase_stride;
+	// optional: the NEXT convolver's pair ring as destination instead of the interleaved slab (same pairing of
+	// channels): element (pair q of stream s, frame mo) at ring_out[(s * pps + q) * ring_out_stride + ((ring_out_pos + mo) & ring_out_mask)]
+	double2 *ring_out;
+	long ring_out_stride, ring_out_mask, ring_out_pos;
+	int ring_out_round_f32;
 	int C, pairs_per_stream;
 	long stream0, n_streams_launch;
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)

@@ -293,6 +293,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
 	const int cha = active ? p.pair_out_ch[2 * qs] : -1, chb = active ? p.pair_out_ch[2 * qs + 1] : -1;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
+	cplx *rout = p.ring_out ? p.ring_out + (s * p.pairs_per_stream + qs) * p.ring_out_stride : nullptr;
 	if constexpr (HOLD2) {
 		cplx v0[16], v[16];
 		if (active) {
@@ -315,7 +316,12 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 			const long f = (long) (j + P * m) * p.N2 + n2 - p.first_n;
 			if (f < 0 || f >= p.in_count) continue;
 			const long mo = 2 * (p.q_blk + f) - p.k_origin;
-			if (wide) {
+			if (rout) {
+				if (chb < 0) { v0[m].y = 0.0; v[m].y = 0.0; }
+				if (mo >= 0 && mo < p.out_count) rout[(p.ring_out_pos + mo) & p.ring_out_mask] = v0[m];
+				if (mo + 1 >= 0 && mo + 1 < p.out_count) rout[(p.ring_out_pos + mo + 1) & p.ring_out_mask] = v[m];
+			}
+			else if (wide) {
 				if (mo >= 0 && mo < p.out_count) *reinterpret_cast<cplx *>(out + mo * p.C + cha) = v0[m];
 				if (mo + 1 >= 0 && mo + 1 < p.out_count) *reinterpret_cast<cplx *>(out + (mo + 1) * p.C + cha) = v[m];
 			}
@@ -350,7 +356,12 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 			if (mo < 0 || mo >= p.out_count) continue;
 			cplx y = v[m];
 			if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
-			if (wide) *reinterpret_cast<cplx *>(out + mo * p.C + cha) = y;
+			if (rout) {
+				if (p.ring_out_round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+				if (chb < 0) y.y = 0.0;
+				rout[(p.ring_out_pos + mo) & p.ring_out_mask] = y;
+			}
+			else if (wide) *reinterpret_cast<cplx *>(out + mo * p.C + cha) = y;
 			else {
 				if (cha >= 0) out[mo * p.C + cha] = y.x;
 				if (chb >= 0) out[mo * p.C + chb] = y.y;
@@ -662,7 +673,7 @@ template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hi
 	static bool granted[2] = { false, false };
 	const int groups = (p.pairs_per_stream + PPS - 1) / PPS;
 	const dim3 grid((unsigned) (p.N2 / Cfg::TW), (unsigned) (p.n_streams_launch * groups)), block(Cfg::THREADS);
-	if (PPS == 4 && p.nph == 2 && p.up == 2 && p.down == 1 && !p.round_f32) {
+	if (PPS == 4 && p.nph == 2 && p.up == 2 && p.down == 1 && !p.round_f32 && !p.ring_out_round_f32) {
 		if constexpr (PPS == 4) {
 			if (!granted[1]) { grant_lds(conv_col_inv<L, PPS, true>, Cfg::LDS); granted[1] = true; }
 			hipLaunchKernelGGL((conv_col_inv<L, PPS, true>), grid, block, Cfg::LDS, st, p);

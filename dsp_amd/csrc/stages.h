@@ -58,8 +58,9 @@ private:
 // resample.cpp
 void resample_polyphase_table(const Spec &sp, int *J, long *out_delay, std::vector<double> &tab);
 
-// conv.cpp: FirDirect / Conv / Resample.  `feeder` (may be null) is the cascade stage immediately before,
+// conv.cpp: FirDirect / Conv / Resample.  `prev` (may be null) is the stage immediately before: when it is another FFT
+// convolver on the same channel pairs its K3 writes this stage's ring directly.  `feeder` (may be null) is the cascade stage immediately before,
 // which can write straight into the convolver's planar ring instead of an interleaved slab.
-Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder);
+Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder, Stage *prev);
 
 }  // namespace dspamd

@@ -221,3 +221,43 @@ def test_every_transform_geometry(amd, tmp_path, monkeypatch, log2n, channels):
     ref = fftconv(x, h)
     assert y.shape == ref.shape
     assert rms(y - ref) < TOL, rms(y - ref)
+
+
+@pytest.mark.parametrize("channels", [2, 3, 8])
+def test_chained_convolvers_feed_each_other(amd, tmp_path, channels):
+    # two FFT convolvers in a row: the first one's K3 writes the second one's pair ring directly (no slab in between);
+    # also through the batch path with several streams
+    import torch
+    h1 = make_filter(700, 11, 90.0)
+    h2 = make_filter(4000, 12, 500.0)
+    p1, p2 = write(tmp_path, h1, "a.raw"), write(tmp_path, h2, "b.raw")
+    chain = f"fir_p -t pcm -e double -c 1 {p1} fir_p -t pcm -e double -c 1 {p2}"
+    S, N = 3, 7000
+    x = np.stack([noise(N, channels, 60 + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, channels, S, 3000)
+    assert "fed-by-conv" in b.plan()
+    y = b.process(torch.from_numpy(x).cuda(), 1777).cpu().numpy()
+    for s in range(S):
+        ref = fftconv(fftconv(x[s], h1), h2)
+        assert y[s].shape == ref.shape
+        assert rms(y[s] - ref) < TOL
+
+
+def test_resampler_feeds_convolver_and_back(amd, tmp_path, monkeypatch):
+    import torch
+    h = make_filter(900, 13, 120.0)
+    p = write(tmp_path, h)
+    for chain in (f"resample 96k fir_p -t pcm -e double -c 1 {p}", f"fir_p -t pcm -e double -c 1 {p} resample 24k"):
+        for merge in ("0", "1"):
+            if merge == "0":
+                monkeypatch.setenv("DSP_AMD_NO_LTI_MERGE", "1")
+            else:
+                monkeypatch.delenv("DSP_AMD_NO_LTI_MERGE", raising=False)
+            S, C, N = 2, 4, 6000
+            x = np.stack([noise(N, C, 70 + s, 0.4) for s in range(S)])
+            b = amd.BatchChain(chain, 48000, C, S, 2048)
+            y = b.process(torch.from_numpy(x).cuda(), 2048).cpu().numpy()
+            for s in range(S):
+                ref, _ = oracle_chain.run(chain.replace(p, "{F}"), x[s], 48000, filt=h)
+                assert ref.shape == y[s].shape, (chain, merge, ref.shape, y[s].shape)
+                assert rms(ref - y[s]) < 1e-11, (chain, merge, rms(ref - y[s]))
