@@ -126,6 +126,30 @@ ConvParams ConvStage::base_params() const
 	return p;
 }
 
+// Transform size for a T-tap filter and calls of max_frames frames: at least 2T (overlap <= 1/2), up to 16x the
+// filter when calls are long (valid fraction (N - T + 1) / N: 1/2 at 2T, 15/16 at 16T); among the admissible sizes
+// the cheapest for such a call: blocks x points x relative cost per point of the row kernel (measured: 1024-point
+// rows 1.0, 2048 ~1.25, 4096 ~1.3).  *cost (optional) = that figure, comparable between plans.
+long conv_plan(long T, long max_frames, bool resampler, double *cost_out)
+{
+	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
+	const long fn = (T - 1 + 7) & ~7L, F = std::max<long>(max_frames, 1);
+	const long want = next_pow2(fn + F);
+	const long hi = std::min(std::min(std::max(lo, want), std::max(lo * 8, resampler ? (1L << 16) : 0L)), 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
+	long N = lo;
+	double best = 0.0;
+	for (long n = lo; n <= std::max(lo, hi); n <<= 1) {
+		const long hop = (n - fn) & ~7L;
+		if (hop <= 0) continue;
+		const long n2 = n / std::min<long>(1L << FFT_MAX_LOG2_N1, ((n >> 10) >= (1L << FFT_MIN_LOG2_N1)) ? (n >> 10) : (n >> FFT_MIN_LOG2_N2));
+		const double c = (n2 >= 4096) ? 1.3 : (n2 >= 2048) ? 1.25 : 1.0;
+		const double cost = (double) ((F + hop - 1) / hop) * ((double) n * c + 16384.0);   // + per-block launch / tail overhead
+		if (best == 0.0 || cost < best) { best = cost; N = n; }
+	}
+	if (cost_out) *cost_out = best;
+	return N;
+}
+
 bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev)
 {
 	name = sp.name;
@@ -170,25 +194,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	// channel pairs share a transform only when they share the filter
 	pps = (n_filters == 1) ? (nsel + 1) / 2 : nsel;
 
-	// transform size: at least 2T (overlap <= 1/2), grown up to 16x the filter when calls are long
-	// (valid fraction (N - T + 1) / N: 1/2 at 2T, 15/16 at 16T)
+	N = conv_plan(T, max_frames, resampler, nullptr);
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
-	const long want = next_pow2(((T + 6) & ~7L) + std::max<long>(max_frames, 1));
-	N = std::min(std::max(lo, want), std::max(lo * 8, resampler ? (1L << 16) : 0L));
-	{
-		// among the admissible sizes take the cheapest for a call of max_frames: blocks x points x relative cost per
-		// point of the row kernel (measured: 1024-point rows 1.0, 2048 ~1.25, 4096 ~1.3)
-		const long fn = (T - 1 + 7) & ~7L, F = std::max<long>(max_frames, 1), hi = N;
-		double best = 0.0;
-		for (long n = lo; n <= hi; n <<= 1) {
-			const long hop = (n - fn) & ~7L;
-			if (hop <= 0) continue;
-			const long n2 = n / std::min<long>(1L << FFT_MAX_LOG2_N1, ((n >> 10) >= (1L << FFT_MIN_LOG2_N1)) ? (n >> 10) : (n >> FFT_MIN_LOG2_N2));
-			const double c = (n2 >= 4096) ? 1.3 : (n2 >= 2048) ? 1.25 : 1.0;
-			const double cost = (double) ((F + hop - 1) / hop) * (double) n * c;
-			if (best == 0.0 || cost < best) { best = cost; N = n; }
-		}
-	}
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
 	if (env) N = std::max(lo, 1L << atoi(env));
 	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));

@@ -320,12 +320,56 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 	std::vector<std::unique_ptr<Spec>> merged;   // specs synthesised here (LTI merges)
 	for (size_t si = 0; si < specs.size(); ++si) {
 		const Spec *sp = specs[si];
+		// fir_p -> fir_p (hilbert -p -> fir_p, ...): two zero-latency convolutions of every channel with one-channel
+		// filters = ONE convolution with h1 * h2 (T1 + T2 - 1 taps; the chain's drain length is the same sum)
+		while (sp->kind == Kind::Conv && si + 1 < specs.size() && specs[si + 1]->kind == Kind::Conv && !getenv("DSP_AMD_NO_LTI_MERGE")) {
+			const Spec *b = specs[si + 1];
+			const bool ok = sp->conv_mode == CONV_ZERO_LATENCY && b->conv_mode == CONV_ZERO_LATENCY && sp->latency == 0 && b->latency == 0
+			                && sp->fch == 1 && b->fch == 1 && num_set(sp->sel) == sp->ch_in && num_set(b->sel) == b->ch_in && sp->ch_in == b->ch_in
+			                && (double) sp->T * (double) b->T <= 2.0e9;
+			if (!ok) break;
+			{
+				// only when the one convolution is cheaper than the two at this call size (transform sizes are powers of
+				// two: a few taps more can push a call into a second, nearly empty block)
+				double ca = 0, cb = 0, cm = 0;
+				conv_plan(sp->T, frames_here, false, &ca);
+				conv_plan(b->T, frames_here, false, &cb);
+				conv_plan(sp->T + b->T - 1, frames_here, false, &cm);
+				if (cm > ca + cb) break;
+			}
+			merged.emplace_back(new Spec(*sp));
+			Spec &m = *merged.back();
+			m.T = sp->T + b->T - 1;
+			m.taps.assign((size_t) m.T, 0.0);
+			for (ssize_t i = 0; i < sp->T; ++i) {
+				const double a = sp->taps[i];
+				if (a == 0.0) continue;
+				double *dst = &m.taps[i];
+				const double *hb = b->taps.data();
+				for (ssize_t j = 0; j < b->T; ++j) dst[j] += a * hb[j];
+			}
+			m.name = sp->name + "+" + b->name;
+			sp = &m;
+			++si;
+		}
 		// fir_p -> integer-ratio resample: two LTI stages on all channels = ONE multi-phase convolution whose branch
 		// filters are h * h_p (one set of FFT passes instead of two, no slab between them)
 		if (sp->kind == Kind::Conv && si + 1 < specs.size() && specs[si + 1]->kind == Kind::Resample && !getenv("DSP_AMD_NO_LTI_MERGE")) {
 			const Spec *rs = specs[si + 1];
 			const bool int_ratio = (rs->rs_n == 1 || rs->rs_d == 1) && rs->rs_n <= 8 && rs->rs_d <= 8;
-			if (int_ratio && sp->conv_mode == CONV_ZERO_LATENCY && sp->latency == 0 && sp->fch == 1 && num_set(sp->sel) == sp->ch_in && sp->ch_in == rs->ch_in) {
+			bool cheaper = false;
+			if (int_ratio) {
+				// the branches of an n-fold upsampler cost about (1 + 2 n) / 3 of a plain convolution of the same size
+				std::vector<double> tab; int J = 0; long od = 0;
+				resample_polyphase_table(*rs, &J, &od, tab);
+				const double w = (1.0 + 2.0 * rs->rs_n) / 3.0;
+				double ca = 0, cb = 0, cm = 0;
+				conv_plan(sp->T, frames_here, false, &ca);
+				conv_plan(J, frames_here, true, &cb);
+				conv_plan(sp->T + J - 1, frames_here, true, &cm);
+				cheaper = (w * cm <= ca + w * cb);
+			}
+			if (int_ratio && cheaper && sp->conv_mode == CONV_ZERO_LATENCY && sp->latency == 0 && sp->fch == 1 && num_set(sp->sel) == sp->ch_in && sp->ch_in == rs->ch_in) {
 				merged.emplace_back(new Spec(*rs));
 				merged.back()->rs_pre = sp->taps;
 				merged.back()->rs_pre_name = sp->name;

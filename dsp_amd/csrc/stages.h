@@ -55,6 +55,9 @@ private:
 	DevBuf d_len, d_off, ring;
 };
 
+// conv.cpp: transform size of the FFT convolver for a T-tap filter and calls of max_frames frames (+ relative cost)
+long conv_plan(long T, long max_frames, bool resampler, double *cost);
+
 // resample.cpp
 void resample_polyphase_table(const Spec &sp, int *J, long *out_delay, std::vector<double> &tab);
 

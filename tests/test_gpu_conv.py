@@ -223,11 +223,14 @@ def test_every_transform_geometry(amd, tmp_path, monkeypatch, log2n, channels):
     assert rms(y - ref) < TOL, rms(y - ref)
 
 
+@pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("channels", [2, 3, 8])
-def test_chained_convolvers_feed_each_other(amd, tmp_path, channels):
-    # two FFT convolvers in a row: the first one's K3 writes the second one's pair ring directly (no slab in between);
-    # also through the batch path with several streams
+def test_chained_convolvers_feed_each_other(amd, tmp_path, monkeypatch, channels, merge):
+    # two FFT convolvers in a row: either merged into one convolution with h1 * h2 (LTI merge), or the first one's K3
+    # writes the second one's pair ring directly (no slab in between); through the batch path with several streams
     import torch
+    if not merge:
+        monkeypatch.setenv("DSP_AMD_NO_LTI_MERGE", "1")
     h1 = make_filter(700, 11, 90.0)
     h2 = make_filter(4000, 12, 500.0)
     p1, p2 = write(tmp_path, h1, "a.raw"), write(tmp_path, h2, "b.raw")
@@ -235,7 +238,7 @@ def test_chained_convolvers_feed_each_other(amd, tmp_path, channels):
     S, N = 3, 7000
     x = np.stack([noise(N, channels, 60 + s) for s in range(S)])
     b = amd.BatchChain(chain, 48000, channels, S, 3000)
-    assert "fed-by-conv" in b.plan()
+    assert ("fir_p+fir_p" if merge else "fed-by-conv") in b.plan()
     y = b.process(torch.from_numpy(x).cuda(), 1777).cpu().numpy()
     for s in range(S):
         ref = fftconv(fftconv(x[s], h1), h2)
