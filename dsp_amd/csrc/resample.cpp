@@ -5,6 +5,7 @@
 #include "stages.h"
 #include "resample_params.h"
 #include <cmath>
+#include <cstdlib>
 #include <sstream>
 
 namespace dspamd {
@@ -20,18 +21,21 @@ public:
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
-	size_t device_bytes() const override { return ring.bytes + tab.bytes; }
+	size_t device_bytes() const override { return ring.bytes + tab.bytes + G.bytes; }
 private:
 	ssize_t emit(long count, double *out, long out_stride, hipStream_t st);
 	int n = 1, d = 1, J = 0, KT = 256;
 	long out_delay = 0, ring_len = 0, q_total = 0, emitted = 0;
-	DevBuf ring, tab;
+	DevBuf ring, tab, G;
+	// GEMM form (kernels_resample.hip): blocks of NB = n g outputs <- DB = d g inputs
+	bool gemm = false;
+	int NB = 0, DB = 0, Kpad = 0, Npad = 0, log2cp = 0;
 };
 
 std::string ResampleStage::describe() const
 {
 	std::ostringstream o;
-	o << "resample[" << fs_in << "->" << fs_out << " " << n << "/" << d << " taps/phase=" << J << " delay=" << out_delay << "]";
+	o << (gemm ? "resample-gemm[" : "resample[") << fs_in << "->" << fs_out << " " << n << "/" << d << " taps/phase=" << J << " delay=" << out_delay << "]";
 	return o.str();
 }
 
@@ -81,6 +85,29 @@ bool ResampleStage::init(const Spec &sp, ssize_t max_frames)
 	resample_polyphase_table(sp, &J, &out_delay, t);
 	if (!tab.upload(t.data(), t.size() * sizeof(double))) return false;
 	long need = (long) J + std::max<long>(max_frames, 1) + (long) KT * d / n + 64;
+	// GEMM form when the block fits the kernel's tiling (NB <= 192 columns, <= 8 channels, span in LDS)
+	{
+		const int g = (n >= 16) ? 1 : (16 + n - 1) / n;
+		NB = n * g; DB = d * g;
+		Npad = (NB + 31) & ~31;                 // two waves x PT column tiles, no guards in the kernel
+		Kpad = (J + DB - 1 + 7) & ~7;          // the kernel walks K in steps of 8 and prefetches one step beyond (zero rows)
+		log2cp = 0;
+		while ((1 << log2cp) < ch_in) ++log2cp;
+		gemm = !getenv("DSP_AMD_RESAMPLE_NO_GEMM") && Npad <= 192 && ch_in <= 8 && resample_gemm_lds_bytes(DB, J, log2cp) <= 160 * 1024;
+		if (gemm) {
+			std::vector<double> gm((size_t) (Kpad + 8) * Npad, 0.0);
+			for (int r = 0; r < NB; ++r) {
+				const long qr = ((long) r * d) / n;
+				const int ph = (int) (((long) r * d) % n);
+				for (int j = 0; j < J; ++j) {
+					const long u = qr - j;                      // in [-(J-1), DB-1]
+					gm[(size_t) (u + J - 1) * Npad + r] = t[(size_t) j * n + ph];
+				}
+			}
+			if (!G.upload(gm.data(), gm.size() * sizeof(double))) return false;
+			need += 2L * DB * (64 >> log2cp) + NB;
+		}
+	}
 	ring_len = 1;
 	while (ring_len < need) ring_len <<= 1;
 	return ring.alloc((size_t) S * ring_len * ch_in * sizeof(double));
@@ -89,6 +116,20 @@ bool ResampleStage::init(const Spec &sp, ssize_t max_frames)
 ssize_t ResampleStage::emit(long count, double *out, long out_stride, hipStream_t st)
 {
 	if (count <= 0) return 0;
+	if (gemm) {
+		ResampleGemmParams g;
+		g.ring = ring.as<double>();
+		g.ring_len = ring_len; g.ring_mask = ring_len - 1; g.q_total = q_total;
+		g.G = G.as<double>();
+		g.NB = NB; g.DB = DB; g.J = J; g.Kpad = Kpad; g.Npad = Npad;
+		g.C = ch_in; g.log2cp = log2cp;
+		g.out_delay = out_delay; g.m_first = emitted; g.m_count = count;
+		g.i_first = (emitted + out_delay) / NB;
+		g.out = out; g.out_stride_frames = out_stride; g.out_frame0 = 0;
+		{ ProfScope ps("resample_gemm_kernel", st); launch_resample_gemm(g, S, st); }
+		emitted += count;
+		return count;
+	}
 	ResampleParams p;
 	p.ring = ring.as<double>();
 	p.ring_len = ring_len; p.ring_mask = ring_len - 1;
