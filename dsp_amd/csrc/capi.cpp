@@ -38,6 +38,29 @@ void dspamd_set_loglevel(int level) { g_loglevel = level; }
 
 const struct effect_info *dspamd_get_effect_info(const char *name) { return registry_lookup(name); }
 
+// ---------------------------------------------------------------- host-side planning (no device needed)
+
+// Build the chain plan (parse, merge, prepare, alignment, drain accounting) and copy the FIR the effect at index
+// `effect` ended up with for output channel `channel` (fir / fir_p / hilbert taps, or the FIR a reverse-IIR effect
+// was designed into).  Returns the number of taps (which may exceed max_taps: nothing beyond max_taps is written),
+// 0 when that channel is not filtered by that effect, -1 on error.  *delay (optional) = the effect's delay on that
+// channel as reported to the host (channel_offsets).
+ssize_t dspamd_plan_fir(const char *chain_str, int fs, int channels, const char *dir, int effect, int channel, double *taps, ssize_t max_taps, ssize_t *delay)
+{
+	ChainPlan plan;
+	if (!build_chain(chain_str, fs, channels, dir, plan)) return -1;
+	const std::vector<const Spec *> specs = plan.specs();
+	if (effect < 0 || effect >= (int) specs.size()) { set_error("plan_fir: no effect %d (chain has %zu)", effect, specs.size()); return -1; }
+	const Spec &sp = *specs[effect];
+	if ((sp.kind != Kind::Conv && sp.kind != Kind::FirDirect) || channel < 0 || channel >= sp.ch_in) { set_error("plan_fir: effect %d (%s) is not an FIR stage", effect, sp.name.c_str()); return -1; }
+	if (!sp.sel[channel]) return 0;
+	int f = 0;
+	if (sp.fch > 1) for (int k = 0; k < channel; ++k) if (sp.sel[k]) ++f;
+	for (ssize_t i = 0; i < sp.T && i < max_taps; ++i) taps[i] = sp.taps[(size_t) i * sp.fch + f];
+	if (delay) *delay = sp.ch_latency.empty() ? (sp.latency + sp.ref) : sp.ch_latency[channel];
+	return sp.T;
+}
+
 // ---------------------------------------------------------------- batch
 
 dspamd_batch *dspamd_batch_create(const char *chain_str, int fs, int channels, int n_streams, ssize_t max_frames, const char *dir)

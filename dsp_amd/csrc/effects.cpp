@@ -179,15 +179,20 @@ SpecPtr parse_biquad(int num, const stream_info *is, const char *sel, int argc, 
 	static const int n_args_of[] = { 0, 1, 1, 1, 2, 2, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 4, 4, 0, 6 };
 	if (num < 1 || num > DSPAMD_BIQUAD_BIQUAD) { set_error("%s: BUG: unknown effect number %d", name, num); return nullptr; }
 	const int n_args = n_args_of[num];
+	double thresh = 80.0;                                   // biquad.c:450
 	while ((opt = g.next(argc - n_args, argv, "r::")) != -1) {
-		if (opt == 'r') *reverse = true;
+		if (opt == 'r') {
+			*reverse = true;
+			if (g.arg) {                                    // biquad.c:391-395
+				char *e2;
+				thresh = (double) strtol(g.arg, &e2, 10);
+				if (bad_endptr(name, g.arg, e2, "thresh")) return nullptr;
+				if (!(thresh >= 10.0 && thresh <= 200.0)) { set_error("%s: error: thresh out of range", name); return nullptr; }
+			}
+		}
 		else { g.print_error(opt, name); usage(name); return nullptr; }
 	}
 	if (argc - g.ind != n_args) { usage(name); return nullptr; }
-	if (*reverse) {
-		set_error("%s: error: -r (time-reversed IIR, reverse_iir.c) is not provided by the GPU backend", name);
-		return nullptr;
-	}
 	const char *const *a = argv + g.ind;
 	char *end;
 	int wt = W_Q, type = num;
@@ -250,6 +255,19 @@ SpecPtr parse_biquad(int num, const stream_info *is, const char *sel, int argc, 
 	}
 	}
 	if (num != DSPAMD_BIQUAD_BIQUAD) biquad_design(type, is->fs, v[0], v[1], v[2], v[3], wt, c);
+	if (*reverse) {
+		// time-reversed IIR (biquad.c:532-533 -> reverse_iir.c:688-723): a section list per selected channel; consecutive
+		// -r effects merge; prepare() turns the lists into one FIR per channel for the FFT convolver (reverse_iir.cpp)
+		SpecPtr r = new_spec(Kind::Conv, name, is, sel);
+		r->flags = EFFECT_FLAG_OPT_REORDERABLE | EFFECT_FLAG_CH_DEPS_IDENTITY;
+		r->riir.assign(is->channels, std::vector<RiirSec>());
+		r->riir_pending = true;
+		RiirSec sec;
+		riir_sec_from_biquad(c, thresh, &sec);
+		for (int k = 0; k < is->channels; ++k) if (sel[k]) r->riir[k].push_back(sec);
+		*reverse = false;                                   // provided
+		return r;
+	}
 	SpecPtr s = new_spec(Kind::Biquad, name, is, sel);
 	s->flags = EFFECT_FLAG_OPT_REORDERABLE | EFFECT_FLAG_CH_DEPS_IDENTITY;
 	s->bq.assign(is->channels, std::array<double, 5>{ 1, 0, 0, 0, 0 });
@@ -727,6 +745,49 @@ SpecPtr parse_resample(const stream_info *is, const char *sel, int argc, const c
 
 // ------------------------------------------------------------------ merge
 
+// prepare() of a reverse-IIR effect (reverse_iir.c:381-636): per channel, the section list becomes one FIR
+// (reverse_iir.cpp) and a delay the host compensates; channels without sections pass through.
+bool riir_prepare(Spec &sp)
+{
+	if (!sp.riir_pending) return true;
+	const int n = sp.ch_in;
+	std::vector<std::vector<double>> h(n);
+	sp.ch_latency.assign(n, 0);
+	ssize_t T = 0;
+	int nsel = 0;
+	for (int k = 0; k < n; ++k) {
+		sp.sel[k] = sp.riir[k].empty() ? 0 : 1;
+		if (!sp.sel[k]) continue;
+		if (!riir_design(sp.name.c_str(), k, sp.riir[k], h[k], &sp.ch_latency[k])) return false;
+		T = std::max<ssize_t>(T, (ssize_t) h[k].size());
+		++nsel;
+	}
+	sp.riir_pending = false;
+	if (nsel == 0) { sp.T = 0; sp.fch = 1; sp.taps.clear(); return true; }
+	// one filter per selected channel, in channel order (fir.c:342-357 mapping); a single shared filter when they agree
+	bool same = true;
+	int first = -1;
+	for (int k = 0; k < n; ++k) {
+		if (!sp.sel[k]) continue;
+		if (first < 0) first = k;
+		else if (h[k] != h[first]) same = false;
+	}
+	sp.T = T;
+	sp.fch = same ? 1 : nsel;
+	sp.taps.assign((size_t) T * sp.fch, 0.0);
+	int f = 0;
+	for (int k = 0; k < n; ++k) {
+		if (!sp.sel[k]) continue;
+		if (same && k != first) continue;
+		for (size_t i = 0; i < h[k].size(); ++i) sp.taps[i * sp.fch + f] = h[k][i];
+		++f;
+	}
+	sp.conv_mode = CONV_ZERO_LATENCY;
+	sp.latency = 0;
+	sp.ref = 0;
+	return true;
+}
+
 bool merge_specs(Spec &d, const Spec &s)
 {
 	if (d.kind != s.kind) return false;
@@ -744,6 +805,14 @@ bool merge_specs(Spec &d, const Spec &s)
 		return true;
 	case Kind::Delay:
 		for (int k = 0; k < n; ++k) d.delay[k] += s.delay[k];   // delay.c:127-141
+		return true;
+	case Kind::Conv:
+		// reverse IIR effects append their sections channel by channel (reverse_iir.c:305-319); nothing else merges
+		if (!d.riir_pending || !s.riir_pending) return false;
+		for (int k = 0; k < n; ++k) {
+			d.riir[k].insert(d.riir[k].end(), s.riir[k].begin(), s.riir[k].end());
+			if (!s.riir[k].empty()) d.sel[k] = 1;
+		}
 		return true;
 	default:
 		return false;

@@ -19,6 +19,16 @@ enum ConvMode {
 	CONV_ZITA_EQUIV = 2,     // zita_convolver contract: float32 in / filter / out, `latency` = part_len frames late
 };
 
+// one second-order section of a time-reversed IIR filter before the per-channel design (reverse_iir.c:40-60)
+enum { RIIR_NONE = 0, RIIR_1R = 1, RIIR_2R = 2, RIIR_CC = 3 };
+struct RiirSec {
+	int pt = RIIR_NONE, qt = RIIR_NONE;      // kind of the pole pair / zero pair
+	double pr[2] = { 0, 0 }, pc_re = 0, pc_im = 0;
+	double qr[2] = { 0, 0 }, qc_re = 0, qc_im = 0;
+	double rr[2] = { 0, 0 }, rc_re = 0, rc_im = 0;   // residues (filled by the design)
+	double g = 1.0, thresh = 80.0;
+};
+
 struct Spec {
 	Kind kind;
 	std::string name;                        // effect name as the registry knows it (e->name)
@@ -36,6 +46,11 @@ struct Spec {
 	int fch = 0;
 	ssize_t T = 0, ref = 0, latency = 0;
 	int conv_mode = CONV_ZERO_LATENCY;
+	// reverse IIR (`biquad -r`, reverse_iir.c): per-channel section lists until prepare() turns them into one FIR per
+	// channel (taps / T / fch) with its own delay, which the host compensates (req_delay[k] -= ch_latency[k])
+	std::vector<std::vector<RiirSec>> riir;  // [ch_in]; non-empty = a reverse-IIR effect
+	bool riir_pending = false;
+	std::vector<ssize_t> ch_latency;         // [ch_in] when the channels' delays differ (reverse IIR)
 
 	int rs_n = 1, rs_d = 1, rs_m = 0;        // Resample: ratio n/d, prototype order m
 	double rs_fc = 0.0;
@@ -69,6 +84,11 @@ bool merge_specs(Spec &dest, const Spec &src);
 void biquad_normalise(double b0, double b1, double b2, double a0, double a1, double a2, std::array<double, 5> &c);
 void biquad_design(int type, double fs, double arg0, double arg1, double arg2, double arg3, int width_type, std::array<double, 5> &c);
 void hilbert_design(ssize_t taps, double angle_rad, std::vector<double> &h);
+
+// reverse_iir.cpp
+void riir_sec_from_biquad(const std::array<double, 5> &c, double thresh, RiirSec *s);
+bool riir_design(const char *name, int channel, std::vector<RiirSec> secs, std::vector<double> &taps, ssize_t *latency);
+bool riir_prepare(Spec &sp);   // the effect's prepare(): section lists -> per-channel FIRs
 
 const effect_info *registry_lookup(const char *name);
 const effect_info *registry_table(int *n);

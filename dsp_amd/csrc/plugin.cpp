@@ -129,6 +129,15 @@ static int plugin_merge(struct effect *dest, struct effect *src)
 	return 1;
 }
 
+static int plugin_prepare(struct effect *e)
+{
+	Node *n = node_of(e);
+	if (!n || n->pipe) return 0;
+	if (!riir_prepare(*n->spec)) return 1;
+	if (e->channel_selector) memcpy(e->channel_selector, n->spec->sel.data(), n->spec->sel.size());
+	return 0;
+}
+
 static void plugin_drain_samples(struct effect *e, ssize_t *samples)
 {
 	Node *n = node_of(e);
@@ -136,6 +145,7 @@ static void plugin_drain_samples(struct effect *e, ssize_t *samples)
 	const Spec &sp = *n->spec;
 	for (int k = 0; k < sp.ch_out; ++k) {
 		if (sp.kind == Kind::Align) samples[k] += sp.delay[k];                                  // align.c:77-82
+		else if (!sp.ch_latency.empty()) { if (sp.sel[k]) samples[k] += sp.ch_latency[k]; }     // reverse_iir.c:234-239
 		else if (sp.sel[k]) samples[k] += sp.latency + sp.T - 1;                                // fir.c:180-187, fir_p.c:235-240
 	}
 }
@@ -147,6 +157,7 @@ static void plugin_channel_offsets(struct effect *e, ssize_t *latency, ssize_t *
 	const Spec &sp = *n->spec;
 	for (int k = 0; k < sp.ch_in; ++k) {
 		if (sp.kind == Kind::Delay) req_delay[k] += sp.delay[k];                                // delay.c:142-147
+		else if (!sp.ch_latency.empty()) { if (sp.sel[k]) req_delay[k] -= sp.ch_latency[k]; }   // reverse_iir.c:275-280
 		else if (sp.sel[k]) { latency[k] += sp.latency; req_delay[k] -= sp.ref; }               // fir.c:208-217
 	}
 }
@@ -199,6 +210,7 @@ struct effect *make_effect(SpecPtr spec, bool noop)
 		case Kind::FirDirect: case Kind::Conv:
 			e->drain_samples = plugin_drain_samples;
 			e->channel_offsets = plugin_channel_offsets;
+			if (sp.riir_pending) { e->merge = plugin_merge; e->prepare = plugin_prepare; }
 			break;
 		case Kind::Resample: e->drain2 = plugin_drain2; break;
 		}

@@ -49,7 +49,7 @@ PLUGIN_SYMBOLS = [
 ]
 API_SYMBOLS = [
     "dspamd_version", "dspamd_last_error", "dspamd_device_count", "dspamd_set_device", "dspamd_set_loglevel",
-    "dspamd_get_effect_info", "dspamd_chain_build", "dspamd_chain_run", "dspamd_chain_drain",
+    "dspamd_get_effect_info", "dspamd_plan_fir", "dspamd_chain_build", "dspamd_chain_run", "dspamd_chain_drain",
     "dspamd_chain_max_out_frames", "dspamd_chain_drain_frames", "dspamd_chain_reset", "dspamd_chain_destroy",
     "dspamd_chain_n_effects", "dspamd_chain_effect_name", "dspamd_batch_create", "dspamd_batch_out_fs",
     "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run",
@@ -91,6 +91,7 @@ def load_library():
         "dspamd_version": (cp, []), "dspamd_last_error": (cp, []), "dspamd_device_count": (i, []),
         "dspamd_set_device": (i, [i]), "dspamd_set_loglevel": (None, [i]),
         "dspamd_get_effect_info": (C.POINTER(_EffectInfo), [cp]),
+        "dspamd_plan_fir": (ssize_t, [cp, i, i, cp, i, i, vp, ssize_t, C.POINTER(ssize_t)]),
         "dspamd_chain_build": (vp, [cp, i, i, cp, C.POINTER(i), C.POINTER(i)]),
         "dspamd_chain_run": (ssize_t, [vp, vp, ssize_t, vp, ssize_t]),
         "dspamd_chain_drain": (ssize_t, [vp, ssize_t, vp, ssize_t]),

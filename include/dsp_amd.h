@@ -38,6 +38,13 @@ void dspamd_set_loglevel(int level);
 /* registry lookup -- mirror of get_effect_info(), effect.c:69-76, for the effects this library provides */
 const struct effect_info *dspamd_get_effect_info(const char *name);
 
+/* host-side planning only (no device needed): build the chain plan -- parse, merge (effects_chain.c:605-641), prepare
+ * (:925-932), alignment, drain accounting -- and copy the FIR that effect number `effect` of the resulting chain
+ * applies to `channel`: the taps of fir / fir_p / hilbert (fir_util.c:25-120, hilbert.c:28-92), or the FIR a
+ * time-reversed IIR effect (`biquad -r`, reverse_iir.c:381-636) is designed into.  Returns the tap count (may exceed
+ * max_taps), 0 if the channel is not filtered, -1 on error; *delay = the delay reported through channel_offsets. */
+ssize_t dspamd_plan_fir(const char *chain_str, int fs, int channels, const char *dir, int effect, int channel, double *taps, ssize_t max_taps, ssize_t *delay);
+
 /* ---- stand-alone chain on HOST buffers (one stream; mirror of effects_chain.h:40-53) ---- */
 typedef struct dspamd_chain dspamd_chain;
 

@@ -140,3 +140,40 @@ def test_plugin_abi_run(amd):
     assert rms(y - ref) < TOL
     e.contents.destroy(e)
     C.CDLL(None).free(e)
+
+
+REVERSE_CHAINS = [
+    "lowpass -r 1k 0.707",                                    # one conjugate pole pair
+    "highpass -r 40 0.707",                                   # poles close to the unit circle: 2^12 comb stages' worth of taps
+    "lowpass_1 -r 2k",                                        # a single real pole
+    "highshelf -r60 8k 0.7 -3",                               # zeros -> FIR part, explicit threshold
+    "lowpass -r 1k 0.707 highpass -r 100 0.707",              # two effects merged into one partial-fraction expansion
+    "lowpass -r 1k 0.5 lowpass -r 1k 0.5",                    # repeated poles -> series states
+    "lowpass -r 1k 0.5",                                      # Q = 0.5: a double real pole inside one section
+    "allpass -r 500 1.0 eq -r 2k 1.5 4",
+]
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("chain", REVERSE_CHAINS)
+def test_reverse_iir_vs_real_reference(amd, chain):
+    # `biquad -r` (reverse_iir.c): the backend designs the equivalent FIR on the host and runs it on the FFT convolver;
+    # the real reference evaluates its comb cascades.  Same stream (host-side alignment included), fp64 rounding apart.
+    x = noise(30000, 2, 91, 0.4)
+    ref = RefChain(chain, 48000, 2).process(x, block=2048)
+    ec = amd.EffectsChain(chain, 48000, 2)
+    y = ec.process(x, block=1777)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    assert rms(y - ref) < 1e-12, rms(y - ref)
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_reverse_iir_channel_subset_and_mixed_chain(amd):
+    # linear-phase crossover style use: forward + reversed section on one channel only; the host delays the other
+    chain = ":0 lowpass 2k 0.707 lowpass -r 2k 0.707 : gain -3"
+    x = noise(20000, 3, 92, 0.4)
+    ref = RefChain(chain, 48000, 3).process(x, block=4096)
+    y = amd.EffectsChain(chain, 48000, 3).process(x, block=1000)
+    assert y.shape == ref.shape
+    assert np.array_equal(y[:, 1:], ref[:, 1:])          # untouched channels: delayed copies, bit-exact
+    assert rms(y - ref) < 1e-12, rms(y - ref)
