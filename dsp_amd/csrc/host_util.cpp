@@ -8,7 +8,13 @@
 
 namespace dspamd {
 
-int g_loglevel = LL_ERROR;
+static int initial_loglevel()
+{
+	const char *e = getenv("DSP_AMD_LOGLEVEL");   // a host's own -v / -q do not reach this library: LL_* number
+	return e ? atoi(e) : LL_ERROR;
+}
+
+int g_loglevel = initial_loglevel();
 static std::mutex g_log_mutex;
 static thread_local char g_err[1024] = "";
 

@@ -29,49 +29,73 @@ Node *node_of(struct effect *e)
 	return (n->magic == NODE_MAGIC) ? n : nullptr;
 }
 
-static bool ensure_pipe(struct effect *e, Node *n)
+static void plugin_destroy(struct effect *e);
+
+static bool is_ours(struct effect *e) { return e && e->destroy == plugin_destroy && node_of(e); }
+
+// the segment `e` belongs to, built on first use from the chain links the host maintains
+static bool ensure_segment(struct effect *e, Node *n)
 {
-	if (n->pipe) return true;
+	if (n->seg) return n->seg->pipe != nullptr;
 	select_device_once();
 	if (device_count() < 1) {
 		set_error("%s: error: no HIP device available (the GPU backend has no CPU fallback)", e->name);
 		return false;
 	}
+	static const bool fuse = !getenv("DSP_AMD_PLUGIN_NO_FUSE");
+	struct effect *first = e, *last = e;
+	if (fuse) {
+		while (is_ours(first->prev) && !node_of(first->prev)->seg && first->prev->ostream.fs == first->istream.fs
+		       && first->prev->ostream.channels == first->istream.channels) first = first->prev;
+		while (is_ours(last->next) && !node_of(last->next)->seg && last->ostream.fs == last->next->istream.fs
+		       && last->ostream.channels == last->next->istream.channels) last = last->next;
+		// an integer `delay` has a no-op run() (delay.c:201-202): it may sit inside a segment but cannot head one
+		while (first != e && node_of(first)->spec->kind == Kind::Delay) first = first->next;
+	}
+	std::shared_ptr<Segment> seg(new Segment);
+	std::vector<const Spec *> specs;
+	for (struct effect *m = first;; m = m->next) {
+		Node *mn = node_of(m);
+		if (mn->spec->riir_pending && !riir_prepare(*mn->spec)) return false;    // a host that skipped prepare()
+		seg->members.push_back(m);
+		specs.push_back(mn->spec.get());
+		if (mn->spec->kind == Kind::Remix || mn->spec->kind == Kind::Resample) seg->in_place = false;
+		if (m == last) break;
+	}
+	const Spec &s0 = *specs.front(), &s1 = *specs.back();
 	const ssize_t cap = 1 << 16;
-	std::vector<const Spec *> specs{ n->spec.get() };
-	n->pipe = Pipeline::compile(specs, n->spec->fs_in, n->spec->ch_in, 1, cap);
-	if (!n->pipe) return false;
-	n->pipe_frames = cap;
-	n->out_cap_frames = n->pipe->max_out_frames(cap);
-	if (!n->d_in.alloc((size_t) cap * n->spec->ch_in * sizeof(double), false)) return false;
-	if (!n->d_out.alloc((size_t) n->out_cap_frames * n->spec->ch_out * sizeof(double), false)) return false;
+	seg->ch_in = s0.ch_in; seg->ch_out = s1.ch_out;
+	for (struct effect *m : seg->members) node_of(m)->seg = seg;     // even on failure: do not retry every block
+	seg->pipe = Pipeline::compile(specs, s0.fs_in, s0.ch_in, 1, cap);
+	if (!seg->pipe) return false;
+	seg->pipe_frames = cap;
+	seg->out_cap_frames = seg->pipe->max_out_frames(cap);
+	if (!seg->d_in.alloc((size_t) cap * seg->ch_in * sizeof(double), false) ||
+	    !seg->d_out.alloc((size_t) seg->out_cap_frames * seg->ch_out * sizeof(double), false)) { seg->pipe.reset(); return false; }
+	if (seg->members.size() > 1) log_msg(LL_VERBOSE, "%s: info: %zu effects fused into one device segment: %s", e->name, seg->members.size(), seg->pipe->plan().c_str());
 	return true;
-}
-
-static bool spec_in_place(const Spec &s)
-{
-	return s.kind != Kind::Remix && s.kind != Kind::Resample;
 }
 
 static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, sample_t *obuf)
 {
 	Node *n = node_of(e);
-	if (!n || !ensure_pipe(e, n)) {
+	if (!n || !ensure_segment(e, n)) {
 		// no error channel in run() (effect.h:47): degrade to silence of the right shape and keep logging
 		const ssize_t f = *frames;
 		memset(obuf, 0, (size_t) f * e->ostream.channels * sizeof(sample_t));
 		return obuf;
 	}
-	const Spec &sp = *n->spec;
-	sample_t *dst = spec_in_place(sp) ? ibuf : obuf;
+	Segment &sg = *n->seg;
+	if (e != sg.members.front()) return ibuf;      // the head already produced the segment's output into this buffer
+	sample_t *dst = sg.in_place ? ibuf : obuf;
 	ssize_t done = 0, produced = 0;
 	const ssize_t total = *frames;
 	while (done < total) {
-		const ssize_t nb = std::min<ssize_t>(total - done, n->pipe_frames);
-		if (!hip_ok(hipMemcpy(n->d_in.p, ibuf + done * sp.ch_in, (size_t) nb * sp.ch_in * sizeof(double), hipMemcpyHostToDevice), "H2D")) break;
-		const ssize_t f = n->pipe->run(n->d_in.as<double>(), nb, n->d_out.as<double>(), n->out_cap_frames, nullptr);
+		const ssize_t nb = std::min<ssize_t>(total - done, sg.pipe_frames);
+		if (!hip_ok(hipMemcpy(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice), "H2D")) break;
+		const ssize_t f = sg.pipe->run(sg.d_in.as<double>(), nb, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 		if (f < 0) break;
-		if (f > 0 && !hip_ok(hipMemcpy(dst + produced * sp.ch_out, n->d_out.p, (size_t) f * sp.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H")) break;
+		if (f > 0 && !hip_ok(hipMemcpy(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H")) break;
 		produced += f;
 		done += nb;
 	}
@@ -86,13 +110,16 @@ static sample_t *plugin_run_noop(struct effect *, ssize_t *, sample_t *ibuf, sam
 
 static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1, sample_t *buf2)
 {
+	// the host flushes every rate changer in chain order and runs what comes out through the effects behind it
+	// (effects_chain.c:1199-1217); the segment's pipeline does the same for its fused stages, the members behind
+	// this effect pass the result through
 	Node *n = node_of(e);
-	if (!n || !n->pipe) { *frames = -1; return buf1; }
-	const Spec &sp = *n->spec;
-	const ssize_t want = std::min<ssize_t>(*frames, n->pipe_frames);
-	const ssize_t f = n->pipe->drain2(want, n->d_out.as<double>(), n->out_cap_frames, nullptr);
+	if (!n || !n->seg || !n->seg->pipe) { *frames = -1; return buf1; }
+	Segment &sg = *n->seg;
+	const ssize_t want = std::min<ssize_t>(*frames, sg.pipe_frames);
+	const ssize_t f = sg.pipe->drain2(want, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 	if (f < 0) { *frames = -1; return buf1; }
-	if (f > 0) (void) hip_ok(hipMemcpy(buf2, n->d_out.p, (size_t) f * sp.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+	if (f > 0) (void) hip_ok(hipMemcpy(buf2, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H");
 	*frames = f;
 	return buf2;
 }
@@ -100,8 +127,8 @@ static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1
 static void plugin_reset(struct effect *e)
 {
 	Node *n = node_of(e);
-	if (n && n->pipe) {
-		n->pipe->reset(nullptr);
+	if (n && n->seg && n->seg->pipe && e == n->seg->members.front()) {
+		n->seg->pipe->reset(nullptr);
 		(void) hipStreamSynchronize(nullptr);
 	}
 }
@@ -111,6 +138,10 @@ static void plugin_destroy(struct effect *e)
 	Node *n = node_of(e);
 	if (n) {
 		(void) hipDeviceSynchronize();
+		if (n->seg) {
+			// the other members keep the segment alive but must not touch this effect any more
+			for (struct effect *&m : n->seg->members) if (m == e) m = nullptr;
+		}
 		delete n;
 	}
 	e->data = nullptr;
@@ -122,7 +153,7 @@ static int plugin_merge(struct effect *dest, struct effect *src)
 {
 	if (dest->merge != src->merge) return 0;
 	Node *d = node_of(dest), *s = node_of(src);
-	if (!d || !s || d->pipe || s->pipe) return 0;   // merge may only happen before the first run()
+	if (!d || !s || d->seg || s->seg) return 0;     // merge may only happen before the first run()
 	if (!merge_specs(*d->spec, *s->spec)) return 0;
 	if (d->spec->kind == Kind::Biquad)
 		memcpy(dest->channel_selector, d->spec->sel.data(), d->spec->sel.size());
@@ -132,7 +163,7 @@ static int plugin_merge(struct effect *dest, struct effect *src)
 static int plugin_prepare(struct effect *e)
 {
 	Node *n = node_of(e);
-	if (!n || n->pipe) return 0;
+	if (!n || n->seg) return 0;
 	if (!riir_prepare(*n->spec)) return 1;
 	if (e->channel_selector) memcpy(e->channel_selector, n->spec->sel.data(), n->spec->sel.size());
 	return 0;

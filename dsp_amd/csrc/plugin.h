@@ -9,15 +9,24 @@ namespace dspamd {
 
 constexpr unsigned NODE_MAGIC = 0x44535041u;   // "DSPA"
 
+// A device-resident segment of the host's chain: consecutive effects of this library (linked through e->prev /
+// e->next when the first of them runs) compiled into ONE fused pipeline -- one H2D copy at the head, the whole
+// segment on the device (cascade fusion, LTI merges, convolvers feeding each other, exactly as in the batch API),
+// one D2H copy; the other members' run() hand the result through.  SURVEY.md section 7 step 4 / section 8(f).
+struct Segment {
+	std::vector<struct effect *> members;    // chain order; members.front() is the head
+	std::unique_ptr<Pipeline> pipe;          // single-stream pipeline for run() on host buffers
+	ssize_t pipe_frames = 0, out_cap_frames = 0;
+	int ch_in = 0, ch_out = 0;
+	bool in_place = true;
+	DevBuf d_in, d_out;
+};
+
 // what e->data points to for every effect this library creates
 struct Node {
 	unsigned magic = NODE_MAGIC;
 	SpecPtr spec;
-	std::unique_ptr<Pipeline> pipe;      // single-effect, single-stream pipeline for run() on host buffers
-	ssize_t pipe_frames = 0;
-	DevBuf d_in, d_out;
-	ssize_t out_cap_frames = 0;
-	bool draining = false;
+	std::shared_ptr<Segment> seg;            // set at the first run() of any member
 };
 
 // wrap a Spec into a calloc'd struct effect (run == NULL when noop)

@@ -54,10 +54,32 @@ def test_file_chain_cli(tmp_path):
         (f"{BIQ} fir_p -t pcm -e double -c 1 {hf} resample 96k", 2, 1e-11),
         (f"fir -t pcm -e double -c 1 {hf} :0 delay 11S : remix 0,1 1 0", 3, 1e-12),
         ("hilbert -p 1023 :1 gain -2 : resample 44.1k", 2, 1e-11),
+        ("lowpass 2k 0.707 lowpass -r 2k 0.707 :0 highpass -r60 30 0.707", 2, 1e-12),   # time-reversed IIR, merged + per channel
     ]:
         ref, gpu = both(tmp_path, in_args, chain, och)
         assert ref.shape == gpu.shape, (chain, ref.shape, gpu.shape)
         assert rms(ref - gpu) < tol, (chain, rms(ref - gpu))
+
+
+def test_consecutive_effects_share_one_device_segment(tmp_path):
+    # the effects of this library that sit next to each other in the host's chain run as ONE fused device pipeline
+    # (one H2D / D2H pair per block): the verbose log says so, and the output is unchanged
+    rng = np.random.Generator(np.random.PCG64(79))
+    x = rng.uniform(-0.3, 0.3, size=(20000, 2))
+    xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
+    o = os.path.join(str(tmp_path), "o.raw")
+    chain = f"gain -3 {BIQ} remix 1 0"
+    r = run_cli(GPU, ["-q", "-t", "pcm", "-e", "double", "-r", "48k", "-c", "2", xin, "-o", "-t", "pcm", "-e", "double", o] + chain.split(),
+                env=dict(os.environ, DSP_AMD_LOGLEVEL="4"))
+    assert "fused into one device segment" in r.stderr, r.stderr[-1500:]
+    fused = np.fromfile(o).reshape(-1, 2)
+    r2 = run_cli(GPU, ["-q", "-t", "pcm", "-e", "double", "-r", "48k", "-c", "2", xin, "-o", "-t", "pcm", "-e", "double", o] + chain.split(),
+                 env=dict(os.environ, DSP_AMD_PLUGIN_NO_FUSE="1"))
+    unfused = np.fromfile(o).reshape(-1, 2)
+    assert fused.shape == unfused.shape and rms(fused - unfused) < 1e-13
+    ro = os.path.join(str(tmp_path), "r.raw")
+    run_cli(REF, ["-q", "-t", "pcm", "-e", "double", "-r", "48k", "-c", "2", xin, "-o", "-t", "pcm", "-e", "double", ro] + chain.split())
+    assert rms(np.fromfile(ro).reshape(-1, 2) - fused) < 1e-12
 
 
 def test_bit_exact_class_cli(tmp_path):
