@@ -123,6 +123,7 @@ ConvParams ConvStage::base_params() const
 	p.ring_out = feed_ring;
 	p.ring_out_stride = feed_stride; p.ring_out_mask = feed_mask; p.ring_out_pos = feed_pos;
 	p.ring_out_round_f32 = feed_round;
+	{ static const char *e = getenv("DSP_AMD_CONV_NT"); p.nt = e ? atoi(e) : 0; }
 	return p;
 }
 

@@ -35,6 +35,7 @@ struct ConvParams {
 	double2 *ring_out;
 	long ring_out_stride, ring_out_mask, ring_out_pos;
 	int ring_out_round_f32;
+	int nt;                             // non-temporal access mask: 1 K1 ring loads, 2 K1 W stores, 4 K2 W loads, 8 K2 W stores, 16 K3 W loads, 32 K3 out stores
 	int C, pairs_per_stream;
 	long stream0, n_streams_launch;
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)

@@ -260,21 +260,23 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 #pragma unroll
 	for (int m = 0; m < 16; ++m) {
 		const long n = (long) (j + P * m) * p.N2 + n2;
-		v[m] = (n < p.valid) ? src[(p.win_base + n) & p.ring_mask] : make_double2(0.0, 0.0);
+		v[m] = (n < p.valid) ? ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1) : make_double2(0.0, 0.0);
 	}
 	lds_barrier();   // twiddle table visible (the data loads stay in flight)
 	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });
 	// the inter-pass twiddle w_N^(n2 k1) is applied by K2 when it reads the row (per row it is a geometric sequence in n2)
 	cplx *W = p.W + (pair - p.pair0) * p.N;
 #pragma unroll
-	for (int m = 0; m < 16; ++m) W[(long) (j + P * m) * p.N2 + n2] = v[m];
+	for (int m = 0; m < 16; ++m) st16(W + (long) (j + P * m) * p.N2 + n2, v[m], p.nt & 2);
 }
 
 // K3: W[pair][k1][n2] --IFFT over k1--> y[n1 N2 + n2]; valid outputs scattered into the interleaved slab.
 // blockIdx.y = stream * groups + group; the workgroup holds PPS pairs of that stream, lanes ordered pair-fastest so
 // that the 16-byte (re, im) = (channel 2q, 2q+1) pieces of one frame leave from adjacent lanes.
-// HOLD2: the two interleaved phases of a 2x upsampler -- phase 0 is held in registers and frames 2q, 2q+1 leave together
-template <int LOG2N1, int PPS, bool HOLD2>
+// MODE 0: plain convolution (one phase, output index = input index: the headline path, no index arithmetic beyond an add);
+// MODE 1: any number of phases / up / down; MODE 2: the two interleaved phases of a 2x upsampler -- phase 0 is held in
+// registers and frames 2q, 2q+1 leave together
+template <int LOG2N1, int PPS, int MODE>
 __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(ConvParams p)
 {
 	using Cfg = ColCfg<LOG2N1, PPS>;
@@ -294,14 +296,15 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	const int cha = active ? p.pair_out_ch[2 * qs] : -1, chb = active ? p.pair_out_ch[2 * qs + 1] : -1;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
 	cplx *rout = p.ring_out ? p.ring_out + (s * p.pairs_per_stream + qs) * p.ring_out_stride : nullptr;
+	constexpr bool HOLD2 = (MODE == 2), PLAIN = (MODE == 0);
 	if constexpr (HOLD2) {
 		cplx v0[16], v[16];
 		if (active) {
 			const cplx *W = p.W + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) v0[m] = W[(long) (j + P * m) * p.N2];
+			for (int m = 0; m < 16; ++m) v0[m] = ld16(W + (long) (j + P * m) * p.N2, p.nt & 16);
 #pragma unroll
-			for (int m = 0; m < 16; ++m) v[m] = W[p.phase_stride + (long) (j + P * m) * p.N2];
+			for (int m = 0; m < 16; ++m) v[m] = ld16(W + p.phase_stride + (long) (j + P * m) * p.N2, p.nt & 16);
 		}
 		else {
 #pragma unroll
@@ -332,12 +335,13 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 		}
 		return;
 	}
-	for (int ph = 0; ph < p.nph; ++ph) {
+	const int nph = PLAIN ? 1 : p.nph;
+	for (int ph = 0; ph < nph; ++ph) {
 		cplx v[16];
 		if (active) {
-			const cplx *W = p.W + ph * p.phase_stride + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
+			const cplx *W = p.W + (PLAIN ? 0 : ph * p.phase_stride) + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) v[m] = W[(long) (j + P * m) * p.N2];
+			for (int m = 0; m < 16; ++m) v[m] = ld16(W + (long) (j + P * m) * p.N2, p.nt & 16);
 		}
 		else {
 #pragma unroll
@@ -350,9 +354,13 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 		for (int m = 0; m < 16; ++m) {
 			const long f = (long) (j + P * m) * p.N2 + n2 - p.first_n;
 			if (f < 0 || f >= p.in_count) continue;
-			long mo = p.up * (p.q_blk + f) + ph;
-			if (p.down > 1) { if (mo % p.down) continue; mo /= p.down; }
-			mo -= p.k_origin;
+			long mo;
+			if constexpr (PLAIN) mo = p.q_blk + f - p.k_origin;
+			else {
+				mo = p.up * (p.q_blk + f) + ph;
+				if (p.down > 1) { if (mo % p.down) continue; mo /= p.down; }
+				mo -= p.k_origin;
+			}
 			if (mo < 0 || mo >= p.out_count) continue;
 			cplx y = v[m];
 			if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
@@ -361,7 +369,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 				if (chb < 0) y.y = 0.0;
 				rout[(p.ring_out_pos + mo) & p.ring_out_mask] = y;
 			}
-			else if (wide) *reinterpret_cast<cplx *>(out + mo * p.C + cha) = y;
+			else if (wide) st16(reinterpret_cast<cplx *>(out + mo * p.C + cha), y, p.nt & 32);
 			else {
 				if (cha >= 0) out[mo * p.C + cha] = y.x;
 				if (chb >= 0) out[mo * p.C + chb] = y.y;
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	cplx *W = p.W + (pair - p.pair0) * p.N + k1 * N2 + j;
 	cplx v[16];
 #pragma unroll
-	for (int m = 0; m < 16; ++m) v[m] = W[P * m];
+	for (int m = 0; m < 16; ++m) v[m] = ld16(W + P * m, p.nt & 4);
 	t256[tid] = p.tw_n2[tid * (N2 / 256)];
 	if (tid < 64) tlo[tid] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
 	row_fft<LOG2N2, true>(v, j, data, map, tw);
 #pragma unroll
-	for (int m = 0; m < 16; ++m) W[P * m] = cmulc(v[m], cmul(twb, steps[m]));
+	for (int m = 0; m < 16; ++m) st16(W + P * m, cmulc(v[m], cmul(twb, steps[m])), p.nt & 8);
 }
 
 // K2 for rows of N2 = WV * 1024 points (WV = 2, 4): the row FFT is itself split 4-step style so that all but one
@@ -670,18 +678,23 @@ template <int L> static void launch_col_fwd(const ConvParams &p, int n_pairs, hi
 template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hipStream_t st)
 {
 	using Cfg = ColCfg<L, PPS>;
-	static bool granted[2] = { false, false };
+	static bool granted[3] = { false, false, false };
 	const int groups = (p.pairs_per_stream + PPS - 1) / PPS;
 	const dim3 grid((unsigned) (p.N2 / Cfg::TW), (unsigned) (p.n_streams_launch * groups)), block(Cfg::THREADS);
 	if (PPS == 4 && p.nph == 2 && p.up == 2 && p.down == 1 && !p.round_f32 && !p.ring_out_round_f32) {
 		if constexpr (PPS == 4) {
-			if (!granted[1]) { grant_lds(conv_col_inv<L, PPS, true>, Cfg::LDS); granted[1] = true; }
-			hipLaunchKernelGGL((conv_col_inv<L, PPS, true>), grid, block, Cfg::LDS, st, p);
+			if (!granted[2]) { grant_lds(conv_col_inv<L, PPS, 2>, Cfg::LDS); granted[2] = true; }
+			hipLaunchKernelGGL((conv_col_inv<L, PPS, 2>), grid, block, Cfg::LDS, st, p);
 			return;
 		}
 	}
-	if (!granted[0]) { grant_lds(conv_col_inv<L, PPS, false>, Cfg::LDS); granted[0] = true; }
-	hipLaunchKernelGGL((conv_col_inv<L, PPS, false>), grid, block, Cfg::LDS, st, p);
+	if (p.nph == 1 && p.up == 1 && p.down == 1) {
+		if (!granted[0]) { grant_lds(conv_col_inv<L, PPS, 0>, Cfg::LDS); granted[0] = true; }
+		hipLaunchKernelGGL((conv_col_inv<L, PPS, 0>), grid, block, Cfg::LDS, st, p);
+		return;
+	}
+	if (!granted[1]) { grant_lds(conv_col_inv<L, PPS, 1>, Cfg::LDS); granted[1] = true; }
+	hipLaunchKernelGGL((conv_col_inv<L, PPS, 1>), grid, block, Cfg::LDS, st, p);
 }
 
 template <int L> static void launch_col_inv(const ConvParams &p, hipStream_t st)

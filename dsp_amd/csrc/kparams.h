@@ -88,6 +88,13 @@ struct ConvGeom {
 };
 
 #ifdef __HIPCC__
+// streaming (non-temporal) 16-byte accesses: data touched once per launch should not displace what the L2 keeps
+typedef double dspamd_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 nt_load(const double2 *p) { const dspamd_v2d v = __builtin_nontemporal_load(reinterpret_cast<const dspamd_v2d *>(p)); return make_double2(v.x, v.y); }
+__device__ __forceinline__ void nt_store(double2 *p, double2 a) { const dspamd_v2d v = { a.x, a.y }; __builtin_nontemporal_store(v, reinterpret_cast<dspamd_v2d *>(p)); }
+__device__ __forceinline__ double2 ld16(const double2 *p, bool nt) { return nt ? nt_load(p) : *p; }
+__device__ __forceinline__ void st16(double2 *p, double2 a, bool nt) { if (nt) nt_store(p, a); else *p = a; }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
 // store of the wave (s_waitcnt vmcnt(0)), which would serialise prefetches and fire-and-forget stores with the
 // compute phase they are meant to overlap.
