@@ -337,17 +337,17 @@ __device__ __forceinline__ OpHead load_head(const double *__restrict__ od)
 }
 
 // cf: this channel's [n_ops][FOP_DOUBLES] constants in global memory (uniform address -> scalar loads);
-// q: LDS [n_ops][FQ_DOUBLES]; st: LDS [n_ops][2]
+// q: LDS [n_ops][FQ_DOUBLES]; st: LDS [n_ops][2]; the ops [j_lo, j_hi) are run
 template <int L>
-__device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__restrict__ cf, const double *q, int n_ops, double *st, int lane)
+__device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__restrict__ cf, const double *q, int j_lo, int j_hi, double *st, int lane)
 {
 	const int row = lane >> 4;
 	PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
-	OpHead cur = load_head(cf);
-	for (int j = 0; j < n_ops; ++j) {
+	OpHead cur = load_head(cf + j_lo * FOP_DOUBLES);
+	for (int j = j_lo; j < j_hi; ++j) {
 		const double *__restrict__ od = cf + j * FOP_DOUBLES;
 		// next op's head: in flight during this op
-		const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : j) * FOP_DOUBLES);
+		const OpHead nxt = load_head(cf + ((j + 1 < j_hi) ? j + 1 : j) * FOP_DOUBLES);
 		if (cur.kind == OP_BIQUAD) {
 			// requested now, consumed after the recurrence that hides their latency
 			double Pw[16], P16[4];
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64 * CG) void cascade_fast(CascadeParams p, const d
 		{                                                                                                                  \
 			double v[L];                                                                                                   \
 			_Pragma("unroll") for (int i = 0; i < L; ++i) v[i] = row[lane * (L + 1) + i];                                 \
-			run_ops_fast<L>(v, cf, wq, p.n_ops, cst, lane);                                                                \
+			run_ops_fast<L>(v, cf, wq, 0, p.n_ops, cst, lane);                                                             \
 			_Pragma("unroll") for (int i = 0; i < L; ++i) row[lane * (L + 1) + i] = v[i];                                 \
 		}                                                                                                                  \
 		lds_barrier();                                                                                                     \
@@ -567,6 +567,163 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 	return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Section-pipelined variant for FEW streams (strong scaling: 256 streams over 8 GPUs leave 32 per GPU).
+//
+// cascade_fast runs one wave per channel through ALL sections of a tile before the next tile: 192 tiles x 10
+// sections in series per channel -- 2.4 ms per launch however few channels there are.  With fewer than ~2000 channels
+// on the GPU the recurrence itself has to be cut: here a channel is served by P waves, wave s owning the sections
+// [s n / P, (s + 1) n / P), and the tiles move from wave to wave through LDS (tile buffers B_0 .. B_P of the channel,
+// every step each wave takes the tile its predecessor finished in the previous step): a systolic pipeline over
+// sections, exact (every section still sees its samples in order with its own carried state), whose critical path
+// per tile is n / P sections instead of n.  Two LDS barriers per step; the HBM traffic (B_0 <- slab, B_P -> slab / ring)
+// is asynchronous as in cascade_fast.  Workgroup = CG channels x P stages waves (CG P <= 16, LDS: (P + 1) tiles per channel).
+template <int CG, int P>
+__global__ __launch_bounds__(64 * CG * P) void cascade_pipe(CascadeParams p, const double *__restrict__ fops)
+{
+	constexpr int L = CASCADE_L, TILE = 64 * L, NTH = 64 * CG * P, CHS = 64 * (L + 1) + 2;
+	constexpr int NE = TILE * CG, KE = (NE + NTH - 1) / NTH;         // I/O elements (one sample each) per thread and tile
+	extern __shared__ __attribute__((aligned(16))) double smem[];
+	const int s = blockIdx.x;
+	const int c0 = p.cg0 + blockIdx.y * CG;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int stage = wave / CG, cc = wave % CG;
+	double *tiles = smem;                                            // [P + 1][CG][CHS]
+	double *st = tiles + (size_t) (P + 1) * CG * CHS;                // [CG][n_ops][2]
+	double *qt = st + (size_t) CG * p.n_ops * 2;                     // [CG][n_ops][FQ_DOUBLES]
+
+	const int n_st = CG * p.n_ops * 2;
+	double *gstate = p.state + ((size_t) s * p.C + c0) * p.n_ops * 2;
+	for (int i = tid; i < n_st; i += NTH) st[i] = gstate[i];
+	for (int i = tid; i < CG * p.n_ops * FQ_DOUBLES; i += NTH) qt[i] = p.fq[(size_t) c0 * p.n_ops * FQ_DOUBLES + i];
+
+	const long n_full = p.frames / TILE;
+	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C + c0;
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.C + c0;
+	double *ringd = p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) : nullptr;
+	// I/O element k of this thread: sample (frame te[k], channel ce[k]) of the tile; LDS offset inside a tile buffer
+	int te[KE], le[KE];
+#pragma unroll
+	for (int k = 0; k < KE; ++k) {
+		const int e = tid + k * NTH;
+		te[k] = e / CG;
+		le[k] = (e % CG) * CHS + te[k] + te[k] / L;
+	}
+	double pf[KE];
+#pragma unroll
+	for (int k = 0; k < KE; ++k) pf[k] = (tid + k * NTH < NE) ? in[(size_t) te[k] * p.C + (tid + k * NTH) % CG] : 0.0;
+	const double *__restrict__ cf = fops + (size_t) (c0 + cc) * p.n_ops * FOP_DOUBLES;
+	const double *wq = qt + (size_t) cc * p.n_ops * FQ_DOUBLES;
+	double *cst = st + cc * p.n_ops * 2;
+	const int j_lo = (stage * p.n_ops) / P, j_hi = ((stage + 1) * p.n_ops) / P;
+	double *b_in = tiles + ((size_t) stage * CG + cc) * CHS;          // B_stage of this channel
+	double *b_out = b_in + (size_t) CG * CHS;                         // B_(stage + 1)
+	double *b_first = tiles, *b_last = tiles + (size_t) P * CG * CHS;
+	__syncthreads();
+
+	// step sigma: B_0 <- tile sigma (I/O);  stage s works on tile sigma - 1 - s;  tile sigma - 1 - P leaves from B_P (I/O)
+	for (long step = 0; step < n_full + P + 1; ++step) {
+		const long my_tile = step - 1 - stage, out_tile = step - 1 - P;
+		const bool act = my_tile >= 0 && my_tile < n_full;
+		// ---- phase A: everybody READS (the tile this stage takes over, the finished tile) ----
+		double v[L];
+		if (act) {
+#pragma unroll
+			for (int i = 0; i < L; ++i) v[i] = b_in[lane * (L + 1) + i];
+		}
+		double r[KE];
+		if (out_tile >= 0) {
+#pragma unroll
+			for (int k = 0; k < KE; ++k) r[k] = (tid + k * NTH < NE) ? b_last[le[k]] : 0.0;
+		}
+		lds_barrier();
+		// ---- phase B: everybody WRITES (new input into B_0, results into B_(s+1)); HBM traffic goes out / is requested ----
+		if (step < n_full) {
+#pragma unroll
+			for (int k = 0; k < KE; ++k) if (tid + k * NTH < NE) b_first[le[k]] = pf[k];
+		}
+		if (out_tile >= 0) {
+			const long t0 = out_tile * TILE;
+#pragma unroll
+			for (int k = 0; k < KE; ++k) {
+				if (tid + k * NTH >= NE) continue;
+				const int ch = (tid + k * NTH) % CG;
+				if (p.write_interleaved) out[(size_t) (t0 + te[k]) * p.C + ch] = r[k];
+				if (ringd) {
+					const int c = c0 + ch;
+					ringd[2 * ((size_t) ((c >> 1) - (c0 >> 1)) * p.ring.row_stride + ((p.ring.pos + t0 + te[k]) & p.ring.mask)) + (c & 1)] = r[k];
+				}
+			}
+		}
+		if (step + 1 < n_full) {
+			const double *nx = in + (size_t) (step + 1) * TILE * p.C;
+#pragma unroll
+			for (int k = 0; k < KE; ++k) pf[k] = (tid + k * NTH < NE) ? nx[(size_t) te[k] * p.C + (tid + k * NTH) % CG] : 0.0;
+		}
+		if (act) {
+			run_ops_fast<L>(v, cf, wq, j_lo, j_hi, cst, lane);
+#pragma unroll
+			for (int i = 0; i < L; ++i) b_out[lane * (L + 1) + i] = v[i];
+		}
+		lds_barrier();
+	}
+	for (int i = tid; i < n_st; i += NTH) gstate[i] = st[i];
+}
+
+template <int CG, int P> static size_t pipe_lds_bytes(int n_ops)
+{
+	return ((size_t) (P + 1) * CG * (64 * (CASCADE_L + 1) + 2) + (size_t) CG * n_ops * 2 + (size_t) CG * n_ops * FQ_DOUBLES) * sizeof(double);
+}
+
+template <int CG, int P> static bool try_launch_pipe(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	const size_t lds = pipe_lds_bytes<CG, P>(p.n_ops);
+	if (lds > 160 * 1024 || p.n_ops < P || (p.C % CG)) return false;
+	static size_t granted = 0;
+	if (lds > granted) {
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_pipe<CG, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		granted = lds;
+	}
+	dim3 grid(n_streams, p.C / CG), block(64 * CG * P);
+	hipLaunchKernelGGL((cascade_pipe<CG, P>), grid, block, lds, stream, p, p.fops);
+	return true;
+}
+
+// few streams: cut the per-channel recurrence into pipeline stages so that the workgroup count still fills the GPU
+static long launch_cascade_pipe(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	static int env = -2;
+	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_PIPE"); env = e ? atoi(e) : -1; }   // 0 = never, CG*100+P = force
+	if (env == 0 || p.cg0 != 0 || !p.fops || p.n_ops < 2) return 0;
+	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
+	const long n_full = p.frames / CASCADE_TILE;
+	if (n_full < 4) return 0;
+	const long channels = (long) n_streams * p.C;
+	int cg, pp;
+	if (env > 0) { cg = env / 100; pp = env % 100; }
+	else {
+		// measured (MI355X, 10 sections, 8 ch/stream): 32 streams 0.54 ms vs 1.38 (cascade_fast), 64 streams 0.94 vs 1.41,
+		// 128 streams 1.71 vs 1.45 -> from 1024 channels on cascade_fast (4 per workgroup) fills the chip better
+		if (channels > 512) return 0;
+		// the widest channel group that still gives ~256 workgroups, then as many stages as the sections allow
+		cg = (channels >= 512 && p.C % 2 == 0) ? 2 : 1;
+		pp = (cg == 2) ? 5 : 10;
+		while (pp > p.n_ops) pp = (pp == 10) ? 5 : (pp == 5) ? 3 : 2;
+	}
+	bool ok = false;
+	if (cg == 1 && pp == 10) ok = try_launch_pipe<1, 10>(p, n_streams, stream);
+	else if (cg == 1 && pp == 5) ok = try_launch_pipe<1, 5>(p, n_streams, stream);
+	else if (cg == 1 && pp == 3) ok = try_launch_pipe<1, 3>(p, n_streams, stream);
+	else if (cg == 1 && pp == 2) ok = try_launch_pipe<1, 2>(p, n_streams, stream);
+	else if (cg == 2 && pp == 5) ok = try_launch_pipe<2, 5>(p, n_streams, stream);
+	else if (cg == 2 && pp == 3) ok = try_launch_pipe<2, 3>(p, n_streams, stream);
+	else if (cg == 2 && pp == 2) ok = try_launch_pipe<2, 2>(p, n_streams, stream);
+	else if (cg == 4 && pp == 3) ok = try_launch_pipe<4, 3>(p, n_streams, stream);
+	else if (cg == 4 && pp == 2) ok = try_launch_pipe<4, 2>(p, n_streams, stream);
+	return ok ? n_full * CASCADE_TILE : 0;
+}
+
 size_t cascade_lds_bytes(int Cg, int n_ops)
 {
 	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2 + (size_t) Cg * n_ops * OPL_DOUBLES) * sizeof(double);
@@ -575,7 +732,8 @@ size_t cascade_lds_bytes(int Cg, int n_ops)
 void launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
 {
 	CascadeParams p = p0;
-	const long done = launch_cascade_fast(p0, n_streams, stream);
+	long done = launch_cascade_pipe(p0, n_streams, stream);
+	if (done == 0) done = launch_cascade_fast(p0, n_streams, stream);
 	if (done > 0) {
 		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block
 		if (done == p0.frames) return;
