@@ -549,7 +549,8 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 	// measured on MI355X (256 x 8 ch, 10 sections): whole frames per workgroup (8 channels) win when the interleaved
 	// slab is written (2.4 vs 3.8 ms); half frames (two independent workgroups per stream) win when only the
 	// convolver's ring rows are written (2.45 vs 2.57 ms)
-	const int cfg_cg = (env_cg >= 0) ? env_cg : ((p.ring.base && !p.write_interleaved) ? 4 : 8);
+	// ... from about 8 sections on; with fewer the launch is memory-bound and whole frames win again (1 section: 1.25 vs 1.84 ms)
+	const int cfg_cg = (env_cg >= 0) ? env_cg : ((p.ring.base && !p.write_interleaved && p.n_ops >= 8) ? 4 : 8);
 	if (cfg_cg == 0 || (p.C & 1) || p.cg0 != 0 || !p.fops) return 0;
 	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
 	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
