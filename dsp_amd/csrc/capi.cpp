@@ -2,6 +2,7 @@
 #include "dsp_amd.h"
 #include "chain.h"
 #include "engine.h"
+#include "pcm_params.h"
 #include <cstring>
 #include <cstdio>
 
@@ -231,6 +232,43 @@ int dspamd_digest(const void *d_buf, int n_streams, ssize_t frames, ssize_t stri
 {
 	launch_digest(static_cast<const double *>(d_buf), n_streams, frames, stride_frames, channels, static_cast<double *>(d_out), static_cast<hipStream_t>(stream));
 	return hip_ok(hipGetLastError(), "digest") ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- wire formats on the device
+
+static size_t pcm_bytes(int fmt)
+{
+	static const size_t b[PCM_N_FORMATS] = { 1, 1, 2, 4, 4, 3, 4, 8 };
+	return (fmt >= 0 && fmt < PCM_N_FORMATS) ? b[fmt] : 0;
+}
+
+size_t dspamd_pcm_sample_bytes(int fmt) { return pcm_bytes(fmt); }
+
+int dspamd_pcm_read(int fmt, const void *d_in, void *d_out, ssize_t n_samples, void *stream)
+{
+	if (!pcm_bytes(fmt)) { set_error("pcm_read: unknown format %d", fmt); return -1; }
+	if (device_count() < 1) { set_error("pcm_read: no HIP device available"); return -1; }
+	PcmReadParams p{ d_in, static_cast<double *>(d_out), (long) n_samples, fmt };
+	launch_pcm_read(p, static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "pcm_read") ? 0 : -1;
+}
+
+int dspamd_pcm_write(int fmt, const void *d_in, ssize_t in_stride_frames, void *d_out, int n_streams, ssize_t frames, int channels,
+                     int dither_prec, ssize_t frames_before, void *d_stats, void *stream)
+{
+	if (!pcm_bytes(fmt)) { set_error("pcm_write: unknown format %d", fmt); return -1; }
+	if (device_count() < 1) { set_error("pcm_write: no HIP device available"); return -1; }
+	PcmWriteParams p;
+	p.in = static_cast<const double *>(d_in);
+	p.out = d_out;
+	p.in_stride_frames = in_stride_frames; p.frames = frames;
+	p.C = channels; p.fmt = fmt;
+	// tpdf_dither_get_mult(), util.h:157-163
+	p.dither_mult = (dither_prec >= 1 && dither_prec <= 32) ? 1.0 / ((double) 0x7fffffff * (double) (1u << (dither_prec - 1))) : 0.0;
+	p.samples_before = (long) frames_before * channels;
+	p.stats = static_cast<double *>(d_stats);
+	launch_pcm_write(p, n_streams, static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "pcm_write") ? 0 : -1;
 }
 
 int dspamd_copy_probe(const void *d_src, void *d_dst, size_t bytes, void *stream)

@@ -54,7 +54,7 @@ API_SYMBOLS = [
     "dspamd_chain_n_effects", "dspamd_chain_effect_name", "dspamd_batch_create", "dspamd_batch_out_fs",
     "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run",
     "dspamd_batch_drain", "dspamd_batch_reset", "dspamd_batch_destroy", "dspamd_batch_plan", "dspamd_batch_n_stages",
-    "dspamd_sgen_sine", "dspamd_digest", "dspamd_copy_probe", "dspamd_profile_enable", "dspamd_profile_collect",
+    "dspamd_sgen_sine", "dspamd_digest", "dspamd_copy_probe", "dspamd_pcm_sample_bytes", "dspamd_pcm_read", "dspamd_pcm_write", "dspamd_profile_enable", "dspamd_profile_collect",
 ]
 
 
@@ -108,6 +108,9 @@ def load_library():
         "dspamd_sgen_sine": (i, [vp, i, ssize_t, i, i, C.c_double, C.c_double, ssize_t, vp]),
         "dspamd_digest": (i, [vp, i, ssize_t, ssize_t, i, vp, vp]),
         "dspamd_copy_probe": (i, [vp, vp, C.c_size_t, vp]),
+        "dspamd_pcm_sample_bytes": (C.c_size_t, [i]),
+        "dspamd_pcm_read": (i, [i, vp, vp, ssize_t, vp]),
+        "dspamd_pcm_write": (i, [i, vp, ssize_t, vp, i, ssize_t, i, i, ssize_t, vp, vp]),
         "dspamd_profile_enable": (None, [i]), "dspamd_profile_collect": (cp, []),
     }
     for name, (res, args) in sig.items():

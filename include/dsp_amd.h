@@ -103,6 +103,19 @@ const char *dspamd_profile_collect(void);
 int dspamd_sgen_sine(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double dfreq, ssize_t pos0, void *stream);
 /* per-stream digests like stats.c:47-76: sum, sum of squares, peak -> d_out[S][3] */
 int dspamd_digest(const void *d_buf, int n_streams, ssize_t frames, ssize_t stride_frames, int channels, void *d_out, void *stream);
+/* ---- wire formats on the device (sampleconv.c:25-149 with the BIT_PERFECT macros of sampleconv.h:35-56) ---- */
+enum { DSPAMD_PCM_U8 = 0, DSPAMD_PCM_S8, DSPAMD_PCM_S16, DSPAMD_PCM_S24 /* in 32 bits */, DSPAMD_PCM_S32, DSPAMD_PCM_S24_3 /* packed */,
+       DSPAMD_PCM_FLOAT, DSPAMD_PCM_DOUBLE };
+size_t dspamd_pcm_sample_bytes(int fmt);
+/* read_buf_<fmt>: n_samples of the wire format -> fp64 samples */
+int dspamd_pcm_read(int fmt, const void *d_in, void *d_out, ssize_t n_samples, void *stream);
+/* the output stage of dsp.c:673-694: [TPDF dither at dither_prec bits (0 = none; util.h:127-178: two Lehmer generators seeded
+ * with 1, advanced once per sample in interleaved order, frames_before = frames of each stream already written)], clip() to
+ * [-1, 1], write_buf_<fmt>.  in: [S][in_stride_frames][channels] fp64; out: packed [S][frames][channels] of the format;
+ * d_stats (optional, zeroed by the caller): [S][2] = clipped samples (64-bit count), peak |sample| (fp64) */
+int dspamd_pcm_write(int fmt, const void *d_in, ssize_t in_stride_frames, void *d_out, int n_streams, ssize_t frames, int channels,
+                     int dither_prec, ssize_t frames_before, void *d_stats, void *stream);
+
 /* plain device copy kernel: measured HBM ceiling next to the 8 TB/s spec (bytes must be a multiple of 16) */
 int dspamd_copy_probe(const void *d_src, void *d_dst, size_t bytes, void *stream);
 

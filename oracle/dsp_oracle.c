@@ -11,6 +11,7 @@
  * (no FMA), so every multiply and add rounds separately.
  */
 #include <complex.h>
+#include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -817,4 +818,74 @@ void orc_zita_equiv_free(void *stp)
 	struct zita_eq *st = stp;
 	free(st->taps); free(st->hist); free(st->obuf); free(st->ibuf);
 	free(st);
+}
+
+/* ------------------------------------------------------------------ wire formats, clip and dither at the sink
+ *
+ * read_buf_<fmt> / write_buf_<fmt>: sampleconv.c:25-149 with the BIT_PERFECT = 1 macros (dsp.h:36,
+ * sampleconv.h:35-56); clip(): dsp.c:673-682; TPDF dither: util.h:127-178 (two Lehmer generators modulo 2^31 - 1,
+ * multipliers 48271 and 16807, both seeded with 1, drawn once per sample in interleaved order) added before the
+ * clip in write_out(), dsp.c:684-699.  Format numbers as DSPAMD_PCM_* (include/dsp_amd.h). */
+
+static inline uint32_t orc_pm_step(uint32_t s, uint32_t a)       /* PM_RAND_R_DEFINE_FUNC, util.h:127-136 */
+{
+	const uint64_t p = (uint64_t) s * a;
+	uint32_t r = (uint32_t) (p & 0x7fffffff) + (uint32_t) (p >> 31);
+	r = (r & 0x7fffffff) + (r >> 31);
+	return r;
+}
+
+void orc_pcm_read(int fmt, const void *in, double *out, ssize_t n)
+{
+	for (ssize_t i = 0; i < n; ++i) {
+		switch (fmt) {
+		case 0: out[i] = ((double) ((const uint8_t *) in)[i] - 128.0) / 128.0; break;
+		case 1: out[i] = (double) ((const int8_t *) in)[i] / 128.0; break;
+		case 2: out[i] = (double) ((const int16_t *) in)[i] / 32768.0; break;
+		case 3: { int32_t x = ((const int32_t *) in)[i]; x = (x & 0x800000) ? (x | ~0x7fffff) : x; out[i] = (double) x / 8388608.0; break; }
+		case 4: out[i] = (double) ((const int32_t *) in)[i] / 2147483648.0; break;
+		case 5: {
+			const uint8_t *b = (const uint8_t *) in + 3 * i;
+			int32_t x = (int32_t) b[0] | ((int32_t) b[1] << 8) | ((int32_t) b[2] << 16);
+			x = (x & 0x800000) ? (x | ~0x7fffff) : x;
+			out[i] = (double) x / 8388608.0;
+			break;
+		}
+		case 6: out[i] = (double) ((const float *) in)[i]; break;
+		default: out[i] = ((const double *) in)[i]; break;
+		}
+	}
+}
+
+/* state[0], state[1]: the two generator states (start at 1, 1); stats[0] += clipped samples, stats[1] = peak */
+void orc_pcm_write(int fmt, const double *in, void *out, ssize_t n, int dither_prec, uint32_t state[2], double stats[2])
+{
+	const double mult = (dither_prec >= 1 && dither_prec <= 32) ? 1.0 / ((double) 0x7fffffff * (double) (((uint32_t) 1) << (dither_prec - 1))) : 0.0;
+	for (ssize_t i = 0; i < n; ++i) {
+		double x = in[i];
+		if (mult != 0.0) {
+			state[0] = orc_pm_step(state[0], 48271);
+			state[1] = orc_pm_step(state[1], 16807);
+			x = x + (double) ((int32_t) state[0] - (int32_t) state[1]) * mult;
+		}
+		const double a = fabs(x);
+		if (stats) { if (a > stats[1]) stats[1] = a; }
+		if (a > 1.0) { if (stats) stats[0] += 1.0; x = signbit(x) ? -1.0 : 1.0; }
+		switch (fmt) {
+		case 0: { const double v = x * 128.0 + 128.0; ((uint8_t *) out)[i] = (uint8_t) ((v > 255.0) ? 255.0 : nearbyint(v)); break; }
+		case 1: { const double v = x * 128.0; ((int8_t *) out)[i] = (int8_t) ((v > 127.0) ? 127.0 : nearbyint(v)); break; }
+		case 2: { const double v = x * 32768.0; ((int16_t *) out)[i] = (int16_t) ((v > 32767.0) ? 32767.0 : nearbyint(v)); break; }
+		case 3: { const double v = x * 8388608.0; ((int32_t *) out)[i] = (int32_t) ((v > 8388607.0) ? 8388607.0 : nearbyint(v)); break; }
+		case 4: { const double v = x * 2147483648.0; ((int32_t *) out)[i] = (int32_t) ((v > 2147483647.0) ? 2147483647.0 : nearbyint(v)); break; }
+		case 5: {
+			const double v = x * 8388608.0;
+			const int32_t q = (int32_t) ((v > 8388607.0) ? 8388607.0 : nearbyint(v));
+			uint8_t *b = (uint8_t *) out + 3 * i;
+			b[0] = (uint8_t) (q & 0xff); b[1] = (uint8_t) ((q >> 8) & 0xff); b[2] = (uint8_t) ((q >> 16) & 0xff);
+			break;
+		}
+		case 6: ((float *) out)[i] = (float) x; break;
+		default: ((double *) out)[i] = x; break;
+		}
+	}
 }

@@ -70,4 +70,8 @@ void *orc_zita_equiv_new(const double *taps, ssize_t n_taps, int part_len);
 void orc_zita_equiv_run(void *st, double *buf, ssize_t frames, int stride);
 void orc_zita_equiv_free(void *st);
 
+/* wire formats (DSPAMD_PCM_* numbering), clip and TPDF dither at the sink: sampleconv.c:25-149, dsp.c:673-699, util.h:127-178 */
+void orc_pcm_read(int fmt, const void *in, double *out, ssize_t n);
+void orc_pcm_write(int fmt, const double *in, void *out, ssize_t n, int dither_prec, unsigned int state[2], double stats[2]);
+
 #endif
