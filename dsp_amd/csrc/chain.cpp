@@ -81,7 +81,7 @@ static std::vector<Token> lex(const char *s)
 
 // names the reference's registry knows (effect.c:46-67) but this library does not provide
 static const char *const k_unprovided[] = {
-	"crossfeed", "matrix4", "matrix4_mb", "st2ms", "ms2st", "decorrelate", "noise", "dither", "ladspa_host",
+	"matrix4", "matrix4_mb", "decorrelate", "noise", "dither", "ladspa_host",
 	"stats", "watch", "levels", nullptr,
 };
 

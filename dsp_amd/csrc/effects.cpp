@@ -331,6 +331,108 @@ SpecPtr parse_remix(const stream_info *is, const char *sel, int argc, const char
 	return s;
 }
 
+// ------------------------------------------------------------------ st2ms / ms2st / crossfeed
+
+static bool pair_of(const char *name, const stream_info *is, const char *sel, int *c0, int *c1)
+{
+	*c0 = *c1 = -1;
+	int n = 0;
+	for (int k = 0; k < is->channels; ++k) if (sel[k]) { if (*c0 < 0) *c0 = k; else *c1 = k; ++n; }
+	if (n != 2) { set_error("%s: error: input channels must be 2", name); return false; }   // st2ms.c:88-91, crossfeed.c:99-102
+	return true;
+}
+
+static void mix_identity(Spec &s, int n_out, int n_in)
+{
+	s.mix_idx.assign(n_out, std::vector<int>());
+	s.mix_w.assign(n_out, std::vector<double>());
+	s.remix.assign(n_out, Selector(n_in, 0));
+	for (int k = 0; k < n_out && k < n_in; ++k) { s.mix_idx[k] = { k }; s.mix_w[k] = { 1.0 }; s.remix[k][k] = 1; }
+}
+
+static void mix_row(Spec &s, int k, std::vector<int> idx, std::vector<double> w)
+{
+	std::fill(s.remix[k].begin(), s.remix[k].end(), 0);
+	for (int c : idx) s.remix[k][c] = 1;
+	s.mix_idx[k] = std::move(idx);
+	s.mix_w[k] = std::move(w);
+}
+
+// st2ms.c:28-54: (s0 + s1) * 0.5, (s0 - s1) * 0.5 on the selected pair; ms2st: s0 + s1, s0 - s1.  Bit-exact.
+SpecPtr parse_st2ms(int num, const stream_info *is, const char *sel, int argc, const char *const *argv)
+{
+	const char *name = argv[0];
+	if (argc != 1) { usage(name); return nullptr; }
+	int c0, c1;
+	if (!pair_of(name, is, sel, &c0, &c1)) return nullptr;
+	if (num != DSPAMD_ST2MS_ST2MS && num != DSPAMD_ST2MS_MS2ST) { set_error("%s: error: effect number out of range", name); return nullptr; }
+	SpecPtr s = new_spec(Kind::Mix, name, is, sel);
+	s->flags = EFFECT_FLAG_PLOT_MIX;
+	mix_identity(*s, is->channels, is->channels);
+	mix_row(*s, c0, { c0, c1 }, { 1.0, 1.0 });
+	mix_row(*s, c1, { c0, c1 }, { 1.0, -1.0 });
+	if (num == DSPAMD_ST2MS_ST2MS) {
+		s->mix_post.assign(is->channels, 1.0);
+		s->mix_post[c0] = s->mix_post[c1] = 0.5;
+	}
+	return s;
+}
+
+// crossfeed.c:89-153
+SpecPtr parse_crossfeed(const stream_info *is, const char *sel, int argc, const char *const *argv)
+{
+	const char *name = argv[0];
+	if (argc != 3) { usage(name); return nullptr; }
+	int c0, c1;
+	if (!pair_of(name, is, sel, &c0, &c1)) return nullptr;
+	char *end;
+	const double freq = parse_freq(argv[1], &end);
+	if (bad_endptr(name, argv[1], end, "f0")) return nullptr;
+	if (!(freq >= 0.0 && freq < is->fs / 2.0)) { set_error("%s: error: f0 out of range", name); return nullptr; }
+	const double sep_db = strtod(argv[2], &end);
+	if (bad_endptr(name, argv[2], end, "separation")) return nullptr;
+	if (!(sep_db >= 0.0)) { set_error("%s: error: separation out of range", name); return nullptr; }
+	SpecPtr s = new_spec(Kind::Crossfeed, name, is, sel);
+	s->flags = EFFECT_FLAG_PLOT_MIX;
+	s->xf_c0 = c0; s->xf_c1 = c1;
+	const double sep = pow(10, sep_db / 20);
+	s->xf_direct = sep / (1 + sep);
+	s->xf_cross = 1 / (1 + sep);
+	biquad_design(DSPAMD_BIQUAD_LOWPASS_1, is->fs, freq, 0, 0, 0, W_Q, s->xf_lp);
+	biquad_design(DSPAMD_BIQUAD_HIGHPASS_1, is->fs, freq, 0, 0, 0, W_Q, s->xf_hp);
+	s->remix.assign(is->channels, Selector(is->channels, 0));
+	for (int k = 0; k < is->channels; ++k) s->remix[k][k] = 1;
+	s->remix[c0][c1] = s->remix[c1][c0] = 1;                         // crossfeed.c:82-87
+	return s;
+}
+
+// One crossfeed = three device stages over a stream widened by four scratch channels:
+//   spread   C -> C+4   scratch = (s1, s0, s0, s1): the inputs of lp[0], hp[0], lp[1], hp[1] (crossfeed.c:41-46)
+//   filters  the four first-order sections, fused into one cascade launch
+//   combine  C+4 -> C   out_c0 = s0 direct + lp[0](s1) cross + hp[0](s0) cross, out_c1 likewise, in the reference's order
+void crossfeed_expand(const Spec &xf, Spec &spread, Spec &filters, Spec &combine)
+{
+	const int C = xf.ch_in, W = C + 4, c0 = xf.xf_c0, c1 = xf.xf_c1;
+	spread = Spec(); filters = Spec(); combine = Spec();
+	spread.kind = Kind::Mix; spread.name = xf.name + ":spread";
+	spread.fs_in = spread.fs_out = xf.fs_in; spread.ch_in = C; spread.ch_out = W;
+	spread.sel = xf.sel;
+	mix_identity(spread, W, C);
+	const int src[4] = { c1, c0, c0, c1 };
+	for (int j = 0; j < 4; ++j) mix_row(spread, C + j, { src[j] }, { 1.0 });
+	filters.kind = Kind::Biquad; filters.name = xf.name + ":filters";
+	filters.fs_in = filters.fs_out = xf.fs_in; filters.ch_in = filters.ch_out = W;
+	filters.sel.assign(W, 0);
+	filters.bq.assign(W, std::array<double, 5>{ { 1, 0, 0, 0, 0 } });
+	for (int j = 0; j < 4; ++j) { filters.sel[C + j] = 1; filters.bq[C + j] = (j & 1) ? xf.xf_hp : xf.xf_lp; }
+	combine.kind = Kind::Mix; combine.name = xf.name + ":combine";
+	combine.fs_in = combine.fs_out = xf.fs_in; combine.ch_in = W; combine.ch_out = C;
+	combine.sel.assign(W, 0);
+	mix_identity(combine, C, W);
+	mix_row(combine, c0, { c0, C + 0, C + 1 }, { xf.xf_direct, xf.xf_cross, xf.xf_cross });
+	mix_row(combine, c1, { c1, C + 2, C + 3 }, { xf.xf_direct, xf.xf_cross, xf.xf_cross });
+}
+
 // ------------------------------------------------------------------ delay
 
 SpecPtr make_delay_spec(const char *name, const stream_info *is, const char *sel, ssize_t samples, bool *noop)
@@ -339,7 +441,65 @@ SpecPtr make_delay_spec(const char *name, const stream_info *is, const char *sel
 	SpecPtr s = new_spec(Kind::Delay, name, is, sel);
 	s->flags = EFFECT_FLAG_OPT_REORDERABLE | EFFECT_FLAG_CH_DEPS_IDENTITY;
 	s->delay.assign(is->channels, 0);
+	s->delay_frac.assign(is->channels, 0.0);
+	s->fd_ap_n.assign(is->channels, 0);
 	for (int k = 0; k < is->channels; ++k) if (sel[k]) s->delay[k] = samples;
+	return s;
+}
+
+// delay_effect_prepare (delay.c:149-204): what is left of the summed fractional amounts becomes a first- or
+// second-order Thiran all-pass (allpass.h:46-71) -- the same transfer function as a biquad section
+//     ap1: (c0 + z^-1) / (1 + c0 z^-1),   ap2: (c1 + c0 z^-1 + z^-2) / (1 + c0 z^-1 + c1 z^-2)
+// which the fused cascade kernel runs; the integer remainder is requested from the host (channel_offsets).
+bool delay_prepare(Spec &sp, bool *noop)
+{
+	*noop = true;
+	if (sp.kind != Kind::Delay || sp.delay_frac.empty()) return true;
+	const int n = sp.ch_in;
+	bool any = false;
+	for (int k = 0; k < n; ++k) {
+		if (sp.fd_ap_n[k] < 1) sp.fd_ap_n[k] = 2;                       // DELAY_FD_AP_N_DEFAULT
+		if (fabs(sp.delay_frac[k] - rint(sp.delay_frac[k])) >= DBL_EPSILON) {
+			const ssize_t adj = (sp.fd_ap_n[k] - 1) - (ssize_t) floor(sp.delay_frac[k] - 0.1);   // DELAY_MIN_FRAC
+			sp.delay[k] -= adj;
+			sp.delay_frac[k] += adj;
+			any = true;
+		}
+		else {
+			sp.delay[k] += lrint(sp.delay_frac[k]);
+			sp.delay_frac[k] = 0.0;
+			sp.fd_ap_n[k] = 0;
+		}
+	}
+	if (!any) return true;                                              // integer amounts only: run() stays a no-op
+	for (int k = 0; k < n; ++k)
+		if (sp.fd_ap_n[k] > 2) { set_error("%s: error: all-pass order %d (Thiran ladder, allpass.h:83-118) is not provided by the GPU backend (orders 1 and 2 are)", sp.name.c_str(), sp.fd_ap_n[k]); return false; }
+	sp.kind = Kind::Biquad;
+	sp.frac_delay = true;
+	sp.bq.assign(n, std::array<double, 5>{ 1, 0, 0, 0, 0 });
+	for (int k = 0; k < n; ++k) {
+		sp.sel[k] = sp.fd_ap_n[k] > 0 ? 1 : 0;
+		if (!sp.sel[k]) continue;
+		const double d = fabs(sp.delay_frac[k]);
+		if (sp.fd_ap_n[k] == 1) {
+			const double c0 = (1.0 - d) / (1.0 + d);
+			sp.bq[k] = { c0, 1.0, 0.0, c0, 0.0 };
+		}
+		else {
+			const double c0 = (4.0 - 2.0 * d) / (1.0 + d), c1 = ((d - 2.0) * (d - 1.0)) / ((d + 1.0) * (d + 2.0));
+			sp.bq[k] = { c1, c0, 1.0, c0, c1 };
+		}
+	}
+	*noop = false;
+	return true;
+}
+
+// delay_effect_init_frac (delay.c:254-257): the whole amount is "fractional" until prepare()
+SpecPtr make_frac_delay_spec(const char *name, const stream_info *is, const char *sel, double samples_frac, int fd_ap_n, bool *noop)
+{
+	SpecPtr s = make_delay_spec(name, is, sel, 0, noop);
+	*noop = (samples_frac == 0.0);
+	for (int k = 0; k < is->channels; ++k) if (sel[k]) { s->delay_frac[k] = samples_frac; s->fd_ap_n[k] = fd_ap_n; }
 	return s;
 }
 
@@ -348,9 +508,21 @@ SpecPtr parse_delay(const stream_info *is, const char *sel, int argc, const char
 	const char *name = argv[0];
 	GetOpt g;
 	int opt;
+	bool do_frac = false;
+	int order = 0;
 	while ((opt = g.next(argc - 1, argv, "f::m:M:b:q:")) != -1) {
-		if (opt == 'f' || opt == 'm' || opt == 'M' || opt == 'b' || opt == 'q') {
-			set_error("%s: error: option -%c (fractional / modulated delay, delay.c:51-53,567-593) is not provided by the GPU backend", name, opt);
+		if (opt == 'f') {                                               // delay.c:696-703
+			do_frac = true;
+			if (g.arg) {
+				char *e2;
+				order = (int) strtol(g.arg, &e2, 10);
+				if (bad_endptr(name, g.arg, e2, "order")) return nullptr;
+				if (!(order > 0 && order <= 50)) { set_error("%s: error: order out of range", name); return nullptr; }
+			}
+			continue;
+		}
+		if (opt == 'm' || opt == 'M' || opt == 'b' || opt == 'q') {
+			set_error("%s: error: option -%c (modulated delay, delay.c:567-593) is not provided by the GPU backend", name, opt);
 			return nullptr;
 		}
 		g.print_error(opt, name);
@@ -361,6 +533,7 @@ SpecPtr parse_delay(const stream_info *is, const char *sel, int argc, const char
 	char *end;
 	const double samples = parse_len_frac(argv[g.ind], is->fs, &end);
 	if (bad_endptr(name, argv[g.ind], end, "delay")) return nullptr;
+	if (do_frac) return make_frac_delay_spec(name, is, sel, samples, order, noop);
 	const ssize_t si = (ssize_t) lrint(samples);
 	if (fabs(samples - si) >= DBL_EPSILON)
 		log_msg(LL_VERBOSE, "%s: info: delay rounded to %gs (%zd samples)", name, (double) si / is->fs, si);
@@ -804,7 +977,11 @@ bool merge_specs(Spec &d, const Spec &s)
 		for (int k = 0; k < n; ++k) if (s.sel[k]) { d.sel[k] = 1; d.bq[k] = s.bq[k]; }
 		return true;
 	case Kind::Delay:
-		for (int k = 0; k < n; ++k) d.delay[k] += s.delay[k];   // delay.c:127-141
+		for (int k = 0; k < n; ++k) {                           // delay.c:127-141
+			d.delay[k] += s.delay[k];
+			d.delay_frac[k] += s.delay_frac[k];
+			d.fd_ap_n[k] = std::max(d.fd_ap_n[k], s.fd_ap_n[k]);
+		}
 		return true;
 	case Kind::Conv:
 		// reverse IIR effects append their sections channel by channel (reverse_iir.c:305-319); nothing else merges

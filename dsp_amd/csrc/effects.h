@@ -11,7 +11,7 @@
 
 namespace dspamd {
 
-enum class Kind { Gain, Add, Biquad, Remix, Delay, Align, FirDirect, Conv, Resample };
+enum class Kind { Gain, Add, Biquad, Remix, Mix, Crossfeed, Delay, Align, FirDirect, Conv, Resample };
 
 enum ConvMode {
 	CONV_ZERO_LATENCY = 0,   // fir_p (fir_p.c): y[n] = sum h[k] x[n-k], no added latency
@@ -39,8 +39,22 @@ struct Spec {
 	std::vector<double> vec;                 // Gain/Add: per-channel operand (1.0 / 0.0 where unselected)
 	std::vector<std::array<double, 5>> bq;   // Biquad: c0..c4 per channel (valid where sel)
 	std::vector<Selector> remix;             // Remix: [ch_out] selectors over ch_in
+	// Mix (st2ms / ms2st, st2ms.c:28-54; the two ends of an expanded crossfeed): out[k] = (sum_j in[idx[k][j]] * w[k][j]) * post[k],
+	// products and sums single-rounded in list order -- `remix` holds the same dependencies as 0/1 rows for channel_deps
+	std::vector<std::vector<int>> mix_idx;
+	std::vector<std::vector<double>> mix_w;
+	std::vector<double> mix_post;            // empty = no post-scale
+	// Crossfeed (crossfeed.c:26-50): the pair (xf_c0, xf_c1), gains, first-order low-/high-pass sections
+	int xf_c0 = -1, xf_c1 = -1;
+	double xf_direct = 1.0, xf_cross = 0.0;
+	std::array<double, 5> xf_lp{ { 1, 0, 0, 0, 0 } }, xf_hp{ { 1, 0, 0, 0, 0 } };
 	std::vector<ssize_t> delay;              // Delay: requested per-channel delay (realised by Align); Align: ring length
 	ssize_t discard = 0;                     // Align: leading frames dropped at end of chain (align.c:53-62)
+	// Delay with a fractional part (`delay -f[order]`, delay.c:149-204): the amounts add up across merged effects
+	// until prepare() splits them into an integer delay (host alignment) and a Thiran all-pass (a cascade section)
+	std::vector<double> delay_frac;          // [ch_in] fractional amount still to be realised
+	std::vector<int> fd_ap_n;                // [ch_in] all-pass order (0 = default) / after prepare: order in use
+	bool frac_delay = false;                 // after prepare: a Biquad-kind spec that also requests delay[k] from the host
 
 	std::vector<double> taps;                // FirDirect/Conv: [T][fch] interleaved
 	int fch = 0;
@@ -67,6 +81,9 @@ using SpecPtr = std::unique_ptr<Spec>;
 SpecPtr parse_biquad(int effect_number, const stream_info *is, const char *sel, int argc, const char *const *argv, bool *unsupported_reverse);
 SpecPtr parse_gain(int effect_number, const stream_info *is, const char *sel, int argc, const char *const *argv);
 SpecPtr parse_remix(const stream_info *is, const char *sel, int argc, const char *const *argv);
+SpecPtr parse_st2ms(int effect_number, const stream_info *is, const char *sel, int argc, const char *const *argv);
+SpecPtr parse_crossfeed(const stream_info *is, const char *sel, int argc, const char *const *argv);
+void crossfeed_expand(const Spec &xf, Spec &spread, Spec &filters, Spec &combine);   // the three device stages of one crossfeed
 SpecPtr parse_delay(const stream_info *is, const char *sel, int argc, const char *const *argv, bool *noop);
 SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv);
 SpecPtr parse_zita(const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv);
@@ -89,6 +106,8 @@ void hilbert_design(ssize_t taps, double angle_rad, std::vector<double> &h);
 void riir_sec_from_biquad(const std::array<double, 5> &c, double thresh, RiirSec *s);
 bool riir_design(const char *name, int channel, std::vector<RiirSec> secs, std::vector<double> &taps, ssize_t *latency);
 bool riir_prepare(Spec &sp);   // the effect's prepare(): section lists -> per-channel FIRs
+SpecPtr make_frac_delay_spec(const char *name, const stream_info *is, const char *sel, double samples_frac, int fd_ap_n, bool *noop);
+bool delay_prepare(Spec &sp, bool *noop);   // delay.c:149-204: integer part + Thiran all-pass section per channel
 
 const effect_info *registry_lookup(const char *name);
 const effect_info *registry_table(int *n);

@@ -216,6 +216,16 @@ void CascadeStage::reset(hipStream_t st)
 bool RemixStage::init(const Spec &sp)
 {
 	max_n = 1;
+	if (sp.kind == Kind::Mix) {
+		weighted = true;
+		for (auto &r : sp.mix_idx) max_n = std::max<int>(max_n, (int) r.size());
+		std::vector<int> idx((size_t) ch_out * max_n, -1);
+		std::vector<double> w((size_t) ch_out * max_n, 0.0);
+		for (int k = 0; k < ch_out; ++k)
+			for (size_t j = 0; j < sp.mix_idx[k].size(); ++j) { idx[(size_t) k * max_n + j] = sp.mix_idx[k][j]; w[(size_t) k * max_n + j] = sp.mix_w[k][j]; }
+		if (!sp.mix_post.empty() && !d_post.upload(sp.mix_post.data(), sp.mix_post.size() * sizeof(double))) return false;
+		return d_idx.upload(idx.data(), idx.size() * sizeof(int)) && d_w.upload(w.data(), w.size() * sizeof(double));
+	}
 	for (auto &r : sp.remix) max_n = std::max(max_n, num_set(r));
 	std::vector<int> idx((size_t) ch_out * max_n, -1);
 	for (int k = 0; k < ch_out; ++k) {
@@ -227,7 +237,8 @@ bool RemixStage::init(const Spec &sp)
 
 ssize_t RemixStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
-	RemixParams p{ in, out, in_stride, out_stride, frames, ch_in, ch_out, d_idx.as<int>(), max_n };
+	RemixParams p{ in, out, in_stride, out_stride, frames, ch_in, ch_out, d_idx.as<int>(), max_n,
+	               weighted ? d_w.as<double>() : nullptr, (weighted && d_post.p) ? d_post.as<double>() : nullptr };
 	{ ProfScope ps("remix_kernel", st); launch_remix(p, S, st); }
 	return frames;
 }
@@ -377,11 +388,24 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 				++si;
 			}
 		}
+		const Spec *parts[3] = { sp, nullptr, nullptr };
+		int n_parts = 1;
+		if (sp->kind == Kind::Crossfeed) {
+			// crossfeed.c:33-50 as three device stages (see crossfeed_expand)
+			Spec *q[3];
+			for (int i = 0; i < 3; ++i) { merged.emplace_back(new Spec); q[i] = merged.back().get(); }
+			crossfeed_expand(*sp, *q[0], *q[1], *q[2]);
+			for (int i = 0; i < 3; ++i) parts[i] = q[i];
+			n_parts = 3;
+		}
+		for (int pi = 0; pi < n_parts; ++pi) {
+		sp = parts[pi];
 		if (sp->fs_in != cur_fs || sp->ch_in != cur_ch) {
 			set_error("pipeline: BUG: stream format mismatch at %s (%d ch @ %d vs %d ch @ %d)", sp->name.c_str(), sp->ch_in, sp->fs_in, cur_ch, cur_fs);
 			return nullptr;
 		}
 		switch (sp->kind) {
+		case Kind::Crossfeed: break;   // expanded above
 		case Kind::Gain: case Kind::Add: case Kind::Biquad:
 			if (!casc) {
 				casc = new CascadeStage;
@@ -392,7 +416,7 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 			break;
 		case Kind::Delay:
 			break;   // realised by Align (delay.c:142-147, 195-202)
-		case Kind::Remix: {
+		case Kind::Remix: case Kind::Mix: {
 			if (!flush()) return nullptr;
 			RemixStage *r = new RemixStage;
 			base(r, *sp);
@@ -422,6 +446,7 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 		cur_fs = sp->fs_out;
 		cur_ch = sp->ch_out;
 		if (!pl->stages.empty()) frames_here = pl->stages.back()->max_out_frames(frames_here);
+		}
 	}
 	if (!flush()) return nullptr;
 	pl->fs_out = cur_fs;

@@ -343,6 +343,7 @@ __device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__res
 {
 	const int row = lane >> 4;
 	PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
+	bool pending = false;            // wave-uniform: gain / add on their own stay single IEEE operations (no `+ 0.0`: keeps -0.0)
 	OpHead cur = load_head(cf + j_lo * FOP_DOUBLES);
 	for (int j = j_lo; j < j_hi; ++j) {
 		const double *__restrict__ od = cf + j * FOP_DOUBLES;
@@ -393,12 +394,14 @@ __device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__res
 			double x0 = dpp_f64<DPP_WAVE_SHR1>(m0), x1 = dpp_f64<DPP_WAVE_SHR1>(m1);
 			if (lane == 0) { x0 = xin.x; x1 = xin.y; }
 			fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
+			pending = true;
 			// state after the last lane's samples = the reference's (m0, m1) at that point
 			if (lane == 63) *reinterpret_cast<double2 *>(st + 2 * j) = make_double2(m0, m1);
 		}
 		else if (cur.kind == OP_MUL || cur.kind == OP_ADD) {
-			apply_fix<L>(v, fix);
+			if (pending) apply_fix<L>(v, fix);
 			fix.x0 = 0.0; fix.x1 = 0.0; fix.nc3 = 0.0; fix.nc4 = 0.0;
+			pending = false;
 			const double g = cur.g;
 			if (cur.kind == OP_MUL) {
 #pragma unroll
@@ -411,7 +414,7 @@ __device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__res
 		}
 		cur = nxt;
 	}
-	apply_fix<L>(v, fix);
+	if (pending) apply_fix<L>(v, fix);
 }
 
 template <int CG>

@@ -2,6 +2,7 @@
 // bench endpoints (sgen sine source, digest sink, copy probe).
 //
 //   remix_kernel  : remix_effect_run_{1a,4,generic}   remix.c:39-101  (ascending-input-channel sums from 0.0)
+//                   + weighted rows: st2ms / ms2st (st2ms.c:28-54), the two ends of a crossfeed (crossfeed.c:41-46)
 //   delay_kernel  : align_channel_run                 align.c:35-44   (per-channel delay of len frames, state carried)
 //   sgen_kernel   : sgen_run_generator (sine)         sgen.c:55-67
 //   digest_kernel : the `stats` quantities            stats.c:47-76
@@ -24,10 +25,23 @@ __global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
 		const int *idx = p.idx + (size_t) k * p.max_n;
 		const double *fr = in + t * p.Cin;
 		double acc = 0.0;
-		for (int j = 0; j < p.max_n; ++j) {
-			const int c = idx[j];
-			if (c < 0) break;
-			acc = __dadd_rn(acc, fr[c]);
+		if (p.w) {
+			// weighted form (st2ms.c:34-38, crossfeed.c:41-46): the first product starts the sum, every operation rounds once
+			const double *w = p.w + (size_t) k * p.max_n;
+			if (idx[0] >= 0) acc = __dmul_rn(fr[idx[0]], w[0]);
+			for (int j = 1; j < p.max_n; ++j) {
+				const int c = idx[j];
+				if (c < 0) break;
+				acc = __dadd_rn(acc, __dmul_rn(fr[c], w[j]));
+			}
+			if (p.post) acc = __dmul_rn(acc, p.post[k]);
+		}
+		else {
+			for (int j = 0; j < p.max_n; ++j) {
+				const int c = idx[j];
+				if (c < 0) break;
+				acc = __dadd_rn(acc, fr[c]);
+			}
 		}
 		out[e] = acc;
 	}

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(256) void resample_push_kernel(const double *in, lo
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int RSG_ROWS = 64;
-constexpr int RSG_MAX_PT = 6;     // column tiles per wave (NB padded <= 2 * 6 * 16 = 192)
 
 __device__ __forceinline__ int rsg_lds_index(int f, int c, int log2cp) { return (f << log2cp) + c + ((f >> 5) << 4); }
 

@@ -68,6 +68,8 @@ struct RemixParams {
 	int Cin, Cout;
 	const int *idx;                      // [Cout][max_n] input channel indices, ascending, -1 terminated rows
 	int max_n;
+	const double *w;                     // Mix: [Cout][max_n] weights (nullptr: plain remix sums from 0.0)
+	const double *post;                  // Mix: [Cout] post-scale or nullptr
 };
 
 struct DelayParams {                     // integer per-channel delay with carried ring (align.c:35-44)

@@ -160,10 +160,20 @@ static int plugin_merge(struct effect *dest, struct effect *src)
 	return 1;
 }
 
+static void plugin_drain_samples(struct effect *e, ssize_t *samples);
+
 static int plugin_prepare(struct effect *e)
 {
 	Node *n = node_of(e);
 	if (!n || n->seg) return 0;
+	if (n->spec->kind == Kind::Delay) {
+		bool noop = true;
+		if (!delay_prepare(*n->spec, &noop)) return 1;
+		e->run = noop ? plugin_run_noop : plugin_run;               // delay.c:201-202
+		if (!noop) { e->merge = nullptr; e->drain_samples = plugin_drain_samples; }
+		if (e->channel_selector) memcpy(e->channel_selector, n->spec->sel.data(), n->spec->sel.size());
+		return 0;
+	}
 	if (!riir_prepare(*n->spec)) return 1;
 	if (e->channel_selector) memcpy(e->channel_selector, n->spec->sel.data(), n->spec->sel.size());
 	return 0;
@@ -176,6 +186,7 @@ static void plugin_drain_samples(struct effect *e, ssize_t *samples)
 	const Spec &sp = *n->spec;
 	for (int k = 0; k < sp.ch_out; ++k) {
 		if (sp.kind == Kind::Align) samples[k] += sp.delay[k];                                  // align.c:77-82
+		else if (sp.frac_delay) samples[k] += sp.fd_ap_n[k];                                    // delay.c:105-110
 		else if (!sp.ch_latency.empty()) { if (sp.sel[k]) samples[k] += sp.ch_latency[k]; }     // reverse_iir.c:234-239
 		else if (sp.sel[k]) samples[k] += sp.latency + sp.T - 1;                                // fir.c:180-187, fir_p.c:235-240
 	}
@@ -187,7 +198,7 @@ static void plugin_channel_offsets(struct effect *e, ssize_t *latency, ssize_t *
 	if (!n) return;
 	const Spec &sp = *n->spec;
 	for (int k = 0; k < sp.ch_in; ++k) {
-		if (sp.kind == Kind::Delay) req_delay[k] += sp.delay[k];                                // delay.c:142-147
+		if (sp.kind == Kind::Delay || sp.frac_delay) req_delay[k] += sp.delay[k];               // delay.c:142-147
 		else if (!sp.ch_latency.empty()) { if (sp.sel[k]) req_delay[k] -= sp.ch_latency[k]; }   // reverse_iir.c:275-280
 		else if (sp.sel[k]) { latency[k] += sp.latency; req_delay[k] -= sp.ref; }               // fir.c:208-217
 	}
@@ -235,9 +246,10 @@ struct effect *make_effect(SpecPtr spec, bool noop)
 		switch (sp.kind) {
 		case Kind::Gain: case Kind::Add: e->merge = plugin_merge; e->plot = plugin_plot; break;
 		case Kind::Biquad: e->merge = plugin_merge; e->plot = plugin_plot; break;
-		case Kind::Delay: e->merge = plugin_merge; e->plot = plugin_plot; e->channel_offsets = plugin_channel_offsets; break;
+		case Kind::Delay: e->merge = plugin_merge; e->plot = plugin_plot; e->channel_offsets = plugin_channel_offsets; e->prepare = plugin_prepare; break;
 		case Kind::Align: e->drain_samples = plugin_drain_samples; e->plot = plugin_plot; break;
 		case Kind::Remix: e->channel_deps = plugin_channel_deps; break;
+		case Kind::Mix: case Kind::Crossfeed: e->channel_deps = plugin_channel_deps; e->plot = plugin_plot; break;
 		case Kind::FirDirect: case Kind::Conv:
 			e->drain_samples = plugin_drain_samples;
 			e->channel_offsets = plugin_channel_offsets;
@@ -286,6 +298,20 @@ struct effect *remix_effect_init(const struct effect_info *ei, const struct stre
 	return s ? make_effect(std::move(s), false) : nullptr;
 }
 
+struct effect *st2ms_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) dir;
+	SpecPtr s = parse_st2ms(ei->effect_number, is, sel, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
+struct effect *crossfeed_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
+{
+	(void) ei; (void) dir;
+	SpecPtr s = parse_crossfeed(is, sel, argc, argv);
+	return s ? make_effect(std::move(s), false) : nullptr;
+}
+
 struct effect *delay_effect_init(const struct effect_info *ei, const struct stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
 {
 	(void) ei; (void) dir;
@@ -298,6 +324,13 @@ struct effect *delay_effect_init_int(const char *name, const struct stream_info 
 {
 	bool noop = false;
 	SpecPtr s = make_delay_spec(name, is, sel, samples_int, &noop);
+	return s ? make_effect(std::move(s), noop) : nullptr;
+}
+
+struct effect *delay_effect_init_frac(const char *name, const struct stream_info *is, const char *sel, double samples_frac, int fd_ap_n)
+{
+	bool noop = false;
+	SpecPtr s = make_frac_delay_spec(name, is, sel, samples_frac, fd_ap_n, &noop);
 	return s ? make_effect(std::move(s), noop) : nullptr;
 }
 
@@ -392,6 +425,9 @@ static const effect_info g_effects[] = {
 	{ "mult",               "multiplier",                                     gain_effect_init, DSPAMD_GAIN_MULT },
 	{ "add",                "value",                                          gain_effect_init, DSPAMD_GAIN_ADD },
 	{ "remix",              "channel_selector|. ...",                         remix_effect_init, 0 },
+	{ "st2ms",              "",                                               st2ms_effect_init, DSPAMD_ST2MS_ST2MS },
+	{ "ms2st",              "",                                               st2ms_effect_init, DSPAMD_ST2MS_MS2ST },
+	{ "crossfeed",          "f0[k] separation",                               crossfeed_effect_init, 0 },
 	{ "delay",              "[-f[order]] [-m|M depth[s|m|S|%]] [-b bw[k]] [-q quality] delay[s|m|S]", delay_effect_init, 0 },
 	{ "resample",           "[bandwidth] fs[k]|x{mult}|/{div}",                        resample_effect_init, 0 },
 	{ "fir",                FIR_OPTS " " FIR_FILTER,                          fir_effect_init, 0 },

@@ -28,14 +28,15 @@ private:
 class RemixStage : public Stage {
 public:
 	bool init(const Spec &sp);
-	const char *type() const override { return "remix"; }
-	std::string describe() const override { return "remix[" + std::to_string(ch_in) + "->" + std::to_string(ch_out) + "]"; }
+	const char *type() const override { return weighted ? "mix" : "remix"; }
+	std::string describe() const override { return std::string(type()) + "[" + std::to_string(ch_in) + "->" + std::to_string(ch_out) + "]"; }
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t) override {}
-	size_t device_bytes() const override { return d_idx.bytes; }
+	size_t device_bytes() const override { return d_idx.bytes + d_w.bytes + d_post.bytes; }
 private:
-	DevBuf d_idx;
+	DevBuf d_idx, d_w, d_post;           // d_w / d_post: weighted rows (Kind::Mix)
 	int max_n = 1;
+	bool weighted = false;
 };
 
 // integer per-channel delay with carried state + end-of-chain discard (the reference's `align`, align.c)

@@ -44,8 +44,9 @@ Effect._fields_ = [
 PLUGIN_SYMBOLS = [
     "biquad_effect_init", "gain_effect_init", "remix_effect_init", "delay_effect_init", "fir_effect_init",
     "fir_p_effect_init", "resample_effect_init", "hilbert_effect_init", "zita_convolver_effect_init",
+    "st2ms_effect_init", "crossfeed_effect_init",
     "fir_effect_init_with_filter", "fir_p_effect_init_with_filter", "zita_convolver_effect_init_with_filter",
-    "delay_effect_init_int",
+    "delay_effect_init_int", "delay_effect_init_frac",
 ]
 API_SYMBOLS = [
     "dspamd_version", "dspamd_last_error", "dspamd_device_count", "dspamd_set_device", "dspamd_set_loglevel",
@@ -118,7 +119,7 @@ def load_library():
         f.restype = res
         f.argtypes = args
     init_sig = [C.POINTER(_EffectInfo), C.POINTER(StreamInfo), cp, cp, i, C.POINTER(cp)]
-    for name in PLUGIN_SYMBOLS[:9]:
+    for name in PLUGIN_SYMBOLS[:11]:
         f = getattr(L, name)
         f.restype = C.POINTER(Effect)
         f.argtypes = init_sig

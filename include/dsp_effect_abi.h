@@ -88,6 +88,8 @@ struct effect *fir_p_effect_init(const struct effect_info *, const struct stream
 struct effect *resample_effect_init(const struct effect_info *, const struct stream_info *, const char *, const char *, int, const char *const *);      /* replaces resample.h:26 */
 struct effect *hilbert_effect_init(const struct effect_info *, const struct stream_info *, const char *, const char *, int, const char *const *);       /* replaces hilbert.h:26 */
 struct effect *zita_convolver_effect_init(const struct effect_info *, const struct stream_info *, const char *, const char *, int, const char *const *); /* replaces zita_convolver.h:32 */
+struct effect *st2ms_effect_init(const struct effect_info *, const struct stream_info *, const char *, const char *, int, const char *const *);         /* replaces st2ms.h:30 (st2ms, ms2st) */
+struct effect *crossfeed_effect_init(const struct effect_info *, const struct stream_info *, const char *, const char *, int, const char *const *);     /* replaces crossfeed.h:25 */
 
 /* filter-in-memory constructors used by other effects (hilbert.c:80,89; fir_p.c:365; matrix4_mb.c:776) */
 struct effect *fir_effect_init_with_filter(const struct effect_info *, const struct stream_info *, const char *, sample_t *filter_data,
@@ -97,6 +99,7 @@ struct effect *fir_p_effect_init_with_filter(const struct effect_info *, const s
 struct effect *zita_convolver_effect_init_with_filter(const struct effect_info *, const struct stream_info *, const char *, sample_t *filter_data,
 	int filter_channels, ssize_t filter_frames, ssize_t ref, int min_part_len, int max_part_len);                /* replaces zita_convolver.h:31 */
 struct effect *delay_effect_init_int(const char *name, const struct stream_info *, const char *, ssize_t samples_int);  /* replaces delay.h:25 */
+struct effect *delay_effect_init_frac(const char *name, const struct stream_info *, const char *, double samples_frac, int fd_ap_n);  /* replaces delay.h:26 */
 
 /* the effect numbers the registry passes in effect_info.effect_number */
 enum {  /* biquad.h:30-51 */
@@ -108,6 +111,9 @@ enum {  /* biquad.h:30-51 */
 };
 enum {  /* gain.h:25-29 */
 	DSPAMD_GAIN_GAIN = 1, DSPAMD_GAIN_MULT, DSPAMD_GAIN_ADD,
+};
+enum {   /* effect_info.effect_number for st2ms_effect_init (st2ms.h:25-28) */
+	DSPAMD_ST2MS_ST2MS = 1, DSPAMD_ST2MS_MS2ST,
 };
 
 #ifdef __cplusplus

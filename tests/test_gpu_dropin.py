@@ -55,6 +55,7 @@ def test_file_chain_cli(tmp_path):
         (f"fir -t pcm -e double -c 1 {hf} :0 delay 11S : remix 0,1 1 0", 3, 1e-12),
         ("hilbert -p 1023 :1 gain -2 : resample 44.1k", 2, 1e-11),
         ("lowpass 2k 0.707 lowpass -r 2k 0.707 :0 highpass -r60 30 0.707", 2, 1e-12),   # time-reversed IIR, merged + per channel
+        ("st2ms :1 delay -f 0.37S : highshelf 6k 0.7 -2 ms2st crossfeed 700 4.5", 2, 1e-12),   # channel-pair effects + fractional delay
     ]:
         ref, gpu = both(tmp_path, in_args, chain, och)
         assert ref.shape == gpu.shape, (chain, ref.shape, gpu.shape)
@@ -87,7 +88,7 @@ def test_bit_exact_class_cli(tmp_path):
     x = rng.uniform(-0.3, 0.3, size=(5000, 4))
     xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
     ref, gpu = both(tmp_path, ["-t", "pcm", "-e", "double", "-r", "48k", "-c", "4", xin],
-                    "gain -6 :1,3 mult 0.3 : add 0.001 remix 0,1 2 . 1,2,3 :0 delay 37S", 4)
+                    "gain -6 :1,3 mult 0.3 : add 0.001 remix 0,1 2 . 1,2,3 :0 delay 37S :2,3 st2ms", 4)
     assert ref.shape == gpu.shape and np.array_equal(ref, gpu)
 
 

@@ -177,3 +177,71 @@ def test_reverse_iir_channel_subset_and_mixed_chain(amd):
     assert y.shape == ref.shape
     assert np.array_equal(y[:, 1:], ref[:, 1:])          # untouched channels: delayed copies, bit-exact
     assert rms(y - ref) < 1e-12, rms(y - ref)
+
+
+FRAC_DELAY_CHAINS = [
+    ("delay -f 0.3S", 2),                                       # default order 2 on every channel
+    ("delay -f1 2.7S", 2),                                      # first-order Thiran all-pass + integer part
+    (":0 delay -f 1.25m", 3),                                   # one channel only: 60 samples, exactly integer -> host delay line
+    (":0 delay -f 1.26m", 3),                                   # ... and 60.48 samples: all-pass on channel 0, nothing on the others
+    ("delay 3S delay -f 0.4S", 2),                              # integer + fractional effects merge (delay.c:127-141)
+    (":0 delay -f1 0.2S :1 delay -f2 5.5S : delay -f 0.25S", 2),  # per-channel amounts and orders add up / take the maximum
+    ("lowpass 2k 0.7 delay -f 10.5S gain -2", 2),               # the all-pass fuses into the biquad cascade
+    (":1 delay -f -2.5S", 2),                                   # negative delay: the host delays the other channel
+]
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("chain,ch", FRAC_DELAY_CHAINS)
+def test_fractional_delay_vs_real_reference(amd, chain, ch):
+    # `delay -f[order]` (delay.c:149-204, allpass.h): orders 1 and 2 are biquad-shaped all-pass sections on the device,
+    # the integer remainder is the host's alignment delay -- same stream as the reference incl. drain
+    x = noise(9000, ch, 93, 0.4)
+    r = RefChain(chain, 48000, ch)
+    ref_drain = r.drain_frames()
+    ref = r.process(x, block=2048)
+    ec = amd.EffectsChain(chain, 48000, ch)
+    assert ec.drain_frames() == ref_drain
+    y = ec.process(x, block=1500)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    assert rms(y - ref) < 1e-13, rms(y - ref)
+
+
+def test_fractional_delay_order_above_two_refused(amd):
+    with pytest.raises(ValueError, match="order 3"):
+        amd.EffectsChain("delay -f3 0.5S", 48000, 2)
+
+
+PAIR_CHAINS = [
+    ("st2ms", 2, True),
+    ("ms2st", 2, True),
+    ("st2ms gain -3 ms2st", 2, True),                            # mid/side processing round trip
+    (":1,3 st2ms", 5, True),                                     # a pair inside a wider stream, other channels untouched
+    ("st2ms :0 lowpass 3k 0.7 : ms2st", 2, False),               # filtered mid channel: cascade between the two mixes
+    ("crossfeed 700 4.5", 2, False),                             # crossfeed.c: direct + low-passed opposite + high-passed own
+    (":0,2 crossfeed 1k 3 : gain -1", 4, False),
+    ("crossfeed 700 6 crossfeed 500 9", 2, False),
+]
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("chain,ch,exact", PAIR_CHAINS)
+def test_channel_pair_effects_vs_real_reference(amd, chain, ch, exact):
+    # st2ms / ms2st (st2ms.c:28-54) are single-rounded sums and products: bit-exact.  crossfeed (crossfeed.c:33-50) runs
+    # its four first-order sections in the fused cascade kernel between a spreading and a combining mix: fp64 rounding apart.
+    x = noise(7000, ch, 94, 0.4)
+    x[5, :] = -0.0                                               # signed zeros survive (no `0.0 +` start of the sums)
+    ref = RefChain(chain, 48000, ch).process(x, block=2048)
+    y = amd.EffectsChain(chain, 48000, ch).process(x, block=1300)
+    assert y.shape == ref.shape
+    if exact:
+        assert np.array_equal(y, ref) and np.array_equal(np.signbit(y), np.signbit(ref))
+    else:
+        assert rms(y - ref) < 1e-13, rms(y - ref)
+
+
+def test_channel_pair_effects_need_two_channels(amd):
+    with pytest.raises(ValueError, match="input channels must be 2"):
+        amd.EffectsChain("st2ms", 48000, 3)
+    with pytest.raises(ValueError, match="input channels must be 2"):
+        amd.EffectsChain(":0 crossfeed 700 4", 48000, 2)

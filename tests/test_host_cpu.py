@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     for h in ("dsp_amd.h", "dsp_effect_abi.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        declared |= set(re.findall(r"\b((?:dspamd|biquad|gain|remix|delay|fir|fir_p|resample|hilbert|zita_convolver)_[a-z0-9_]+)\s*\(", src))
+        declared |= set(re.findall(r"\b((?:dspamd|biquad|gain|remix|delay|fir|fir_p|resample|hilbert|zita_convolver|st2ms|crossfeed)_[a-z0-9_]+)\s*\(", src))
     assert declared, "no declarations found"
     assert declared == set(API_SYMBOLS) | set(PLUGIN_SYMBOLS), declared ^ (set(API_SYMBOLS) | set(PLUGIN_SYMBOLS))
     for s in declared:
@@ -27,7 +27,8 @@ def test_registry_matches_reference_names():
     import dsp_amd
     L = dsp_amd.load_library()
     for name, num in [("lowpass", 7), ("eq", 13), ("linkwitz_transform", 17), ("biquad", 19), ("gain", 1), ("add", 3),
-                      ("remix", 0), ("delay", 0), ("fir", 0), ("fir_p", 0), ("resample", 0), ("hilbert", 0), ("zita_convolver", 0)]:
+                      ("remix", 0), ("delay", 0), ("fir", 0), ("fir_p", 0), ("resample", 0), ("hilbert", 0), ("zita_convolver", 0),
+                      ("st2ms", 1), ("ms2st", 2), ("crossfeed", 0)]:
         ei = L.dspamd_get_effect_info(name.encode())
         assert ei and ei.contents.name == name.encode() and ei.contents.effect_number == num
     assert not L.dspamd_get_effect_info(b"no_such_effect")
