@@ -336,82 +336,90 @@ __device__ __forceinline__ OpHead load_head(const double *__restrict__ od)
 	return h;
 }
 
-// cf: this channel's [n_ops][FOP_DOUBLES] constants in global memory (uniform address -> scalar loads);
-// q: LDS [n_ops][FQ_DOUBLES]; st: LDS [n_ops][2]; the ops [j_lo, j_hi) are run
+// one op (section j) of a channel on the tile held in v.  od: the op's [FOP_DOUBLES] constants in global memory (uniform
+// address -> scalar loads), cur: their first 64 bytes (fetched by the caller, one op ahead); q: LDS [n_ops][FQ_DOUBLES];
+// st: LDS [n_ops][2].  `fix` / `pending` carry the zero-input response that the NEXT op (or the caller, at the end) adds.
+template <int L>
+__device__ __forceinline__ void run_op_fast(double (&v)[L], const OpHead &cur, const double *__restrict__ od, const double *q, int j, double *st,
+                                            int lane, PendingFix &fix, bool &pending)
+{
+	const int row = lane >> 4;
+	if (cur.kind == OP_BIQUAD) {
+		// requested now, consumed after the recurrence that hides their latency
+		double Pw[16], P16[4];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) P16[i] = od[FOP_P16 + i];
+		const double2 qa = *reinterpret_cast<const double2 *>(q + j * FQ_DOUBLES + 4 * (lane & 15));
+		const double2 qb = *reinterpret_cast<const double2 *>(q + j * FQ_DOUBLES + 4 * (lane & 15) + 2);
+		const double2 xin = *reinterpret_cast<const double2 *>(st + 2 * j);
+		__builtin_amdgcn_sched_barrier(0);
+		const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, nc3 = -cur.c3, nc4 = -cur.c4;
+		double m0 = 0.0, m1 = 0.0;
+		{
+			// zero-state recurrence of this section on (previous section's output + its pending zero-input response)
+			double x0 = fix.x0, x1 = fix.x1;
+#pragma unroll
+			for (int i = 0; i < L; ++i) {
+				const double s = v[i] + x0;
+				const double t = fix.nc4 * x0;
+				x0 = fma(fix.nc3, x0, x1);
+				x1 = t;
+				const double r = fma(c0, s, m0);
+				m0 = fma(nc3, r, fma(c1, s, m1));
+				m1 = fma(nc4, r, c2 * s);
+				v[i] = r;
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// within-row inclusive scan of the zero-state end states; row totals in lanes 15, 31, 47
+		row_scan(m0, m1, Pw);
+		const double T00 = readlane_f64(m0, 15), T01 = readlane_f64(m1, 15);
+		const double T10 = readlane_f64(m0, 31), T11 = readlane_f64(m1, 31);
+		const double T20 = readlane_f64(m0, 47), T21 = readlane_f64(m1, 47);
+		// true state at the end of each row: E_(-1) = carried state, E_r = P^(16L) E_(r-1) + T_r
+		const double E00 = fma(P16[0], xin.x, fma(P16[1], xin.y, T00)), E01 = fma(P16[2], xin.x, fma(P16[3], xin.y, T01));
+		const double E10 = fma(P16[0], E00, fma(P16[1], E01, T10)), E11 = fma(P16[2], E00, fma(P16[3], E01, T11));
+		const double E20 = fma(P16[0], E10, fma(P16[1], E11, T20)), E21 = fma(P16[2], E10, fma(P16[3], E11, T21));
+		const double cr0 = (row == 0) ? xin.x : (row == 1) ? E00 : (row == 2) ? E10 : E20;
+		const double cr1 = (row == 0) ? xin.y : (row == 1) ? E01 : (row == 2) ? E11 : E21;
+		m0 = fma(qa.x, cr0, fma(qa.y, cr1, m0));        // true state after this lane's samples
+		m1 = fma(qb.x, cr0, fma(qb.y, cr1, m1));
+		double x0 = dpp_f64<DPP_WAVE_SHR1>(m0), x1 = dpp_f64<DPP_WAVE_SHR1>(m1);
+		if (lane == 0) { x0 = xin.x; x1 = xin.y; }
+		fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
+		pending = true;
+		// state after the last lane's samples = the reference's (m0, m1) at that point
+		if (lane == 63) *reinterpret_cast<double2 *>(st + 2 * j) = make_double2(m0, m1);
+	}
+	else if (cur.kind == OP_MUL || cur.kind == OP_ADD) {
+		if (pending) apply_fix<L>(v, fix);
+		fix.x0 = 0.0; fix.x1 = 0.0; fix.nc3 = 0.0; fix.nc4 = 0.0;
+		pending = false;
+		const double g = cur.g;
+		if (cur.kind == OP_MUL) {
+#pragma unroll
+			for (int i = 0; i < L; ++i) v[i] = __dmul_rn(v[i], g);
+		}
+		else {
+#pragma unroll
+			for (int i = 0; i < L; ++i) v[i] = __dadd_rn(v[i], g);
+		}
+	}
+}
+
+// cf: this channel's [n_ops][FOP_DOUBLES] constants; the ops [j_lo, j_hi) are run
 template <int L>
 __device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__restrict__ cf, const double *q, int j_lo, int j_hi, double *st, int lane)
 {
-	const int row = lane >> 4;
 	PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
 	bool pending = false;            // wave-uniform: gain / add on their own stay single IEEE operations (no `+ 0.0`: keeps -0.0)
 	OpHead cur = load_head(cf + j_lo * FOP_DOUBLES);
 	for (int j = j_lo; j < j_hi; ++j) {
-		const double *__restrict__ od = cf + j * FOP_DOUBLES;
 		// next op's head: in flight during this op
 		const OpHead nxt = load_head(cf + ((j + 1 < j_hi) ? j + 1 : j) * FOP_DOUBLES);
-		if (cur.kind == OP_BIQUAD) {
-			// requested now, consumed after the recurrence that hides their latency
-			double Pw[16], P16[4];
-#pragma unroll
-			for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];
-#pragma unroll
-			for (int i = 0; i < 4; ++i) P16[i] = od[FOP_P16 + i];
-			const double2 qa = *reinterpret_cast<const double2 *>(q + j * FQ_DOUBLES + 4 * (lane & 15));
-			const double2 qb = *reinterpret_cast<const double2 *>(q + j * FQ_DOUBLES + 4 * (lane & 15) + 2);
-			const double2 xin = *reinterpret_cast<const double2 *>(st + 2 * j);
-			__builtin_amdgcn_sched_barrier(0);
-			const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, nc3 = -cur.c3, nc4 = -cur.c4;
-			double m0 = 0.0, m1 = 0.0;
-			{
-				// zero-state recurrence of this section on (previous section's output + its pending zero-input response)
-				double x0 = fix.x0, x1 = fix.x1;
-#pragma unroll
-				for (int i = 0; i < L; ++i) {
-					const double s = v[i] + x0;
-					const double t = fix.nc4 * x0;
-					x0 = fma(fix.nc3, x0, x1);
-					x1 = t;
-					const double r = fma(c0, s, m0);
-					m0 = fma(nc3, r, fma(c1, s, m1));
-					m1 = fma(nc4, r, c2 * s);
-					v[i] = r;
-				}
-			}
-			__builtin_amdgcn_sched_barrier(0);
-			// within-row inclusive scan of the zero-state end states; row totals in lanes 15, 31, 47
-			row_scan(m0, m1, Pw);
-			const double T00 = readlane_f64(m0, 15), T01 = readlane_f64(m1, 15);
-			const double T10 = readlane_f64(m0, 31), T11 = readlane_f64(m1, 31);
-			const double T20 = readlane_f64(m0, 47), T21 = readlane_f64(m1, 47);
-			// true state at the end of each row: E_(-1) = carried state, E_r = P^(16L) E_(r-1) + T_r
-			const double E00 = fma(P16[0], xin.x, fma(P16[1], xin.y, T00)), E01 = fma(P16[2], xin.x, fma(P16[3], xin.y, T01));
-			const double E10 = fma(P16[0], E00, fma(P16[1], E01, T10)), E11 = fma(P16[2], E00, fma(P16[3], E01, T11));
-			const double E20 = fma(P16[0], E10, fma(P16[1], E11, T20)), E21 = fma(P16[2], E10, fma(P16[3], E11, T21));
-			const double cr0 = (row == 0) ? xin.x : (row == 1) ? E00 : (row == 2) ? E10 : E20;
-			const double cr1 = (row == 0) ? xin.y : (row == 1) ? E01 : (row == 2) ? E11 : E21;
-			m0 = fma(qa.x, cr0, fma(qa.y, cr1, m0));        // true state after this lane's samples
-			m1 = fma(qb.x, cr0, fma(qb.y, cr1, m1));
-			double x0 = dpp_f64<DPP_WAVE_SHR1>(m0), x1 = dpp_f64<DPP_WAVE_SHR1>(m1);
-			if (lane == 0) { x0 = xin.x; x1 = xin.y; }
-			fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
-			pending = true;
-			// state after the last lane's samples = the reference's (m0, m1) at that point
-			if (lane == 63) *reinterpret_cast<double2 *>(st + 2 * j) = make_double2(m0, m1);
-		}
-		else if (cur.kind == OP_MUL || cur.kind == OP_ADD) {
-			if (pending) apply_fix<L>(v, fix);
-			fix.x0 = 0.0; fix.x1 = 0.0; fix.nc3 = 0.0; fix.nc4 = 0.0;
-			pending = false;
-			const double g = cur.g;
-			if (cur.kind == OP_MUL) {
-#pragma unroll
-				for (int i = 0; i < L; ++i) v[i] = __dmul_rn(v[i], g);
-			}
-			else {
-#pragma unroll
-				for (int i = 0; i < L; ++i) v[i] = __dadd_rn(v[i], g);
-			}
-		}
+		run_op_fast<L>(v, cur, cf + j * FOP_DOUBLES, q, j, st, lane, fix, pending);
 		cur = nxt;
 	}
 	if (pending) apply_fix<L>(v, fix);
@@ -572,134 +580,137 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Section-pipelined variant for FEW streams (strong scaling: 256 streams over 8 GPUs leave 32 per GPU).
+// Wavefront variant for FEW streams (strong scaling: 256 streams over 8 GPUs leave 32 per GPU = 256 channels).
 //
-// cascade_fast runs one wave per channel through ALL sections of a tile before the next tile: 192 tiles x 10
-// sections in series per channel -- 2.4 ms per launch however few channels there are.  With fewer than ~2000 channels
-// on the GPU the recurrence itself has to be cut: here a channel is served by P waves, wave s owning the sections
-// [s n / P, (s + 1) n / P), and the tiles move from wave to wave through LDS (tile buffers B_0 .. B_P of the channel,
-// every step each wave takes the tile its predecessor finished in the previous step): a systolic pipeline over
-// sections, exact (every section still sees its samples in order with its own carried state), whose critical path
-// per tile is n / P sections instead of n.  Two LDS barriers per step; the HBM traffic (B_0 <- slab, B_P -> slab / ring)
-// is asynchronous as in cascade_fast.  Workgroup = CG channels x P stages waves (CG P <= 16, LDS: (P + 1) tiles per channel).
+// cascade_fast runs one wave per channel through all sections of a tile before the next tile: 192 tiles x 10 sections in
+// series per channel, 2.4 ms per launch however few channels there are.  With fewer than ~2000 channels on the GPU the
+// time axis of a channel has to be shared between waves: here the P waves of a channel own the tiles t = w, w + P,
+// w + 2 P, ... and each runs ALL sections on its tile, skewed by one step: at step sigma wave w is at unit sigma - w of
+// its sequence, (tile m, section j) = divmod(unit, n_ops).  Section j of tile t needs the state that section j left
+// after tile t - 1 -- produced by wave w - 1 exactly one step earlier (by wave P - 1, n_ops - P + 1 steps earlier, for
+// w = 0), so ONE LDS barrier per step orders everything, and because P <= n_ops no two waves of a channel ever touch
+// the same section in the same step.  The tiles stay in registers for all their sections; what moves between waves is
+// the 16-byte section state.  Every wave loads and stores its own tiles, one per n_ops steps, prefetched a whole tile
+// period ahead and naturally staggered across the waves.  (A first version handed the TILES from wave to wave through
+// LDS, one section per wave: 16 KB of LDS traffic per wave and step and two barriers -- 0.59 ms at 32 streams against
+// 0.45 ms for this one.)
 template <int CG, int P>
-__global__ __launch_bounds__(64 * CG * P) void cascade_pipe(CascadeParams p, const double *__restrict__ fops)
+__global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, const double *__restrict__ fops)
 {
-	constexpr int L = CASCADE_L, TILE = 64 * L, NTH = 64 * CG * P, CHS = 64 * (L + 1) + 2;
-	constexpr int NE = TILE * CG, KE = (NE + NTH - 1) / NTH;         // I/O elements (one sample each) per thread and tile
+	constexpr int L = CASCADE_L, TILE = 64 * L, NTH = 64 * CG * P;
 	extern __shared__ __attribute__((aligned(16))) double smem[];
 	const int s = blockIdx.x;
 	const int c0 = p.cg0 + blockIdx.y * CG;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int stage = wave / CG, cc = wave % CG;
-	double *tiles = smem;                                            // [P + 1][CG][CHS]
-	double *st = tiles + (size_t) (P + 1) * CG * CHS;                // [CG][n_ops][2]
+	const int w = wave / CG, cc = wave % CG, c = c0 + cc;
+	double *st = smem;                                               // [CG][n_ops][2]
 	double *qt = st + (size_t) CG * p.n_ops * 2;                     // [CG][n_ops][FQ_DOUBLES]
-
 	const int n_st = CG * p.n_ops * 2;
 	double *gstate = p.state + ((size_t) s * p.C + c0) * p.n_ops * 2;
 	for (int i = tid; i < n_st; i += NTH) st[i] = gstate[i];
 	for (int i = tid; i < CG * p.n_ops * FQ_DOUBLES; i += NTH) qt[i] = p.fq[(size_t) c0 * p.n_ops * FQ_DOUBLES + i];
 
 	const long n_full = p.frames / TILE;
-	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C + c0;
-	double *out = p.out + (size_t) s * p.out_stride_frames * p.C + c0;
-	double *ringd = p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) : nullptr;
-	// I/O element k of this thread: sample (frame te[k], channel ce[k]) of the tile; LDS offset inside a tile buffer
-	int te[KE], le[KE];
-#pragma unroll
-	for (int k = 0; k < KE; ++k) {
-		const int e = tid + k * NTH;
-		te[k] = e / CG;
-		le[k] = (e % CG) * CHS + te[k] + te[k] / L;
-	}
-	double pf[KE];
-#pragma unroll
-	for (int k = 0; k < KE; ++k) pf[k] = (tid + k * NTH < NE) ? in[(size_t) te[k] * p.C + (tid + k * NTH) % CG] : 0.0;
-	const double *__restrict__ cf = fops + (size_t) (c0 + cc) * p.n_ops * FOP_DOUBLES;
-	const double *wq = qt + (size_t) cc * p.n_ops * FQ_DOUBLES;
-	double *cst = st + cc * p.n_ops * 2;
-	const int j_lo = (stage * p.n_ops) / P, j_hi = ((stage + 1) * p.n_ops) / P;
-	double *b_in = tiles + ((size_t) stage * CG + cc) * CHS;          // B_stage of this channel
-	double *b_out = b_in + (size_t) CG * CHS;                         // B_(stage + 1)
-	double *b_first = tiles, *b_last = tiles + (size_t) P * CG * CHS;
+	const int n_ops = p.n_ops;
+	// HBM is accessed frame-major (element i of a lane = frame 64 i + lane of the tile: consecutive lanes on consecutive
+	// frames / ring elements), the recurrence wants lane-major (lane = L consecutive frames): each wave transposes through
+	// its own padded LDS tile (frame f at f + f / L), twice per tile -- no barrier, a wave's LDS operations are in order
+	double *tb = qt + (size_t) CG * p.n_ops * FQ_DOUBLES + (size_t) wave * (TILE + TILE / L);
+	const int fm_off = lane + (lane >> 4), lm_off = lane * (L + 1);      // + (64 + 64 / L) i  /  + i
+	const double *in = p.in + ((size_t) s * p.in_stride_frames + lane) * p.C + c;
+	double *out = p.out + ((size_t) s * p.out_stride_frames + lane) * p.C + c;
+	double *ringc = p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c >> 1)) * p.ring.row_stride) + (c & 1) : nullptr;
+	const double *__restrict__ cf = fops + (size_t) c * n_ops * FOP_DOUBLES;
+	const double *wq = qt + (size_t) cc * n_ops * FQ_DOUBLES;
+	double *cst = st + cc * n_ops * 2;
+
+	// the last tile's owner finishes last: wave wl after its tiles
+	const int wl = (int) ((n_full - 1) % P);
+	const long n_steps = wl + ((n_full - 1) / P + 1) * n_ops;
+	long steps = 0;                                                  // barriers passed so far (every wave passes n_steps of them)
+	OpHead cur = load_head(cf);
 	__syncthreads();
 
-	// step sigma: B_0 <- tile sigma (I/O);  stage s works on tile sigma - 1 - s;  tile sigma - 1 - P leaves from B_P (I/O)
-	for (long step = 0; step < n_full + P + 1; ++step) {
-		const long my_tile = step - 1 - stage, out_tile = step - 1 - P;
-		const bool act = my_tile >= 0 && my_tile < n_full;
-		// ---- phase A: everybody READS (the tile this stage takes over, the finished tile) ----
-		double v[L];
-		if (act) {
+	auto load_raw = [&](double (&r)[L], long t) {
+		const double *src = in + (size_t) t * TILE * p.C;
 #pragma unroll
-			for (int i = 0; i < L; ++i) v[i] = b_in[lane * (L + 1) + i];
-		}
-		double r[KE];
-		if (out_tile >= 0) {
+		for (int i = 0; i < L; ++i) r[i] = src[(size_t) i * 64 * p.C];
+	};
+	// all sections on the tile in x (one step each), then the tile goes out
+	auto process = [&](double (&x)[L], long t) {
+		PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
+		bool pending = false;
+		for (int j = 0; j < n_ops; ++j) {
+			const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
+			if (!(p.debug & 4)) run_op_fast<L>(x, cur, cf + j * FOP_DOUBLES, wq, j, cst, lane, fix, pending);
+			cur = nxt;
+			if (j + 1 == n_ops) {
+				if (pending) apply_fix<L>(x, fix);
 #pragma unroll
-			for (int k = 0; k < KE; ++k) r[k] = (tid + k * NTH < NE) ? b_last[le[k]] : 0.0;
-		}
-		lds_barrier();
-		// ---- phase B: everybody WRITES (new input into B_0, results into B_(s+1)); HBM traffic goes out / is requested ----
-		if (step < n_full) {
+				for (int i = 0; i < L; ++i) tb[lm_off + i] = x[i];
 #pragma unroll
-			for (int k = 0; k < KE; ++k) if (tid + k * NTH < NE) b_first[le[k]] = pf[k];
-		}
-		if (out_tile >= 0) {
-			const long t0 = out_tile * TILE;
+				for (int i = 0; i < L; ++i) x[i] = tb[fm_off + (64 + 64 / L) * i];
+				if (!(p.debug & 1)) {
+					const size_t f0 = (size_t) t * TILE;
+					if (p.write_interleaved) {
 #pragma unroll
-			for (int k = 0; k < KE; ++k) {
-				if (tid + k * NTH >= NE) continue;
-				const int ch = (tid + k * NTH) % CG;
-				if (p.write_interleaved) out[(size_t) (t0 + te[k]) * p.C + ch] = r[k];
-				if (ringd) {
-					const int c = c0 + ch;
-					ringd[2 * ((size_t) ((c >> 1) - (c0 >> 1)) * p.ring.row_stride + ((p.ring.pos + t0 + te[k]) & p.ring.mask)) + (c & 1)] = r[k];
+						for (int i = 0; i < L; ++i) out[(f0 + 64 * i) * p.C] = x[i];
+					}
+					if (ringc) {
+						const long e0 = p.ring.pos + (long) f0 + lane;
+#pragma unroll
+						for (int i = 0; i < L; ++i) ringc[2 * (size_t) ((e0 + 64 * i) & p.ring.mask)] = x[i];
+					}
 				}
 			}
+			lds_barrier();
 		}
-		if (step + 1 < n_full) {
-			const double *nx = in + (size_t) (step + 1) * TILE * p.C;
+		steps += n_ops;
+	};
+
+	for (int i = 0; i < w; ++i) lds_barrier();                       // the skew: wave w starts at step w
+	steps = w;
+	if (w < n_full) {
+		double raw[L], x[L];
+		load_raw(raw, w);
+		for (long t = w; t < n_full; t += P) {
+			// the wait for this tile's loads sits here, BEFORE the next tile's loads are issued (vmcnt counts in order)
 #pragma unroll
-			for (int k = 0; k < KE; ++k) pf[k] = (tid + k * NTH < NE) ? nx[(size_t) te[k] * p.C + (tid + k * NTH) % CG] : 0.0;
-		}
-		if (act) {
-			run_ops_fast<L>(v, cf, wq, j_lo, j_hi, cst, lane);
+			for (int i = 0; i < L; ++i) tb[fm_off + (64 + 64 / L) * i] = raw[i];
 #pragma unroll
-			for (int i = 0; i < L; ++i) b_out[lane * (L + 1) + i] = v[i];
+			for (int i = 0; i < L; ++i) x[i] = tb[lm_off + i];
+			// unconditional (the last one re-reads this tile): a conditional load would have to select between old and new
+			// registers, which costs a wait right behind the loads
+			if (!(p.debug & 2)) load_raw(raw, (t + P < n_full) ? t + P : t);
+			process(x, t);
 		}
-		lds_barrier();
 	}
+	for (; steps < n_steps; ++steps) lds_barrier();
+	__syncthreads();
 	for (int i = tid; i < n_st; i += NTH) gstate[i] = st[i];
 }
 
-template <int CG, int P> static size_t pipe_lds_bytes(int n_ops)
+template <int CG, int P> static bool try_launch_wave(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
-	return ((size_t) (P + 1) * CG * (64 * (CASCADE_L + 1) + 2) + (size_t) CG * n_ops * 2 + (size_t) CG * n_ops * FQ_DOUBLES) * sizeof(double);
-}
-
-template <int CG, int P> static bool try_launch_pipe(const CascadeParams &p, int n_streams, hipStream_t stream)
-{
-	const size_t lds = pipe_lds_bytes<CG, P>(p.n_ops);
+	const size_t lds = ((size_t) CG * p.n_ops * 2 + (size_t) CG * p.n_ops * FQ_DOUBLES + (size_t) CG * P * (CASCADE_TILE + 64)) * sizeof(double);
 	if (lds > 160 * 1024 || p.n_ops < P || (p.C % CG)) return false;
 	static size_t granted = 0;
 	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_pipe<CG, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_wave<CG, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
 		granted = lds;
 	}
 	dim3 grid(n_streams, p.C / CG), block(64 * CG * P);
-	hipLaunchKernelGGL((cascade_pipe<CG, P>), grid, block, lds, stream, p, p.fops);
+	hipLaunchKernelGGL((cascade_wave<CG, P>), grid, block, lds, stream, p, p.fops);
 	return true;
 }
 
-// few streams: cut the per-channel recurrence into pipeline stages so that the workgroup count still fills the GPU
-static long launch_cascade_pipe(const CascadeParams &p, int n_streams, hipStream_t stream)
+// few streams: the tiles of a channel are dealt out to P waves (see cascade_wave) so that the chip stays full
+static long launch_cascade_wave(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
 	static int env = -2;
-	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_PIPE"); env = e ? atoi(e) : -1; }   // 0 = never, CG*100+P = force
-	if (env == 0 || p.cg0 != 0 || !p.fops || p.n_ops < 2) return 0;
+	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_WAVE"); env = e ? atoi(e) : -1; }   // 0 = never, CG*100+P = force
+	if (env == 0 || p.cg0 != 0 || !p.fops || p.n_ops < 1) return 0;
 	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
 	const long n_full = p.frames / CASCADE_TILE;
 	if (n_full < 4) return 0;
@@ -707,24 +718,26 @@ static long launch_cascade_pipe(const CascadeParams &p, int n_streams, hipStream
 	int cg, pp;
 	if (env > 0) { cg = env / 100; pp = env % 100; }
 	else {
-		// measured (MI355X, 10 sections, 8 ch/stream): 32 streams 0.54 ms vs 1.38 (cascade_fast), 64 streams 0.94 vs 1.41,
-		// 128 streams 1.71 vs 1.45 -> from 1024 channels on cascade_fast (4 per workgroup) fills the chip better
-		if (channels > 512) return 0;
-		// the widest channel group that still gives ~256 workgroups, then as many stages as the sections allow
-		cg = (channels >= 512 && p.C % 2 == 0) ? 2 : 1;
-		pp = (cg == 2) ? 5 : 10;
-		while (pp > p.n_ops) pp = (pp == 10) ? 5 : (pp == 5) ? 3 : 2;
+		if (channels > 1024) return 0;                      // enough channels: one wave per channel already fills the chip
+		// about 256 workgroups of 10 - 12 waves
+		cg = (channels > 512 && p.C % 4 == 0) ? 4 : (channels > 256 && p.C % 2 == 0) ? 2 : 1;
+		pp = (cg == 4) ? 3 : (cg == 2) ? 5 : 10;
+		while (pp > p.n_ops || pp > n_full) pp = (pp == 10) ? 5 : (pp == 5) ? 3 : (pp == 3) ? 2 : 1;
 	}
 	bool ok = false;
-	if (cg == 1 && pp == 10) ok = try_launch_pipe<1, 10>(p, n_streams, stream);
-	else if (cg == 1 && pp == 5) ok = try_launch_pipe<1, 5>(p, n_streams, stream);
-	else if (cg == 1 && pp == 3) ok = try_launch_pipe<1, 3>(p, n_streams, stream);
-	else if (cg == 1 && pp == 2) ok = try_launch_pipe<1, 2>(p, n_streams, stream);
-	else if (cg == 2 && pp == 5) ok = try_launch_pipe<2, 5>(p, n_streams, stream);
-	else if (cg == 2 && pp == 3) ok = try_launch_pipe<2, 3>(p, n_streams, stream);
-	else if (cg == 2 && pp == 2) ok = try_launch_pipe<2, 2>(p, n_streams, stream);
-	else if (cg == 4 && pp == 3) ok = try_launch_pipe<4, 3>(p, n_streams, stream);
-	else if (cg == 4 && pp == 2) ok = try_launch_pipe<4, 2>(p, n_streams, stream);
+	if (cg == 1 && pp == 10) ok = try_launch_wave<1, 10>(p, n_streams, stream);
+	else if (cg == 1 && pp == 5) ok = try_launch_wave<1, 5>(p, n_streams, stream);
+	else if (cg == 1 && pp == 3) ok = try_launch_wave<1, 3>(p, n_streams, stream);
+	else if (cg == 1 && pp == 2) ok = try_launch_wave<1, 2>(p, n_streams, stream);
+	else if (cg == 1 && pp == 1) ok = try_launch_wave<1, 1>(p, n_streams, stream);
+	else if (cg == 2 && pp == 5) ok = try_launch_wave<2, 5>(p, n_streams, stream);
+	else if (cg == 2 && pp == 3) ok = try_launch_wave<2, 3>(p, n_streams, stream);
+	else if (cg == 2 && pp == 2) ok = try_launch_wave<2, 2>(p, n_streams, stream);
+	else if (cg == 2 && pp == 1) ok = try_launch_wave<2, 1>(p, n_streams, stream);
+	else if (cg == 4 && pp == 3) ok = try_launch_wave<4, 3>(p, n_streams, stream);
+	else if (cg == 4 && pp == 2) ok = try_launch_wave<4, 2>(p, n_streams, stream);
+	else if (cg == 4 && pp == 1) ok = try_launch_wave<4, 1>(p, n_streams, stream);
+	else if (cg == 8 && pp == 1) ok = try_launch_wave<8, 1>(p, n_streams, stream);
 	return ok ? n_full * CASCADE_TILE : 0;
 }
 
@@ -736,7 +749,7 @@ size_t cascade_lds_bytes(int Cg, int n_ops)
 void launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
 {
 	CascadeParams p = p0;
-	long done = launch_cascade_pipe(p0, n_streams, stream);
+	long done = launch_cascade_wave(p0, n_streams, stream);
 	if (done == 0) done = launch_cascade_fast(p0, n_streams, stream);
 	if (done > 0) {
 		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block
