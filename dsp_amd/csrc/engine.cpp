@@ -168,6 +168,34 @@ bool CascadeStage::finalize()
 		if (!fops.upload(tab.data(), tab.size() * sizeof(double))) return false;
 		if (!fq.upload(q.data(), q.size() * sizeof(double))) return false;
 	}
+	// table of cascade_rows: one set of wave-uniform constants per group of 4 channels -- only when the 4 channels of
+	// every group run identical biquad sections (the usual case: one filter bank on all channels of a stream)
+	if (ch_in % 4 == 0) {
+		bool uniform = true;
+		for (int c = 0; c < ch_in && uniform; ++c)
+			for (int j = 0; j < n_ops && uniform; ++j) {
+				const OpDesc &a = host[(size_t) (c & ~3) * n_ops + j], &b = host[(size_t) c * n_ops + j];
+				if (a.kind != b.kind || a.g != b.g || memcmp(a.c, b.c, sizeof(a.c)) != 0) uniform = false;
+				if (a.kind != OP_BIQUAD) uniform = false;    // gain / add / unselected channels among the sections: left to cascade_fast
+			}
+		if (uniform) {
+			std::vector<double> tab((size_t) (ch_in / 4) * n_ops * FOP_DOUBLES, 0.0);
+			int lg = 0;
+			while ((1 << lg) < ROWS_L) ++lg;
+			for (int g = 0; g < ch_in / 4; ++g)
+				for (int j = 0; j < n_ops; ++j) {
+					const OpDesc &od = host[(size_t) (4 * g) * n_ops + j];
+					double *d = &tab[((size_t) g * n_ops + j) * FOP_DOUBLES];
+					long long kind = od.kind;
+					memcpy(&d[0], &kind, sizeof(kind));
+					d[1] = od.g;
+					for (int i = 0; i < 5; ++i) d[2 + i] = od.c[i];
+					if (od.kind != OP_BIQUAD) continue;
+					for (int k = 0; k < 4; ++k) for (int i = 0; i < 4; ++i) d[FOP_PW + 4 * k + i] = od.P[lg + k][i];
+				}
+			if (!frows.upload(tab.data(), tab.size() * sizeof(double))) return false;
+		}
+	}
 	if (!state.alloc((size_t) S * ch_in * n_ops * 2 * sizeof(double))) return false;
 	// channel group per workgroup: the whole stream when it fits in LDS (contiguous, vectorisable loads)
 	Cg = (ch_in <= 16) ? ch_in : 8;
@@ -197,6 +225,7 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.ops = ops.as<OpDesc>();
 	p.fops = fops.as<double>();
 	p.fq = fq.as<double>();
+	p.frows = frows.p ? frows.as<double>() : nullptr;
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;

@@ -26,6 +26,7 @@
 // before the current tile's recurrences so HBM latency hides under the fp64 work; the per-(channel, op)
 // coefficients are staged in LDS once per launch and read as broadcasts.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include "kparams.h"
@@ -580,6 +581,242 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Rows variant: a wave = FOUR channels, one per 16-lane DPP row, lane = ROWS_L = 32 consecutive frames.
+//
+// In cascade_fast the cross-lane part of a section (64-lane carry: row scan, three row carries through readlanes, the
+// Q product, about 90 instructions with a long dependent chain) costs as much time as the 128-instruction recurrence it
+// follows (scripts/ubench/recbench: 260 of 540 ns per section and tile).  Giving every channel one DPP row instead of a
+// whole wave removes the cross-row carries altogether -- the row's incoming state enters at its first lane BEFORE the
+// 4-step row scan, which then spreads it -- and twice as many frames per lane halve what is left per sample:
+// (256 + ~50) instructions per 4 x 512 samples against 4 x (128 + ~90) per 4 x 1024 (scripts/ubench/secbench: 304 ns of
+// SIMD time per 1024 samples against 540).  Four channels per wave leave a quarter of the waves, so the time axis is
+// shared as in cascade_wave (below).  The constants stay wave-uniform scalars: the four channels of a group must run
+// identical biquad sections (frows table), anything else goes to cascade_wave / cascade_fast.
+constexpr int RW_L = ROWS_L, RW_TILE = ROWS_TILE, RW_ROW = 16 * (RW_L + 1);
+template <int L>
+__device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, const double *__restrict__ od, double *st_row, int j, int q,
+                                            PendingFix &fix, bool &pending)
+{
+	// every op of a rows launch is a biquad section (a second kind in this loop makes the register allocator keep two
+	// copies of the tile: 37 spilled VGPRs); chains with gain / add among the sections run on cascade_fast
+	{
+		double Pw[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];                // P^(L 2^k), k = 0..3: requested now, used after the recurrence
+		const double2 xin = *reinterpret_cast<const double2 *>(st_row + 2 * j);   // the row's carried state
+		__builtin_amdgcn_sched_barrier(0);
+		const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, nc3 = -cur.c3, nc4 = -cur.c4;
+		double m0 = 0.0, m1 = 0.0;
+		{
+			double x0 = fix.x0, x1 = fix.x1;
+#pragma unroll
+			for (int i = 0; i < L; ++i) {
+				const double s = v[i] + x0;
+				const double t = fix.nc4 * x0;
+				x0 = fma(fix.nc3, x0, x1);
+				x1 = t;
+				const double r = fma(c0, s, m0);
+				m0 = fma(nc3, r, fma(c1, s, m1));
+				m1 = fma(nc4, r, c2 * s);
+				v[i] = r;
+				if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the scheduler's look-ahead (register pressure)
+			}
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// the carried state enters at the row's first lane as P^L xin; the scan spreads it: afterwards (m0, m1) is the TRUE
+		// state at the end of every lane's frames
+		const double e0 = fma(Pw[0], xin.x, fma(Pw[1], xin.y, m0)), e1 = fma(Pw[2], xin.x, fma(Pw[3], xin.y, m1));
+		if (q == 0) { m0 = e0; m1 = e1; }
+		row_scan(m0, m1, Pw);
+		double x0 = dpp_f64<DPP_ROW_SHR1>(m0), x1 = dpp_f64<DPP_ROW_SHR1>(m1);
+		if (q == 0) { x0 = xin.x; x1 = xin.y; }
+		fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
+		pending = true;
+		if (q == 15) *reinterpret_cast<double2 *>(st_row + 2 * j) = make_double2(m0, m1);
+	}
+}
+
+typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 rw_as_d2(rw_u32x4 v) { return __builtin_bit_cast(double2, v); }
+__device__ __forceinline__ rw_u32x4 rw_as_u4(double2 v) { return __builtin_bit_cast(rw_u32x4, v); }
+
+// cascade_rows: workgroup = (stream, group of 4 channels) x P waves.  The P waves share the TIME axis of the group the way
+// cascade_wave does (wave w owns the tiles w, w + P, ..., one section per step, one LDS barrier per step, the 16-byte
+// section states of the four rows travel from wave to wave through LDS), so that 2048 channels still give 2048 waves.
+// Every wave moves its own tiles: 16-byte (frame, channel pair) elements between HBM and registers (buffer instructions:
+// descriptor base in SGPRs + ONE per-lane offset register + a wave-uniform slot offset -- plain pointers cost a 64-bit
+// address pair per slot and direction, 96 VGPRs), transposed to the lane-major layout of the recurrence through a
+// wave-private LDS tile (rows placed so that both access patterns are bank-conflict free), one tile per n_ops steps,
+// prefetched a whole tile period ahead.
+constexpr int RW_TB = 4 * RW_ROW + 16;                          // doubles per wave-private transposer
+__device__ __forceinline__ int rw_row_base(int r) { return r * RW_ROW + ((r >> 1) << 4); }   // rows 0..3 at 0, 528, 1072, 1600
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void cascade_rows(CascadeParams p, const double *__restrict__ frows, int P)
+{
+	constexpr int L = RW_L, TILE = RW_TILE, K = 16;             // K slots (16 B) per lane and tile: 512 frames x 2 pairs / 64
+	extern __shared__ __attribute__((aligned(16))) double smem[];
+	const int s = blockIdx.x;
+	const int c0 = p.cg0 + blockIdx.y * 4;
+	const int tid = threadIdx.x, lane = tid & 63, nth = 64 * P;
+	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // position in the wavefront
+	const int n_ops = p.n_ops;
+	double *st = smem;                                          // [4][n_ops][2]
+	double *tb = st + 4 * n_ops * 2 + (size_t) w * RW_TB;       // this wave's transposer
+
+	const int n_st = 4 * n_ops * 2;
+	double *gstate = p.state + ((size_t) s * p.C + c0) * n_ops * 2;
+	for (int i = tid; i < n_st; i += nth) st[i] = gstate[i];
+
+	const long n_full = p.frames / TILE;
+	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
+	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.in + (size_t) s * p.in_stride_frames * p.C + c0), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t) s * p.out_stride_frames * p.C + c0, 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(
+		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) : p.out, 0, 0x7fffffff, RSRC_FLAGS);
+	const bool has_ring = p.ring.base != nullptr;
+	const int ring_row_bytes = (int) (p.ring.row_stride * 16);
+	// slab order: slot k of a lane = frame (lane >> 1) + 32 k, pair lane & 1 -- 64 lanes cover 32 frames x 32 bytes
+	const int pr = lane & 1, f0 = lane >> 1;
+	const int vo_slab = (f0 * p.C + 2 * pr) * 8, so_slab = 32 * p.C * 8, tile_bytes = TILE * p.C * 8;
+	double *tb_slab = tb + rw_row_base(2 * pr) + f0;            // slot k at + 33 k; the pair's second channel one row further
+	// row order (ring-only output): slot k = pair k >> 3, frame lane + 64 (k & 7) -- one store instruction = 1 KB of ONE ring row
+	double *tb_rows = tb + lane + (lane >> 5);                  // + rw_row_base(2 (k >> 3)) + 66 (k & 7)
+	const int r = lane >> 4, q = lane & 15;                     // this lane's channel (row) and position in the row
+	double *tb_lane = tb + rw_row_base(r) + q * (L + 1);
+	double *st_row = st + r * n_ops * 2;
+	const double *__restrict__ cf = frows + (size_t) (c0 >> 2) * n_ops * FOP_DOUBLES;
+
+	// the last tile's owner finishes last: wave wl after its tiles
+	const int wl = (int) ((n_full - 1) % P);
+	const long n_steps = wl + ((n_full - 1) / P + 1) * n_ops;
+	long steps = 0;
+	OpHead cur = load_head(cf);
+	__syncthreads();
+	// settle the first head BEFORE any loop: s_waitcnt cannot tell scalar loads apart, so a wait for `cur` placed behind the
+	// loads of the next head and of the scan matrices would expose a scalar-load round trip in every section
+	if (cur.kind == OP_BIQUAD) {
+		for (int i = 0; i < w; ++i) lds_barrier();              // the skew: wave w starts at step w
+		steps = w;
+		if (w < n_full) {
+			double2 raw[K];
+			double x[L];
+#pragma unroll
+			for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_slab, w * tile_bytes + k * so_slab, 0));
+			// results of tile t_out (lane-major in the transposer) -> HBM
+			auto fetch_out = [&](double2 (&y)[K]) {
+				if (p.write_interleaved) {
+#pragma unroll
+					for (int k = 0; k < K; ++k) y[k] = make_double2(tb_slab[(L + 1) * k], tb_slab[(L + 1) * k + RW_ROW]);
+				}
+				else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) {
+						const double *a = tb_rows + rw_row_base(2 * (k >> 3)) + (64 + 64 / L) * (k & 7);
+						y[k] = make_double2(a[0], a[RW_ROW]);
+					}
+				}
+			};
+			auto store_out = [&](const double2 (&y)[K], long t_out) {
+				if (p.debug & 1) return;
+				if (p.write_interleaved) {
+					const int tbb = (int) t_out * tile_bytes;
+#pragma unroll
+					for (int k = 0; k < K; ++k) __builtin_amdgcn_raw_buffer_store_b128(rw_as_u4(y[k]), r_out, vo_slab, tbb + k * so_slab, 0);
+					if (has_ring) {
+						// both destinations: the ring in slab order too (pair = lane & 1)
+						const long e0 = p.ring.pos + t_out * TILE + f0;
+#pragma unroll
+						for (int k = 0; k < K; ++k)
+							__builtin_amdgcn_raw_buffer_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 32 * k) & p.ring.mask) * 16 + pr * ring_row_bytes, 0, 0);
+					}
+				}
+				else if (has_ring) {
+					const long e0 = p.ring.pos + t_out * TILE + lane;
+#pragma unroll
+					for (int k = 0; k < K; ++k)
+						__builtin_amdgcn_raw_buffer_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 64 * (k & 7)) & p.ring.mask) * 16, (k >> 3) * ring_row_bytes, 0);
+				}
+			};
+			for (long t = w; t < n_full; t += P) {
+				// Order matters (vmcnt counts loads and stores together, in order): the previous tile's results are read out of the
+				// transposer, THEN this tile's loads are waited for (nothing else is in flight: the stores before them went out a
+				// whole tile ago), and only then do the stores and the next tile's loads go out.
+				double2 y[K];
+				if (t > w) fetch_out(y);
+#pragma unroll
+				for (int k = 0; k < K; ++k) { tb_slab[(L + 1) * k] = raw[k].x; tb_slab[(L + 1) * k + RW_ROW] = raw[k].y; }
+				if (t > w) store_out(y, t - P);
+#pragma unroll
+				for (int i = 0; i < L; ++i) x[i] = tb_lane[i];
+				if (!(p.debug & 2)) {
+					// unconditional (the last one re-reads this tile): a conditional load would have to select between old and
+					// new registers, which costs a wait right behind the loads
+					const int tb_next = (int) ((t + P < n_full) ? t + P : t) * tile_bytes;
+#pragma unroll
+					for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_slab, tb_next + k * so_slab, 0));
+				}
+				PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
+				bool pending = false;
+				for (int j = 0; j < n_ops; ++j) {
+					const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
+					run_op_rows<L>(x, cur, cf + j * FOP_DOUBLES, st_row, j, q, fix, pending);
+					cur = nxt;
+					if (j + 1 == n_ops) {
+						if (pending) apply_fix<L>(x, fix);
+#pragma unroll
+						for (int i = 0; i < L; ++i) tb_lane[i] = x[i];
+					}
+					lds_barrier();       // (two sections per barrier were measured: no gain)
+				}
+				steps += n_ops;
+			}
+			{
+				// the last tile of this wave
+				const long t_last = w + ((n_full - 1 - w) / P) * P;
+				double2 y[K];
+				fetch_out(y);
+				store_out(y, t_last);
+			}
+		}
+		for (; steps < n_steps; ++steps) lds_barrier();
+	}
+	__syncthreads();
+	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
+}
+
+// 0 = not eligible; otherwise the number of leading frames taken
+static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	static int env = -2;
+	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_ROWS"); env = e ? atoi(e) : -1; }   // 0 = never, P = force that many waves per group
+	if (env == 0 || !p.frows || (p.C % 4) || p.cg0 != 0) return 0;
+	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
+	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
+	const long n_full = p.frames / RW_TILE;
+	if (n_full < 1) return 0;
+	// 32-bit byte offsets inside one stream's slab / ring rows
+	if ((double) std::max(p.in_stride_frames, p.out_stride_frames) * p.C * 8 >= 2.0e9 || (double) p.ring.row_stride * 16 * (p.C / 2) >= 2.0e9) return 0;
+	// waves per group: enough to put two waves on every SIMD (2048 in all); 8 is what the LDS transposers allow.  Below 256
+	// groups (128 streams x 8 ch) that is not reached and one channel per wave (cascade_wave) fills the chip better:
+	// measured at 32 / 64 / 128 / 256 streams x 8 ch: rows 0.86 / 0.89 / 0.92 / 2.0 ms, wave 0.45 / 0.82 / 1.46 / - ms
+	const long groups = (long) n_streams * (p.C / 4);
+	if (env < 0 && groups < 256) return 0;
+	int P = (env > 0) ? env : (int) std::min<long>(8, std::max<long>(1, (2048 + groups - 1) / groups));
+	if (P > 8) P = 8;
+	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
+	const size_t lds = ((size_t) 4 * p.n_ops * 2 + (size_t) P * RW_TB) * sizeof(double);
+	if (lds > 160 * 1024) return 0;
+	static size_t granted = 0;
+	if (lds > granted) {
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		granted = lds;
+	}
+	dim3 grid(n_streams, p.C / 4), block(64 * P);
+	hipLaunchKernelGGL(cascade_rows, grid, block, lds, stream, p, p.frows, P);
+	return n_full * RW_TILE;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Wavefront variant for FEW streams (strong scaling: 256 streams over 8 GPUs leave 32 per GPU = 256 channels).
 //
 // cascade_fast runs one wave per channel through all sections of a tile before the next tile: 192 tiles x 10 sections in
@@ -749,7 +986,8 @@ size_t cascade_lds_bytes(int Cg, int n_ops)
 void launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
 {
 	CascadeParams p = p0;
-	long done = launch_cascade_wave(p0, n_streams, stream);
+	long done = launch_cascade_rows(p0, n_streams, stream);
+	if (done == 0) done = launch_cascade_wave(p0, n_streams, stream);
 	if (done == 0) done = launch_cascade_fast(p0, n_streams, stream);
 	if (done > 0) {
 		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block

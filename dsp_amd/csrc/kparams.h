@@ -31,6 +31,8 @@ struct alignas(16) OpDesc {
 //   fq   [C][n_ops][16][4]        Q[i] = P^(L (i + 1)): carry of the previous row's end state to lane i of a row
 // with P = A = [[-c3, 1], [-c4, 0]].
 constexpr int FOP_DOUBLES = 32, FOP_PW = 8, FOP_P16 = 24, FQ_DOUBLES = 64;
+// cascade_rows: a wave = 4 channels x 16 lanes x ROWS_L consecutive frames; its tables are fops-shaped with L = ROWS_L
+constexpr int ROWS_L = 32, ROWS_TILE = 16 * ROWS_L;
 
 // The FFT convolver's input ring (one row per channel PAIR, 16-byte elements (x_a[n], x_b[n]) = the complex
 // sequence the convolver transforms) that the cascade kernel may write instead of the interleaved block.
@@ -55,6 +57,7 @@ struct CascadeParams {
 	const OpDesc *ops;                   // [C][n_ops]
 	const double *fops;                  // [C][n_ops][FOP_DOUBLES] fast-kernel constants (scalar loads)
 	const double *fq;                    // [C][n_ops][FQ_DOUBLES] per-lane carry matrices
+	const double *frows;                 // [C / 4][n_ops][FOP_DOUBLES] constants of cascade_rows (L = ROWS_L), or nullptr: groups of 4 channels differ
 	double *state;                       // [S][C][n_ops][2]
 	PlanarRing ring;                     // optional second destination (ring.base != nullptr)
 	int write_interleaved;               // 0: only the ring is written

@@ -22,7 +22,7 @@ public:
 private:
 	std::vector<std::vector<OpDesc>> cols;   // [op][channel]
 	std::vector<std::string> names;
-	DevBuf ops, state, fops, fq;
+	DevBuf ops, state, fops, fq, frows;
 };
 
 class RemixStage : public Stage {
