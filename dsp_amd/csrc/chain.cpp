@@ -8,6 +8,7 @@
 // same calls the reference host makes.
 #include "chain.h"
 #include <algorithm>
+#include <cerrno>
 #include <cstring>
 #include <numeric>
 #include <functional>
@@ -146,8 +147,22 @@ static size_t parse_tokens(Parser &P, size_t pos, Selector ch_mask, bool in_bloc
 			last_ch = ch;
 		}
 		if (tok.id == T_SOURCE) {
-			set_error("chain: error: effects files (@%s) are not supported by the stand-alone host", tok.str.c_str());
-			return npos;
+			// ec_parse_file (effects_chain.c:336-372): the file's effects act on the active selection; relative paths
+			// inside it are relative to ITS directory
+			const std::string path = full_path(P.dir, tok.str.c_str(), P.stream->fs, num_set(ch_sel));
+			std::string text;
+			if (!read_text_file(path, text)) { set_error("error: failed to load effects file: %s: %s", path.c_str(), strerror(errno)); return npos; }
+			const size_t slash = path.rfind('/');
+			const std::string sub_dir = (slash == std::string::npos) ? "." : path.substr(0, slash);
+			log_msg(LL_VERBOSE, "info: begin effects file: %s", path.c_str());
+			const std::vector<Token> sub_toks = lex(text.c_str());
+			Parser sub{ P.plan, P.stream, sub_dir.c_str(), &sub_toks };
+			const size_t end = parse_tokens(sub, 0, ch_sel, false, depth + 1);
+			if (end == npos) return npos;
+			if (end != sub_toks.size()) { set_error("chain: error: unexpected token in %s: %s", path.c_str(), sub_toks[end].str.c_str()); return npos; }
+			log_msg(LL_VERBOSE, "info: end effects file: %s", path.c_str());
+			++pos;
+			continue;
 		}
 		if (tok.id == T_BLOCK_START) {
 			const size_t end = parse_tokens(P, pos + 1, ch_sel, true, depth + 1);

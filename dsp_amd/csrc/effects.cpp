@@ -679,7 +679,7 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 		set_error("%s: error: only raw filter files are supported by the GPU backend (use -t pcm -e double -c N): %s", name, spec);
 		return false;
 	}
-	std::string path = join_path(dir, spec);
+	std::string path = full_path(dir, spec, is->fs, num_set(copy_sel(sel, is->channels)));   // fir_util.c:85
 	FILE *f = fopen(path.c_str(), "rb");
 	if (!f) { set_error("%s: error: failed to open filter file: %s", name, path.c_str()); return false; }
 	fseek(f, 0, SEEK_END);

@@ -230,7 +230,7 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
 	{ static const char *dbg = getenv("DSP_AMD_CASCADE_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
-	{ ProfScope ps("cascade_kernel", st); launch_cascade(p, S, st); }
+	{ ProfScope ps("cascade_kernel", st); ps.rename(launch_cascade(p, S, st)); }
 	if (ring.base) ring.pos = (ring.pos + frames) & ring.mask;
 	return frames;
 }

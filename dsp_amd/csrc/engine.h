@@ -34,6 +34,7 @@ struct Profiler {
 	std::vector<Rec> recs;
 	void begin(const char *name, hipStream_t st);
 	void end(hipStream_t st);
+	void rename_last(const char *name) { if (!recs.empty()) recs.back().name = name; }
 	// after a device sync: accumulate (name -> total ms, count), then drop the events
 	void collect(std::vector<std::string> &names, std::vector<double> &ms, std::vector<long> &counts);
 	~Profiler();
@@ -43,6 +44,7 @@ struct ProfScope {
 	hipStream_t st; bool on;
 	ProfScope(const char *name, hipStream_t s) : st(s), on(g_prof.on) { if (on) g_prof.begin(name, st); }
 	~ProfScope() { if (on) g_prof.end(st); }
+	void rename(const char *name) { if (on && name) g_prof.rename_last(name); }   // the launcher knows which kernel it picked
 };
 
 // One fused device stage.  in/out are [S][stride][C] slabs; a stage may be run in place when
@@ -90,7 +92,7 @@ private:
 
 // kernel launchers (kernels_*.hip)
 size_t cascade_lds_bytes(int Cg, int n_ops);
-void launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream);
+const char *launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream);   // returns the name of the kernel that took the block
 void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream);
 void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream);
 void launch_copy_slab(const double *in, long in_stride, double *out, long out_stride, long frames, long skip, int C, int n_streams, hipStream_t stream);

@@ -226,6 +226,39 @@ std::string join_path(const char *dir, const char *path)
 	return out;
 }
 
+// construct_full_path (util.c:276-343): `~/`, relative-to-dir, and the substitutions %r (rate), %k (rate / 1000),
+// %c (channels), %% in effects-file and filter-file names
+std::string full_path(const char *dir, const char *path, int fs, int channels)
+{
+	std::string sub;
+	for (const char *q = path; *q; ++q) {
+		if (q[0] == '%' && q[1] != '\0') {
+			char buf[64];
+			switch (q[1]) {
+			case 'r': snprintf(buf, sizeof(buf), "%d", fs); sub += buf; ++q; continue;
+			case 'k': snprintf(buf, sizeof(buf), "%.10g", fs / 1000.0); sub += buf; ++q; continue;
+			case 'c': snprintf(buf, sizeof(buf), "%d", channels); sub += buf; ++q; continue;
+			case '%': sub += '%'; ++q; continue;
+			default: break;
+			}
+		}
+		sub += *q;
+	}
+	return join_path(dir, sub.c_str());
+}
+
+bool read_text_file(const std::string &path, std::string &out)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return false;
+	char buf[4096];
+	size_t n;
+	out.clear();
+	while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, n);
+	fclose(f);
+	return true;
+}
+
 bool read_raw_doubles(const std::string &path, std::vector<double> &out)
 {
 	FILE *f = fopen(path.c_str(), "rb");

@@ -38,6 +38,8 @@ struct GetOpt {
 
 ssize_t next_fast_fftw_len(ssize_t min_len);                      // util.c:434-458 (latency reported by `fir`)
 std::string join_path(const char *dir, const char *path);         // "~/" and relative paths (util.c:276-343, no %-substitution)
+std::string full_path(const char *dir, const char *path, int fs, int channels);   // + %r %k %c %% (util.c:276-343)
+bool read_text_file(const std::string &path, std::string &out);
 bool read_raw_doubles(const std::string &path, std::vector<double> &out);
 
 }  // namespace dspamd

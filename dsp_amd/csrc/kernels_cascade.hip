@@ -983,20 +983,22 @@ size_t cascade_lds_bytes(int Cg, int n_ops)
 	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2 + (size_t) Cg * n_ops * OPL_DOUBLES) * sizeof(double);
 }
 
-void launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
+const char *launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
 {
 	CascadeParams p = p0;
+	const char *name = "cascade_rows";
 	long done = launch_cascade_rows(p0, n_streams, stream);
-	if (done == 0) done = launch_cascade_wave(p0, n_streams, stream);
-	if (done == 0) done = launch_cascade_fast(p0, n_streams, stream);
+	if (done == 0) { name = "cascade_wave"; done = launch_cascade_wave(p0, n_streams, stream); }
+	if (done == 0) { name = "cascade_fast"; done = launch_cascade_fast(p0, n_streams, stream); }
 	if (done > 0) {
 		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block
-		if (done == p0.frames) return;
+		if (done == p0.frames) return name;
 		p.in = p0.in + (size_t) done * p0.C;
 		p.out = p0.out + (size_t) done * p0.C;
 		p.frames = p0.frames - done;
 		if (p.ring.base) p.ring.pos = (p0.ring.pos + done) & p0.ring.mask;
 	}
+	else name = "cascade_kernel";
 	const int n_groups = (p.C - p.cg0 + p.Cg - 1) / p.Cg;
 	const int waves = p.Cg < 8 ? (p.Cg < 1 ? 1 : p.Cg) : 8;
 	dim3 grid(n_streams, n_groups), block(64 * waves);
@@ -1007,6 +1009,7 @@ void launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
 		lds_granted = lds;
 	}
 	hipLaunchKernelGGL(cascade_kernel, grid, block, lds, stream, p, p.ops);
+	return name;
 }
 
 }  // namespace dspamd

@@ -264,3 +264,23 @@ def test_many_streams_rows_cascade(amd, tail):
         ref, _ = oracle_chain.run(chain, x[s], 48000)
         assert y[s].shape == ref.shape
         assert rms(y[s] - ref) < TOL, (s, rms(y[s] - ref))
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_effects_files_vs_real_reference(amd, tmp_path):
+    # `@file` sources (effects_chain.c:336-372): comments, quoting, a nested file in a sub-directory with paths relative to
+    # ITS directory, %r / %c substitution in file names (util.c:276-343), the active channel selection carried into the file
+    d = tmp_path / "fx"
+    (d / "sub").mkdir(parents=True)
+    h = np.array([0.5, -0.25, 0.125, 0.0625, -0.03125] * 8)
+    h.astype("<f8").tofile(str(d / "sub" / "h_48000.raw"))
+    (d / "sub" / "inner.fx").write_text("# inner file\nfir_p -t pcm -e double -c 1 h_%r.raw   # relative to sub/\n\"gain\" -1.5\n")
+    (d / "main_2.fx").write_text("lowpass 2k 0.7\n:0 @sub/inner.fx\n: highshelf 5k 0.7 -2 # trailing comment\n")
+    chain = "gain -3 :0,1 @main_%c.fx : delay 3S"
+    x = noise(6000, 3, 95, 0.4)
+    ref = RefChain(chain, 48000, 3, directory=str(d)).process(x, block=2048)
+    y = amd.EffectsChain(chain, 48000, 3, directory=str(d)).process(x, block=1500)
+    assert y.shape == ref.shape
+    assert rms(y - ref) < 1e-13, rms(y - ref)
+    with pytest.raises(ValueError, match="failed to load effects file"):
+        amd.EffectsChain("@nope.fx", 48000, 2, directory=str(d))
