@@ -169,30 +169,40 @@ bool CascadeStage::finalize()
 		if (!fq.upload(q.data(), q.size() * sizeof(double))) return false;
 	}
 	// table of cascade_rows: one set of wave-uniform constants per group of 4 channels -- only when the 4 channels of
-	// every group run identical biquad sections (the usual case: one filter bank on all channels of a stream)
+	// every group run identical ops (the usual case: one filter bank on all channels of a stream) and those ops are biquad
+	// sections and gains.  A gain in front of a section is folded into that section's b coefficients (same states, the
+	// product rounds differently in the last bit -- the sections are not bit-exact anyway), gains behind the last section
+	// become one factor applied to the finished tile ([1] of the last op's entry); `add`, unselected channels and chains
+	// without any section stay with cascade_wave / cascade_fast (a pure gain chain must remain bit-exact).
 	if (ch_in % 4 == 0) {
-		bool uniform = true;
+		bool uniform = true, any_biquad = false;
 		for (int c = 0; c < ch_in && uniform; ++c)
 			for (int j = 0; j < n_ops && uniform; ++j) {
 				const OpDesc &a = host[(size_t) (c & ~3) * n_ops + j], &b = host[(size_t) c * n_ops + j];
 				if (a.kind != b.kind || a.g != b.g || memcmp(a.c, b.c, sizeof(a.c)) != 0) uniform = false;
-				if (a.kind != OP_BIQUAD) uniform = false;    // gain / add / unselected channels among the sections: left to cascade_fast
+				if (a.kind != OP_BIQUAD && a.kind != OP_MUL) uniform = false;
+				if (a.kind == OP_BIQUAD) any_biquad = true;
 			}
-		if (uniform) {
+		if (uniform && any_biquad) {
 			std::vector<double> tab((size_t) (ch_in / 4) * n_ops * FOP_DOUBLES, 0.0);
 			int lg = 0;
 			while ((1 << lg) < ROWS_L) ++lg;
-			for (int g = 0; g < ch_in / 4; ++g)
+			for (int g = 0; g < ch_in / 4; ++g) {
+				double gain = 1.0;
 				for (int j = 0; j < n_ops; ++j) {
 					const OpDesc &od = host[(size_t) (4 * g) * n_ops + j];
 					double *d = &tab[((size_t) g * n_ops + j) * FOP_DOUBLES];
-					long long kind = od.kind;
+					long long kind = (od.kind == OP_BIQUAD) ? OP_BIQUAD : OP_SKIP;
 					memcpy(&d[0], &kind, sizeof(kind));
-					d[1] = od.g;
+					d[1] = 1.0;
+					if (od.kind == OP_MUL) { gain *= od.g; continue; }
 					for (int i = 0; i < 5; ++i) d[2 + i] = od.c[i];
-					if (od.kind != OP_BIQUAD) continue;
+					for (int i = 0; i < 3; ++i) d[2 + i] *= gain;            // y = H(g x): b coefficients scaled, a and the states untouched
+					gain = 1.0;
 					for (int k = 0; k < 4; ++k) for (int i = 0; i < 4; ++i) d[FOP_PW + 4 * k + i] = od.P[lg + k][i];
 				}
+				tab[((size_t) g * n_ops + (n_ops - 1)) * FOP_DOUBLES + 1] = gain;   // gains behind the last section
+			}
 			if (!frows.upload(tab.data(), tab.size() * sizeof(double))) return false;
 		}
 	}

@@ -591,15 +591,16 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 // (256 + ~50) instructions per 4 x 512 samples against 4 x (128 + ~90) per 4 x 1024 (scripts/ubench/secbench: 304 ns of
 // SIMD time per 1024 samples against 540).  Four channels per wave leave a quarter of the waves, so the time axis is
 // shared as in cascade_wave (below).  The constants stay wave-uniform scalars: the four channels of a group must run
-// identical biquad sections (frows table), anything else goes to cascade_wave / cascade_fast.
+// identical biquad sections (gains among them are folded into the sections by the host: frows table, engine.cpp);
+// anything else goes to cascade_wave / cascade_fast.
 constexpr int RW_L = ROWS_L, RW_TILE = ROWS_TILE, RW_ROW = 16 * (RW_L + 1);
 template <int L>
 __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, const double *__restrict__ od, double *st_row, int j, int q,
                                             PendingFix &fix, bool &pending)
 {
-	// every op of a rows launch is a biquad section (a second kind in this loop makes the register allocator keep two
-	// copies of the tile: 37 spilled VGPRs); chains with gain / add among the sections run on cascade_fast
-	{
+	// (a second op kind with its own code in this loop makes the register allocator keep two copies of the tile: 37 spilled
+	// VGPRs -- which is why gains are folded into the sections on the host)
+	if (cur.kind == OP_BIQUAD) {           // anything else is a gain that the table folded into a neighbouring section: a no-op step
 		double Pw[16];
 #pragma unroll
 		for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];                // P^(L 2^k), k = 0..3: requested now, used after the recurrence
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	__syncthreads();
 	// settle the first head BEFORE any loop: s_waitcnt cannot tell scalar loads apart, so a wait for `cur` placed behind the
 	// loads of the next head and of the scan matrices would expose a scalar-load round trip in every section
-	if (cur.kind == OP_BIQUAD) {
+	if (cur.kind == OP_BIQUAD || cur.kind == OP_SKIP) {
 		for (int i = 0; i < w; ++i) lds_barrier();              // the skew: wave w starts at step w
 		steps = w;
 		if (w < n_full) {
@@ -760,9 +761,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				for (int j = 0; j < n_ops; ++j) {
 					const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
 					run_op_rows<L>(x, cur, cf + j * FOP_DOUBLES, st_row, j, q, fix, pending);
+					const double post = cur.g;                           // last op's entry: product of the gains behind the last section
 					cur = nxt;
 					if (j + 1 == n_ops) {
 						if (pending) apply_fix<L>(x, fix);
+						if (post != 1.0) {
+#pragma unroll
+							for (int i = 0; i < L; ++i) x[i] *= post;
+						}
 #pragma unroll
 						for (int i = 0; i < L; ++i) tb_lane[i] = x[i];
 					}

@@ -247,13 +247,16 @@ def test_channel_pair_effects_need_two_channels(amd):
         amd.EffectsChain(":0 crossfeed 700 4", 48000, 2)
 
 
+@pytest.mark.parametrize("gains", [False, True])
 @pytest.mark.parametrize("tail", ["", " fir_p coefs:0.5,0.25,-0.125,0.0625"])
-def test_many_streams_rows_cascade(amd, tail):
+def test_many_streams_rows_cascade(amd, tail, gains):
     # > 1024 channels with identical biquad sections on all channels: cascade_rows (a wave = 4 channels, one per DPP row,
     # 32 frames per lane).  Block sizes exercise whole tiles (512 frames), the generic remainder kernel and state carried
     # from call to call; with a convolver behind it the results leave through the pair ring (row-ordered stores).
     import torch
-    chain = "lowpass 3k 0.707 highshelf 8k 0.7 -3 eq 300 1.5 4 eq 1200 2.0 -2.5 highpass 30 0.707" + tail
+    # gains among the sections: folded into the next section's b coefficients / applied to the finished tile
+    chain = ("gain -3 lowpass 3k 0.707 highshelf 8k 0.7 -3 mult 1.25 eq 300 1.5 4 eq 1200 2.0 -2.5 highpass 30 0.707 gain 2 mult -0.9" if gains else
+             "lowpass 3k 0.707 highshelf 8k 0.7 -3 eq 300 1.5 4 eq 1200 2.0 -2.5 highpass 30 0.707") + tail
     S, C, N = 136, 8, 11000
     rng = np.random.Generator(np.random.PCG64(4242))
     x = rng.uniform(-0.5, 0.5, size=(S, N, C))
