@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_traffic.json from a scripts/profile_round.sh run: HBM bytes per launch of the bench's kernels.
+
+usage: make_traffic.py gpurun_out/<tag> <tag>
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  Corrections (MI355X_MICROARCH.md "HBM", checked in the same run against
+copy_probe_kernel = 1 GiB read + 1 GiB write): FETCH_SIZE under-counts wide contiguous 16 B/lane loads by 2x on gfx950
+(factor taken from the probe); kernels whose loads are 32-byte pieces (the cascade reads half a frame per lane group) are
+taken 1:1 -- with x2 they would exceed what the kernel can request at all.  conv_col_fwd's average is diluted by the
+one-pair filter-preparation launch: scaled by launches / (launches - 1)."""
+import json, sys, os
+
+src, tag = sys.argv[1], sys.argv[2]
+raw = json.load(open(os.path.join(src, "pmc_hbm.json")))
+bench = json.load(open(os.path.join(src, "bench.json")))
+cfg = bench["config"]
+S, C, B, T = cfg["streams"], cfg["channels"], cfg["block_frames"], cfg["taps"]
+samples = S * C * B
+N = 1
+while N < B + T - 1: N *= 2
+pairs = S * C // 2
+
+def find(sub):
+    for k, v in raw.items():
+        if sub in k: return k, v
+    return None, None
+
+probe_k, probe = find("copy_probe_kernel")
+fetch_factor = (1 << 20) / probe["FETCH_SIZE"]["per_launch_raw"] if probe else 2.0
+kernels = {}
+spec = {   # bench name -> (rocprof substring, fetch factor, designed bytes)
+    "cascade_rows": ("cascade_rows", 1.0, samples * 16),
+    "cascade_fast": ("cascade_fast", 1.0, samples * 16),
+    "cascade_wave": ("cascade_wave", 1.0, samples * 16),
+    "conv_col_fwd": ("conv_col_fwd", fetch_factor, pairs * N * 32),
+    "conv_row": ("conv_row<10, 0>", fetch_factor, pairs * N * 32),
+    "conv_col_inv": ("conv_col_inv", fetch_factor, pairs * N * 16 + samples * 8),
+}
+for name, (sub, ff, designed) in spec.items():
+    k, v = find(sub)
+    if not v or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v: continue
+    dil = 1.0
+    if name == "conv_col_fwd":
+        n = v["FETCH_SIZE"]["launches"]
+        dil = n / (n - 1.0) if n > 1 else 1.0
+    fr = v["FETCH_SIZE"]["per_launch_raw"] * 1024 * dil
+    wr = v["WRITE_SIZE"]["per_launch_raw"] * 1024 * dil
+    kernels[name] = {"rocprof_name": k.split("(")[0].replace("void ", ""), "fetch_raw": fr, "fetch_corrected": fr * ff, "write": wr,
+                     "traffic": fr * ff + wr, "algorithmic_bytes_of_kernel": float(designed)}
+out = {
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`, {tag}; scripts/profile_round.sh + scripts/make_traffic.py",
+    "units": "bytes per launch",
+    "calibration": f"copy_probe_kernel (1 GiB read + 1 GiB write, 16 B/lane, contiguous) in the same run: FETCH_SIZE factor {fetch_factor:.3f}, WRITE_SIZE {probe['WRITE_SIZE']['per_launch_raw'] / (1 << 20):.3f} GiB" if probe else "no probe",
+    "kernels": kernels,
+    "workload_key": f"{S}x{C}x{B}x{T}",
+}
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_traffic.json")
+json.dump(out, open(dst, "w"), indent=1)
+print("wrote", dst)
+for k, v in kernels.items():
+    print(f"  {k:14s} fetch {v['fetch_corrected'] / 2**30:6.3f} GiB  write {v['write'] / 2**30:6.3f} GiB  total {v['traffic'] / 2**30:6.3f} GiB  designed {v['algorithmic_bytes_of_kernel'] / 2**30:6.3f} GiB")
