@@ -6,6 +6,13 @@
 // (the reference never merges biquads that act on the same channel, biquad.c:344-351, so a chain of
 // 10 biquads is 10 full passes over the block there; here it is one read and one write).
 //
+// Four kernels share the arithmetic below and differ in how they spread it over the chip (launch_cascade picks):
+//   cascade_rows   a wave = 4 channels (one per DPP row), 32 frames per lane, time axis shared by skewed waves -- many
+//                  channels with identical sections (the headline kernel)
+//   cascade_wave   a wave = 1 channel, 16 frames per lane, time axis shared by up to 10 skewed waves -- few channels
+//   cascade_fast   a wave = 1 channel, cooperative workgroup I/O -- per-channel coefficients, add, unselected channels
+//   cascade_kernel generic: any channel count, remainders shorter than a tile, L = 1 tail steps
+//
 // Math.  One TDF-II section with x = (m0, m1):
 //     r[n] = c0 s[n] + m0[n],   x[n+1] = A x[n] + B s[n],   A = [[-c3, 1], [-c4, 0]]
 // A wave owns 64*L consecutive samples of one channel, lane l owning samples [lL, lL+L):
