@@ -264,3 +264,55 @@ def test_resampler_feeds_convolver_and_back(amd, tmp_path, monkeypatch):
                 ref, _ = oracle_chain.run(chain.replace(p, "{F}"), x[s], 48000, filt=h)
                 assert ref.shape == y[s].shape, (chain, merge, ref.shape, y[s].shape)
                 assert rms(ref - y[s]) < 1e-11, (chain, merge, rms(ref - y[s]))
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_headline_workload_full_size_vs_real_reference(amd, tmp_path):
+    """BASELINE.json's headline shape itself -- 256 streams x 8 ch, 10 biquads + fir_p(65536), two steps of 196608 frames --
+    on the device-resident batch path (cascade_rows feeding the pair ring, N = 2^18 transforms), checked against the REAL
+    reference run on whole streams picked across the batch (the CPU needs ~1 s per stream), plus linearity over the batch."""
+    import torch
+    taps, S, C, B = 65536, 256, 8, 196608
+    h = make_filter(taps)
+    p = write(tmp_path, h)
+    biq = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 eq 800 1.0 -1 "
+           "eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    chain = f"{biq} fir_p -t pcm -e double -c 1 {p}"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    assert "N=262144" in b.plan() and "fed-by-cascade" in b.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x = torch.rand((S, 2 * B, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = torch.cat([b.run(x[:, k * B:(k + 1) * B, :].contiguous()).clone() for k in range(2)], dim=1)
+    assert y.shape == (S, 2 * B, C)
+    for s in (0, 101, 255):
+        ref = RefChain(chain, 48000, C).run(x[s].cpu().numpy())       # fir_p: as many frames out as in (the tail stays inside)
+        got = y[s].cpu().numpy()
+        assert ref.shape == got.shape
+        assert rms(ref - got) < 1e-12, (s, rms(ref - got))
+    # linearity over the whole batch, second instance with its own state: chain(0.5 x) = 0.5 chain(x) (exact scaling by a power
+    # of two: every operation of the path commutes with it bit for bit)
+    b2 = amd.BatchChain(chain, 48000, C, S, B)
+    y2 = b2.run((0.5 * x[:, :B, :]).contiguous())
+    assert torch.equal(y2, 0.5 * y[:, :B, :])
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_config4_full_size_vs_real_reference(amd, tmp_path):
+    """BASELINE config 4 at full size: 256 streams x 8 ch, 10 biquads + fir_p(65536) + resample 48k -> 96k, complete streams
+    (run + drain) against the real reference on streams picked across the batch."""
+    import torch
+    taps, S, C, B = 65536, 256, 8, 195584
+    h = make_filter(taps)
+    p = write(tmp_path, h)
+    biq = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 eq 800 1.0 -1 "
+           "eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    chain = f"{biq} fir_p -t pcm -e double -c 1 {p} resample 96k"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    g = torch.Generator(device="cuda"); g.manual_seed(12)
+    x = torch.rand((S, B + 50000, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = b.process(x, B)
+    for s in (3, 128, 254):
+        ref = RefChain(chain, 48000, C).process(x[s].cpu().numpy(), block=65536)
+        got = y[s].cpu().numpy()
+        assert ref.shape == got.shape, (ref.shape, got.shape)
+        assert rms(ref - got) < 1e-11, (s, rms(ref - got))
