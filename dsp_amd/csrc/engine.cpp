@@ -168,29 +168,33 @@ bool CascadeStage::finalize()
 		if (!fops.upload(tab.data(), tab.size() * sizeof(double))) return false;
 		if (!fq.upload(q.data(), q.size() * sizeof(double))) return false;
 	}
-	// table of cascade_rows: one set of wave-uniform constants per group of 4 channels -- only when the 4 channels of
-	// every group run identical ops (the usual case: one filter bank on all channels of a stream) and those ops are biquad
-	// sections and gains.  A gain in front of a section is folded into that section's b coefficients (same states, the
-	// product rounds differently in the last bit -- the sections are not bit-exact anyway), gains behind the last section
-	// become one factor applied to the finished tile ([1] of the last op's entry); `add`, unselected channels and chains
-	// without any section stay with cascade_wave / cascade_fast (a pure gain chain must remain bit-exact).
-	if (ch_in % 4 == 0) {
-		bool uniform = true, any_biquad = false;
+	// tables of cascade_rows: one set of wave-uniform constants per channel PAIR -- only when the two channels of every pair
+	// run identical ops (the usual case: one filter bank on all channels of a stream) and those ops are biquad sections and
+	// gains.  A gain in front of a section is folded into that section's b coefficients (same states, the product rounds
+	// differently in the last bit -- the sections are not bit-exact anyway), gains behind the last section become one factor
+	// applied to the finished tile ([1] of the last op's entry); `add`, unselected channels and chains without any section
+	// stay with cascade_wave / cascade_fast (a pure gain chain must remain bit-exact).
+	rows4_ok = false;
+	if (ch_in % 2 == 0) {
+		bool uniform = true, any_biquad = false, quad = (ch_in % 4 == 0);
+		auto same = [](const OpDesc &a, const OpDesc &b) { return a.kind == b.kind && a.g == b.g && memcmp(a.c, b.c, sizeof(a.c)) == 0; };
 		for (int c = 0; c < ch_in && uniform; ++c)
 			for (int j = 0; j < n_ops && uniform; ++j) {
-				const OpDesc &a = host[(size_t) (c & ~3) * n_ops + j], &b = host[(size_t) c * n_ops + j];
-				if (a.kind != b.kind || a.g != b.g || memcmp(a.c, b.c, sizeof(a.c)) != 0) uniform = false;
+				const OpDesc &a = host[(size_t) (c & ~1) * n_ops + j], &b = host[(size_t) c * n_ops + j];
+				if (!same(a, b)) uniform = false;
 				if (a.kind != OP_BIQUAD && a.kind != OP_MUL) uniform = false;
 				if (a.kind == OP_BIQUAD) any_biquad = true;
+				if (quad && !same(host[(size_t) (c & ~3) * n_ops + j], b)) quad = false;
 			}
 		if (uniform && any_biquad) {
-			std::vector<double> tab((size_t) (ch_in / 4) * n_ops * FOP_DOUBLES, 0.0);
+			const int n_pairs = ch_in / 2;
+			std::vector<double> tab((size_t) n_pairs * n_ops * FOP_DOUBLES, 0.0), q((size_t) n_pairs * n_ops * FQ_DOUBLES, 0.0);
 			int lg = 0;
 			while ((1 << lg) < ROWS_L) ++lg;
-			for (int g = 0; g < ch_in / 4; ++g) {
+			for (int g = 0; g < n_pairs; ++g) {
 				double gain = 1.0;
 				for (int j = 0; j < n_ops; ++j) {
-					const OpDesc &od = host[(size_t) (4 * g) * n_ops + j];
+					const OpDesc &od = host[(size_t) (2 * g) * n_ops + j];
 					double *d = &tab[((size_t) g * n_ops + j) * FOP_DOUBLES];
 					long long kind = (od.kind == OP_BIQUAD) ? OP_BIQUAD : OP_SKIP;
 					memcpy(&d[0], &kind, sizeof(kind));
@@ -200,10 +204,21 @@ bool CascadeStage::finalize()
 					for (int i = 0; i < 3; ++i) d[2 + i] *= gain;            // y = H(g x): b coefficients scaled, a and the states untouched
 					gain = 1.0;
 					for (int k = 0; k < 4; ++k) for (int i = 0; i < 4; ++i) d[FOP_PW + 4 * k + i] = od.P[lg + k][i];
+					// Q[i] = (A^L)^(i+1), L = ROWS_L, in extended precision
+					long double A[4] = { -(long double) od.c[3], 1.0L, -(long double) od.c[4], 0.0L }, AL[4] = { 1.0L, 0.0L, 0.0L, 1.0L }, t[4];
+					for (int i = 0; i < ROWS_L; ++i) { mat_mul(AL, A, t); memcpy(AL, t, sizeof(t)); }
+					long double Q[4] = { AL[0], AL[1], AL[2], AL[3] };
+					for (int i = 0; i < 16; ++i) {
+						for (int k = 0; k < 4; ++k) q[((size_t) g * n_ops + j) * FQ_DOUBLES + 4 * i + k] = (double) Q[k];
+						mat_mul(Q, AL, t);
+						memcpy(Q, t, sizeof(t));
+					}
 				}
 				tab[((size_t) g * n_ops + (n_ops - 1)) * FOP_DOUBLES + 1] = gain;   // gains behind the last section
 			}
 			if (!frows.upload(tab.data(), tab.size() * sizeof(double))) return false;
+			if (!frq.upload(q.data(), q.size() * sizeof(double))) return false;
+			rows4_ok = quad;
 		}
 	}
 	if (!state.alloc((size_t) S * ch_in * n_ops * 2 * sizeof(double))) return false;
@@ -236,6 +251,8 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.fops = fops.as<double>();
 	p.fq = fq.as<double>();
 	p.frows = frows.p ? frows.as<double>() : nullptr;
+	p.frq = frq.p ? frq.as<double>() : nullptr;
+	p.rows4_ok = rows4_ok ? 1 : 0;
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;

@@ -600,10 +600,20 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 // shared as in cascade_wave (below).  The constants stay wave-uniform scalars: the four channels of a group must run
 // identical biquad sections (gains among them are folded into the sections by the host: frows table, engine.cpp);
 // anything else goes to cascade_wave / cascade_fast.
-constexpr int RW_L = ROWS_L, RW_TILE = ROWS_TILE, RW_ROW = 16 * (RW_L + 1);
-template <int L>
-__device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, const double *__restrict__ od, double *st_row, int j, int q,
-                                            PendingFix &fix, bool &pending)
+constexpr int RW_L = ROWS_L, RW_ROW = 16 * (RW_L + 1);
+// value of lane 15 of row 0 / 2 in every lane of row 1 / 3; rows 0 and 2 read 0.0 (two v_readlane pairs and a select)
+__device__ __forceinline__ double bcast15_f64(double v, int lane)
+{
+	const double a = readlane_f64(v, 15), b = readlane_f64(v, 47);
+	return (lane & 16) ? ((lane & 32) ? b : a) : 0.0;
+}
+
+// One section on the tile in v.  G channels per wave: 64 / G lanes each (G = 4: one DPP row, G = 2: two rows), lane = L
+// consecutive frames.  pos: this lane's position inside its channel (0 .. 64 / G - 1); qrow: LDS [16][4] doubles,
+// Q[i] = P^(L (i + 1)) of this section (G = 2 only: carry of the lower row's end state into lane i of the upper row).
+template <int L, int G>
+__device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, const double *__restrict__ od, double *st_row, const double *qrow, int j, int pos,
+                                            int lane, PendingFix &fix, bool &pending)
 {
 	// (a second op kind with its own code in this loop makes the register allocator keep two copies of the tile: 37 spilled
 	// VGPRs -- which is why gains are folded into the sections on the host)
@@ -611,7 +621,7 @@ __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, c
 		double Pw[16];
 #pragma unroll
 		for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];                // P^(L 2^k), k = 0..3: requested now, used after the recurrence
-		const double2 xin = *reinterpret_cast<const double2 *>(st_row + 2 * j);   // the row's carried state
+		const double2 xin = *reinterpret_cast<const double2 *>(st_row + 2 * j);   // the channel's carried state
 		__builtin_amdgcn_sched_barrier(0);
 		const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, nc3 = -cur.c3, nc4 = -cur.c4;
 		double m0 = 0.0, m1 = 0.0;
@@ -631,49 +641,83 @@ __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, c
 			}
 		}
 		__builtin_amdgcn_sched_barrier(0);
-		// the carried state enters at the row's first lane as P^L xin; the scan spreads it: afterwards (m0, m1) is the TRUE
+		// the carried state enters at the channel's first lane as P^L xin; the scan spreads it: afterwards (m0, m1) is the TRUE
 		// state at the end of every lane's frames
 		const double e0 = fma(Pw[0], xin.x, fma(Pw[1], xin.y, m0)), e1 = fma(Pw[2], xin.x, fma(Pw[3], xin.y, m1));
-		if (q == 0) { m0 = e0; m1 = e1; }
+		if (pos == 0) { m0 = e0; m1 = e1; }
 		row_scan(m0, m1, Pw);
+		double lo0 = 0.0, lo1 = 0.0;
+		if (G == 2) {
+			// upper row of the channel: + Q[i] (end state of the lower row, which is final already).  Q is fetched here, not in
+			// front of the recurrence: 8 VGPRs less across it
+			const double2 qa = *reinterpret_cast<const double2 *>(qrow + 4 * (pos & 15));
+			const double2 qb = *reinterpret_cast<const double2 *>(qrow + 4 * (pos & 15) + 2);
+			lo0 = bcast15_f64(m0, lane); lo1 = bcast15_f64(m1, lane);               // 0.0 in the lower rows
+			m0 = fma(qa.x, lo0, fma(qa.y, lo1, m0));
+			m1 = fma(qb.x, lo0, fma(qb.y, lo1, m1));
+		}
+		// incoming state of a lane = true state of the lane before it
 		double x0 = dpp_f64<DPP_ROW_SHR1>(m0), x1 = dpp_f64<DPP_ROW_SHR1>(m1);
-		if (q == 0) { x0 = xin.x; x1 = xin.y; }
+		if (G == 2 && pos == 16) { x0 = lo0; x1 = lo1; }
+		if (pos == 0) { x0 = xin.x; x1 = xin.y; }
 		fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
 		pending = true;
-		if (q == 15) *reinterpret_cast<double2 *>(st_row + 2 * j) = make_double2(m0, m1);
+		if (pos == 64 / G - 1) *reinterpret_cast<double2 *>(st_row + 2 * j) = make_double2(m0, m1);
 	}
 }
 
 typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
+// 128-bit buffer store, hand-issued with idle cycles behind it.  The compiler stages the four data dwords of consecutive
+// slots in ONE register quad (v_mov right behind the store) and inserts no wait state when the store has an SGPR soffset --
+// the documented exception of the "VMEM store data > 64 bits overwritten by a VALU write" hazard.  On gfx950 the exception
+// does not hold: with two waves on the SIMD the first dword (low half of a double) was sporadically replaced by the NEXT
+// slot's in lanes 12-15 of every row -- relative errors of 1e-7 in single output samples, different from run to run
+// (scripts/dbg_rows5.py compares identical runs bit for bit).  With the nops behind the store: none.
+__device__ __forceinline__ void rw_store_b128(rw_u32x4 data, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
+{
+	// (leading nops: the hazard recognizer does not look into inline asm, and an SGPR operand may have been written by a VALU
+	// instruction -- v_readlane of a spilled SGPR -- right in front: 5 wait states before a VMEM instruction may read it)
+	asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 7" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 __device__ __forceinline__ double2 rw_as_d2(rw_u32x4 v) { return __builtin_bit_cast(double2, v); }
 __device__ __forceinline__ rw_u32x4 rw_as_u4(double2 v) { return __builtin_bit_cast(rw_u32x4, v); }
 
-// cascade_rows: workgroup = (stream, group of 4 channels) x P waves.  The P waves share the TIME axis of the group the way
+// cascade_rows<G>: workgroup = (stream, group of G channels) x P waves.  The P waves share the TIME axis of the group the way
 // cascade_wave does (wave w owns the tiles w, w + P, ..., one section per step, one LDS barrier per step, the 16-byte
-// section states of the four rows travel from wave to wave through LDS), so that 2048 channels still give 2048 waves.
+// section states of the channels travel from wave to wave through LDS), so that 2048 channels still give 2048 waves.
+// G = 4: one DPP row and 512 frames per channel and tile -- 1024 channels and more.  G = 2: two rows and 1024 frames per
+// channel (one extra carry step from the lower to the upper row, per-lane matrices from an LDS table) -- twice the
+// workgroups when the channels are few (strong scaling).
 // Every wave moves its own tiles: 16-byte (frame, channel pair) elements between HBM and registers (buffer instructions:
 // descriptor base in SGPRs + ONE per-lane offset register + a wave-uniform slot offset -- plain pointers cost a 64-bit
 // address pair per slot and direction, 96 VGPRs), transposed to the lane-major layout of the recurrence through a
 // wave-private LDS tile (rows placed so that both access patterns are bank-conflict free), one tile per n_ops steps,
 // prefetched a whole tile period ahead.
-constexpr int RW_TB = 4 * RW_ROW + 16;                          // doubles per wave-private transposer
-__device__ __forceinline__ int rw_row_base(int r) { return r * RW_ROW + ((r >> 1) << 4); }   // rows 0..3 at 0, 528, 1072, 1600
+constexpr int RW_TB = 4 * RW_ROW + 16;                          // doubles per wave-private transposer (either G)
+// G = 4: rows of 16 x 33 doubles at 0, 528, 1072, 1600;  G = 2: rows of 32 x 33 doubles at 0, 1056
+template <int G> __device__ __forceinline__ int rw_row_base(int r) { return (G == 4) ? r * RW_ROW + ((r >> 1) << 4) : r * 2 * RW_ROW; }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void cascade_rows(CascadeParams p, const double *__restrict__ frows, int P)
+template <int G>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P)
 {
-	constexpr int L = RW_L, TILE = RW_TILE, K = 16;             // K slots (16 B) per lane and tile: 512 frames x 2 pairs / 64
+	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
+	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
+	constexpr int PARTNER = (G == 4) ? RW_ROW : 2 * RW_ROW;            // LDS distance between the two channels of a pair
 	extern __shared__ __attribute__((aligned(16))) double smem[];
 	const int s = blockIdx.x;
-	const int c0 = p.cg0 + blockIdx.y * 4;
+	const int c0 = p.cg0 + blockIdx.y * G;
 	const int tid = threadIdx.x, lane = tid & 63, nth = 64 * P;
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // position in the wavefront
 	const int n_ops = p.n_ops;
-	double *st = smem;                                          // [4][n_ops][2]
-	double *tb = st + 4 * n_ops * 2 + (size_t) w * RW_TB;       // this wave's transposer
+	double *st = smem;                                          // [G][n_ops][2]
+	double *qt = st + G * n_ops * 2;                            // [n_ops][16][4] (G = 2 only)
+	double *tb = qt + ((G == 2) ? n_ops * FQ_DOUBLES : 0) + (size_t) w * RW_TB;       // this wave's transposer
 
-	const int n_st = 4 * n_ops * 2;
+	const int n_st = G * n_ops * 2;
 	double *gstate = p.state + ((size_t) s * p.C + c0) * n_ops * 2;
 	for (int i = tid; i < n_st; i += nth) st[i] = gstate[i];
+	if (G == 2) for (int i = tid; i < n_ops * FQ_DOUBLES; i += nth) qt[i] = frq[(size_t) (c0 >> 1) * n_ops * FQ_DOUBLES + i];
 
 	const long n_full = p.frames / TILE;
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
@@ -683,16 +727,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) : p.out, 0, 0x7fffffff, RSRC_FLAGS);
 	const bool has_ring = p.ring.base != nullptr;
 	const int ring_row_bytes = (int) (p.ring.row_stride * 16);
-	// slab order: slot k of a lane = frame (lane >> 1) + 32 k, pair lane & 1 -- 64 lanes cover 32 frames x 32 bytes
-	const int pr = lane & 1, f0 = lane >> 1;
-	const int vo_slab = (f0 * p.C + 2 * pr) * 8, so_slab = 32 * p.C * 8, tile_bytes = TILE * p.C * 8;
-	double *tb_slab = tb + rw_row_base(2 * pr) + f0;            // slot k at + 33 k; the pair's second channel one row further
-	// row order (ring-only output): slot k = pair k >> 3, frame lane + 64 (k & 7) -- one store instruction = 1 KB of ONE ring row
+	// slab order: slot k of a lane = (frame f0 + FPS k, pair pr).  G = 4: 64 lanes cover 32 frames x 2 pairs (32 contiguous
+	// bytes per frame); G = 2: 64 frames of the one pair
+	const int pr = (G == 4) ? (lane & 1) : 0, f0 = (G == 4) ? (lane >> 1) : lane;
+	const int vo_slab = (f0 * p.C + 2 * pr) * 8, so_slab = FPS * p.C * 8, tile_bytes = TILE * p.C * 8;
+	// LDS position of slot k: G = 4: row 2 pr, frame f0 + 32 k at + 33 k;  G = 2: frame lane + 64 k at lane + lane / 32 + 66 k
+	double *tb_slab = tb + ((G == 4) ? rw_row_base<G>(2 * pr) + f0 : lane + (lane >> 5));
+	constexpr int SLAB_K = (G == 4) ? (L + 1) : 2 * (L + 1);
+	// row order (ring-only output, G = 4): slot k = pair k >> 3, frame lane + 64 (k & 7) -- one store instruction = 1 KB of ONE
+	// ring row.  (G = 2 has one pair: slab order is row order.)
 	double *tb_rows = tb + lane + (lane >> 5);                  // + rw_row_base(2 (k >> 3)) + 66 (k & 7)
-	const int r = lane >> 4, q = lane & 15;                     // this lane's channel (row) and position in the row
-	double *tb_lane = tb + rw_row_base(r) + q * (L + 1);
-	double *st_row = st + r * n_ops * 2;
-	const double *__restrict__ cf = frows + (size_t) (c0 >> 2) * n_ops * FOP_DOUBLES;
+	const int ch = lane / LPC, pos = lane % LPC;                // this lane's channel inside the group and position in it
+	double *tb_lane = tb + rw_row_base<G>(ch) + pos * (L + 1);
+	double *st_row = st + ch * n_ops * 2;
+	const double *__restrict__ cf = frows + (size_t) (c0 >> 1) * n_ops * FOP_DOUBLES;     // one entry per channel PAIR
 
 	// the last tile's owner finishes last: wave wl after its tiles
 	const int wl = (int) ((n_full - 1) % P);
@@ -711,16 +759,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
 			for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_slab, w * tile_bytes + k * so_slab, 0));
 			// results of tile t_out (lane-major in the transposer) -> HBM
+			const bool slab_order = p.write_interleaved || G == 2;
 			auto fetch_out = [&](double2 (&y)[K]) {
-				if (p.write_interleaved) {
+				if (slab_order) {
 #pragma unroll
-					for (int k = 0; k < K; ++k) y[k] = make_double2(tb_slab[(L + 1) * k], tb_slab[(L + 1) * k + RW_ROW]);
+					for (int k = 0; k < K; ++k) y[k] = make_double2(tb_slab[SLAB_K * k], tb_slab[SLAB_K * k + PARTNER]);
 				}
 				else {
 #pragma unroll
 					for (int k = 0; k < K; ++k) {
-						const double *a = tb_rows + rw_row_base(2 * (k >> 3)) + (64 + 64 / L) * (k & 7);
-						y[k] = make_double2(a[0], a[RW_ROW]);
+						const double *a = tb_rows + rw_row_base<G>(2 * (k >> 3)) + (64 + 64 / L) * (k & 7);
+						y[k] = make_double2(a[0], a[PARTNER]);
 					}
 				}
 			};
@@ -729,20 +778,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				if (p.write_interleaved) {
 					const int tbb = (int) t_out * tile_bytes;
 #pragma unroll
-					for (int k = 0; k < K; ++k) __builtin_amdgcn_raw_buffer_store_b128(rw_as_u4(y[k]), r_out, vo_slab, tbb + k * so_slab, 0);
-					if (has_ring) {
-						// both destinations: the ring in slab order too (pair = lane & 1)
-						const long e0 = p.ring.pos + t_out * TILE + f0;
+					for (int k = 0; k < K; ++k) rw_store_b128(rw_as_u4(y[k]), r_out, vo_slab, tbb + k * so_slab);
+				}
+				if (has_ring && slab_order) {
+					const long e0 = p.ring.pos + t_out * TILE + f0;
 #pragma unroll
-						for (int k = 0; k < K; ++k)
-							__builtin_amdgcn_raw_buffer_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 32 * k) & p.ring.mask) * 16 + pr * ring_row_bytes, 0, 0);
-					}
+					for (int k = 0; k < K; ++k)
+						rw_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + FPS * k) & p.ring.mask) * 16 + pr * ring_row_bytes, 0);
 				}
 				else if (has_ring) {
 					const long e0 = p.ring.pos + t_out * TILE + lane;
 #pragma unroll
 					for (int k = 0; k < K; ++k)
-						__builtin_amdgcn_raw_buffer_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 64 * (k & 7)) & p.ring.mask) * 16, (k >> 3) * ring_row_bytes, 0);
+						rw_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 64 * (k & 7)) & p.ring.mask) * 16, (k >> 3) * ring_row_bytes);
 				}
 			};
 			for (long t = w; t < n_full; t += P) {
@@ -752,7 +800,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				double2 y[K];
 				if (t > w) fetch_out(y);
 #pragma unroll
-				for (int k = 0; k < K; ++k) { tb_slab[(L + 1) * k] = raw[k].x; tb_slab[(L + 1) * k + RW_ROW] = raw[k].y; }
+				for (int k = 0; k < K; ++k) { tb_slab[SLAB_K * k] = raw[k].x; tb_slab[SLAB_K * k + PARTNER] = raw[k].y; }
 				if (t > w) store_out(y, t - P);
 #pragma unroll
 				for (int i = 0; i < L; ++i) x[i] = tb_lane[i];
@@ -767,7 +815,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 				bool pending = false;
 				for (int j = 0; j < n_ops; ++j) {
 					const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
-					run_op_rows<L>(x, cur, cf + j * FOP_DOUBLES, st_row, j, q, fix, pending);
+					run_op_rows<L, G>(x, cur, cf + j * FOP_DOUBLES, st_row, qt + j * FQ_DOUBLES, j, pos, lane, fix, pending);
 					const double post = cur.g;                           // last op's entry: product of the gains behind the last section
 					cur = nxt;
 					if (j + 1 == n_ops) {
@@ -797,36 +845,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
 }
 
+template <int G> static long try_launch_rows(const CascadeParams &p, int n_streams, int P, hipStream_t stream)
+{
+	constexpr int TILE = (64 / G) * RW_L;
+	const long n_full = p.frames / TILE;
+	if (n_full < 1 || (p.C % G)) return 0;
+	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
+	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G == 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB) * sizeof(double);
+	if (lds > 160 * 1024) return 0;
+	static size_t granted = 0;
+	if (lds > granted) {
+		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_rows<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+		granted = lds;
+	}
+	dim3 grid(n_streams, p.C / G), block(64 * P);
+	hipLaunchKernelGGL(cascade_rows<G>, grid, block, lds, stream, p, p.frows, p.frq, P);
+	return n_full * TILE;
+}
+
 // 0 = not eligible; otherwise the number of leading frames taken
 static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
 	static int env = -2;
-	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_ROWS"); env = e ? atoi(e) : -1; }   // 0 = never, P = force that many waves per group
-	if (env == 0 || !p.frows || (p.C % 4) || p.cg0 != 0) return 0;
+	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_ROWS"); env = e ? atoi(e) : -1; }   // 0 = never, G*100 + P = force
+	if (env == 0 || !p.frows || !p.frq || p.cg0 != 0) return 0;
 	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
 	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
-	const long n_full = p.frames / RW_TILE;
-	if (n_full < 1) return 0;
 	// 32-bit byte offsets inside one stream's slab / ring rows
 	if ((double) std::max(p.in_stride_frames, p.out_stride_frames) * p.C * 8 >= 2.0e9 || (double) p.ring.row_stride * 16 * (p.C / 2) >= 2.0e9) return 0;
-	// waves per group: enough to put two waves on every SIMD (2048 in all); 8 is what the LDS transposers allow.  Below 256
-	// groups (128 streams x 8 ch) that is not reached and one channel per wave (cascade_wave) fills the chip better:
-	// measured at 32 / 64 / 128 / 256 streams x 8 ch: rows 0.86 / 0.89 / 0.92 / 2.0 ms, wave 0.45 / 0.82 / 1.46 / - ms
-	const long groups = (long) n_streams * (p.C / 4);
-	if (env < 0 && groups < 256) return 0;
-	int P = (env > 0) ? env : (int) std::min<long>(8, std::max<long>(1, (2048 + groups - 1) / groups));
-	if (P > 8) P = 8;
-	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
-	const size_t lds = ((size_t) 4 * p.n_ops * 2 + (size_t) P * RW_TB) * sizeof(double);
-	if (lds > 160 * 1024) return 0;
-	static size_t granted = 0;
-	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		granted = lds;
+	// Four channels per wave when that still gives 2048 waves of at most 8 per group (what the LDS transposers allow), i.e.
+	// from 1024 channels; two per wave from 512 channels; below that a workgroup per channel pair no longer covers the CUs
+	// and cascade_wave (one channel per wave, up to 10 waves per channel) wins.  Measured, 10 sections, ms per launch at
+	// 32 / 64 / 128 / 256 streams x 8 ch:  wave 0.45 / 0.82 / 1.46 / -,  rows<2> 0.52 / 0.55 / 1.11 / 3.1,  rows<4> - / - / 1.0 / 2.0
+	const long channels = (long) n_streams * p.C;
+	int G = (channels >= 1024 && p.rows4_ok) ? 4 : 2, P;
+	if (env > 0) { G = env / 100; P = env % 100; if (G == 4 && !p.rows4_ok) return 0; }
+	else {
+		if (channels < 512) return 0;
+		P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
 	}
-	dim3 grid(n_streams, p.C / 4), block(64 * P);
-	hipLaunchKernelGGL(cascade_rows, grid, block, lds, stream, p, p.frows, P);
-	return n_full * RW_TILE;
+	if (P > 8) P = 8;
+	if (P < 1) P = 1;
+	return (G == 4) ? try_launch_rows<4>(p, n_streams, P, stream) : try_launch_rows<2>(p, n_streams, P, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

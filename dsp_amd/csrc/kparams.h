@@ -32,7 +32,7 @@ struct alignas(16) OpDesc {
 // with P = A = [[-c3, 1], [-c4, 0]].
 constexpr int FOP_DOUBLES = 32, FOP_PW = 8, FOP_P16 = 24, FQ_DOUBLES = 64;
 // cascade_rows: a wave = 4 channels x 16 lanes x ROWS_L consecutive frames; its tables are fops-shaped with L = ROWS_L
-constexpr int ROWS_L = 32, ROWS_TILE = 16 * ROWS_L;
+constexpr int ROWS_L = 32;
 
 // The FFT convolver's input ring (one row per channel PAIR, 16-byte elements (x_a[n], x_b[n]) = the complex
 // sequence the convolver transforms) that the cascade kernel may write instead of the interleaved block.
@@ -57,7 +57,10 @@ struct CascadeParams {
 	const OpDesc *ops;                   // [C][n_ops]
 	const double *fops;                  // [C][n_ops][FOP_DOUBLES] fast-kernel constants (scalar loads)
 	const double *fq;                    // [C][n_ops][FQ_DOUBLES] per-lane carry matrices
-	const double *frows;                 // [C / 4][n_ops][FOP_DOUBLES] constants of cascade_rows (L = ROWS_L), or nullptr: groups of 4 channels differ
+	const double *frows;                 // [C / 2][n_ops][FOP_DOUBLES] constants of cascade_rows (L = ROWS_L) per channel PAIR, or nullptr: the
+	                                     // channels of a pair differ / ops other than sections and gains
+	const double *frq;                   // [C / 2][n_ops][16][4] Q[i] = P^(ROWS_L (i + 1)) (cascade_rows<2>: lower row -> upper row carry)
+	int rows4_ok;                        // the two pairs of every group of 4 channels are identical too (cascade_rows<4>)
 	double *state;                       // [S][C][n_ops][2]
 	PlanarRing ring;                     // optional second destination (ring.base != nullptr)
 	int write_interleaved;               // 0: only the ring is written

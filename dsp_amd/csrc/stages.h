@@ -22,7 +22,8 @@ public:
 private:
 	std::vector<std::vector<OpDesc>> cols;   // [op][channel]
 	std::vector<std::string> names;
-	DevBuf ops, state, fops, fq, frows;
+	DevBuf ops, state, fops, fq, frows, frq;
+	bool rows4_ok = false;
 };
 
 class RemixStage : public Stage {

@@ -1,0 +1,13 @@
+import sys, os, json, collections, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import dsp_amd, torch
+chain = [c for c in json.load(open('tests/golden/golden.json'))['cases'] if c['name'] == 'config2'][0]['chain']
+S, C, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+x = torch.rand((S, n, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+outs = []
+for rep in range(4):
+    b = dsp_amd.BatchChain(chain, 48000, C, S, n)
+    outs.append(b.run(x).clone())
+diff = sum(int((outs[0] != o).sum().item()) for o in outs[1:])
+print("S", S, "C", C, "n", n, "elements differing between identical runs:", diff)
