@@ -617,7 +617,7 @@ __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, c
 {
 	// (a second op kind with its own code in this loop makes the register allocator keep two copies of the tile: 37 spilled
 	// VGPRs -- which is why gains are folded into the sections on the host)
-	if (cur.kind == OP_BIQUAD) {           // anything else is a gain that the table folded into a neighbouring section: a no-op step
+	{                                      // (the caller skips gains that the table folded into a neighbouring section: no-op steps)
 		double Pw[16];
 #pragma unroll
 		for (int i = 0; i < 16; ++i) Pw[i] = od[FOP_PW + i];                // P^(L 2^k), k = 0..3: requested now, used after the recurrence
@@ -672,12 +672,13 @@ typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
 // the documented exception of the "VMEM store data > 64 bits overwritten by a VALU write" hazard.  On gfx950 the exception
 // does not hold: with two waves on the SIMD the first dword (low half of a double) was sporadically replaced by the NEXT
 // slot's in lanes 12-15 of every row -- relative errors of 1e-7 in single output samples, different from run to run
-// (scripts/dbg_rows5.py compares identical runs bit for bit).  With the nops behind the store: none.
+// (scripts/check_determinism.py compares identical runs bit for bit).  One wait state behind the store is enough (s_nop 0: no
+// differences in 8 runs); two are used, as LLVM does for gfx940 where it sees the hazard.
 __device__ __forceinline__ void rw_store_b128(rw_u32x4 data, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
 {
 	// (leading nops: the hazard recognizer does not look into inline asm, and an SGPR operand may have been written by a VALU
 	// instruction -- v_readlane of a spilled SGPR -- right in front: 5 wait states before a VMEM instruction may read it)
-	asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 7" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+	asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ double2 rw_as_d2(rw_u32x4 v) { return __builtin_bit_cast(double2, v); }
 __device__ __forceinline__ rw_u32x4 rw_as_u4(double2 v) { return __builtin_bit_cast(rw_u32x4, v); }
@@ -804,6 +805,10 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				if (t > w) store_out(y, t - P);
 #pragma unroll
 				for (int i = 0; i < L; ++i) x[i] = tb_lane[i];
+				// the tile is settled HERE, once: left in flight into the section loop it makes the compiler wait for all LDS and
+				// scalar traffic (one counter) in front of every recurrence -- behind the requests that the recurrence should hide
+#pragma unroll
+				for (int i = 0; i < L; ++i) asm volatile("" : "+v"(x[i]));
 				if (!(p.debug & 2)) {
 					// unconditional (the last one re-reads this tile): a conditional load would have to select between old and
 					// new registers, which costs a wait right behind the loads
@@ -814,8 +819,15 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
 				bool pending = false;
 				for (int j = 0; j < n_ops; ++j) {
+					// the kind is looked at BEFORE the next head is requested: a wait for `cur` behind that request (s_waitcnt cannot
+					// tell scalar loads apart) would expose a scalar-load round trip in every step
+					const bool section = (cur.kind == OP_BIQUAD);
+					__builtin_amdgcn_sched_barrier(0);
 					const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
-					run_op_rows<L, G>(x, cur, cf + j * FOP_DOUBLES, st_row, qt + j * FQ_DOUBLES, j, pos, lane, fix, pending);
+					if (section) run_op_rows<L, G>(x, cur, cf + j * FOP_DOUBLES, st_row, qt + j * FQ_DOUBLES, j, pos, lane, fix, pending);
+					else asm volatile("" :: "s"(nxt.kind), "s"(nxt.g), "s"(nxt.c0), "s"(nxt.c1), "s"(nxt.c2), "s"(nxt.c3), "s"(nxt.c4));
+					// (the no-op path settles the next head too: otherwise `cur` counts as possibly in flight at the loop header and the
+					// compiler waits for ALL scalar loads in front of every recurrence)
 					const double post = cur.g;                           // last op's entry: product of the gains behind the last section
 					cur = nxt;
 					if (j + 1 == n_ops) {

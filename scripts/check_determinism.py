@@ -1,3 +1,4 @@
+# identical runs of the same batch must agree bit for bit: usage check_determinism.py <streams> <channels> <frames>  (see rw_store_b128 in kernels_cascade.hip)
 import sys, os, json, collections, numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import dsp_amd, torch
