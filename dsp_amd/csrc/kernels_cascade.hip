@@ -667,18 +667,16 @@ __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, c
 }
 
 typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
-// 128-bit buffer store, hand-issued with idle cycles behind it.  The compiler stages the four data dwords of consecutive
-// slots in ONE register quad (v_mov right behind the store) and inserts no wait state when the store has an SGPR soffset --
-// the documented exception of the "VMEM store data > 64 bits overwritten by a VALU write" hazard.  On gfx950 the exception
-// does not hold: with two waves on the SIMD the first dword (low half of a double) was sporadically replaced by the NEXT
-// slot's in lanes 12-15 of every row -- relative errors of 1e-7 in single output samples, different from run to run
-// (scripts/check_determinism.py compares identical runs bit for bit).  One wait state behind the store is enough (s_nop 0: no
-// differences in 8 runs); two are used, as LLVM does for gfx940 where it sees the hazard.
+// 128-bit buffer store with the slot offset folded into the per-lane offset (soffset = 0).  With a wave-uniform SGPR soffset
+// the compiler stages the four data dwords of consecutive slots in ONE register quad (v_mov right behind the store) and
+// inserts no wait state -- the documented exception of the "VMEM store data > 64 bits overwritten by a VALU write" hazard.
+// On gfx950 the exception does not hold: with two waves on the SIMD the first dword (low half of a double) was sporadically
+// replaced by the NEXT slot's in lanes 12-15 of every row -- relative errors of 1e-7 in single output samples, different from
+// run to run (scripts/check_determinism.py compares identical runs bit for bit; one wait state behind the store cures it).
+// Without an SGPR soffset the compiler sees the hazard and places the wait states itself.
 __device__ __forceinline__ void rw_store_b128(rw_u32x4 data, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff)
 {
-	// (leading nops: the hazard recognizer does not look into inline asm, and an SGPR operand may have been written by a VALU
-	// instruction -- v_readlane of a spilled SGPR -- right in front: 5 wait states before a VMEM instruction may read it)
-	asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+	__builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voff + soff, 0, 0);
 }
 __device__ __forceinline__ double2 rw_as_d2(rw_u32x4 v) { return __builtin_bit_cast(double2, v); }
 __device__ __forceinline__ rw_u32x4 rw_as_u4(double2 v) { return __builtin_bit_cast(rw_u32x4, v); }
