@@ -5,6 +5,7 @@
 // drive HIP kernels.  run() works on the host's interleaved fp64 buffers (one PCIe round trip per call: this
 // is the compatibility path; throughput work goes through the device-resident batch API, capi.cpp).
 #include "plugin.h"
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +77,65 @@ static bool ensure_segment(struct effect *e, Node *n)
 	return true;
 }
 
+// true when [p, p + n) is registered (DMA-able).  A buffer is registered the fourth time in a row the host hands over the
+// same pointer in the same role; buffers that share pages (the reference's two block buffers are small neighbouring heap
+// allocations) are registered as ONE range, because a copy may not straddle registered and pageable memory; at most 4
+// ranges; any failure drops every registration and switches the mechanism off for this segment.
+static inline char *page_lo(const void *p) { return (char *) ((uintptr_t) p & ~(uintptr_t) 4095); }
+static inline char *page_hi(const void *p, size_t n) { return (char *) (((uintptr_t) p + n + 4095) & ~(uintptr_t) 4095); }
+
+void Segment::unpin_all()
+{
+	if (pins.empty()) return;
+	(void) hipDeviceSynchronize();
+	for (const Pin &r : pins) if (hipHostUnregister(r.base) != hipSuccess) (void) hipGetLastError();
+	pins.clear();
+}
+
+void Segment::before_copy(const void *p, size_t n)
+{
+	if (pins.empty() || !p || n == 0) return;
+	char *lo = page_lo(p), *hi = page_hi(p, n);
+	for (const Pin &r : pins) {
+		const bool inside = lo >= r.base && hi <= r.base + r.bytes, apart = hi <= r.base || lo >= r.base + r.bytes;
+		if (!inside && !apart) { unpin_all(); pin_off = true; return; }
+	}
+}
+
+bool Segment::pinned(int which, const void *p, size_t n)
+{
+	// opt-in (DSP_AMD_PLUGIN_PIN=1): registering takes milliseconds once -- not something to spring on a real-time host --
+	// and buys 10 % at the reference's 2048-frame blocks (scripts/exp_cli_rate.sh), where the host's own I/O dominates
+	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return e && atoi(e) != 0; }();
+	if (!enabled || pin_off || !p || n == 0) return false;
+	char *lo = page_lo(p), *hi = page_hi(p, n);
+	for (const Pin &r : pins) if (lo >= r.base && hi <= r.base + r.bytes) return true;
+	if (p != last_ptr[which]) { last_ptr[which] = p; seen[which] = 1; return false; }
+	if (++seen[which] < 4) return false;
+	// grow over every registration this range touches
+	(void) hipDeviceSynchronize();
+	for (size_t i = 0; i < pins.size();) {
+		const Pin r = pins[i];
+		if (lo <= r.base + r.bytes && hi >= r.base) {
+			lo = std::min(lo, r.base); hi = std::max(hi, r.base + r.bytes);
+			if (hipHostUnregister(r.base) != hipSuccess) (void) hipGetLastError();
+			pins.erase(pins.begin() + i);
+		}
+		else ++i;
+	}
+	if (pins.size() >= 4 || hipHostRegister(lo, (size_t) (hi - lo), hipHostRegisterDefault) != hipSuccess) {
+		(void) hipGetLastError();
+		unpin_all();
+		pin_off = true;
+		return false;
+	}
+	pins.push_back(Pin{ lo, (size_t) (hi - lo) });
+	log_msg(LL_VERBOSE, "info: host buffer %p (%zu KiB) registered for DMA", (void *) lo, (size_t) (hi - lo) >> 10);
+	return true;
+}
+
+Segment::~Segment() { unpin_all(); }
+
 static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, sample_t *obuf)
 {
 	Node *n = node_of(e);
@@ -90,15 +150,24 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	sample_t *dst = sg.in_place ? ibuf : obuf;
 	ssize_t done = 0, produced = 0;
 	const ssize_t total = *frames;
+	// everything of one call is queued on the null stream in order (copy in, stages, copy out, next chunk ...) and waited
+	// for once; with registered host buffers the copies are asynchronous DMA, with pageable ones they simply block
+	const size_t in_bytes = (size_t) total * sg.ch_in * sizeof(double);
+	const size_t out_bytes = (size_t) sg.pipe->max_out_frames(total) * sg.ch_out * sizeof(double);
+	(void) sg.pinned(0, ibuf, in_bytes);
+	if (dst != ibuf) (void) sg.pinned(1, dst, out_bytes);
+	sg.before_copy(ibuf, in_bytes);
+	sg.before_copy(dst, out_bytes);
 	while (done < total) {
 		const ssize_t nb = std::min<ssize_t>(total - done, sg.pipe_frames);
-		if (!hip_ok(hipMemcpy(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice), "H2D")) break;
+		if (!hip_ok(hipMemcpyAsync(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice, nullptr), "H2D")) break;
 		const ssize_t f = sg.pipe->run(sg.d_in.as<double>(), nb, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 		if (f < 0) break;
-		if (f > 0 && !hip_ok(hipMemcpy(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H")) break;
+		if (f > 0 && !hip_ok(hipMemcpyAsync(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost, nullptr), "D2H")) break;
 		produced += f;
 		done += nb;
 	}
+	(void) hip_ok(hipStreamSynchronize(nullptr), "sync");
 	*frames = produced;
 	return dst;
 }
@@ -119,7 +188,10 @@ static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1
 	const ssize_t want = std::min<ssize_t>(*frames, sg.pipe_frames);
 	const ssize_t f = sg.pipe->drain2(want, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 	if (f < 0) { *frames = -1; return buf1; }
-	if (f > 0) (void) hip_ok(hipMemcpy(buf2, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+	if (f > 0) {
+		sg.before_copy(buf2, (size_t) f * sg.ch_out * sizeof(double));
+		(void) hip_ok(hipMemcpy(buf2, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+	}
 	*frames = f;
 	return buf2;
 }

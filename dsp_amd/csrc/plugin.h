@@ -20,6 +20,17 @@ struct Segment {
 	int ch_in = 0, ch_out = 0;
 	bool in_place = true;
 	DevBuf d_in, d_out;
+	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the
+	// HIP runtime after a few sightings: the copies then run as DMA instead of through the runtime's pageable-memory staging.
+	struct Pin { char *base; size_t bytes; };
+	std::vector<Pin> pins;
+	const void *last_ptr[2] = { nullptr, nullptr };
+	int seen[2] = { 0, 0 };
+	bool pin_off = false;
+	bool pinned(int which, const void *p, size_t n);     // which: 0 = input, 1 = output buffer of run()
+	void before_copy(const void *p, size_t n);           // a range half inside a registration cannot be copied: drop all of them
+	void unpin_all();
+	~Segment();
 };
 
 // what e->data points to for every effect this library creates
