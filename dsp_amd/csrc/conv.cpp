@@ -74,6 +74,11 @@ private:
 	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, first_n = 0, lat = 0, ring_len = 0, pos = 0;
 	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
 	bool fed = false, all_selected = false;
+	// plain zero-latency convolution of all channels straight from the interleaved slab: K1 reads the new frames there and
+	// files what later windows need in the ring itself -- no de-interleaving pass (6.4 GB of traffic at the headline shape)
+	bool direct = false;
+	const double *cur_slab = nullptr;
+	long cur_slab_stride = 0, cur_q0 = 0;
 	long pairs_per_chunk = 0;
 	int n_sub = 1;                       // chunks in flight on separate HIP streams (each with its own W)
 	std::vector<hipStream_t> sub;
@@ -96,7 +101,7 @@ std::string ConvStage::describe() const
 	if (resampler) o << " " << fs_in << "->" << fs_out << " " << up << "/" << down << " delay=" << out_delay;
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
-	  << (round_f32 ? " f32-io" : "") << "]";
+	  << (round_f32 ? " f32-io" : "") << ((direct && !fed) ? " slab-direct" : "") << "]";
 	return o.str();
 }
 
@@ -231,6 +236,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		if (ib >= 0) soc[sel_ch[ib]] = 2 * q + 1;
 		for (int s = 0; s < S; ++s) ph[(size_t) s * pps + q] = (n_filters == 1) ? 0 : q;
 	}
+	direct = !resampler && all_selected && n_filters == 1 && (ch_in % 2) == 0 && !round_f32 && lat == 0 && !getenv("DSP_AMD_CONV_NO_DIRECT");
 	if (!slot_of_channel.upload(soc.data(), soc.size() * sizeof(int))) return false;
 	if (!pair_h.upload(ph.data(), ph.size() * sizeof(int))) return false;
 	if (!pair_out_ch.upload(poc.data(), poc.size() * sizeof(int))) return false;
@@ -379,6 +385,7 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 		p.q_blk = q_blk;
 		p.k_origin = k_origin;
 		p.out_count = out_count;
+		if (cur_slab && !resampler) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; }
 		const int row_mode = (nph > 1) ? 2 : 0;
 		if (n_sub > 1) {
 			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
@@ -426,7 +433,11 @@ ssize_t ConvStage::emit(long count, double *out, long out_stride, hipStream_t st
 
 ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
-	if (!fed) push(in, in_stride, frames, out, out_stride, st);
+	const bool use_direct = direct && !fed && ((((size_t) in) & 15) == 0) && (double) in_stride * ch_in * 8 < 1.0e18;
+	cur_slab = use_direct ? in : nullptr;
+	cur_slab_stride = in_stride;
+	cur_q0 = q_abs;
+	if (!fed && !use_direct) push(in, in_stride, frames, out, out_stride, st);
 	if (resampler) {
 		pos = (pos + frames) & (ring_len - 1);
 		q_total += frames;

@@ -15,6 +15,11 @@ struct ConvParams {
 	// The ring holds the complex sequence itself: (first channel of the pair, second channel or 0.0) per frame.
 	const double2 *ring;
 	long ring_row_stride, ring_mask, win_base, valid;
+	// K1 direct mode (slab != nullptr): the NEW frames of the window (n >= first_n) come straight from the interleaved input
+	// slab -- frame slab_frame0 + n - first_n of stream pair / pairs_per_stream, channels (2 q, 2 q + 1) -- instead of the
+	// ring, and K1 itself files the frames that later windows need (the last first_n of the block) in the ring
+	const double *slab;
+	long slab_stride_frames, slab_frame0;
 	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
 	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
 	double2 *W;                         // [pairs in chunk][N] work spectrum / time buffer

@@ -257,10 +257,30 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 	for (int i = tid; i < N1; i += NT) twt[i] = p.tw_n1[i];
 	const cplx *src = p.ring + pair * p.ring_row_stride;
 	cplx v[16];
+	if (p.slab) {
+		// direct mode: history from the ring, new frames from the interleaved slab (16 bytes = the pair's two channels);
+		// frames that later windows look back at go into the ring on the way
+		cplx *ringw = const_cast<cplx *>(src);
+		const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
+		const cplx *slab = reinterpret_cast<const cplx *>(p.slab + ((size_t) s * p.slab_stride_frames + p.slab_frame0) * p.C) + qs;
+		const long hp = p.C >> 1, keep_from = (p.in_count > p.first_n) ? p.in_count : p.first_n;
 #pragma unroll
-	for (int m = 0; m < 16; ++m) {
-		const long n = (long) (j + P * m) * p.N2 + n2;
-		v[m] = (n < p.valid) ? ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1) : make_double2(0.0, 0.0);
+		for (int m = 0; m < 16; ++m) {
+			const long n = (long) (j + P * m) * p.N2 + n2;
+			if (n >= p.valid) v[m] = make_double2(0.0, 0.0);
+			else if (n >= p.first_n) {
+				v[m] = ld16(slab + (n - p.first_n) * hp, p.nt & 1);
+				if (n >= keep_from) ringw[(p.win_base + n) & p.ring_mask] = v[m];
+			}
+			else v[m] = ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1);
+		}
+	}
+	else {
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			const long n = (long) (j + P * m) * p.N2 + n2;
+			v[m] = (n < p.valid) ? ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1) : make_double2(0.0, 0.0);
+		}
 	}
 	lds_barrier();   // twiddle table visible (the data loads stay in flight)
 	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });

@@ -316,3 +316,27 @@ def test_config4_full_size_vs_real_reference(amd, tmp_path):
         got = y[s].cpu().numpy()
         assert ref.shape == got.shape, (ref.shape, got.shape)
         assert rms(ref - got) < 1e-11, (s, rms(ref - got))
+
+
+@pytest.mark.parametrize("taps,cap", [(5000, 4096), (5000, 65536), (40000, 16384)])
+def test_slab_direct_history_over_ragged_calls(amd, tmp_path, taps, cap):
+    """A plain fir_p on all channels reads its new frames straight from the interleaved slab and files the history for later
+    windows itself (no de-interleaving pass): calls shorter than the history, longer than one block, single frames."""
+    import torch
+    h = make_filter(taps, seed=3, decay=taps / 6.0)
+    chain = f"fir_p -t pcm -e double -c 1 {write(tmp_path, h)}"
+    S, C = 3, 4
+    b = amd.BatchChain(chain, 48000, C, S, cap)
+    assert "slab-direct" in b.plan()
+    rng = np.random.Generator(np.random.PCG64(31))
+    sizes = [1, 100, cap, 37, 3000, cap, cap // 2 + 1, 7, 2 * taps if 2 * taps <= cap else cap, 999]
+    x = rng.uniform(-0.5, 0.5, size=(S, sum(sizes), C))
+    xd = torch.from_numpy(x).cuda()
+    outs, k = [], 0
+    for n in sizes:
+        outs.append(b.run(xd[:, k:k + n, :].contiguous()).clone())
+        k += n
+    y = torch.cat(outs, dim=1).cpu().numpy()
+    for s in range(S):
+        ref = fftconv(x[s], h)[:x.shape[1]]
+        assert rms(y[s] - ref) < TOL, (s, rms(y[s] - ref))
