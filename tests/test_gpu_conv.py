@@ -340,3 +340,29 @@ def test_slab_direct_history_over_ragged_calls(amd, tmp_path, taps, cap):
     for s in range(S):
         ref = fftconv(x[s], h)[:x.shape[1]]
         assert rms(y[s] - ref) < TOL, (s, rms(y[s] - ref))
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("cfg", ["config3", "config5"])
+def test_convolver_configs_full_size_vs_real_reference(amd, tmp_path, cfg):
+    """BASELINE config 3 (256 x 8 ch, fir_p 65536: the slab-direct K1 at N = 2^18) and the config-5 stand-in (1024 x 2 ch,
+    hilbert -p 4095 feeding fir_p 131072) at full size, complete streams (run + drain), against the real reference."""
+    import torch
+    if cfg == "config3":
+        taps, S, C, B = 65536, 256, 8, 196608
+        chain = f"fir_p -t pcm -e double -c 1 {write(tmp_path, make_filter(taps))}"
+        want = "slab-direct"
+    else:
+        taps, S, C, B = 131072, 1024, 2, 131072
+        chain = f"hilbert -p 4095 fir_p -t pcm -e double -c 1 {write(tmp_path, make_filter(taps))}"
+        want = "fed-by-conv"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    assert want in b.plan(), b.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(13)
+    x = torch.rand((S, B + 30000, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = b.process(x, B)
+    for s in (1, S // 2, S - 1):
+        ref = RefChain(chain, 48000, C).process(x[s].cpu().numpy(), block=65536)
+        got = y[s].cpu().numpy()
+        assert ref.shape == got.shape, (ref.shape, got.shape)
+        assert rms(ref - got) < 1e-12, (s, rms(ref - got))
