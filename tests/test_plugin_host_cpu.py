@@ -1,0 +1,144 @@
+"""CPU-only: the effect objects this library hands to a host behave like the reference's through the parts of the plugin ABI
+that need no device -- init (argument parsing, NULL on error), flags, merge, prepare, channel_offsets, drain_samples,
+channel_deps -- checked call for call against the real reference's own objects (oracle/_ref/libdspref.so, effect.h:39-59)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle_api import RefChain
+
+pytestmark = pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+
+
+def _libs():
+    import dsp_amd
+    from dsp_amd.lib import Effect, StreamInfo, _EffectInfo, ssize_t
+    A = dsp_amd.load_library()
+    R = RefChain.lib()
+    R.get_effect_info.restype = C.POINTER(_EffectInfo)
+    R.get_effect_info.argtypes = [C.c_char_p]
+    return A, R, Effect, StreamInfo, _EffectInfo, ssize_t
+
+
+class Obj:
+    """one effect of one library, driven through its vtable"""
+
+    def __init__(self, lib, get_info, name, args, fs, channels, sel, Effect, StreamInfo, ssize_t):
+        self.Effect, self.ssize_t, self.ch = Effect, ssize_t, channels
+        ei = get_info(name.encode())
+        assert ei, name
+        init = C.CFUNCTYPE(C.POINTER(Effect), C.c_void_p, C.POINTER(StreamInfo), C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p))(ei.contents.init)
+        si = StreamInfo(fs, channels)
+        selb = bytes(1 if k in sel else 0 for k in range(channels))
+        argv = (C.c_char_p * (len(args) + 1))(name.encode(), *[a.encode() for a in args])
+        self.e = init(C.cast(ei, C.c_void_p), C.byref(si), selb, None, len(args) + 1, argv)
+        self.libc = C.CDLL(None)
+
+    def ok(self):
+        return bool(self.e)
+
+    def call_prepare(self):
+        p = self.e.contents.prepare
+        return C.CFUNCTYPE(C.c_int, C.POINTER(self.Effect))(p)(self.e) if p else 0
+
+    def merge(self, other):
+        m = self.e.contents.merge
+        return m(self.e, other.e) if m else 0
+
+    def offsets(self):
+        lat = (self.ssize_t * self.ch)(); req = (self.ssize_t * self.ch)()
+        f = self.e.contents.channel_offsets
+        if f:
+            f(self.e, lat, req)
+        return list(lat), list(req)
+
+    def drain(self):
+        d = (self.ssize_t * self.ch)()
+        f = self.e.contents.drain_samples
+        if f:
+            f(self.e, d)
+        return list(d)
+
+    def deps(self):
+        f = self.e.contents.channel_deps
+        if not f:
+            return None
+        rows = [(C.c_char * self.ch)() for _ in range(self.ch)]
+        for k in range(self.ch):
+            rows[k][k] = 1                                    # the host pre-sets identity (effects_chain.c:687-700)
+        ptrs = (C.c_void_p * self.ch)(*[C.addressof(r) for r in rows])
+        C.CFUNCTYPE(None, C.POINTER(self.Effect), C.c_void_p)(f)(self.e, ptrs)
+        return [[int(r[j] != b"\0") for j in range(self.ch)] for r in rows]
+
+    def has_run(self):
+        return bool(C.cast(self.e.contents.run, C.c_void_p).value)
+
+    def free(self):
+        if self.e:
+            if C.cast(self.e.contents.destroy, C.c_void_p).value:     # destroy_effect(), effect.c:78-85: all callbacks may be NULL
+                self.e.contents.destroy(self.e)
+            self.libc.free(self.e)
+            self.e = None
+
+
+def pair(name, args, fs=48000, channels=4, sel=None):
+    A, R, Effect, StreamInfo, _EffectInfo, ssize_t = _libs()
+    sel = set(range(channels)) if sel is None else set(sel)
+    a = Obj(A, A.dspamd_get_effect_info, name, args, fs, channels, sel, Effect, StreamInfo, ssize_t)
+    r = Obj(R, R.get_effect_info, name, args, fs, channels, sel, Effect, StreamInfo, ssize_t)
+    return a, r
+
+
+@pytest.mark.parametrize("args,sel", [
+    (["10S"], None), (["-3S"], [1]), (["1.5m"], [0, 2]),
+    (["-f", "0.3S"], None), (["-f1", "2.7S"], [0]), (["-f2", "7.25S"], [1, 3]), (["-f", "1.25m"], [0]), (["-f", "-2.5S"], [2]),
+])
+def test_delay_offsets_and_drain(args, sel):
+    a, r = pair("delay", args, sel=sel)
+    assert a.ok() and r.ok()
+    assert a.e.contents.flags == r.e.contents.flags
+    assert a.call_prepare() == r.call_prepare() == 0
+    assert a.offsets() == r.offsets()
+    assert a.drain() == r.drain()
+    a.free(); r.free()
+
+
+def test_delay_merge_adds_amounts_and_takes_the_highest_order():
+    objs = []
+    for args in (["3S"], ["-f1", "0.4S"], ["-f", "0.35S"]):
+        objs.append(pair("delay", args, channels=2))
+    (a0, r0), rest = objs[0], objs[1:]
+    for a, r in rest:
+        assert a0.merge(a) == r0.merge(r) == 1
+    assert a0.call_prepare() == r0.call_prepare() == 0
+    # 3 + 0.4 + 0.35 = 3.75 samples; orders max(0, 1, 0) = 1 (an explicit order beats the default of the others):
+    # integer part 3, first-order all-pass for 0.75, one more sample to drain
+    assert a0.offsets() == r0.offsets() == ([0, 0], [3, 3])
+    assert a0.drain() == r0.drain() == [1, 1]
+    for a, r in objs:
+        a.free(); r.free()
+
+
+@pytest.mark.parametrize("name,args,sel,good", [
+    ("st2ms", [], [0, 1], True), ("ms2st", [], [1, 3], True), ("st2ms", [], [0, 1, 2], False), ("st2ms", ["x"], [0, 1], False),
+    ("crossfeed", ["700", "4.5"], [0, 2], True), ("crossfeed", ["700"], [0, 2], False), ("crossfeed", ["700", "-1"], [0, 2], False),
+    ("crossfeed", ["30k", "3"], [0, 1], False),
+    ("delay", ["-f99", "1S"], None, False), ("delay", ["-f", "abc"], None, False), ("delay", [], None, False),
+])
+def test_pair_effects_init_and_deps(name, args, sel, good):
+    a, r = pair(name, args, sel=sel)
+    assert a.ok() == r.ok() == good
+    if good:
+        assert a.e.contents.flags == r.e.contents.flags
+        assert a.deps() == r.deps()
+        assert a.has_run() and r.has_run()
+    a.free(); r.free()
+
+
+def test_zero_delays_are_dropped_by_the_host():
+    # an effect that does nothing comes back with run == NULL and the host drops it (effects_chain.c:586-590)
+    for args in (["0S"], ["-f", "0S"]):
+        a, r = pair("delay", args)
+        assert a.ok() and r.ok() and not a.has_run() and not r.has_run()
+        a.free(); r.free()
