@@ -10,6 +10,8 @@ if len(sys.argv) > 4:   # optional tail, e.g. 'fir_p 40000' / 'fir_p 40000 resam
     taps = int(sys.argv[5]); rng = np.random.default_rng(1); h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / 5000.0) / 50
     f = tempfile.NamedTemporaryFile(suffix='.raw', delete=False); h.astype('<f8').tofile(f); f.close()
     chain += f' {sys.argv[4]} -t pcm -e double -c 1 {f.name} ' + ' '.join(sys.argv[6:])
+if os.environ.get('CHAIN'):   # whole chain from the environment instead
+    chain = os.environ['CHAIN']
 g = torch.Generator(device="cuda"); g.manual_seed(3)
 x = torch.rand((S, n, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
 outs = []
