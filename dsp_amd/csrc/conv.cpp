@@ -236,7 +236,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		if (ib >= 0) soc[sel_ch[ib]] = 2 * q + 1;
 		for (int s = 0; s < S; ++s) ph[(size_t) s * pps + q] = (n_filters == 1) ? 0 : q;
 	}
-	direct = !resampler && all_selected && n_filters == 1 && (ch_in % 2) == 0 && !round_f32 && lat == 0 && !getenv("DSP_AMD_CONV_NO_DIRECT");
+	direct = all_selected && n_filters == 1 && (ch_in % 2) == 0 && !round_f32 && lat == 0 && !getenv("DSP_AMD_CONV_NO_DIRECT");
 	if (!slot_of_channel.upload(soc.data(), soc.size() * sizeof(int))) return false;
 	if (!pair_h.upload(ph.data(), ph.size() * sizeof(int))) return false;
 	if (!pair_out_ch.upload(poc.data(), poc.size() * sizeof(int))) return false;
@@ -385,7 +385,7 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 		p.q_blk = q_blk;
 		p.k_origin = k_origin;
 		p.out_count = out_count;
-		if (cur_slab && !resampler) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; }
+		if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; p.slab_store = resampler ? 0 : 1; }
 		const int row_mode = (nph > 1) ? 2 : 0;
 		if (n_sub > 1) {
 			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
@@ -436,14 +436,30 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 	const bool use_direct = direct && !fed && ((((size_t) in) & 15) == 0) && (double) in_stride * ch_in * 8 < 1.0e18;
 	cur_slab = use_direct ? in : nullptr;
 	cur_slab_stride = in_stride;
-	cur_q0 = q_abs;
+	cur_q0 = resampler ? q_total : q_abs;
 	if (!fed && !use_direct) push(in, in_stride, frames, out, out_stride, st);
 	if (resampler) {
+		const long pos0 = pos;
 		pos = (pos + frames) & (ring_len - 1);
 		q_total += frames;
 		// full-rate outputs k with floor(k down / up) < q_total are computable: k < ceil(q_total up / down)
 		const long avail = std::max<long>(0, max_out_frames(q_total) - out_delay) - emitted;
-		return emit(std::min<long>(avail, max_out_frames(frames)), out, out_stride, st);
+		const ssize_t got = emit(std::min<long>(avail, max_out_frames(frames)), out, out_stride, st);
+		if (use_direct) {
+			// the windows of later calls (and of the drain) start at the next unemitted output's input index minus the history:
+			// only that tail of this call has to be in the ring
+			long keep_from = ((emitted + out_delay) * down) / up - first_n - 8;
+			if (merged_pre) keep_from = std::min(keep_from, q_total - (J_rs + down + first_n + 16));
+			const long off = std::max<long>(0, std::min<long>(frames, keep_from - cur_q0));
+			if (off < frames) {
+				const long sv = pos;
+				pos = (pos0 + off) & (ring_len - 1);
+				push(in + (size_t) off * ch_in, in_stride, frames - off, out, out_stride, st);
+				pos = sv;
+			}
+			cur_slab = nullptr;
+		}
+		return got;
 	}
 	// plain convolution: output frame m of this call = convolution at ring index pos + m
 	convolve(q_abs, q_abs + frames - 1, q_abs, frames, out, out_stride, st);
@@ -456,6 +472,7 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 ssize_t ConvStage::drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st)
 {
 	if (!resampler) return -1;
+	cur_slab = nullptr;
 	// total output length is ceil(N up / down) (resample.c:163-188): the tail is computed against zero input
 	const long left = max_out_frames(q_total) - emitted;
 	if (q_total == 0 || left <= 0) return -1;

@@ -15,11 +15,13 @@ struct ConvParams {
 	// The ring holds the complex sequence itself: (first channel of the pair, second channel or 0.0) per frame.
 	const double2 *ring;
 	long ring_row_stride, ring_mask, win_base, valid;
-	// K1 direct mode (slab != nullptr): the NEW frames of the window (n >= first_n) come straight from the interleaved input
-	// slab -- frame slab_frame0 + n - first_n of stream pair / pairs_per_stream, channels (2 q, 2 q + 1) -- instead of the
-	// ring, and K1 itself files the frames that later windows need (the last first_n of the block) in the ring
+	// K1 direct mode (slab != nullptr): every window element that lies in the CURRENT call's input -- slab frame
+	// fr = slab_frame0 + n - first_n >= 0 of stream pair / pairs_per_stream, channels (2 q, 2 q + 1) -- comes straight from
+	// the interleaved slab, older ones from the ring; with slab_store K1 itself files the frames that later windows need
+	// (the last first_n of the block) in the ring
 	const double *slab;
-	long slab_stride_frames, slab_frame0;
+	long slab_stride_frames, slab_frame0;   // slab frame of window element first_n (negative: the window starts in older calls)
+	int slab_store;                         // 1: K1 files the history itself (plain convolution); 0: the host pushes the tail of the call
 	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
 	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
 	double2 *W;                         // [pairs in chunk][N] work spectrum / time buffer

@@ -258,18 +258,21 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 	const cplx *src = p.ring + pair * p.ring_row_stride;
 	cplx v[16];
 	if (p.slab) {
-		// direct mode: history from the ring, new frames from the interleaved slab (16 bytes = the pair's two channels);
-		// frames that later windows look back at go into the ring on the way
+		// direct mode: what lies in the current call's input comes from the interleaved slab (16 bytes = the pair's two
+		// channels), older frames from the ring; with slab_store the frames that later windows look back at go into the ring
+		// on the way
 		cplx *ringw = const_cast<cplx *>(src);
 		const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
 		const cplx *slab = reinterpret_cast<const cplx *>(p.slab + ((size_t) s * p.slab_stride_frames + p.slab_frame0) * p.C) + qs;
-		const long hp = p.C >> 1, keep_from = (p.in_count > p.first_n) ? p.in_count : p.first_n;
+		const long hp = p.C >> 1;
+		const long keep_from = p.slab_store ? ((p.in_count > p.first_n) ? p.in_count : p.first_n) : p.N;
 #pragma unroll
 		for (int m = 0; m < 16; ++m) {
 			const long n = (long) (j + P * m) * p.N2 + n2;
+			const long fr = n - p.first_n;                        // slab frame relative to slab_frame0 (folded into `slab`)
 			if (n >= p.valid) v[m] = make_double2(0.0, 0.0);
-			else if (n >= p.first_n) {
-				v[m] = ld16(slab + (n - p.first_n) * hp, p.nt & 1);
+			else if (fr + p.slab_frame0 >= 0) {
+				v[m] = ld16(slab + fr * hp, p.nt & 1);
 				if (n >= keep_from) ringw[(p.win_base + n) & p.ring_mask] = v[m];
 			}
 			else v[m] = ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1);
