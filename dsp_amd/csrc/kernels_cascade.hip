@@ -633,7 +633,10 @@ __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, c
 				const double t = fix.nc4 * x0;
 				x0 = fma(fix.nc3, x0, x1);
 				x1 = t;
-				const double r = fma(c0, s, m0);
+				// three-address form by hand: left to itself the compiler accumulates r into m0's register (v_fmac) and then
+				// copies it to the tile register -- one v_mov_b64 per sample, 10 % of the section's instructions
+				double r;
+				asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(c0), "v"(s), "v"(m0));
 				m0 = fma(nc3, r, fma(c1, s, m1));
 				m1 = fma(nc4, r, c2 * s);
 				v[i] = r;
