@@ -348,11 +348,11 @@ __device__ __forceinline__ OpHead load_head(const double *__restrict__ od)
 // address -> scalar loads), cur: their first 64 bytes (fetched by the caller, one op ahead); q: LDS [n_ops][FQ_DOUBLES];
 // st: LDS [n_ops][2].  `fix` / `pending` carry the zero-input response that the NEXT op (or the caller, at the end) adds.
 template <int L>
-__device__ __forceinline__ void run_op_fast(double (&v)[L], const OpHead &cur, const double *__restrict__ od, const double *q, int j, double *st,
+__device__ __forceinline__ void run_op_fast(double (&v)[L], long long kind, const OpHead &cur, const double *__restrict__ od, const double *q, int j, double *st,
                                             int lane, PendingFix &fix, bool &pending)
 {
 	const int row = lane >> 4;
-	if (cur.kind == OP_BIQUAD) {
+	if (kind == OP_BIQUAD) {
 		// requested now, consumed after the recurrence that hides their latency
 		double Pw[16], P16[4];
 #pragma unroll
@@ -401,12 +401,12 @@ __device__ __forceinline__ void run_op_fast(double (&v)[L], const OpHead &cur, c
 		// state after the last lane's samples = the reference's (m0, m1) at that point
 		if (lane == 63) *reinterpret_cast<double2 *>(st + 2 * j) = make_double2(m0, m1);
 	}
-	else if (cur.kind == OP_MUL || cur.kind == OP_ADD) {
+	else if (kind == OP_MUL || kind == OP_ADD) {
 		if (pending) apply_fix<L>(v, fix);
 		fix.x0 = 0.0; fix.x1 = 0.0; fix.nc3 = 0.0; fix.nc4 = 0.0;
 		pending = false;
 		const double g = cur.g;
-		if (cur.kind == OP_MUL) {
+		if (kind == OP_MUL) {
 #pragma unroll
 			for (int i = 0; i < L; ++i) v[i] = __dmul_rn(v[i], g);
 		}
@@ -425,9 +425,12 @@ __device__ __forceinline__ void run_ops_fast(double (&v)[L], const double *__res
 	bool pending = false;            // wave-uniform: gain / add on their own stay single IEEE operations (no `+ 0.0`: keeps -0.0)
 	OpHead cur = load_head(cf + j_lo * FOP_DOUBLES);
 	for (int j = j_lo; j < j_hi; ++j) {
-		// next op's head: in flight during this op
-		const OpHead nxt = load_head(cf + ((j + 1 < j_hi) ? j + 1 : j) * FOP_DOUBLES);
-		run_op_fast<L>(v, cur, cf + j * FOP_DOUBLES, q, j, st, lane, fix, pending);
+		// the kind is looked at BEFORE the next head is requested: s_waitcnt cannot tell scalar loads apart, and a wait for
+		// `cur` behind that request would expose a scalar-load round trip in every op
+		const long long kind = cur.kind;
+		__builtin_amdgcn_sched_barrier(0);
+		const OpHead nxt = load_head(cf + ((j + 1 < j_hi) ? j + 1 : j) * FOP_DOUBLES);      // in flight during this op
+		run_op_fast<L>(v, kind, cur, cf + j * FOP_DOUBLES, q, j, st, lane, fix, pending);
 		cur = nxt;
 	}
 	if (pending) apply_fix<L>(v, fix);
@@ -965,8 +968,10 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 		PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
 		bool pending = false;
 		for (int j = 0; j < n_ops; ++j) {
+			const long long kind = cur.kind;                 // before the next head is requested (see run_ops_fast)
+			__builtin_amdgcn_sched_barrier(0);
 			const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
-			if (!(p.debug & 4)) run_op_fast<L>(x, cur, cf + j * FOP_DOUBLES, wq, j, cst, lane, fix, pending);
+			if (!(p.debug & 4)) run_op_fast<L>(x, kind, cur, cf + j * FOP_DOUBLES, wq, j, cst, lane, fix, pending);
 			cur = nxt;
 			if (j + 1 == n_ops) {
 				if (pending) apply_fix<L>(x, fix);
