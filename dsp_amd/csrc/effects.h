@@ -55,6 +55,9 @@ struct Spec {
 	std::vector<double> delay_frac;          // [ch_in] fractional amount still to be realised
 	std::vector<int> fd_ap_n;                // [ch_in] all-pass order (0 = default) / after prepare: order in use
 	bool frac_delay = false;                 // after prepare: a Biquad-kind spec that also requests delay[k] from the host
+	// further sections of the same effect (all-pass orders above 2 factor into several second-order sections): [section][ch]
+	std::vector<std::vector<std::array<double, 5>>> bq_more;
+	std::vector<Selector> sel_more;
 
 	std::vector<double> taps;                // FirDirect/Conv: [T][fch] interleaved
 	int fch = 0;

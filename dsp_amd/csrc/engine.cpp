@@ -469,6 +469,15 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 				pl->stages.emplace_back(casc);
 			}
 			casc->add(*sp);
+			for (size_t i = 0; i < sp->bq_more.size(); ++i) {           // the further sections of a high-order all-pass
+				merged.emplace_back(new Spec(*sp));
+				Spec &more = *merged.back();
+				more.bq = sp->bq_more[i];
+				more.sel = sp->sel_more[i];
+				more.bq_more.clear(); more.sel_more.clear();
+				more.name = sp->name + ":" + std::to_string(i + 2);
+				casc->add(more);
+			}
 			break;
 		case Kind::Delay:
 			break;   // realised by Align (delay.c:142-147, 195-202)

@@ -188,6 +188,13 @@ FRAC_DELAY_CHAINS = [
     (":0 delay -f1 0.2S :1 delay -f2 5.5S : delay -f 0.25S", 2),  # per-channel amounts and orders add up / take the maximum
     ("lowpass 2k 0.7 delay -f 10.5S gain -2", 2),               # the all-pass fuses into the biquad cascade
     (":1 delay -f -2.5S", 2),                                   # negative delay: the host delays the other channel
+    ("delay -f3 0.4S", 2),                                      # orders above 2: the reference's Thiran ladder (allpass.h:83-118) ...
+    (":0 delay -f5 2.3S : lowpass 3k 0.7", 3),                  # ... here factored into second-order all-pass sections
+    ("delay -f8 0.77S", 2),
+    (":0 delay -f4 1.5S :1 delay -f7 0.2S", 2),                 # different orders per channel: different numbers of sections
+    ("delay -f10 12.5S", 2),
+    ("delay -f24 0.3S", 2),
+    (":1 delay -f32 7.77S", 2),
 ]
 
 
@@ -207,9 +214,10 @@ def test_fractional_delay_vs_real_reference(amd, chain, ch):
     assert rms(y - ref) < 1e-13, rms(y - ref)
 
 
-def test_fractional_delay_order_above_two_refused(amd):
-    with pytest.raises(ValueError, match="order 3"):
-        amd.EffectsChain("delay -f3 0.5S", 48000, 2)
+def test_fractional_delay_very_high_order_refused(amd):
+    # the factorisation into second-order sections loses accuracy as the poles cluster: refused rather than wrong
+    with pytest.raises(ValueError, match="all-pass order 40"):
+        amd.EffectsChain("delay -f40 0.5S", 48000, 2)
 
 
 PAIR_CHAINS = [

@@ -93,6 +93,7 @@ def pair(name, args, fs=48000, channels=4, sel=None):
 @pytest.mark.parametrize("args,sel", [
     (["10S"], None), (["-3S"], [1]), (["1.5m"], [0, 2]),
     (["-f", "0.3S"], None), (["-f1", "2.7S"], [0]), (["-f2", "7.25S"], [1, 3]), (["-f", "1.25m"], [0]), (["-f", "-2.5S"], [2]),
+    (["-f3", "0.4S"], None), (["-f5", "2.3S"], [0, 1]), (["-f8", "0.77S"], [3]), (["-f10", "12.5S"], None),
 ])
 def test_delay_offsets_and_drain(args, sel):
     a, r = pair("delay", args, sel=sel)
