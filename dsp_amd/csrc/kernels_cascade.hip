@@ -653,18 +653,32 @@ __device__ __forceinline__ void run_op_rows(double (&v)[L], const OpHead &cur, c
 		if (pos == 0) { m0 = e0; m1 = e1; }
 		row_scan(m0, m1, Pw);
 		double lo0 = 0.0, lo1 = 0.0;
-		if (G == 2) {
-			// upper row of the channel: + Q[i] (end state of the lower row, which is final already).  Q is fetched here, not in
-			// front of the recurrence: 8 VGPRs less across it
+		if (G <= 2) {
+			// rows above the channel's first: + Q[i] (end state of the row below, which is final by then).  Q is fetched here, not
+			// in front of the recurrence: 8 VGPRs less across it
 			const double2 qa = *reinterpret_cast<const double2 *>(qrow + 4 * (pos & 15));
 			const double2 qb = *reinterpret_cast<const double2 *>(qrow + 4 * (pos & 15) + 2);
-			lo0 = bcast15_f64(m0, lane); lo1 = bcast15_f64(m1, lane);               // 0.0 in the lower rows
-			m0 = fma(qa.x, lo0, fma(qa.y, lo1, m0));
-			m1 = fma(qb.x, lo0, fma(qb.y, lo1, m1));
+			if (G == 2) {
+				lo0 = bcast15_f64(m0, lane); lo1 = bcast15_f64(m1, lane);           // 0.0 in the lower rows
+				m0 = fma(qa.x, lo0, fma(qa.y, lo1, m0));
+				m1 = fma(qb.x, lo0, fma(qb.y, lo1, m1));
+			}
+			else {
+				// one channel per wave: rows 1, 2, 3 in turn, each taking the finished end state of the row below it
+#pragma unroll
+				for (int r = 1; r < 4; ++r) {
+					const double e0 = readlane_f64(m0, 16 * r - 1), e1 = readlane_f64(m1, 16 * r - 1);
+					if ((lane >> 4) == r) {
+						lo0 = e0; lo1 = e1;
+						m0 = fma(qa.x, e0, fma(qa.y, e1, m0));
+						m1 = fma(qb.x, e0, fma(qb.y, e1, m1));
+					}
+				}
+			}
 		}
 		// incoming state of a lane = true state of the lane before it
 		double x0 = dpp_f64<DPP_ROW_SHR1>(m0), x1 = dpp_f64<DPP_ROW_SHR1>(m1);
-		if (G == 2 && pos == 16) { x0 = lo0; x1 = lo1; }
+		if (G <= 2 && (pos & 15) == 0 && pos > 0) { x0 = lo0; x1 = lo1; }
 		if (pos == 0) { x0 = xin.x; x1 = xin.y; }
 		fix.x0 = x0; fix.x1 = x1; fix.nc3 = nc3; fix.nc4 = nc4;
 		pending = true;
@@ -709,6 +723,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
 	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
 	constexpr int PARTNER = (G == 4) ? RW_ROW : 2 * RW_ROW;            // LDS distance between the two channels of a pair
+	// G = 1: one channel per wave -- 8-byte elements (32 per lane and tile), frame lane + 64 k at LDS lane + lane / 32 + 66 k
 	extern __shared__ __attribute__((aligned(16))) double smem[];
 	const int s = blockIdx.x;
 	const int c0 = p.cg0 + blockIdx.y * G;
@@ -716,20 +731,20 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // position in the wavefront
 	const int n_ops = p.n_ops;
 	double *st = smem;                                          // [G][n_ops][2]
-	double *qt = st + G * n_ops * 2;                            // [n_ops][16][4] (G = 2 only)
-	double *tb = qt + ((G == 2) ? n_ops * FQ_DOUBLES : 0) + (size_t) w * RW_TB;       // this wave's transposer
+	double *qt = st + G * n_ops * 2;                            // [n_ops][16][4] (G <= 2 only)
+	double *tb = qt + ((G <= 2) ? n_ops * FQ_DOUBLES : 0) + (size_t) w * RW_TB;       // this wave's transposer
 
 	const int n_st = G * n_ops * 2;
 	double *gstate = p.state + ((size_t) s * p.C + c0) * n_ops * 2;
 	for (int i = tid; i < n_st; i += nth) st[i] = gstate[i];
-	if (G == 2) for (int i = tid; i < n_ops * FQ_DOUBLES; i += nth) qt[i] = frq[(size_t) (c0 >> 1) * n_ops * FQ_DOUBLES + i];
+	if (G <= 2) for (int i = tid; i < n_ops * FQ_DOUBLES; i += nth) qt[i] = frq[(size_t) (c0 >> 1) * n_ops * FQ_DOUBLES + i];
 
 	const long n_full = p.frames / TILE;
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
 	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.in + (size_t) s * p.in_stride_frames * p.C + c0), 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t) s * p.out_stride_frames * p.C + c0, 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(
-		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) : p.out, 0, 0x7fffffff, RSRC_FLAGS);
+		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) + ((G == 1) ? (c0 & 1) : 0) : p.out, 0, 0x7fffffff, RSRC_FLAGS);
 	const bool has_ring = p.ring.base != nullptr;
 	const int ring_row_bytes = (int) (p.ring.row_stride * 16);
 	// slab order: slot k of a lane = (frame f0 + FPS k, pair pr).  G = 4: 64 lanes cover 32 frames x 2 pairs (32 contiguous
@@ -743,7 +758,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	// ring row.  (G = 2 has one pair: slab order is row order.)
 	double *tb_rows = tb + lane + (lane >> 5);                  // + rw_row_base(2 (k >> 3)) + 66 (k & 7)
 	const int ch = lane / LPC, pos = lane % LPC;                // this lane's channel inside the group and position in it
-	double *tb_lane = tb + rw_row_base<G>(ch) + pos * (L + 1);
+	double *tb_lane = tb + ((G == 1) ? 0 : rw_row_base<G>(ch)) + pos * (L + 1);
 	double *st_row = st + ch * n_ops * 2;
 	const double *__restrict__ cf = frows + (size_t) (c0 >> 1) * n_ops * FOP_DOUBLES;     // one entry per channel PAIR
 
@@ -759,14 +774,41 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 		for (int i = 0; i < w; ++i) lds_barrier();              // the skew: wave w starts at step w
 		steps = w;
 		if (w < n_full) {
-			double2 raw[K];
+			double2 raw[K];                                         // G = 1: 32 eight-byte elements, element k in raw[k >> 1]
 			double x[L];
+			auto load_raw = [&](long t) {
+				const int tbb = (int) t * tile_bytes;
+				if constexpr (G == 1) {
 #pragma unroll
-			for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_slab, w * tile_bytes + k * so_slab, 0));
+					for (int k = 0; k < 2 * K; ++k) {
+						const double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_in, vo_slab, tbb + k * so_slab, 0));
+						if (k & 1) raw[k >> 1].y = v; else raw[k >> 1].x = v;
+					}
+				}
+				else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_slab, tbb + k * so_slab, 0));
+				}
+			};
+			auto raw_to_tb = [&]() {
+				if constexpr (G == 1) {
+#pragma unroll
+					for (int k = 0; k < 2 * K; ++k) tb_rows[(64 + 64 / L) * k] = (k & 1) ? raw[k >> 1].y : raw[k >> 1].x;
+				}
+				else {
+#pragma unroll
+					for (int k = 0; k < K; ++k) { tb_slab[SLAB_K * k] = raw[k].x; tb_slab[SLAB_K * k + PARTNER] = raw[k].y; }
+				}
+			};
+			load_raw(w);
 			// results of tile t_out (lane-major in the transposer) -> HBM
 			const bool slab_order = p.write_interleaved || G == 2;
 			auto fetch_out = [&](double2 (&y)[K]) {
-				if (slab_order) {
+				if constexpr (G == 1) {
+#pragma unroll
+					for (int k = 0; k < 2 * K; ++k) { const double v = tb_rows[(64 + 64 / L) * k]; if (k & 1) y[k >> 1].y = v; else y[k >> 1].x = v; }
+				}
+				else if (slab_order) {
 #pragma unroll
 					for (int k = 0; k < K; ++k) y[k] = make_double2(tb_slab[SLAB_K * k], tb_slab[SLAB_K * k + PARTNER]);
 				}
@@ -780,6 +822,18 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 			};
 			auto store_out = [&](const double2 (&y)[K], long t_out) {
 				if (p.debug & 1) return;
+				if constexpr (G == 1) {
+					typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+					const int tbb = (int) t_out * tile_bytes;
+					const long e0 = p.ring.pos + t_out * TILE + lane;
+#pragma unroll
+					for (int k = 0; k < 2 * K; ++k) {
+						const u32x2 v = __builtin_bit_cast(u32x2, (k & 1) ? y[k >> 1].y : y[k >> 1].x);
+						if (p.write_interleaved) __builtin_amdgcn_raw_buffer_store_b64(v, r_out, vo_slab + tbb + k * so_slab, 0, 0);
+						if (has_ring) __builtin_amdgcn_raw_buffer_store_b64(v, r_ring, (int) ((e0 + 64 * k) & p.ring.mask) * 16, 0, 0);
+					}
+					return;
+				}
 				if (p.write_interleaved) {
 					const int tbb = (int) t_out * tile_bytes;
 #pragma unroll
@@ -804,8 +858,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// whole tile ago), and only then do the stores and the next tile's loads go out.
 				double2 y[K];
 				if (t > w) fetch_out(y);
-#pragma unroll
-				for (int k = 0; k < K; ++k) { tb_slab[SLAB_K * k] = raw[k].x; tb_slab[SLAB_K * k + PARTNER] = raw[k].y; }
+				raw_to_tb();
 				if (t > w) store_out(y, t - P);
 #pragma unroll
 				for (int i = 0; i < L; ++i) x[i] = tb_lane[i];
@@ -813,16 +866,9 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// scalar traffic (one counter) in front of every recurrence -- behind the requests that the recurrence should hide
 #pragma unroll
 				for (int i = 0; i < L; ++i) asm volatile("" : "+v"(x[i]));
-				if (!(p.debug & 2)) {
-					// unconditional (the last one re-reads this tile): a conditional load would have to select between old and
-					// new registers, which costs a wait right behind the loads
-					const int tb_next = (int) ((t + P < n_full) ? t + P : t) * tile_bytes;
-#pragma unroll
-					for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_slab, tb_next + k * so_slab, 0));
-				}
 				PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
 				bool pending = false;
-				for (int j = 0; j < n_ops; ++j) {
+				auto step = [&](int j) {
 					// the kind is looked at BEFORE the next head is requested: a wait for `cur` behind that request (s_waitcnt cannot
 					// tell scalar loads apart) would expose a scalar-load round trip in every step
 					const bool section = (cur.kind == OP_BIQUAD);
@@ -844,7 +890,12 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 						for (int i = 0; i < L; ++i) tb_lane[i] = x[i];
 					}
 					lds_barrier();       // (two sections per barrier were measured: no gain)
-				}
+				};
+				// The next tile's loads: unconditional (the last one re-reads this tile) -- a conditional load has to select between
+				// old and new registers, which costs a wait right behind the loads -- and at the boundary (issuing them one step
+				// later, to shorten the boundary step everybody waits for, was measured: slower for G = 1 and 2, no gain for 4)
+				if (!(p.debug & 2)) load_raw((t + P < n_full) ? t + P : t);
+				for (int j = 0; j < n_ops; ++j) step(j);
 				steps += n_ops;
 			}
 			{
@@ -867,7 +918,7 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	const long n_full = p.frames / TILE;
 	if (n_full < 1 || (p.C % G)) return 0;
 	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
-	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G == 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB) * sizeof(double);
+	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB) * sizeof(double);
 	if (lds > 160 * 1024) return 0;
 	static size_t granted = 0;
 	if (lds > granted) {
@@ -890,19 +941,15 @@ static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream
 	// 32-bit byte offsets inside one stream's slab / ring rows
 	if ((double) std::max(p.in_stride_frames, p.out_stride_frames) * p.C * 8 >= 2.0e9 || (double) p.ring.row_stride * 16 * (p.C / 2) >= 2.0e9) return 0;
 	// Four channels per wave when that still gives 2048 waves of at most 8 per group (what the LDS transposers allow), i.e.
-	// from 1024 channels; two per wave from 512 channels; below that a workgroup per channel pair no longer covers the CUs
-	// and cascade_wave (one channel per wave, up to 10 waves per channel) wins.  Measured, 10 sections, ms per launch at
-	// 32 / 64 / 128 / 256 streams x 8 ch:  wave 0.45 / 0.82 / 1.46 / -,  rows<2> 0.52 / 0.55 / 1.11 / 3.1,  rows<4> - / - / 1.0 / 2.0
+	// from 1024 channels; two per wave from 512 channels; one per wave (all four DPP rows, three sequential row carries,
+	// 8-byte elements) below that.  Measured, 10 sections, ms per launch at 32 / 64 / 128 / 256 streams x 8 ch: see DESIGN.md.
 	const long channels = (long) n_streams * p.C;
-	int G = (channels >= 1024 && p.rows4_ok) ? 4 : 2, P;
-	if (env > 0) { G = env / 100; P = env % 100; if (G == 4 && !p.rows4_ok) return 0; }
-	else {
-		if (channels < 512) return 0;
-		P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
-	}
+	int G = (channels >= 1024 && p.rows4_ok) ? 4 : (channels >= 512) ? 2 : 1, P;
+	if (env > 0) { G = env / 100; P = env % 100; if ((G == 4 && !p.rows4_ok) || (G != 4 && G != 2 && G != 1)) return 0; }
+	else P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
 	if (P > 8) P = 8;
 	if (P < 1) P = 1;
-	return (G == 4) ? try_launch_rows<4>(p, n_streams, P, stream) : try_launch_rows<2>(p, n_streams, P, stream);
+	return (G == 4) ? try_launch_rows<4>(p, n_streams, P, stream) : (G == 2) ? try_launch_rows<2>(p, n_streams, P, stream) : try_launch_rows<1>(p, n_streams, P, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
