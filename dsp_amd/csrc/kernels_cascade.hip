@@ -764,7 +764,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 
 	// the last tile's owner finishes last: wave wl after its tiles
 	const int wl = (int) ((n_full - 1) % P);
-	const long n_steps = wl + ((n_full - 1) / P + 1) * n_ops;
+	const long n_steps = wl + ((n_full - 1) / P + 1) * (n_ops + 1);
 	long steps = 0;
 	OpHead cur = load_head(cf);
 	__syncthreads();
@@ -857,7 +857,11 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// transposer, THEN this tile's loads are waited for (nothing else is in flight: the stores before them went out a
 				// whole tile ago), and only then do the stores and the next tile's loads go out.
 				double2 y[K];
-				if (t > w) fetch_out(y);
+				if (t > w) {
+#pragma unroll
+					for (int i = 0; i < L; ++i) tb_lane[i] = x[i];
+					fetch_out(y);
+				}
 				raw_to_tb();
 				if (t > w) store_out(y, t - P);
 #pragma unroll
@@ -886,8 +890,6 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 #pragma unroll
 							for (int i = 0; i < L; ++i) x[i] *= post;
 						}
-#pragma unroll
-						for (int i = 0; i < L; ++i) tb_lane[i] = x[i];
 					}
 					lds_barrier();       // (two sections per barrier were measured: no gain)
 				};
@@ -895,13 +897,19 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// old and new registers, which costs a wait right behind the loads -- and at the boundary (issuing them one step
 				// later, to shorten the boundary step everybody waits for, was measured: slower for G = 1 and 2, no gain for 4)
 				if (!(p.debug & 2)) load_raw((t + P < n_full) ? t + P : t);
+				// The tile traffic is a step of its own: inside a section step it made that step (which every wave of the group
+				// waits for) up to 1.8 x as long, and with P waves skewed by one step almost every step had one such wave.  As an
+				// (n_ops + 1)-th step it runs beside the other waves' sections and costs one step in n_ops + 1.
+				lds_barrier();
 				for (int j = 0; j < n_ops; ++j) step(j);
-				steps += n_ops;
+				steps += n_ops + 1;
 			}
 			{
 				// the last tile of this wave
 				const long t_last = w + ((n_full - 1 - w) / P) * P;
 				double2 y[K];
+#pragma unroll
+				for (int i = 0; i < L; ++i) tb_lane[i] = x[i];
 				fetch_out(y);
 				store_out(y, t_last);
 			}
@@ -1000,7 +1008,7 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 
 	// the last tile's owner finishes last: wave wl after its tiles
 	const int wl = (int) ((n_full - 1) % P);
-	const long n_steps = wl + ((n_full - 1) / P + 1) * n_ops;
+	const long n_steps = wl + ((n_full - 1) / P + 1) * (n_ops + 1);
 	long steps = 0;                                                  // barriers passed so far (every wave passes n_steps of them)
 	OpHead cur = load_head(cf);
 	__syncthreads();
