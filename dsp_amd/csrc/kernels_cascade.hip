@@ -11,7 +11,7 @@
 //                  channels with identical sections (the headline kernel)
 //   cascade_wave   a wave = 1 channel, 16 frames per lane, time axis shared by up to 10 skewed waves -- few channels
 //   cascade_fast   a wave = 1 channel, cooperative workgroup I/O -- per-channel coefficients, add, unselected channels
-//   cascade_kernel generic: any channel count, remainders shorter than a tile, L = 1 tail steps
+//   cascade_kernel generic: any channel count, remainders shorter than a tile (L = 4 and L = 1 tail steps)
 //
 // Math.  One TDF-II section with x = (m0, m1):
 //     r[n] = c0 s[n] + m0[n],   x[n+1] = A x[n] + B s[n],   A = [[-c3, 1], [-c4, 0]]
@@ -249,7 +249,18 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 				for (int i = 0; i < L16; ++i) row[lane * (L16 + 1) + i] = v[i];
 			}
 			else {
-				for (int t1 = 0; t1 < nfr; t1 += 64) {
+				// whole groups of 256 frames as L = 4 steps (a step costs about the same whatever L is: the scans dominate), the
+				// rest as L = 1 steps that can be cut at any sample
+				int t1 = 0;
+				for (; t1 + 256 <= nfr; t1 += 256) {
+					double v[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) v[i] = row[lds_index(t1 + 4 * lane + i)];
+					run_ops<4, OPL_DOUBLES, 8 + 4 * 2>(v, ops, p.n_ops, cst, lane, 63);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) row[lds_index(t1 + 4 * lane + i)] = v[i];
+				}
+				for (; t1 < nfr; t1 += 64) {
 					const int t = t1 + lane;
 					const int nvalid = min(64, nfr - t1);
 					double v[1];

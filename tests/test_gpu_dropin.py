@@ -106,7 +106,7 @@ def test_registered_host_buffers(tmp_path):
     rng = np.random.Generator(np.random.PCG64(79))
     x = rng.uniform(-0.3, 0.3, size=(40000, 2))
     xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
-    env = dict(os.environ, DSP_AMD_PLUGIN_PIN="1", DSP_AMD_LOGLEVEL="4")
+    env = dict(os.environ, DSP_AMD_PLUGIN_PIN="1", DSP_AMD_PLUGIN_MAPPED_KB="0", DSP_AMD_LOGLEVEL="4")   # (no mapped staging: the copy path)
     for chain, tol in ((f"gain -3 {BIQ}", 1e-12), ("hilbert -p 1023 :1 gain -2 : resample 44.1k", 1e-11)):
         ro, go = os.path.join(str(tmp_path), "r.raw"), os.path.join(str(tmp_path), "g.raw")
         args = ["-q", "-t", "pcm", "-e", "double", "-r", "48k", "-c", "2", xin, "-o", "-t", "pcm", "-e", "double"]
