@@ -21,6 +21,7 @@ struct dspamd_batch {
 struct dspamd_chain {
 	dspamd_batch *b = nullptr;
 	DevBuf d_in, d_out;
+	MappedPair mapped;
 	ssize_t cap = 0, out_cap = 0;
 };
 
@@ -141,6 +142,7 @@ dspamd_chain *dspamd_chain_build(const char *chain_str, int fs, int channels, co
 		dspamd_chain_destroy(c);
 		return nullptr;
 	}
+	c->mapped.alloc();
 	if (out_fs) *out_fs = b->pipe->fs_out;
 	if (out_channels) *out_channels = b->pipe->ch_out;
 	return c;
@@ -150,6 +152,15 @@ ssize_t dspamd_chain_run(dspamd_chain *c, const double *in, ssize_t frames, doub
 {
 	const int ci = c->b->pipe->ch_in, co = c->b->pipe->ch_out;
 	ssize_t done = 0, produced = 0;
+	if (frames > 0 && frames <= c->cap && c->mapped.fits((size_t) frames * ci * sizeof(double), (size_t) c->b->pipe->max_out_frames(frames) * co * sizeof(double))) {
+		// small block: no copy commands (engine.h, MappedPair)
+		memcpy(c->mapped.in, in, (size_t) frames * ci * sizeof(double));
+		const ssize_t f = dspamd_batch_run(c->b, c->mapped.in, frames, c->mapped.out, (ssize_t) (c->mapped.bytes / (co * sizeof(double))), nullptr);
+		if (!hip_ok(hipStreamSynchronize(nullptr), "sync") || f < 0) return -1;
+		if (f > out_capacity_frames) { set_error("chain_run: output capacity exceeded"); return -1; }
+		if (f > 0) memcpy(out, c->mapped.out, (size_t) f * co * sizeof(double));
+		return f;
+	}
 	while (done < frames) {
 		const ssize_t nb = std::min(frames - done, c->cap);
 		if (!hip_ok(hipMemcpy(c->d_in.p, in + done * ci, (size_t) nb * ci * sizeof(double), hipMemcpyHostToDevice), "H2D")) return -1;

@@ -71,6 +71,25 @@ bool DevBuf::alloc(size_t n, bool zero)
 	return true;
 }
 
+void MappedPair::alloc()
+{
+	static const long kb = [] { const char *v = getenv("DSP_AMD_PLUGIN_MAPPED_KB"); return v ? atol(v) : 32L; }();
+	if (kb <= 0 || bytes) return;
+	void *a = nullptr, *b = nullptr;
+	if (hipHostMalloc(&a, (size_t) kb << 10, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&b, (size_t) kb << 10, hipHostMallocDefault) == hipSuccess) {
+		in = static_cast<double *>(a); out = static_cast<double *>(b); bytes = (size_t) kb << 10;
+		return;
+	}
+	(void) hipGetLastError();
+	if (a) (void) hipHostFree(a);
+}
+
+MappedPair::~MappedPair()
+{
+	if (in) (void) hipHostFree(in);
+	if (out) (void) hipHostFree(out);
+}
+
 bool DevBuf::upload(const void *src, size_t n)
 {
 	if (!alloc(n, false)) return false;

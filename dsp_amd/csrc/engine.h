@@ -26,6 +26,21 @@ struct DevBuf {
 	template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// Small host blocks (LADSPA hosts: 64 ... 1024 frames): two page-locked, device-mapped staging buffers that the first kernel
+// reads and the last kernel writes over PCIe directly -- no copy commands, one launch sequence and one wait per call.  Measured
+// (DESIGN.md section 6): faster than H2D / D2H copy commands up to a few tens of KB per block, slower at 128 KB; the limit is
+// DSP_AMD_PLUGIN_MAPPED_KB (default 32, 0 = off).
+struct MappedPair {
+	double *in = nullptr, *out = nullptr;
+	size_t bytes = 0;                           // of each; 0 = not available
+	MappedPair() = default;
+	MappedPair(const MappedPair &) = delete;
+	MappedPair &operator=(const MappedPair &) = delete;
+	~MappedPair();
+	void alloc();                               // failure just leaves bytes == 0
+	bool fits(size_t in_bytes, size_t out_bytes) const { return bytes && in_bytes <= bytes && out_bytes <= bytes; }
+};
+
 // Optional per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on
 // (bench.py's roofline object).  Off by default; when on, every launch site brackets itself.
 struct Profiler {

@@ -73,21 +73,7 @@ static bool ensure_segment(struct effect *e, Node *n)
 	seg->out_cap_frames = seg->pipe->max_out_frames(cap);
 	if (!seg->d_in.alloc((size_t) cap * seg->ch_in * sizeof(double), false) ||
 	    !seg->d_out.alloc((size_t) seg->out_cap_frames * seg->ch_out * sizeof(double), false)) { seg->pipe.reset(); return false; }
-	{
-		static const long mapped_kb = [] { const char *v = getenv("DSP_AMD_PLUGIN_MAPPED_KB"); return v ? atol(v) : 32L; }();   // measured: faster than copy commands up to a few tens of KB, slower at 128 KB
-		if (mapped_kb > 0) {
-			seg->h_bytes = (size_t) mapped_kb << 10;
-			void *a = nullptr, *b = nullptr;
-			if (hipHostMalloc(&a, seg->h_bytes, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&b, seg->h_bytes, hipHostMallocDefault) == hipSuccess) {
-				seg->h_in = static_cast<double *>(a); seg->h_out = static_cast<double *>(b);
-			}
-			else {
-				(void) hipGetLastError();
-				if (a) (void) hipHostFree(a);
-				seg->h_bytes = 0;
-			}
-		}
-	}
+	seg->mapped.alloc();
 	if (seg->members.size() > 1) log_msg(LL_VERBOSE, "%s: info: %zu effects fused into one device segment: %s", e->name, seg->members.size(), seg->pipe->plan().c_str());
 	return true;
 }
@@ -149,12 +135,7 @@ bool Segment::pinned(int which, const void *p, size_t n)
 	return true;
 }
 
-Segment::~Segment()
-{
-	unpin_all();
-	if (h_in) (void) hipHostFree(h_in);
-	if (h_out) (void) hipHostFree(h_out);
-}
+Segment::~Segment() { unpin_all(); }
 
 static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, sample_t *obuf)
 {
@@ -174,12 +155,12 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	// for once; with registered host buffers the copies are asynchronous DMA, with pageable ones they simply block
 	const size_t in_bytes = (size_t) total * sg.ch_in * sizeof(double);
 	const size_t out_bytes = (size_t) sg.pipe->max_out_frames(total) * sg.ch_out * sizeof(double);
-	if (sg.h_in && total <= sg.pipe_frames && in_bytes <= sg.h_bytes && out_bytes <= sg.h_bytes) {
+	if (total <= sg.pipe_frames && sg.mapped.fits(in_bytes, out_bytes)) {
 		// small block: the kernels work on the mapped staging buffers themselves
-		memcpy(sg.h_in, ibuf, in_bytes);
-		const ssize_t f = sg.pipe->run(sg.h_in, total, sg.h_out, (ssize_t) (sg.h_bytes / (sg.ch_out * sizeof(double))), nullptr);
+		memcpy(sg.mapped.in, ibuf, in_bytes);
+		const ssize_t f = sg.pipe->run(sg.mapped.in, total, sg.mapped.out, (ssize_t) (sg.mapped.bytes / (sg.ch_out * sizeof(double))), nullptr);
 		(void) hip_ok(hipStreamSynchronize(nullptr), "sync");
-		if (f > 0) memcpy(dst, sg.h_out, (size_t) f * sg.ch_out * sizeof(double));
+		if (f > 0) memcpy(dst, sg.mapped.out, (size_t) f * sg.ch_out * sizeof(double));
 		*frames = f < 0 ? 0 : f;
 		return dst;
 	}

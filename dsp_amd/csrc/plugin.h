@@ -20,11 +20,7 @@ struct Segment {
 	int ch_in = 0, ch_out = 0;
 	bool in_place = true;
 	DevBuf d_in, d_out;
-	// Small blocks (LADSPA hosts: 64 ... 1024 frames, up to 32 KB by default): two page-locked, device-mapped staging buffers
-	// that the first kernel reads and the last kernel writes over PCIe directly -- no copy commands, one launch sequence and one
-	// wait per run().  nullptr = not available (allocation failed or DSP_AMD_PLUGIN_MAPPED_KB=0).
-	double *h_in = nullptr, *h_out = nullptr;
-	size_t h_bytes = 0;
+	MappedPair mapped;                       // staging for small blocks (engine.h)
 	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the
 	// HIP runtime after a few sightings: the copies then run as DMA instead of through the runtime's pageable-memory staging.
 	struct Pin { char *base; size_t bytes; };
