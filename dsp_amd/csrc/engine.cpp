@@ -160,6 +160,9 @@ bool CascadeStage::finalize()
 		for (int j = 0; j < n_ops; ++j)
 			host[(size_t) c * n_ops + j] = cols[j][c];
 	if (!ops.upload(host.data(), host.size() * sizeof(OpDesc))) return false;
+	host_ops = host;
+	chunk_linear = true;
+	for (const OpDesc &od : host) if (od.kind == OP_ADD) chunk_linear = false;
 	// tables of the fast kernel: wave-uniform constants (scalar loads) and per-lane carry matrices
 	{
 		std::vector<double> tab((size_t) ch_in * n_ops * FOP_DOUBLES, 0.0), q((size_t) ch_in * n_ops * FQ_DOUBLES, 0.0);
@@ -258,6 +261,100 @@ std::string CascadeStage::describe() const
 	return o.str();
 }
 
+// K chunks of len frames each, or false: not worth it / not possible.  The chunks must be whole tiles of whichever kernel
+// launch_cascade will pick for S K C channels (cascade_rows<4>: 512 frames, <2>: 1024, <1>: 2048; cascade_wave / _fast: 1024).
+bool CascadeStage::choose_chunks(long frames, int *K_out, long *len_out) const
+{
+	static const int env = [] { const char *e = getenv("DSP_AMD_CASCADE_CHUNKS"); return e ? atoi(e) : -1; }();   // 0 = never, K = force
+	const long channels = (long) S * ch_in;
+	const int D = 2 * n_ops;
+	if (env == 0 || !chunk_linear || n_ops < 1 || D > 64) return false;
+	if (env < 0 && (channels > 512 || frames < 8192)) return false;
+	const long k_target = (env > 0) ? env : (2048 + channels - 1) / channels;
+	for (long unit : { 512L, 1024L, 2048L }) {
+		if (frames % unit) continue;
+		const long f = frames / unit;
+		long K = 1;
+		auto scan_fits = [&](long k) {                      // cascade_chunk_carry: K D doubles of LDS, (groups x D) threads
+			long g = 1;
+			while (g * g < k) ++g;
+			return k * D <= 8192 && ((k + g - 1) / g) * D <= 1024;
+		};
+		for (long k = std::min(f, k_target); k >= 1; --k) if (f % k == 0 && scan_fits(k)) { K = k; break; }
+		if (K < 4) continue;
+		const long len = frames / K, V = channels * K;
+		const long tile = (V >= 1024 && rows4_ok) ? 512 : frows.p ? (V >= 512 ? 1024 : 2048) : 1024;
+		if (len % tile) continue;
+		if ((double) len * D * sizeof(double) * ch_in > 256e6) continue;
+		*K_out = (int) K; *len_out = len;
+		return true;
+	}
+	return false;
+}
+
+// M (state after len frames of silence, per unit state) and H (the outputs on the way) by running the sections themselves,
+// in extended precision; channels with identical ops share one table
+bool CascadeStage::build_chunk_plan(long frames, int K, long len)
+{
+	const int D = 2 * n_ops;
+	std::vector<int> cls(ch_in, -1);
+	std::vector<int> rep;
+	auto same = [&](int a, int b) {
+		for (int j = 0; j < n_ops; ++j) {
+			const OpDesc &x = host_ops[(size_t) a * n_ops + j], &y = host_ops[(size_t) b * n_ops + j];
+			if (x.kind != y.kind || x.g != y.g || memcmp(x.c, y.c, sizeof(x.c)) != 0) return false;
+		}
+		return true;
+	};
+	for (int c = 0; c < ch_in; ++c) {
+		for (size_t r = 0; r < rep.size() && cls[c] < 0; ++r) if (same(rep[r], c)) cls[c] = (int) r;
+		if (cls[c] < 0) { cls[c] = (int) rep.size(); rep.push_back(c); }
+	}
+	int n_pow = 1;                                         // scan group size g = ceil(sqrt(K)): tables M, M^2 .. M^g
+	while (n_pow * n_pow < K) ++n_pow;
+	std::vector<double> H(rep.size() * (size_t) len * D, 0.0), Mp(rep.size() * (size_t) n_pow * D * D, 0.0);
+	std::vector<long double> M((size_t) D * D), T((size_t) D * D), st(D);
+	for (size_t r = 0; r < rep.size(); ++r) {
+		const OpDesc *od = &host_ops[(size_t) rep[r] * n_ops];
+		std::fill(M.begin(), M.end(), 0.0L);
+		for (int k = 0; k < D; ++k) {
+			if (od[k / 2].kind != OP_BIQUAD) continue;          // gains carry no state: zero column
+			std::fill(st.begin(), st.end(), 0.0L);
+			st[k] = 1.0L;
+			for (long i = 0; i < len; ++i) {
+				long double v = 0.0L;
+				for (int j = 0; j < n_ops; ++j) {
+					if (od[j].kind == OP_MUL) { v *= (long double) od[j].g; continue; }
+					if (od[j].kind != OP_BIQUAD) continue;
+					const long double y = (long double) od[j].c[0] * v + st[2 * j];                                  // biquad.h:76-92
+					st[2 * j] = (long double) od[j].c[1] * v - (long double) od[j].c[3] * y + st[2 * j + 1];
+					st[2 * j + 1] = (long double) od[j].c[2] * v - (long double) od[j].c[4] * y;
+					v = y;
+				}
+				H[(r * (size_t) len + i) * D + k] = (double) v;
+			}
+			for (int q = 0; q < D; ++q) M[(size_t) q * D + k] = st[q];
+		}
+		std::vector<long double> Pw = M;                       // M^(pw + 1)
+		for (int pw = 0; pw < n_pow; ++pw) {
+			for (size_t e = 0; e < Pw.size(); ++e) Mp[((r * (size_t) n_pow + pw) * D * D) + e] = (double) Pw[e];
+			for (int a = 0; a < D; ++a)
+				for (int b = 0; b < D; ++b) {
+					long double acc = 0.0L;
+					for (int k = 0; k < D; ++k) acc += Pw[(size_t) a * D + k] * M[(size_t) k * D + b];
+					T[(size_t) a * D + b] = acc;
+				}
+			Pw = T;
+		}
+	}
+	chunk.frames = 0;
+	if (!chunk.cls.upload(cls.data(), cls.size() * sizeof(int)) || !chunk.H.upload(H.data(), H.size() * sizeof(double)) ||
+	    !chunk.Mp.upload(Mp.data(), Mp.size() * sizeof(double)) ||
+	    !chunk.cstate.alloc((size_t) S * K * ch_in * D * sizeof(double)) || !chunk.X.alloc((size_t) S * K * ch_in * D * sizeof(double))) return false;
+	chunk.frames = frames; chunk.len = len; chunk.K = K; chunk.n_pow = n_pow; chunk.n_cls = (int) rep.size();
+	return true;
+}
+
 ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
 	CascadeParams p;
@@ -276,6 +373,28 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
 	{ static const char *dbg = getenv("DSP_AMD_CASCADE_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
+	int K = 0;
+	long len = 0;
+	const bool plan_now = (last_frames == frames) || (double) frames * S * ch_in >= 1048576.0;    // (tables + allocations: about a millisecond)
+	last_frames = frames;
+	if (!ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) &&
+	    (chunk.frames == frames || (plan_now && choose_chunks(frames, &K, &len)))) {
+		if (chunk.frames != frames && !build_chunk_plan(frames, K, len)) return -1;
+		// S K zero-state "streams" of len frames, then the carried states and the correction
+		p.frames = chunk.len;
+		p.in_stride_frames = p.out_stride_frames = chunk.len;
+		p.state = chunk.cstate.as<double>();
+		(void) hipMemsetAsync(chunk.cstate.p, 0, chunk.cstate.bytes, st);
+		{ ProfScope ps("cascade_kernel", st); ps.rename(launch_cascade(p, S * chunk.K, st)); }
+		ChunkParams cp;
+		cp.out = out; cp.out_stride_frames = out_stride; cp.len = chunk.len;
+		cp.C = ch_in; cp.K = chunk.K; cp.D = 2 * n_ops; cp.n_pow = chunk.n_pow; cp.n_cls = chunk.n_cls;
+		cp.cls = chunk.cls.as<int>(); cp.H = chunk.H.as<double>(); cp.Mp = chunk.Mp.as<double>();
+		cp.cstate = chunk.cstate.as<double>(); cp.X = chunk.X.as<double>(); cp.state = state.as<double>();
+		{ ProfScope ps("cascade_chunk_carry", st); launch_chunk_carry(cp, S, st); }
+		{ ProfScope ps("cascade_chunk_fix", st); launch_chunk_fix(cp, S, st); }
+		return frames;
+	}
 	{ ProfScope ps("cascade_kernel", st); ps.rename(launch_cascade(p, S, st)); }
 	if (ring.base) ring.pos = (ring.pos + frames) & ring.mask;
 	return frames;

@@ -108,6 +108,8 @@ private:
 // kernel launchers (kernels_*.hip)
 size_t cascade_lds_bytes(int Cg, int n_ops);
 const char *launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream);   // returns the name of the kernel that took the block
+void launch_chunk_carry(const ChunkParams &p, int n_streams, hipStream_t stream);
+void launch_chunk_fix(const ChunkParams &p, int n_streams, hipStream_t stream);
 void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream);
 void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream);
 void launch_copy_slab(const double *in, long in_stride, double *out, long out_stride, long frames, long skip, int C, int n_streams, hipStream_t stream);

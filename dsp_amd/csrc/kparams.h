@@ -67,6 +67,19 @@ struct CascadeParams {
 	int debug;                           // experiment switches (DSP_AMD_CASCADE_DEBUG): 1 = no stores, 2 = no reloads
 };
 
+// chunked cascade (kernels_chunk.hip): a call of K * len frames run as K zero-state chunks + carry + correction
+struct ChunkParams {
+	double *out;                         // [S][out_stride][C], holds the zero-state outputs
+	long out_stride_frames, len;
+	int C, K, D, n_pow, n_cls;           // D = 2 n_ops state variables per channel
+	const int *cls;                      // [C] table index of the channel (channels with identical ops share tables)
+	const double *H;                     // [n_cls][len][D] zero-input response at frame i to unit state k
+	const double *Mp;                    // [n_cls][n_pow][D][D] M^(j+1), j = 0 .. n_pow-1 (n_pow = scan group size g); M = state transition over len frames
+	const double *cstate;                // [S K][C][D] end states of the zero-state chunks
+	double *X;                           // [S K][C][D] true state at the start of every chunk
+	double *state;                       // [S][C][D] carried state: in = before the call, out = after it
+};
+
 // ---- pointwise kernels ----
 struct RemixParams {
 	const double *in; double *out;

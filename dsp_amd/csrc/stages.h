@@ -24,6 +24,13 @@ private:
 	std::vector<std::string> names;
 	DevBuf ops, state, fops, fq, frows, frq;
 	bool rows4_ok = false;
+	// few channels, long calls: the time axis is cut into K chunks that run as independent zero-state "streams" (kernels_chunk.hip)
+	std::vector<OpDesc> host_ops;            // [C][n_ops]
+	bool chunk_linear = false;               // sections and gains only (an `add` is not linear in the state)
+	struct ChunkPlan { long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X; } chunk;
+	long last_frames = 0;                    // a plan is built for a call size seen twice in a row, or big enough to pay at once
+	bool choose_chunks(long frames, int *K, long *len) const;
+	bool build_chunk_plan(long frames, int K, long len);
 };
 
 class RemixStage : public Stage {

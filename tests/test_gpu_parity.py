@@ -300,3 +300,42 @@ def test_effects_files_vs_real_reference(amd, tmp_path):
     assert rms(y - ref) < 1e-13, rms(y - ref)
     with pytest.raises(ValueError, match="failed to load effects file"):
         amd.EffectsChain("@nope.fx", 48000, 2, directory=str(d))
+
+
+@pytest.mark.parametrize("S,C,N,gains", [(1, 8, 196608, False), (1, 8, 98304, True), (3, 2, 65536, False), (1, 1, 40960, True)])
+def test_few_channels_chunked_cascade(amd, S, C, N, gains):
+    # few channels, long calls (BASELINE config 2: ONE 8-channel stream): the time axis is cut into K chunks that run as
+    # independent zero-state streams, then cascade_chunk_carry / cascade_chunk_fix put the carried states back
+    # (kernels_chunk.hip).  Two calls: the state at the end of the first is the start of the second.
+    import torch
+    chain = ("gain -3 lowpass 3k 0.707 highshelf 8k 0.7 -3 mult 1.25 eq 300 1.5 4 eq 60 2.0 -2.5 highpass 30 0.707 gain 2" if gains else
+             "lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 eq 800 1.0 -1 eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    rng = np.random.Generator(np.random.PCG64(515))
+    x = rng.uniform(-0.5, 0.5, size=(S, 2 * N, C))
+    b = amd.BatchChain(chain, 48000, C, S, N)
+    L = amd.load_library()
+    L.dspamd_profile_enable(1)
+    y = b.process(torch.from_numpy(x).cuda(), N).cpu().numpy()
+    names = {ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()}
+    L.dspamd_profile_enable(0)
+    assert "cascade_chunk_fix" in names and "cascade_chunk_carry" in names, names
+    for s in range(S):
+        ref, _ = oracle_chain.run(chain, x[s], 48000)
+        assert y[s].shape == ref.shape
+        assert rms(y[s] - ref) < TOL, (s, rms(y[s] - ref))
+
+
+def test_chunked_cascade_not_used_with_add(amd):
+    # `add` is not linear in the state: the ordinary kernels run
+    import torch
+    chain = "lowpass 1k 0.707 add 0.001 eq 300 1.5 4"
+    x = np.random.Generator(np.random.PCG64(516)).uniform(-0.5, 0.5, size=(1, 131072, 2))
+    b = amd.BatchChain(chain, 48000, 2, 1, 65536)
+    L = amd.load_library()
+    L.dspamd_profile_enable(1)
+    y = b.process(torch.from_numpy(x).cuda(), 65536).cpu().numpy()
+    names = {ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()}
+    L.dspamd_profile_enable(0)
+    assert "cascade_chunk_fix" not in names, names
+    ref, _ = oracle_chain.run(chain, x[0], 48000)
+    assert rms(y[0] - ref) < TOL
