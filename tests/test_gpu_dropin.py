@@ -116,3 +116,27 @@ def test_registered_host_buffers(tmp_path):
         ref, gpu = np.fromfile(ro).reshape(-1, 2), np.fromfile(go).reshape(-1, 2)
         assert ref.shape == gpu.shape, (chain, ref.shape, gpu.shape)
         assert rms(ref - gpu) < tol, (chain, rms(ref - gpu))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_chains_cli(tmp_path, seed):
+    # the generator of tests/test_gpu_fuzz.py through the PLUGIN path: the reference's own chain runtime (parser, merge /
+    # optimise, auto-inserted align effects, drain) driving this library's effects, against the stock CLI
+    from test_gpu_fuzz import gen_chain
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    channels = int(rng.choice([1, 2, 2, 3, 4, 6]))
+    chain = gen_chain(rng, channels)
+    x = rng.uniform(-0.5, 0.5, size=(int(rng.integers(3000, 20000)), channels))
+    xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
+    in_args = ["-b", str(int(rng.choice([512, 2048, 4096]))), "-t", "pcm", "-e", "double", "-r", "48k", "-c", str(channels), xin]
+    outs = []
+    for exe, tag in ((REF, "ref"), (GPU, "gpu")):
+        o = os.path.join(str(tmp_path), f"out_{tag}.raw")
+        r = subprocess.run([exe, "-q"] + in_args + ["-o", "-t", "pcm", "-e", "double", o] + chain.split(),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        outs.append((r.returncode, np.fromfile(o) if r.returncode == 0 else None))
+    assert outs[0][0] == outs[1][0], (chain, outs[0][0], outs[1][0])
+    if outs[0][0] == 0:
+        ref, gpu = outs[0][1], outs[1][1]
+        assert ref.shape == gpu.shape, (chain, ref.shape, gpu.shape)
+        assert rms(ref - gpu) <= 1e-10 * max(rms(ref), 1e-3), (chain, rms(ref - gpu))

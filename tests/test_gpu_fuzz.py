@@ -1,0 +1,118 @@
+"""Seeded random effects chains through the stand-alone host path (`EffectsChain`: chain parser -> merge/optimise -> fused
+device pipeline) against the REAL reference's chain runtime in-process (oracle/_ref/libdspref.so) on the same input, with
+different call sizes on the two sides.  The generator draws from every effect this library provides -- all biquad types and
+width units, time-reversed sections, gains, remix, integer / fractional delays, direct and FFT FIRs, hilbert, resample,
+mid/side, crossfeed -- under random channel selections; what the reference refuses must be refused here too."""
+import numpy as np
+import pytest
+
+from oracle_api import RefChain, rms
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")]
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import dsp_amd
+    assert dsp_amd.load_library().dspamd_device_count() >= 1, "no HIP device: GPU tests must fail loudly, not fall back"
+    return dsp_amd
+
+
+def gen_chain(rng, channels):
+    """-> (chain text, output channels known so far)"""
+    ch, fs, out = channels, 48000, []
+
+    def f0(lo=30.0, hi=9000.0):
+        return "%.6g" % float(np.exp(rng.uniform(np.log(lo), np.log(min(hi, 0.4 * fs)))))
+
+    def width(shelf=False):
+        k = rng.integers(0, 5 if shelf else 4)
+        if k == 0: return "%.4g" % rng.uniform(0.3, 4.0)
+        if k == 1: return "%.4gq" % rng.uniform(0.3, 4.0)
+        if k == 2: return "%.4go" % rng.uniform(0.2, 3.0)
+        if k == 3: return "%.4gh" % rng.uniform(20.0, 400.0)
+        return "%.4g%s" % ((rng.uniform(0.3, 1.0), "s") if rng.integers(2) else (rng.uniform(3.0, 12.0), "d"))
+
+    def db():
+        return "%.4g" % rng.uniform(-9.0, 6.0)
+
+    def coefs(n, decay):
+        h = rng.standard_normal(n) * np.exp(-np.arange(n) / decay)
+        return "coefs:" + ",".join("%.17g" % v for v in h / np.sqrt(np.sum(h * h)) / 3)
+
+    def selector():
+        nonlocal out
+        if ch < 2 or rng.integers(3) == 0:
+            out.append(":")
+            return list(range(ch))
+        k = int(rng.integers(1, ch))
+        sel = sorted(rng.choice(ch, size=k, replace=False).tolist())
+        out.append(":" + ",".join(str(c) for c in sel))
+        return sel
+
+    n_sel = ch
+    for _ in range(int(rng.integers(2, 9))):
+        if rng.integers(4) == 0:
+            n_sel = len(selector())
+        r = rng.integers(0, 100)
+        rev = " -r" if rng.integers(8) == 0 else ""
+        if r < 8: out.append(f"gain {db()}")
+        elif r < 11: out.append("mult %.5g" % rng.uniform(-1.5, 1.5))
+        elif r < 13: out.append("add %.3g" % rng.uniform(-1e-3, 1e-3))
+        elif r < 22: out.append(f"{rng.choice(['lowpass', 'highpass', 'bandpass_skirt', 'bandpass_peak', 'notch', 'allpass'])}{rev} {f0()} {width()}")
+        elif r < 32: out.append(f"eq{rev} {f0()} {width()} {db()}")
+        elif r < 38: out.append(f"{rng.choice(['lowshelf', 'highshelf'])}{rev} {f0(80, 6000)} {width(True)} {db()}")
+        elif r < 43: out.append(f"{rng.choice(['lowpass_1', 'highpass_1', 'allpass_1', 'lowpass_1p'])} {f0()}")
+        elif r < 46: out.append(f"{rng.choice(['lowshelf_1', 'highshelf_1'])} {f0()} {db()}")
+        elif r < 48: out.append(f"linkwitz_transform {f0(40, 120)} 0.9 {f0(20, 60)} 0.6")
+        elif r < 50: out.append("deemph")
+        elif r < 52: out.append("biquad 0.5 0.2 -0.1 1.0 -0.3 0.2")
+        elif r < 58:
+            out.append("delay %dS" % rng.integers(0, 300) if rng.integers(3) else "delay %.4gm" % rng.uniform(0.05, 3.0))
+        elif r < 63: out.append("delay -f%s %.5gS" % (rng.choice(["", "1", "2", "5"]), rng.uniform(0.05, 40.0)))
+        elif r < 69: out.append(f"fir {coefs(int(rng.integers(2, 33)), 6.0)}")                # direct form
+        elif r < 74: out.append(f"{rng.choice(['fir', 'fir_p'])} {coefs(int(rng.integers(40, 700)), 90.0)}")
+        elif r < 77: out.append("hilbert%s %d" % (rng.choice(["", " -p"]), 2 * int(rng.integers(20, 300)) + 1))
+        elif r < 82 and fs == 48000:
+            new = int(rng.choice([44100, 96000, 24000, 32000]))
+            out.append(":"); n_sel = ch
+            out.append(f"resample {new}")
+            fs = new
+        elif r < 88:
+            out.append(":"); n_sel = ch
+            k = int(rng.integers(1, 5))
+            rows = []
+            for _ in range(k):
+                m = int(rng.integers(0, min(ch, 3) + 1))
+                rows.append(",".join(str(c) for c in sorted(rng.choice(ch, size=m, replace=False).tolist())) if m else ".")
+            out.append("remix " + " ".join(rows))
+            ch = n_sel = k
+        elif r < 94 and n_sel == 2:
+            out.append(str(rng.choice(["st2ms", "ms2st"])))
+        elif r < 100 and n_sel == 2:
+            out.append("crossfeed %s %.3g" % (f0(300, 1200), rng.uniform(2.0, 9.0)))
+        else:
+            out.append(f"eq {f0()} 1.0 {db()}")
+    return " ".join(out)
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_random_chain_vs_real_reference(amd, seed):
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    channels = int(rng.choice([1, 2, 2, 3, 4, 6]))
+    chain = gen_chain(rng, channels)
+    n = int(rng.integers(3000, 20000))
+    x = rng.uniform(-0.5, 0.5, size=(n, channels))
+    try:
+        ref = RefChain(chain, 48000, channels)
+    except ValueError:
+        with pytest.raises(ValueError):
+            amd.EffectsChain(chain, 48000, channels)
+        return
+    yr = ref.process(x, block=int(rng.choice([512, 2048, 4096])))
+    ec = amd.EffectsChain(chain, 48000, channels)
+    y = ec.process(x, block=int(rng.choice([333, 1024, 2048, 5000])))
+    assert (ec.ofs, ec.ochannels) == (ref.ofs, ref.ochannels), chain
+    assert y.shape == yr.shape, (chain, y.shape, yr.shape)
+    scale = max(rms(yr), 1e-3)
+    assert rms(y - yr) <= 1e-10 * scale, (chain, rms(y - yr), scale)
