@@ -116,3 +116,29 @@ def test_random_chain_vs_real_reference(amd, seed):
     assert y.shape == yr.shape, (chain, y.shape, yr.shape)
     scale = max(rms(yr), 1e-3)
     assert rms(y - yr) <= 1e-10 * scale, (chain, rms(y - yr), scale)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_chain_batch_vs_real_reference(amd, seed):
+    # the same generator through the BATCH path (S independent streams in one fused pipeline, buffers resident in HBM): many
+    # streams reach the kernels that share the chip differently (cascade_rows / _wave / _fast, chunked cascade, batched FFTs)
+    import torch
+    rng = np.random.Generator(np.random.PCG64(11000 + seed))
+    channels = int(rng.choice([2, 4, 8]))
+    S = int(rng.choice([3, 40, 130, 260]))
+    chain = gen_chain(rng, channels)
+    block = int(rng.choice([2048, 4096, 8192]))
+    n = block * int(rng.integers(1, 4)) + int(rng.integers(0, block))
+    x = rng.uniform(-0.5, 0.5, size=(S, n, channels))
+    try:
+        RefChain(chain, 48000, channels)
+    except ValueError:
+        with pytest.raises(ValueError):
+            amd.BatchChain(chain, 48000, channels, S, block)
+        return
+    b = amd.BatchChain(chain, 48000, channels, S, block)
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    for s in sorted({0, S // 2, S - 1}):
+        yr = RefChain(chain, 48000, channels).process(x[s], block=2048)
+        assert y[s].shape == yr.shape, (chain, s, y[s].shape, yr.shape)
+        assert rms(y[s] - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain, s, rms(y[s] - yr))
