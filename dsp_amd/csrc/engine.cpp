@@ -161,8 +161,10 @@ bool CascadeStage::finalize()
 			host[(size_t) c * n_ops + j] = cols[j][c];
 	if (!ops.upload(host.data(), host.size() * sizeof(OpDesc))) return false;
 	host_ops = host;
-	chunk_linear = true;
-	for (const OpDesc &od : host) if (od.kind == OP_ADD) chunk_linear = false;
+	// (a chain of gains alone stays bit-exact on the ordinary path; the correction pass would turn -0.0 into +0.0)
+	bool has_add = false, has_section = false;
+	for (const OpDesc &od : host) { if (od.kind == OP_ADD) has_add = true; if (od.kind == OP_BIQUAD) has_section = true; }
+	chunk_linear = has_section && !has_add;
 	// tables of the fast kernel: wave-uniform constants (scalar loads) and per-lane carry matrices
 	{
 		std::vector<double> tab((size_t) ch_in * n_ops * FOP_DOUBLES, 0.0), q((size_t) ch_in * n_ops * FQ_DOUBLES, 0.0);

@@ -18,8 +18,8 @@ def amd():
     return dsp_amd
 
 
-def gen_chain(rng, channels):
-    """-> (chain text, output channels known so far)"""
+def gen_chain(rng, channels, cascade_only=False):
+    """-> chain text; cascade_only: sections and gains under channel selections, nothing else"""
     ch, fs, out = channels, 48000, []
 
     def f0(lo=30.0, hi=9000.0):
@@ -54,8 +54,9 @@ def gen_chain(rng, channels):
     for _ in range(int(rng.integers(2, 9))):
         if rng.integers(4) == 0:
             n_sel = len(selector())
-        r = rng.integers(0, 100)
-        rev = " -r" if rng.integers(8) == 0 else ""
+        r = rng.integers(0, 52) if cascade_only else rng.integers(0, 100)
+        if cascade_only and 11 <= r < 13: r = 0            # (`add` is not linear in the state: the chunked cascade steps aside)
+        rev = " -r" if rng.integers(8) == 0 and not cascade_only else ""
         if r < 8: out.append(f"gain {db()}")
         elif r < 11: out.append("mult %.5g" % rng.uniform(-1.5, 1.5))
         elif r < 13: out.append("add %.3g" % rng.uniform(-1e-3, 1e-3))
@@ -142,3 +143,28 @@ def test_random_chain_batch_vs_real_reference(amd, seed):
         yr = RefChain(chain, 48000, channels).process(x[s], block=2048)
         assert y[s].shape == yr.shape, (chain, s, y[s].shape, yr.shape)
         assert rms(y[s] - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain, s, rms(y[s] - yr))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_cascade_chunked_vs_real_reference(amd, seed):
+    # few channels, long calls, sections and gains only: the chunked cascade (kernels_chunk.hip) on random section sets,
+    # channel selections (several table classes) and call sizes; three calls, so the carried state crosses call boundaries
+    import torch
+    rng = np.random.Generator(np.random.PCG64(13000 + seed))
+    channels = int(rng.choice([1, 2, 4, 8]))
+    S = int(rng.choice([1, 1, 2, 5]))
+    chain = gen_chain(rng, channels, cascade_only=True)
+    block = 2048 * int(rng.integers(4, 33))               # (whole tiles of every cascade kernel: a chunk plan always exists)
+    x = rng.uniform(-0.5, 0.5, size=(S, 3 * block, channels))
+    b = amd.BatchChain(chain, 48000, channels, S, block)
+    L = amd.load_library()
+    L.dspamd_profile_enable(1)
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    names = {ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()}
+    L.dspamd_profile_enable(0)
+    if any(t[0].isalpha() and t not in ("gain", "mult") for t in chain.split()):     # at least one section
+        assert "cascade_chunk_fix" in names, (chain, block, names)
+    for s in sorted({0, S - 1}):
+        yr = RefChain(chain, 48000, channels).process(x[s], block=2048)
+        assert y[s].shape == yr.shape, (chain, s, y[s].shape, yr.shape)
+        assert rms(y[s] - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain, s, block, rms(y[s] - yr))
