@@ -18,8 +18,9 @@ def amd():
     return dsp_amd
 
 
-def gen_chain(rng, channels, cascade_only=False):
-    """-> chain text; cascade_only: sections and gains under channel selections, nothing else"""
+def gen_chain(rng, channels, cascade_only=False, extended=False):
+    """-> chain text; cascade_only: sections and gains under channel selections, nothing else; extended: more exotic arguments
+    (odd resampling ratios and bandwidths, one filter per channel, hilbert angles, high all-pass orders)"""
     ch, fs, out = channels, 48000, []
 
     def f0(lo=30.0, hi=9000.0):
@@ -70,14 +71,21 @@ def gen_chain(rng, channels, cascade_only=False):
         elif r < 52: out.append("biquad 0.5 0.2 -0.1 1.0 -0.3 0.2")
         elif r < 58:
             out.append("delay %dS" % rng.integers(0, 300) if rng.integers(3) else "delay %.4gm" % rng.uniform(0.05, 3.0))
-        elif r < 63: out.append("delay -f%s %.5gS" % (rng.choice(["", "1", "2", "5"]), rng.uniform(0.05, 40.0)))
+        elif r < 63: out.append("delay -f%s %.5gS" % (rng.choice(["", "1", "2", "5", "9", "16"] if extended else ["", "1", "2", "5"]), rng.uniform(0.05, 40.0)))
         elif r < 69: out.append(f"fir {coefs(int(rng.integers(2, 33)), 6.0)}")                # direct form
-        elif r < 74: out.append(f"{rng.choice(['fir', 'fir_p'])} {coefs(int(rng.integers(40, 700)), 90.0)}")
-        elif r < 77: out.append("hilbert%s %d" % (rng.choice(["", " -p"]), 2 * int(rng.integers(20, 300)) + 1))
+        elif r < 74:
+            if extended and n_sel > 1 and rng.integers(2):                                     # one filter per selected channel, ragged lengths
+                per = "/".join(coefs(int(rng.integers(3, 200)), 40.0)[6:] for _ in range(n_sel))
+                out.append(f"{rng.choice(['fir', 'fir_p'])} coefs:{per}")
+            else:
+                out.append(f"{rng.choice(['fir', 'fir_p'])} {coefs(int(rng.integers(40, 700)), 90.0)}")
+        elif r < 77:
+            opt = rng.choice(["", " -p", " -a 45", " -p -a -30"]) if extended else rng.choice(["", " -p"])
+            out.append("hilbert%s %d" % (opt, 2 * int(rng.integers(20, 300)) + 1))
         elif r < 82 and fs == 48000:
-            new = int(rng.choice([44100, 96000, 24000, 32000]))
+            new = int(rng.choice([44100, 96000, 24000, 32000, 16000, 88200, 37800, 22050, 47999] if extended else [44100, 96000, 24000, 32000]))
             out.append(":"); n_sel = ch
-            out.append(f"resample {new}")
+            out.append(f"resample {'0.9 ' if extended and rng.integers(3) == 0 else ''}{new}")
             fs = new
         elif r < 88:
             out.append(":"); n_sel = ch
@@ -168,3 +176,25 @@ def test_random_cascade_chunked_vs_real_reference(amd, seed):
         yr = RefChain(chain, 48000, channels).process(x[s], block=2048)
         assert y[s].shape == yr.shape, (chain, s, y[s].shape, yr.shape)
         assert rms(y[s] - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain, s, block, rms(y[s] - yr))
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_chain_extended_vs_real_reference(amd, seed):
+    # more exotic arguments: odd resampling ratios (47999: 47999/48000) and bandwidths, one filter per selected channel with
+    # ragged lengths, hilbert phase angles, all-pass orders up to 16
+    rng = np.random.Generator(np.random.PCG64(17000 + seed))
+    channels = int(rng.choice([1, 2, 2, 3, 4]))
+    chain = gen_chain(rng, channels, extended=True)
+    x = rng.uniform(-0.5, 0.5, size=(int(rng.integers(3000, 12000)), channels))
+    try:
+        ref = RefChain(chain, 48000, channels)
+    except ValueError:
+        with pytest.raises(ValueError):
+            amd.EffectsChain(chain, 48000, channels)
+        return
+    yr = ref.process(x, block=int(rng.choice([512, 2048, 4096])))
+    ec = amd.EffectsChain(chain, 48000, channels)
+    y = ec.process(x, block=int(rng.choice([333, 1024, 2048, 5000])))
+    assert (ec.ofs, ec.ochannels) == (ref.ofs, ref.ochannels), chain
+    assert y.shape == yr.shape, (chain[:300], y.shape, yr.shape)
+    assert rms(y - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain[:300], rms(y - yr))
