@@ -198,3 +198,35 @@ def test_random_chain_extended_vs_real_reference(amd, seed):
     assert (ec.ofs, ec.ochannels) == (ref.ofs, ref.ochannels), chain
     assert y.shape == yr.shape, (chain[:300], y.shape, yr.shape)
     assert rms(y - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain[:300], rms(y - yr))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_chain_ragged_calls(amd, seed):
+    # calls of any size, one after the other (a LADSPA host's 1 ... 1024 frames, then a big one): the stream the calls add up
+    # to must not depend on how it was cut -- carried states, convolver rings, resampler phases, mapped-staging vs copy path
+    rng = np.random.Generator(np.random.PCG64(19000 + seed))
+    channels = int(rng.choice([1, 2, 2, 3, 4]))
+    chain = gen_chain(rng, channels, extended=bool(seed & 1))
+    n = int(rng.integers(4000, 16000))
+    x = rng.uniform(-0.5, 0.5, size=(n, channels))
+    try:
+        ref = RefChain(chain, 48000, channels)
+    except ValueError:
+        with pytest.raises(ValueError):
+            amd.EffectsChain(chain, 48000, channels)
+        return
+    yr = ref.process(x, block=2048)
+    ec = amd.EffectsChain(chain, 48000, channels)
+    outs, p = [], 0
+    while p < n:
+        k = int(rng.choice([1, 2, 7, 64, 100, 256, 1000, 1024, 3000, 5000]))
+        outs.append(ec.run(x[p:p + k]))
+        p += k
+    while True:
+        o = ec.drain(2048)
+        if o is None:
+            break
+        outs.append(o)
+    y = np.concatenate([o for o in outs if o.shape[0]]) if any(o.shape[0] for o in outs) else np.zeros((0, ec.ochannels))
+    assert y.shape == yr.shape, (chain[:300], y.shape, yr.shape)
+    assert rms(y - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain[:300], rms(y - yr))
