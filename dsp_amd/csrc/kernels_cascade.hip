@@ -734,6 +734,10 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
 	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
 	constexpr int PARTNER = (G == 4) ? RW_ROW : 2 * RW_ROW;            // LDS distance between the two channels of a pair
+	// the tile traffic of a wave is one step of its sequence (see the main loop).  (Two steps for G = 1 -- results out in one,
+	// the new tile in in the next -- were measured: 0.452 against 0.432 ms at 32 streams.  What G = 1 pays for is not the length
+	// of that step but the 8-byte accesses themselves: each of the 8 channel groups of a stream touches every 64-byte frame.)
+	constexpr int IO_STEPS = 1;
 	// G = 1: one channel per wave -- 8-byte elements (32 per lane and tile), frame lane + 64 k at LDS lane + lane / 32 + 66 k
 	extern __shared__ __attribute__((aligned(16))) double smem[];
 	const int s = blockIdx.x;
@@ -775,7 +779,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 
 	// the last tile's owner finishes last: wave wl after its tiles
 	const int wl = (int) ((n_full - 1) % P);
-	const long n_steps = wl + ((n_full - 1) / P + 1) * (n_ops + 1);
+	const long n_steps = wl + ((n_full - 1) / P + 1) * (n_ops + IO_STEPS);
 	long steps = 0;
 	OpHead cur = load_head(cf);
 	__syncthreads();
@@ -913,7 +917,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// (n_ops + 1)-th step it runs beside the other waves' sections and costs one step in n_ops + 1.
 				lds_barrier();
 				for (int j = 0; j < n_ops; ++j) step(j);
-				steps += n_ops + 1;
+				steps += n_ops + IO_STEPS;
 			}
 			{
 				// the last tile of this wave
@@ -1019,7 +1023,7 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 
 	// the last tile's owner finishes last: wave wl after its tiles
 	const int wl = (int) ((n_full - 1) % P);
-	const long n_steps = wl + ((n_full - 1) / P + 1) * (n_ops + 1);
+	const long n_steps = wl + ((n_full - 1) / P + 1) * n_ops;
 	long steps = 0;                                                  // barriers passed so far (every wave passes n_steps of them)
 	OpHead cur = load_head(cf);
 	__syncthreads();
