@@ -88,3 +88,35 @@ def test_ladspa_frontend_matches_reference_build(tmp_path, label, n_in, n_out, b
     diff = np.abs(ref.astype(np.float64) - gpu.astype(np.float64))
     assert float(np.max(diff)) <= 1.5 * np.spacing(np.float32(np.max(np.abs(ref)))), float(np.max(diff))
     assert np.count_nonzero(diff) <= 1e-3 * diff.size, np.count_nonzero(diff)
+
+
+@needs_builds
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_ladspa_random_chains(tmp_path, seed):
+    # the generator of tests/test_gpu_fuzz.py (without rate changes: the LADSPA build has no resample) as plugin configs
+    from oracle_api import RefChain
+    from test_gpu_fuzz import gen_chain
+    rng = np.random.Generator(np.random.PCG64(23000 + seed))
+    channels = int(rng.choice([1, 2, 2, 3, 4]))
+    while True:
+        chain = gen_chain(rng, channels)
+        if "resample" not in chain: break
+    try:
+        n_out = RefChain(chain, 48000, channels).ochannels
+    except ValueError:
+        pytest.skip("chain refused by the reference")
+    cfg = str(tmp_path)
+    with open(os.path.join(cfg, "config_fuzz"), "w") as f:
+        f.write(f"input_channels={channels}\noutput_channels={n_out}\neffects_chain={chain}\n")
+    x = rng.uniform(-0.5, 0.5, size=(int(rng.integers(5000, 20000)), channels)).astype(np.float32)
+    fin = os.path.join(cfg, "in.npy"); np.save(fin, x)
+    blocks = str(rng.choice(["64", "256,1000", "1024", "128,1,512"]))
+    _, ref = host(REF, cfg, "ladspa_dsp:fuzz", blocks, fin, os.path.join(cfg, "ref.npy"))
+    _, gpu = host(GPU, cfg, "ladspa_dsp:fuzz", blocks, fin, os.path.join(cfg, "gpu.npy"))
+    assert ref.shape == gpu.shape == (x.shape[0], n_out)
+    diff = np.abs(ref.astype(np.float64) - gpu.astype(np.float64))
+    assert float(np.max(diff)) <= 1.5 * np.spacing(np.float32(max(float(np.max(np.abs(ref))), 1e-3))), (chain[:200], float(np.max(diff)))
+    # (no count of differing floats here: in the quiet tails of time-reversed sections 1e-13 absolute is more than half an ulp)
+    ref_rms = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    assert float(np.sqrt(np.mean(diff ** 2))) <= 2e-8 * max(ref_rms, 1e-3), (chain[:200], float(np.sqrt(np.mean(diff ** 2))), ref_rms)
