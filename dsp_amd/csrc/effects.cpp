@@ -669,6 +669,7 @@ struct FirOpts {
 	const char *type = nullptr, *enc = nullptr;
 	int channels = 0;
 	bool big_endian = false;
+	bool fs_given = false;           // -r fs (not `any`): a container's own rate must then match (fir_util.c:103-109)
 };
 
 // option grammar of fir_util.c:122-185 ("a::t:e:BLNr:c:")
@@ -696,6 +697,7 @@ static bool parse_fir_opts(const char *name, const stream_info *is, GetOpt &g, i
 				if (bad_endptr(name, g.arg, end, "sample rate")) return false;
 				if (fs <= 0) { set_error("%s: error: sample rate must be > 0", name); return false; }
 				if (fs != is->fs) { set_error("%s: error: sample rate mismatch: stream_fs=%d requested_fs=%ld", name, is->fs, fs); return false; }
+				o.fs_given = true;
 			}
 			break;
 		case 'c':
@@ -711,8 +713,70 @@ static bool parse_fir_opts(const char *name, const stream_info *is, GetOpt &g, i
 	return true;
 }
 
-// fir_util.c:25-120.  "coefs:a,b,c/d,e,f" literals, or a raw PCM file (-t pcm -e double|float|s32|s24|s16, -c N).
-// Container formats (wav/flac/...) go through libsndfile/ffmpeg in the reference and are not available here.
+// RIFF/WAVE filter files (the usual export of room-correction tools).  The reference reads them through libsndfile
+// (codec.c:83, sndfile.c: sf_readf_double with libsndfile's default normalisation), i.e. integer PCM divided by 2^(bits-1),
+// unsigned 8-bit as (v - 128) / 128, float and double as stored; channel count and rate are the file's.  Formats: PCM
+// 8/16/24/32 bit, IEEE float 32/64 bit, plain and WAVE_FORMAT_EXTENSIBLE headers, little-endian RIFF.
+static bool read_wav(const char *name, const std::string &path, const std::vector<unsigned char> &raw, std::vector<double> &data, int *fch, ssize_t *T, int *fs)
+{
+	auto u16 = [&](size_t o) { return (unsigned) raw[o] | ((unsigned) raw[o + 1] << 8); };
+	auto u32 = [&](size_t o) { return (uint32_t) raw[o] | ((uint32_t) raw[o + 1] << 8) | ((uint32_t) raw[o + 2] << 16) | ((uint32_t) raw[o + 3] << 24); };
+	if (raw.size() < 12 || memcmp(&raw[0], "RIFF", 4) != 0 || memcmp(&raw[8], "WAVE", 4) != 0) {
+		set_error("%s: error: not a RIFF/WAVE file: %s", name, path.c_str());
+		return false;
+	}
+	unsigned tag = 0, channels = 0, bits = 0, align = 0;
+	size_t d_off = 0, d_len = 0;
+	bool have_fmt = false;
+	for (size_t o = 12; o + 8 <= raw.size();) {
+		const size_t len = u32(o + 4), body = o + 8;
+		if (memcmp(&raw[o], "fmt ", 4) == 0 && len >= 16 && body + 16 <= raw.size()) {
+			tag = u16(body); channels = u16(body + 2); *fs = (int) u32(body + 4); align = u16(body + 12); bits = u16(body + 14);
+			if (tag == 0xFFFE && len >= 26 && body + 26 <= raw.size()) tag = u16(body + 24);    // extensible: first word of the sub-format GUID
+			have_fmt = true;
+		}
+		else if (memcmp(&raw[o], "data", 4) == 0) {
+			d_off = body;
+			d_len = std::min(len, raw.size() - body);      // (streamed files carry 0xFFFFFFFF here)
+			break;
+		}
+		o = body + len + (len & 1);
+	}
+	const unsigned bytes = bits / 8;
+	if (!have_fmt || !d_off || channels < 1 || (tag != 1 && tag != 3) || bits % 8 || align != channels * bytes ||
+	    (tag == 1 && (bytes < 1 || bytes > 4)) || (tag == 3 && bytes != 4 && bytes != 8)) {
+		set_error("%s: error: unsupported WAVE format (PCM 8/16/24/32 bit and IEEE float 32/64 bit are read): %s", name, path.c_str());
+		return false;
+	}
+	const size_t n = d_len / bytes / channels * channels;
+	*fch = (int) channels;
+	*T = (ssize_t) (n / channels);
+	data.resize(n);
+	for (size_t i = 0; i < n; ++i) {
+		const unsigned char *b = &raw[d_off + i * bytes];
+		if (tag == 3) {
+			if (bytes == 4) { float v; memcpy(&v, b, 4); data[i] = (double) v; }
+			else { double v; memcpy(&v, b, 8); data[i] = v; }
+		}
+		else if (bytes == 1) data[i] = ((int) b[0] - 128) / 128.0;
+		else {
+			int32_t v = 0;
+			for (unsigned k = 0; k < bytes; ++k) v |= (int32_t) ((uint32_t) b[k] << (8 * (k + 4 - bytes)));   // left-justified in 32 bits
+			data[i] = (double) v / 2147483648.0;
+		}
+	}
+	return true;
+}
+
+static bool has_wav_ext(const std::string &path)
+{
+	const size_t dot = path.rfind('.');
+	return dot != std::string::npos && (strcasecmp(path.c_str() + dot, ".wav") == 0 || strcasecmp(path.c_str() + dot, ".wavex") == 0);
+}
+
+// fir_util.c:25-120.  "coefs:a,b,c/d,e,f" literals, a raw PCM file (-t pcm -e double|float|s32|s24|s16, -c N), or a RIFF/WAVE
+// file (-t wav | wavex | sndfile, or no -t and a .wav / .wavex name: codec.c:83, 200-211).  The other containers libsndfile /
+// ffmpeg give the reference (flac, aiff, ...) are not read.
 static bool read_filter(const char *name, const stream_info *is, const char *sel, const char *dir, const FirOpts &o, const char *spec,
 	std::vector<double> &data, int *fch, ssize_t *T)
 {
@@ -759,11 +823,12 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 		return true;
 	}
 	if (strncmp(spec, "file:", 5) == 0) spec += 5;
-	if (!o.type || strcmp(o.type, "pcm") != 0) {
-		set_error("%s: error: only raw filter files are supported by the GPU backend (use -t pcm -e double -c N): %s", name, spec);
+	std::string path = full_path(dir, spec, is->fs, num_set(copy_sel(sel, is->channels)));   // fir_util.c:85
+	const bool wav = o.type ? (!strcmp(o.type, "wav") || !strcmp(o.type, "wavex") || !strcmp(o.type, "sndfile")) : has_wav_ext(path);
+	if (!wav && (!o.type || strcmp(o.type, "pcm") != 0)) {
+		set_error("%s: error: filter files are read as raw PCM (-t pcm -e double -c N) or RIFF/WAVE (.wav): %s", name, spec);
 		return false;
 	}
-	std::string path = full_path(dir, spec, is->fs, num_set(copy_sel(sel, is->channels)));   // fir_util.c:85
 	FILE *f = fopen(path.c_str(), "rb");
 	if (!f) { set_error("%s: error: failed to open filter file: %s", name, path.c_str()); return false; }
 	fseek(f, 0, SEEK_END);
@@ -772,6 +837,16 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 	std::vector<unsigned char> raw(sz > 0 ? sz : 0);
 	if (sz > 0 && fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); set_error("%s: error: read failed: %s", name, path.c_str()); return false; }
 	fclose(f);
+	if (wav) {
+		int file_fs = 0;
+		if (!read_wav(name, path, raw, data, fch, T, &file_fs)) return false;
+		if (file_fs != is->fs && o.fs_given) {       // fir_util.c:103-109 (without -r the mismatch is ignored)
+			set_error("%s: error: sample rate mismatch: fs=%d filter_fs=%d", name, is->fs, file_fs);
+			return false;
+		}
+		if (*T < 1) { set_error("%s: error: filter length must be >= 1", name); return false; }
+		return true;
+	}
 	const char *enc = o.enc ? o.enc : "s16";   // pcm.c:47 default
 	int bytes;
 	if (!strcmp(enc, "double")) bytes = 8;

@@ -366,3 +366,65 @@ def test_convolver_configs_full_size_vs_real_reference(amd, tmp_path, cfg):
         got = y[s].cpu().numpy()
         assert ref.shape == got.shape, (ref.shape, got.shape)
         assert rms(ref - got) < 1e-12, (s, rms(ref - got))
+
+
+def _wav_bytes(samples, fmt, fs=48000, extensible=False, extra_chunk=False):
+    """samples [frames][channels] float in [-1, 1) -> (RIFF/WAVE bytes, the values libsndfile hands back as doubles)"""
+    import struct
+    frames, ch = samples.shape
+    if fmt == "u8":
+        q = np.clip(np.round(samples * 128.0) + 128, 0, 255).astype(np.uint8); raw = q.tobytes(); dec = (q.astype(np.float64) - 128) / 128.0; tag, bits = 1, 8
+    elif fmt == "s16":
+        q = np.clip(np.round(samples * 32768.0), -32768, 32767).astype("<i2"); raw = q.tobytes(); dec = q / 32768.0; tag, bits = 1, 16
+    elif fmt == "s24":
+        q = np.clip(np.round(samples * 8388608.0), -8388608, 8388607).astype("<i4")
+        raw = b"".join(int(v).to_bytes(4, "little", signed=True)[:3] for v in q.reshape(-1)); dec = q / 8388608.0; tag, bits = 1, 24
+    elif fmt == "s32":
+        q = np.clip(np.round(samples * 2147483648.0), -2147483648, 2147483647).astype("<i4"); raw = q.tobytes(); dec = q / 2147483648.0; tag, bits = 1, 32
+    elif fmt == "f32":
+        q = samples.astype("<f4"); raw = q.tobytes(); dec = q.astype(np.float64); tag, bits = 3, 32
+    else:
+        q = samples.astype("<f8"); raw = q.tobytes(); dec = q; tag, bits = 3, 64
+    align = ch * bits // 8
+    if extensible:
+        guid = struct.pack("<H", tag) + bytes.fromhex("000000001000800000aa00389b71")
+        fmt_body = struct.pack("<HHIIHHHHI", 0xFFFE, ch, fs, fs * align, align, bits, 22, bits, (1 << ch) - 1) + guid
+    else:
+        fmt_body = struct.pack("<HHIIHH", tag, ch, fs, fs * align, align, bits)
+    chunks = b"fmt " + struct.pack("<I", len(fmt_body)) + fmt_body
+    if extra_chunk:
+        chunks += b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"       # odd length: one pad byte
+    chunks += b"data" + struct.pack("<I", len(raw)) + raw + (b"\x00" if len(raw) & 1 else b"")
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks, dec
+
+
+@pytest.mark.parametrize("fmt,ch,ext,extra", [("s16", 1, False, False), ("s24", 2, False, True), ("s32", 1, True, False), ("u8", 1, False, False),
+                                               ("f32", 2, True, True), ("f64", 1, False, False)])
+def test_wav_filter_files(amd, tmp_path, fmt, ch, ext, extra):
+    # RIFF/WAVE filter files (what the reference reads through libsndfile, absent here): the values must be the ones libsndfile
+    # hands back (integer PCM / 2^(bits-1), u8 as (v - 128) / 128, floats as stored), so the chain equals the same chain with the
+    # decoded values as a coefs: literal -- in this library bit for bit, in the real reference to rounding
+    rng = np.random.Generator(np.random.PCG64(808))
+    T = 300 if fmt != "u8" else 40
+    h = rng.standard_normal((T, ch)) * np.exp(-np.arange(T) / 50.0)[:, None]
+    h = h / np.max(np.abs(h)) * 0.5
+    data, dec = _wav_bytes(h, fmt, fs=44100 if fmt == "s16" else 48000, extensible=ext, extra_chunk=extra)   # (rate mismatch ignored without -r)
+    path = os.path.join(str(tmp_path), "filt_%s.WAV" % fmt)
+    open(path, "wb").write(data)
+    lit = "coefs:" + "/".join(",".join("%.17g" % v for v in dec[:, c]) for c in range(ch))
+    x = noise(5000, 2, 81)
+    sel = ":0,1 " if ch == 2 else ""
+    y = amd.EffectsChain(f"{sel}fir_p {path}", 48000, 2).process(x, block=1024)
+    y_lit = amd.EffectsChain(f"{sel}fir_p {lit}", 48000, 2).process(x, block=1024)
+    assert np.array_equal(y, y_lit)
+    ref = RefChain(f"{sel}fir_p {lit}", 48000, 2).process(x, block=2048)
+    assert y.shape == ref.shape and rms(y - ref) < 1e-12
+    # explicit type, and the error paths: -r with another rate than the file's, not a WAVE file
+    y2 = amd.EffectsChain(f"{sel}fir -t wav {path}", 48000, 2).process(x, block=1024)
+    assert rms(y2 - RefChain(f"{sel}fir {lit}", 48000, 2).process(x, block=2048)) < 1e-12
+    if fmt == "s16":
+        with pytest.raises(ValueError):
+            amd.EffectsChain(f"fir_p -r 48k {path}", 48000, 2)
+    bad = os.path.join(str(tmp_path), "bad.wav"); open(bad, "wb").write(b"RIFX" + data[4:])
+    with pytest.raises(ValueError):
+        amd.EffectsChain(f"fir_p {bad}", 48000, 2)

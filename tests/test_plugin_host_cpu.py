@@ -185,3 +185,29 @@ def test_odd_arguments_same_verdict(name, args):
     a, r = pair(name, args, channels=2)
     assert a.ok() == r.ok(), (name, args, a.ok(), r.ok())
     a.free(); r.free()
+
+
+def test_wav_filter_file_init_cpu(tmp_path):
+    # filter ingestion is host-side: a RIFF/WAVE file gives a `fir` effect with the file's length in its drain accounting
+    # (fir.c:180-187), a damaged header or an unsupported sample format gives NULL -- no device needed
+    import struct
+    A, R, Effect, StreamInfo, _EffectInfo, ssize_t = _libs()
+    A.dspamd_get_effect_info.restype = C.POINTER(_EffectInfo)
+    A.dspamd_get_effect_info.argtypes = [C.c_char_p]
+    q = (np.arange(1, 101) * 100).astype("<i2")
+    body = struct.pack("<HHIIHH", 1, 1, 48000, 96000, 2, 16)
+    wav = b"RIFF" + struct.pack("<I", 4 + 8 + len(body) + 8 + q.nbytes) + b"WAVE" + b"fmt " + struct.pack("<I", len(body)) + body + b"data" + struct.pack("<I", q.nbytes) + q.tobytes()
+    good = tmp_path / "h.wav"; good.write_bytes(wav)
+    lit = "coefs:" + ",".join("%.17g" % (v / 32768.0) for v in q)
+    a = Obj(A, A.dspamd_get_effect_info, "fir", [str(good)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t)
+    b = Obj(A, A.dspamd_get_effect_info, "fir", [lit], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t)
+    r = Obj(R, R.get_effect_info, "fir", [lit], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t)
+    assert a.ok() and b.ok() and r.ok()
+    assert a.drain() == b.drain() == r.drain()
+    assert a.offsets() == b.offsets() == r.offsets()
+    adpcm = wav[:20] + struct.pack("<H", 2) + wav[22:]            # format tag 2: not read
+    bad = tmp_path / "adpcm.wav"; bad.write_bytes(adpcm)
+    assert not Obj(A, A.dspamd_get_effect_info, "fir", [str(bad)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok()
+    trunc = tmp_path / "trunc.wav"; trunc.write_bytes(wav[:30])
+    assert not Obj(A, A.dspamd_get_effect_info, "fir", [str(trunc)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok()
+    assert not Obj(A, A.dspamd_get_effect_info, "fir", ["-r", "48k", str(good).replace("h.wav", "missing.wav")], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok()
