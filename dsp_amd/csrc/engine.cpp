@@ -267,11 +267,21 @@ std::string CascadeStage::describe() const
 // launch_cascade will pick for S K C channels (cascade_rows<4>: 512 frames, <2>: 1024, <1>: 2048; cascade_wave / _fast: 1024).
 bool CascadeStage::choose_chunks(long frames, int *K_out, long *len_out) const
 {
-	static const int env = [] { const char *e = getenv("DSP_AMD_CASCADE_CHUNKS"); return e ? atoi(e) : -1; }();   // 0 = never, K = force
+	const char *env_s = getenv("DSP_AMD_CASCADE_CHUNKS");        // 0 = never, K = force up to K chunks (read per plan: tests switch it)
+	const int env = env_s ? atoi(env_s) : -1;
 	const long channels = (long) S * ch_in;
 	const int D = 2 * n_ops;
 	if (env == 0 || !chunk_linear || n_ops < 1 || D > 64) return false;
-	if (env < 0 && (channels > 512 || frames < 8192)) return false;
+	if (env < 0) {
+		if (channels > 512 || frames < 8192) return false;
+		// Three launches against one: estimated times in microseconds, fitted to scripts/exp_chunk_threshold.sh.  Direct: the
+		// P <= 8 skewed waves of a channel finish a 2048-frame tile every (n_ops + 1) x 1.9 us, or the chip is full (1.17e6 section-samples
+		// per us for one channel per wave); chunked: cascade_rows<4> at full rate, the scan, one more pass over the output.
+		const double work = (double) channels * frames * n_ops;
+		const double t_direct = 20.0 + std::max(frames * (n_ops + 1) * 1.9 / (2048.0 * 8.0), work / 1.17e6);
+		const double t_chunk = std::max(16.0, 1.25 * work / 2.06e6) + 8.0 + std::max(16.0, (double) channels * frames * 16.0 / 4.0e6);
+		if (t_chunk > 0.8 * t_direct) return false;
+	}
 	const long k_target = (env > 0) ? env : (2048 + channels - 1) / channels;
 	for (long unit : { 512L, 1024L, 2048L }) {
 		if (frames % unit) continue;

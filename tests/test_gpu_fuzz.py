@@ -154,10 +154,11 @@ def test_random_chain_batch_vs_real_reference(amd, seed):
 
 
 @pytest.mark.parametrize("seed", range(40))
-def test_random_cascade_chunked_vs_real_reference(amd, seed):
+def test_random_cascade_chunked_vs_real_reference(amd, monkeypatch, seed):
     # few channels, long calls, sections and gains only: the chunked cascade (kernels_chunk.hip) on random section sets,
     # channel selections (several table classes) and call sizes; three calls, so the carried state crosses call boundaries
     import torch
+    monkeypatch.setenv("DSP_AMD_CASCADE_CHUNKS", "4096")      # always chunk (by default only where the cost model says it pays)
     rng = np.random.Generator(np.random.PCG64(13000 + seed))
     channels = int(rng.choice([1, 2, 4, 8]))
     S = int(rng.choice([1, 1, 2, 5]))
