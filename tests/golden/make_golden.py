@@ -37,7 +37,7 @@ def main():
     cases = []
     arrays = {}
 
-    def add(name, chain, fs, ch, frames, seed, block, filt=None, amp=0.5):
+    def add(name, chain, fs, ch, frames, seed, block, filt=None, amp=0.5, oracle=True):
         x = noise(frames, ch, seed, amp)
         c = chain
         if filt is not None:
@@ -49,7 +49,7 @@ def main():
         y = rc.process(x, block=block)
         arrays[f"{name}__out"] = y
         cases.append(dict(name=name, chain=chain, fs=fs, channels=ch, frames=frames, seed=seed, amp=amp,
-                          block=block, ofs=rc.ofs, ochannels=rc.ochannels, effects=rc.effect_names()))
+                          block=block, ofs=rc.ofs, ochannels=rc.ochannels, effects=rc.effect_names(), oracle=oracle))
 
     # impulse responses -> coefficient known answers for every biquad type
     biquads = ["lowpass_1 1k", "highpass_1 300", "allpass_1 2k", "lowshelf_1 200 4", "highshelf_1 5k -3",
@@ -80,6 +80,14 @@ def main():
     add("hilbert_p255", "hilbert -p 255", 48000, 1, 800, 13, 256)
     add("chain4", "gain -3 lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 {F} resample 96k", 48000, 2, 1200, 14, 400,
         filt=make_filter(700, seed=14), amp=0.4)
+
+    # checked against the real reference only (oracle=False: the C restatement does not cover them)
+    add("riir", "lowpass 2k 0.707 lowpass -r 2k 0.707 :0 highpass -r60 30 0.707", 48000, 2, 3000, 15, 1000, oracle=False)
+    add("delay_frac", ":0 delay -f 0.37S :1 delay -f5 7.3S : eq 500 1.0 2", 48000, 2, 1200, 16, 500, oracle=False)
+    add("midside", "st2ms :1 mult 0.5 : ms2st", 48000, 2, 600, 17, 256, oracle=False)
+    add("crossfeed", "crossfeed 700 4.5", 48000, 2, 1500, 18, 512, oracle=False)
+    add("fir_p_ragged", "fir_p coefs:0.5,0.25,-0.125,0.0625,0.03,0.01,0.5,0.25,-0.125,0.0625,0.03,0.01,0.5,0.25,-0.125,0.0625,0.03,0.01,0.2,0.1,"
+        "0.5,0.25,-0.125,0.0625,0.03,0.01,0.5,0.25,-0.125,0.0625,0.03,0.01,0.5,0.25,-0.125,0.0625,0.03,0.01,0.2,0.1/0.9,-0.3,0.1", 48000, 2, 900, 19, 300, oracle=False)
 
     np.savez_compressed(os.path.join(HERE, "golden.npz"), **arrays)
     with open(os.path.join(HERE, "golden.json"), "w") as f:

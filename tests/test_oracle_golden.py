@@ -30,7 +30,10 @@ def test_biquad_impulse_responses():
         assert np.array_equal(y[:, 0], G["biquad_ir"][i]), b
 
 
-@pytest.mark.parametrize("case", META["cases"], ids=[c["name"] for c in META["cases"]])
+ORACLE_CASES = [c for c in META["cases"] if c.get("oracle", True)]     # (the 8(f) rows are pinned on the real reference only)
+
+
+@pytest.mark.parametrize("case", ORACLE_CASES, ids=[c["name"] for c in ORACLE_CASES])
 def test_case(case):
     x = noise(case["frames"], case["channels"], case["seed"], case["amp"])
     filt = G[case["name"] + "__filter"] if case["name"] + "__filter" in G else None
