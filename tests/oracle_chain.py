@@ -19,7 +19,8 @@ BIQ = {"lowpass_1": (1, 1), "highpass_1": (2, 1), "allpass_1": (3, 1), "lowshelf
        "notch": (11, 2), "allpass": (12, 2), "eq": (13, 3), "lowshelf": (14, 3), "highshelf": (15, 3),
        "lowpass_transform": (16, 4), "highpass_transform": (17, 4), "linkwitz_transform": (17, 4),
        "deemph": (18, 0), "biquad": (19, 6)}
-OTHER = {"gain": 1, "mult": 1, "add": 1, "remix": None, "delay": 1, "fir": None, "fir_p": None, "resample": None, "hilbert": None}
+OTHER = {"gain": 1, "mult": 1, "add": 1, "remix": None, "delay": 1, "fir": None, "fir_p": None, "resample": None, "hilbert": None,
+         "st2ms": 0, "ms2st": 0, "crossfeed": 2}
 
 
 def parse_freq(s):
@@ -157,6 +158,18 @@ def build(chain, fs, ch, filt=None):
             rate = int(round(parse_freq(args[-1])))
             e.update(kind="resample", ofs=rate)
             fs = rate
+        elif name in ("st2ms", "ms2st"):
+            # st2ms.c:28-54: exactly two selected channels (st2ms.c:96-99), sum / difference, halved for st2ms
+            pair = np.nonzero(sel)[0]
+            assert len(pair) == 2, "st2ms / ms2st need two selected channels"
+            e.update(kind="midside", pair=(int(pair[0]), int(pair[1])), scale=0.5 if name == "st2ms" else None)
+        elif name == "crossfeed":
+            # crossfeed.c:33-50, 128-137: direct + low-passed opposite + high-passed own channel (first-order sections at f0)
+            pair = np.nonzero(sel)[0]
+            assert len(pair) == 2, "crossfeed needs two selected channels"
+            sep = 10.0 ** (float(args[1]) / 20.0)
+            e.update(kind="crossfeed", pair=(int(pair[0]), int(pair[1])), direct=sep / (1 + sep), cross=1 / (1 + sep),
+                     lp=biquad_coefs("lowpass_1", [args[0]], fs), hp=biquad_coefs("highpass_1", [args[0]], fs))
         else:
             raise ValueError(name)
         effs.append(e)
@@ -279,4 +292,19 @@ def run(chain, x, fs, filt=None):
         elif kind == "resample":
             x = O.resample(x, e["ifs"], e["ofs"])
             fs = e["ofs"]
+        elif kind == "midside":
+            c0, c1 = e["pair"]
+            s0, s1 = x[:, c0].copy(), x[:, c1].copy()
+            x[:, c0] = (s0 + s1) if e["scale"] is None else (s0 + s1) * e["scale"]      # every operation rounds once, as in C
+            x[:, c1] = (s0 - s1) if e["scale"] is None else (s0 - s1) * e["scale"]
+        elif kind == "crossfeed":
+            c0, c1 = e["pair"]
+            s0, s1 = x[:, c0].copy(), x[:, c1].copy()
+
+            def section(c, v):
+                y, m = np.ascontiguousarray(v.copy()), np.zeros(2)
+                L.orc_biquad_run(c.ctypes.data, m.ctypes.data, y.ctypes.data, y.shape[0], 1)
+                return y
+            x[:, c0] = (s0 * e["direct"]) + (section(e["lp"], s1) * e["cross"]) + (section(e["hp"], s0) * e["cross"])
+            x[:, c1] = (s1 * e["direct"]) + (section(e["lp"], s0) * e["cross"]) + (section(e["hp"], s1) * e["cross"])
     return x, fs

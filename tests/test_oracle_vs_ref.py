@@ -203,3 +203,14 @@ def test_sgen_sine_matches_cli(tmp_path):
     ref = np.fromfile(out).reshape(-1, 2)
     y = O.sgen_sine(4800, 2, 48000, 1234.5)
     assert ref.shape == y.shape and np.array_equal(ref, y)
+
+
+@pytest.mark.parametrize("chain,ch", [("st2ms :1 gain -2 : ms2st", 2), (":0,2 st2ms : lowpass 1k 0.7 :0,2 ms2st", 3),
+                                      ("crossfeed 500 6", 2), (":1,2 crossfeed 1.2k 3 : eq 300 1 2", 4)])
+def test_pair_effects_bitexact(chain, ch):
+    # the restatement of st2ms / ms2st (st2ms.c:28-54) and crossfeed (crossfeed.c:33-50) against the real reference, bit for bit
+    import oracle_chain
+    x = noise(2000, ch)
+    ref = RefChain(chain, FS, ch).process(x, block=512)
+    y, _ = oracle_chain.run(chain, x, FS)
+    assert y.shape == ref.shape and np.array_equal(ref, y)
