@@ -231,6 +231,55 @@ void orc_delay_run(double *buf, ssize_t frames, int stride, double *ring, ssize_
 	*p = q;
 }
 
+/* Fractional delay of one channel, `delta` samples through a Thiran all-pass of order n (delay.c:170-188): first and second
+ * order in closed form (allpass.h:46-71, coefficients delay.c:174-181), higher orders the ladder of allpass.h:83-118 with the
+ * coefficients of allpass.c:31-35.  state: 4 doubles (n <= 2: i0, o0, i1, o1) or n doubles (ladder m0), carried between calls. */
+void orc_frac_delay_run(double *buf, ssize_t frames, int stride, int n, double delta, double *state)
+{
+	if (n == 1) {
+		const double c0 = (1.0 - delta) / (1.0 + delta);
+		for (ssize_t i = 0; i < frames; ++i) {
+			const double s = buf[i*stride];
+			const double r = state[0] + c0 * (s - state[1]);
+			state[0] = s;
+			state[1] = r;
+			buf[i*stride] = r;
+		}
+	}
+	else if (n == 2) {
+		const double c0 = (4.0 - 2.0*delta) / (1.0 + delta);
+		const double c1 = ((delta - 2.0) * (delta - 1.0)) / ((delta + 1.0) * (delta + 2.0));
+		for (ssize_t i = 0; i < frames; ++i) {
+			const double s = buf[i*stride];
+			const double r = state[2] + c0 * (state[0] - state[1]) + c1 * (s - state[3]);
+			state[2] = state[0];
+			state[0] = s;
+			state[3] = state[1];
+			state[1] = r;
+			buf[i*stride] = r;
+		}
+	}
+	else if (n > 2) {
+		double m1[64];
+		if (n > 64) return;
+		for (ssize_t i = 0; i < frames; ++i) {
+			const double s = buf[i*stride];
+			double u = s;
+			for (int k = 0; k < n; ++k) {
+				u = u * (delta - k) + state[k];
+				u *= -1.0 / (delta + (k + 1));
+				m1[k] = u;
+			}
+			double y = 0.0;
+			for (int k = n - 1; k >= 0; --k) {
+				y += 2.0 * m1[k];
+				state[k] += y * (2*k + 1);
+			}
+			buf[i*stride] = s + y;
+		}
+	}
+}
+
 /* ------------------------------------------------------------ fir direct */
 
 struct fir_direct {

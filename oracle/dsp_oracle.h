@@ -39,6 +39,7 @@ void orc_gain_run(double *buf, ssize_t frames, int channels, const double *mult)
 void orc_add_run(double *buf, ssize_t frames, int channels, const double *add);
 void orc_remix_run(const double *in, double *out, ssize_t frames, int in_channels, int out_channels, const char *sel);
 void orc_delay_run(double *buf, ssize_t frames, int stride, double *ring, ssize_t len, ssize_t *p);
+void orc_frac_delay_run(double *buf, ssize_t frames, int stride, int n, double delta, double *state);
 
 void *orc_fir_direct_new(const double *taps, ssize_t n_taps);
 void orc_fir_direct_run(void *st, double *buf, ssize_t frames, int stride);

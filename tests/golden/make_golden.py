@@ -83,7 +83,7 @@ def main():
 
     # checked against the real reference only (oracle=False: the C restatement does not cover them)
     add("riir", "lowpass 2k 0.707 lowpass -r 2k 0.707 :0 highpass -r60 30 0.707", 48000, 2, 3000, 15, 1000, oracle=False)
-    add("delay_frac", ":0 delay -f 0.37S :1 delay -f5 7.3S : eq 500 1.0 2", 48000, 2, 1200, 16, 500, oracle=False)
+    add("delay_frac", ":0 delay -f 0.37S :1 delay -f5 7.3S : eq 500 1.0 2", 48000, 2, 1200, 16, 500)
     add("midside", "st2ms :1 mult 0.5 : ms2st", 48000, 2, 600, 17, 256)
     add("crossfeed", "crossfeed 700 4.5", 48000, 2, 1500, 18, 512)
     add("fir_p_ragged", "fir_p coefs:0.5,0.25,-0.125,0.0625,0.03,0.01,0.5,0.25,-0.125,0.0625,0.03,0.01,0.5,0.25,-0.125,0.0625,0.03,0.01,0.2,0.1,"

@@ -47,6 +47,7 @@ class Oracle:
             L.orc_add_run.argtypes = [C.c_void_p, _ss, C.c_int, C.c_void_p]
             L.orc_remix_run.argtypes = [C.c_void_p, C.c_void_p, _ss, C.c_int, C.c_int, C.c_void_p]
             L.orc_delay_run.argtypes = [C.c_void_p, _ss, C.c_int, C.c_void_p, _ss, C.POINTER(_ss)]
+            L.orc_frac_delay_run.argtypes = [C.c_void_p, _ss, C.c_int, C.c_int, C.c_double, C.c_void_p]
             for name in ("fir_direct", "fir"):
                 getattr(L, f"orc_{name}_new").restype = C.c_void_p
                 getattr(L, f"orc_{name}_new").argtypes = [C.c_void_p, _ss]

@@ -140,9 +140,16 @@ def build(chain, fs, ch, filt=None):
             e.update(kind="remix", mat=m, och=och)
             ch = och
         elif name == "delay":
-            a = args[0]
-            n = int(a[:-1]) if a.endswith("S") else int(round(float(a.rstrip("s")) * fs))
-            e.update(kind="delay", n=np.where(sel, n, 0), merge="delay", reorder=True)
+            # delay.c:688-742: [-f[order]] amount[s|m|S]; without -f the amount is rounded to whole samples (lrint)
+            a = list(args)
+            frac, order = False, 0
+            if a[0].startswith("-f"):
+                frac, order = True, (int(a[0][2:]) if len(a[0]) > 2 else 0)
+                a = a[1:]
+            t = a[0]
+            v = float(t[:-1]) if t.endswith("S") else float(t[:-1]) * fs / 1000.0 if t.endswith("m") else float(t.rstrip("s")) * fs
+            e.update(kind="delay", n=np.where(sel, 0 if frac else int(np.rint(v)), 0), frac=np.where(sel, v if frac else 0.0, 0.0),
+                     apn=np.where(sel, order, 0), merge="delay", reorder=True)
         elif name in ("fir", "fir_p", "hilbert"):
             if name == "hilbert":
                 h = O.hilbert_taps(int(args[-1]))[:, None]
@@ -200,8 +207,8 @@ def optimize(effs):
                         d["vec"] = d["vec"] * s["vec"]; merged = True
                     elif d["merge"] == "add":
                         d["vec"] = d["vec"] + s["vec"]; merged = True
-                    elif d["merge"] == "delay":
-                        d["n"] = d["n"] + s["n"]; merged = True
+                    elif d["merge"] == "delay":      # delay.c:126-140
+                        d["n"] = d["n"] + s["n"]; d["frac"] = d["frac"] + s["frac"]; d["apn"] = np.maximum(d["apn"], s["apn"]); merged = True
                     elif d["merge"] == "biquad" and not (set(d["coefs"]) & set(s["coefs"])):
                         d["coefs"].update(s["coefs"]); merged = True   # biquad.c:344-376
                 if merged:
@@ -209,6 +216,27 @@ def optimize(effs):
                 else:
                     j += 1
         i += 1
+    return effs
+
+
+def prepare(effs):
+    """delay.c:149-205: the fractional part of a (merged) delay goes to a Thiran all-pass of order apn (default 2), which by itself
+    delays by apn - 1 + fraction samples; the integer request is reduced by as much (it may become negative: the host's alignment
+    then treats the channel as late, align.c:125-152)."""
+    for e in effs:
+        if e["kind"] != "delay":
+            continue
+        n, fr, apn = e["n"].astype(np.int64), e["frac"].astype(np.float64), np.where(e["apn"] < 1, 2, e["apn"]).astype(np.int64)
+        for k in range(len(n)):
+            if abs(fr[k] - np.rint(fr[k])) >= np.finfo(np.float64).eps:
+                adj = int(apn[k] - 1) - int(np.floor(fr[k] - 0.1))
+                n[k] -= adj
+                fr[k] += adj
+            else:
+                n[k] += int(np.rint(fr[k]))
+                fr[k] = 0.0
+                apn[k] = 0
+        e.update(n=n, frac=fr, apn=apn)
     return effs
 
 
@@ -228,8 +256,8 @@ def drain_frames(effs):
             T = e["taps"].shape[0]
             samples = samples + np.where(e["sel"], int(O.lib().orc_next_fast_fftw_len(T)) + T - 1, 0)
         elif k == "delay":
-            n = e["n"] - e["n"].min()
-            samples = samples + n
+            n = e["n"] - min(0, int(e["n"].min()))
+            samples = samples + n + e["apn"]             # delay.c:105-110
         elif k == "resample":
             g = np.gcd(e["ofs"], e["ifs"])
             n, d = e["ofs"] // g, e["ifs"] // g
@@ -249,7 +277,7 @@ def run(chain, x, fs, filt=None):
     the input ends (effects_chain.c:1193-1198), so IIR tails ring into later FIRs."""
     L = O.lib()
     x = np.ascontiguousarray(x, dtype=np.float64).copy()
-    effs = optimize(build(chain, fs, x.shape[1], filt))
+    effs = prepare(optimize(build(chain, fs, x.shape[1], filt)))
     x = np.vstack([x, np.zeros((drain_frames(effs), x.shape[1]))])
     discard = 0
     for e in effs:
@@ -268,8 +296,13 @@ def run(chain, x, fs, filt=None):
             L.orc_remix_run(x.ctypes.data, out.ctypes.data, x.shape[0], ch, e["och"], m.ctypes.data)
             x = out
         elif kind == "delay":
-            # realised by an align effect: the LEAST-delayed channel is the reference (align.c:125-146)
-            n = e["n"] - e["n"].min()
+            for k in range(ch):
+                if e["apn"][k] > 0:
+                    st = np.zeros(max(4, int(e["apn"][k])))
+                    L.orc_frac_delay_run(x.ctypes.data + 8 * k, x.shape[0], ch, int(e["apn"][k]), abs(float(e["frac"][k])), st.ctypes.data)
+            # the integer part is realised by an align effect with the requested lengths; requests that went negative (the
+            # all-pass's own delay) count from the most negative one (align.c:125-146)
+            n = e["n"] - min(0, int(e["n"].min()))
             for k in range(ch):
                 if n[k] > 0:
                     ring = np.zeros(int(n[k]))
@@ -307,4 +340,4 @@ def run(chain, x, fs, filt=None):
                 return y
             x[:, c0] = (s0 * e["direct"]) + (section(e["lp"], s1) * e["cross"]) + (section(e["hp"], s0) * e["cross"])
             x[:, c1] = (s1 * e["direct"]) + (section(e["lp"], s0) * e["cross"]) + (section(e["hp"], s1) * e["cross"])
-    return x, fs
+    return x[discard:], fs

@@ -16,7 +16,7 @@ META = json.load(open(os.path.join(HERE, "golden", "golden.json")))
 pytestmark = pytest.mark.skipif(not Oracle.available(), reason="oracle/liboracle.so not built")
 
 # bit-exact class vs FFT-based class (SURVEY.md section 8(d) parity bar)
-EXACT = {"config1", "config2", "gain_sel", "remix", "remix_up", "delay", "fir_direct", "midside", "crossfeed"}
+EXACT = {"config1", "config2", "gain_sel", "remix", "remix_up", "delay", "fir_direct", "midside", "crossfeed", "delay_frac"}
 
 
 def noise(frames, ch, seed, amp):

@@ -214,3 +214,16 @@ def test_pair_effects_bitexact(chain, ch):
     ref = RefChain(chain, FS, ch).process(x, block=512)
     y, _ = oracle_chain.run(chain, x, FS)
     assert y.shape == ref.shape and np.array_equal(ref, y)
+
+
+@pytest.mark.parametrize("chain,ch", [("delay 37S", 2), ("delay 10S :0 delay 72S", 2), ("delay -f 0.37S", 2), (":0 delay -f 0.37S :1 delay -f5 7.3S : eq 500 1.0 2", 2),
+                                      ("delay -f1 0.5S :1 delay 3S", 2), ("delay 0.2m :0 delay -f 1.5m", 2), ("delay -f 0.37S :1 delay 5S", 2),
+                                      (":0,2 delay -f9 11.7S :1 delay -f 0.05S : lowpass 3k 0.7", 3), ("gain -3 :2 delay 1m : delay -f16 20.5S", 3)])
+def test_delays_bitexact(chain, ch):
+    # integer and fractional delays (delay.c:126-205, allpass.h:46-118; realised through the host's alignment, align.c:125-146):
+    # merged amounts, default and explicit all-pass orders, requests that go negative -- bit for bit, lengths included
+    import oracle_chain
+    x = noise(1500, ch)
+    ref = RefChain(chain, FS, ch).process(x, block=500)
+    y, _ = oracle_chain.run(chain, x, FS)
+    assert y.shape == ref.shape and np.array_equal(ref, y)
