@@ -113,7 +113,7 @@ static size_t parse_tokens(Parser &P, size_t pos, Selector ch_mask, bool in_bloc
 	if (depth > 32) { set_error("chain: error: maximum recursion depth exceeded"); return npos; }
 	int last_ch = P.stream->channels;
 	Selector ch_sel = ch_mask;
-	std::string last_sel;
+	std::string last_sel, ch_changed_by;      // ch_changed_by: the effect that last changed the channel count (prev_effect, effects_chain.c:504)
 	bool have_last_sel = false, allow_fail = false;
 	while (pos < T.size()) {
 		const Token &tok = T[pos];
@@ -143,7 +143,13 @@ static size_t parse_tokens(Parser &P, size_t pos, Selector ch_mask, bool in_bloc
 		}
 		if (last_ch != ch) {   // re-parse the active selector against the new channel count (:497-511)
 			if (!have_last_sel) ch_sel = ch_mask;
-			else if (!parse_selector_masked(last_sel.c_str(), ch_sel, ch_mask, ch)) return npos;
+			else if (!parse_selector_masked(last_sel.c_str(), ch_sel, ch_mask, ch)) {
+				// the reference's two notes (effects_chain.c:503-504), folded into the message the C API hands back
+				const std::string why = last_error();
+				set_error("%s; note: active channel selector defined here: %s; note: number of channels modified by this effect: %s",
+				          why.c_str(), last_sel.c_str(), ch_changed_by.empty() ? "?" : ch_changed_by.c_str());
+				return npos;
+			}
 			last_ch = ch;
 		}
 		if (tok.id == T_SOURCE) {
@@ -199,6 +205,7 @@ static size_t parse_tokens(Parser &P, size_t pos, Selector ch_mask, bool in_bloc
 				}
 				else {
 					P.plan->effects.push_back(e);
+					if (e->ostream.channels != P.stream->channels) ch_changed_by = tok.str;
 					*P.stream = e->ostream;
 				}
 				e = nx;

@@ -669,7 +669,7 @@ struct FirOpts {
 	const char *type = nullptr, *enc = nullptr;
 	int channels = 0;
 	bool big_endian = false;
-	bool fs_given = false;           // -r fs (not `any`): a container's own rate must then match (fir_util.c:103-109)
+	bool any_fs = false;             // `-r any` (fir_util.c:148-150: p.fs = 0); otherwise p.fs = the stream's rate (:130) and a container's own rate must match (:103-109)
 };
 
 // option grammar of fir_util.c:122-185 ("a::t:e:BLNr:c:")
@@ -692,12 +692,13 @@ static bool parse_fir_opts(const char *name, const stream_info *is, GetOpt &g, i
 		case 'B': o.big_endian = true; break;
 		case 'L': case 'N': o.big_endian = false; break;
 		case 'r':
-			if (strcmp(g.arg, "any") != 0) {
+			if (strcmp(g.arg, "any") == 0) o.any_fs = true;
+			else {
 				const long fs = lround(parse_freq(g.arg, &end));
 				if (bad_endptr(name, g.arg, end, "sample rate")) return false;
 				if (fs <= 0) { set_error("%s: error: sample rate must be > 0", name); return false; }
 				if (fs != is->fs) { set_error("%s: error: sample rate mismatch: stream_fs=%d requested_fs=%ld", name, is->fs, fs); return false; }
-				o.fs_given = true;
+				o.any_fs = false;
 			}
 			break;
 		case 'c':
@@ -840,9 +841,12 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 	if (wav) {
 		int file_fs = 0;
 		if (!read_wav(name, path, raw, data, fch, T, &file_fs)) return false;
-		if (file_fs != is->fs && o.fs_given) {       // fir_util.c:103-109 (without -r the mismatch is ignored)
-			set_error("%s: error: sample rate mismatch: fs=%d filter_fs=%d", name, is->fs, file_fs);
-			return false;
+		if (file_fs != is->fs) {                      // fir_util.c:103-109: refused unless `-r any` was given
+			if (!o.any_fs) {
+				set_error("%s: error: sample rate mismatch: fs=%d filter_fs=%d", name, is->fs, file_fs);
+				return false;
+			}
+			log_msg(4, "%s: info: ignoring sample rate mismatch: fs=%d filter_fs=%d", name, is->fs, file_fs);
 		}
 		if (*T < 1) { set_error("%s: error: filter length must be >= 1", name); return false; }
 		return true;

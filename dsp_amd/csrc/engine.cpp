@@ -1,6 +1,9 @@
 // engine.cpp -- pipeline compiler and the simple stages (cascade, remix, align/delay).
 // The FFT convolution and resample stages live in conv.cpp.
 #include "engine.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
 #include "stages.h"
 #include <cmath>
 #include <cstdlib>
@@ -14,6 +17,19 @@ bool hip_ok(hipError_t e, const char *what)
 	if (e == hipSuccess) return true;
 	set_error("HIP error in %s: %s", what, hipGetErrorString(e));
 	return false;
+}
+
+void grant_dynamic_lds(const void *kernel, size_t bytes)
+{
+	static std::mutex mu;
+	static std::map<std::pair<const void *, int>, size_t> granted;
+	int dev = 0;
+	(void) hipGetDevice(&dev);
+	std::lock_guard<std::mutex> lock(mu);
+	size_t &g = granted[std::make_pair(kernel, dev)];
+	if (bytes <= g) return;
+	if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) == hipSuccess) g = bytes;
+	else (void) hipGetLastError();   // the launch itself will report the failure
 }
 
 int device_count()
@@ -306,7 +322,24 @@ bool CascadeStage::choose_chunks(long frames, int *K_out, long *len_out) const
 
 // M (state after len frames of silence, per unit state) and H (the outputs on the way) by running the sections themselves,
 // in extended precision; channels with identical ops share one table
-bool CascadeStage::build_chunk_plan(long frames, int K, long len)
+CascadeStage::ChunkPlan *CascadeStage::chunk_plan_for(long frames, int K, long len)
+{
+	for (size_t i = 0; i < chunk_plans.size(); ++i)
+		if (chunk_plans[i]->frames == frames) {
+			std::rotate(chunk_plans.begin(), chunk_plans.begin() + i, chunk_plans.begin() + i + 1);
+			return chunk_plans.front().get();
+		}
+	std::unique_ptr<ChunkPlan> c(new ChunkPlan);
+	if (!build_chunk_plan(*c, frames, K, len)) return nullptr;
+	if (chunk_plans.size() >= 4) {
+		(void) hipDeviceSynchronize();          // the plan about to go may still be in use by queued launches
+		chunk_plans.pop_back();
+	}
+	chunk_plans.insert(chunk_plans.begin(), std::move(c));
+	return chunk_plans.front().get();
+}
+
+bool CascadeStage::build_chunk_plan(ChunkPlan &chunk, long frames, int K, long len)
 {
 	const int D = 2 * n_ops;
 	std::vector<int> cls(ch_in, -1);
@@ -387,11 +420,10 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	{ static const char *dbg = getenv("DSP_AMD_CASCADE_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
 	int K = 0;
 	long len = 0;
-	const bool plan_now = (last_frames == frames) || (double) frames * S * ch_in >= 1048576.0;    // (tables + allocations: about a millisecond)
-	last_frames = frames;
-	if (!ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) &&
-	    (chunk.frames == frames || (plan_now && choose_chunks(frames, &K, &len)))) {
-		if (chunk.frames != frames && !build_chunk_plan(frames, K, len)) return -1;
+	if (!ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) {
+		ChunkPlan *cpl = chunk_plan_for(frames, K, len);
+		if (!cpl) return -1;
+		ChunkPlan &chunk = *cpl;
 		// S K zero-state "streams" of len frames, then the carried states and the correction
 		p.frames = chunk.len;
 		p.in_stride_frames = p.out_stride_frames = chunk.len;
@@ -701,7 +733,7 @@ ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long ou
 	if (frames <= 0) return 0;
 	if (stages.empty()) {
 		launch_copy_slab(d_in, frames, d_out, out_stride, frames, 0, ch_in, S, st);
-		return frames;
+		return hip_ok(hipGetLastError(), "copy_slab") ? frames : -1;
 	}
 	const double *cur = d_in;
 	long cur_stride = frames;
@@ -722,6 +754,8 @@ ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long ou
 		}
 		F = s->run(cur, cur_stride, F, dst, dst_stride, st);
 		if (F < 0) return F;
+		// a launch that failed (bad configuration, LDS not granted on this device ...) must not pass stale memory on as audio
+		if (!hip_ok(hipGetLastError(), s->type())) return -1;
 		cur = dst;
 		cur_stride = dst_stride;
 		if (F == 0) {
@@ -741,6 +775,7 @@ ssize_t Pipeline::drain2(ssize_t block_frames, double *d_out, long out_stride, h
 		double *dst = last ? d_out : tmp[0].as<double>();
 		long dst_stride = last ? out_stride : (long) (tmp[0].bytes / sizeof(double) / S / s->ch_out);
 		ssize_t F = s->drain2(block_frames, dst, dst_stride, st);
+		if (!hip_ok(hipGetLastError(), s->type())) return -1;
 		if (F < 0) { ++drain_stage; continue; }
 		const double *cur = dst;
 		long cur_stride = dst_stride;
@@ -752,6 +787,7 @@ ssize_t Pipeline::drain2(ssize_t block_frames, double *d_out, long out_stride, h
 			long d2_stride = nlast ? out_stride : (long) (tmp[which].bytes / sizeof(double) / S / n->ch_out);
 			which ^= 1;
 			F = n->run(cur, cur_stride, F, d2, d2_stride, st);
+			if (!hip_ok(hipGetLastError(), n->type())) return -1;
 			cur = d2;
 			cur_stride = d2_stride;
 		}

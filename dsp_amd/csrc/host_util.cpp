@@ -146,7 +146,7 @@ bool parse_selector_masked(const char *s, Selector &b, const Selector &mask, int
 	if (!parse_selector(s, tmp, nb)) return false;
 	for (int i = 0, k = 0; i < nb; ++i, ++k) {
 		while (k < n && !mask[k]) ++k;
-		if (k == n) return false;
+		if (k == n) { set_error("parse_selector_masked(): BUG: too many channels"); return false; }   // util.c:203-207
 		if (tmp[i]) b[k] = 1;
 	}
 	return true;

@@ -561,11 +561,7 @@ template <int CG> static bool try_launch_fast(const CascadeParams &p, int n_stre
 {
 	const size_t lds = fast_lds_bytes<CG>(p.n_ops);
 	if (lds > 160 * 1024) return false;
-	static size_t granted = 0;
-	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_fast<CG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		granted = lds;
-	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_fast<CG>), lds);
 	dim3 grid(n_streams, p.C / CG), block(64 * CG);
 	hipLaunchKernelGGL((cascade_fast<CG>), grid, block, lds, stream, p, p.fops);
 	return true;
@@ -574,11 +570,7 @@ template <int CG> static bool try_launch_fast(const CascadeParams &p, int n_stre
 // 0 = not eligible; otherwise the number of leading frames the fast kernel took
 static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
-	static int env_cg = -2;
-	if (env_cg == -2) {
-		const char *e = getenv("DSP_AMD_CASCADE_FAST");     // channels per workgroup (8, 4, 2) or 0 to disable
-		env_cg = e ? atoi(e) : -1;
-	}
+	static const int env_cg = [] { const char *e = getenv("DSP_AMD_CASCADE_FAST"); return e ? atoi(e) : -1; }();   // channels per workgroup (8, 4, 2) or 0 to disable
 	// measured on MI355X (256 x 8 ch, 10 sections): whole frames per workgroup (8 channels) win when the interleaved
 	// slab is written (2.4 vs 3.8 ms); half frames (two independent workgroups per stream) win when only the
 	// convolver's ring rows are written (2.45 vs 2.57 ms)
@@ -943,11 +935,7 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
 	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB) * sizeof(double);
 	if (lds > 160 * 1024) return 0;
-	static size_t granted = 0;
-	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_rows<G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		granted = lds;
-	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G>), lds);
 	dim3 grid(n_streams, p.C / G), block(64 * P);
 	hipLaunchKernelGGL(cascade_rows<G>, grid, block, lds, stream, p, p.frows, p.frq, P);
 	return n_full * TILE;
@@ -956,8 +944,7 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 // 0 = not eligible; otherwise the number of leading frames taken
 static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
-	static int env = -2;
-	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_ROWS"); env = e ? atoi(e) : -1; }   // 0 = never, G*100 + P = force
+	static const int env = [] { const char *e = getenv("DSP_AMD_CASCADE_ROWS"); return e ? atoi(e) : -1; }();   // 0 = never, G*100 + P = force
 	if (env == 0 || !p.frows || !p.frq || p.cg0 != 0) return 0;
 	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
 	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
@@ -1093,11 +1080,7 @@ template <int CG, int P> static bool try_launch_wave(const CascadeParams &p, int
 {
 	const size_t lds = ((size_t) CG * p.n_ops * 2 + (size_t) CG * p.n_ops * FQ_DOUBLES + (size_t) CG * P * (CASCADE_TILE + 64)) * sizeof(double);
 	if (lds > 160 * 1024 || p.n_ops < P || (p.C % CG)) return false;
-	static size_t granted = 0;
-	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_wave<CG, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		granted = lds;
-	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_wave<CG, P>), lds);
 	dim3 grid(n_streams, p.C / CG), block(64 * CG * P);
 	hipLaunchKernelGGL((cascade_wave<CG, P>), grid, block, lds, stream, p, p.fops);
 	return true;
@@ -1106,8 +1089,7 @@ template <int CG, int P> static bool try_launch_wave(const CascadeParams &p, int
 // few streams: the tiles of a channel are dealt out to P waves (see cascade_wave) so that the chip stays full
 static long launch_cascade_wave(const CascadeParams &p, int n_streams, hipStream_t stream)
 {
-	static int env = -2;
-	if (env == -2) { const char *e = getenv("DSP_AMD_CASCADE_WAVE"); env = e ? atoi(e) : -1; }   // 0 = never, CG*100+P = force
+	static const int env = [] { const char *e = getenv("DSP_AMD_CASCADE_WAVE"); return e ? atoi(e) : -1; }();   // 0 = never, CG*100+P = force
 	if (env == 0 || p.cg0 != 0 || !p.fops || p.n_ops < 1) return 0;
 	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
 	const long n_full = p.frames / CASCADE_TILE;
@@ -1164,11 +1146,7 @@ const char *launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t s
 	const int waves = p.Cg < 8 ? (p.Cg < 1 ? 1 : p.Cg) : 8;
 	dim3 grid(n_streams, n_groups), block(64 * waves);
 	const size_t lds = cascade_lds_bytes(p.Cg, p.n_ops);
-	static size_t lds_granted = 0;   // LDS above 64 KiB must be requested once per process
-	if (lds > lds_granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		lds_granted = lds;
-	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_kernel), lds);
 	hipLaunchKernelGGL(cascade_kernel, grid, block, lds, stream, p, p.ops);
 	return name;
 }

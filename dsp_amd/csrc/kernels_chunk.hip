@@ -142,11 +142,7 @@ __global__ __launch_bounds__(256) void cascade_chunk_fix(ChunkParams p)
 
 template <int DH> static void launch_carry(const ChunkParams &p, int n_streams, size_t lds, hipStream_t stream)
 {
-	static size_t granted = 0;
-	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(cascade_chunk_carry<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		granted = lds;
-	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_chunk_carry<DH>), lds);
 	hipLaunchKernelGGL(cascade_chunk_carry<DH>, dim3(n_streams, p.C), dim3(1024), lds, stream, p);
 }
 

@@ -647,6 +647,10 @@ __global__ __launch_bounds__(NT) void conv_deinterleave(DeintParams p)
 // with separately rounded products and sums.
 __global__ __launch_bounds__(NT) void fir_direct_kernel(FirDirectParams p)
 {
+	// bit-exact contract: every product and every sum rounded on its own, as the reference's x86-64 build does.  hipcc
+	// contracts a * b + c into one fused operation by default -- also through __dmul_rn / __dadd_rn, which are plain
+	// operators to the optimiser (round 1 shipped that: outputs one ulp off the reference in a third of the samples)
+#pragma clang fp contract(off)
 	const int s = blockIdx.y;
 	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
 	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
@@ -664,7 +668,8 @@ __global__ __launch_bounds__(NT) void fir_direct_kernel(FirDirectParams p)
 			const long ti = t - m;
 			// history slot q holds x[-(q+1)] relative to this block's first frame
 			const double x = (ti >= 0) ? in[ti * p.C + c] : hr[c * FIR_DIRECT_MAX + (-ti - 1)];
-			acc = __dadd_rn(acc, __dmul_rn(x, h[m]));
+			const double prod = x * h[m];      // (plain operators: the pragma above governs them, not the bodies of inlined helpers)
+			acc = acc + prod;
 		}
 		out[e] = acc;
 		// new history: the last T-1 inputs of [old history | this block]
@@ -685,38 +690,33 @@ __global__ __launch_bounds__(NT) void fir_direct_kernel(FirDirectParams p)
 
 // ------------------------------------------------------------------ launchers
 
-template <class K> static void grant_lds(K kernel, size_t bytes)
-{
-	(void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
-}
+template <class K> static void grant_lds(K kernel, size_t bytes) { grant_dynamic_lds(reinterpret_cast<const void *>(kernel), bytes); }
 
 template <int L> static void launch_col_fwd(const ConvParams &p, int n_pairs, hipStream_t st)
 {
 	using Cfg = ColCfg<L, 1>;
-	static bool granted = false;
-	if (!granted) { grant_lds(conv_col_fwd<L>, Cfg::LDS); granted = true; }
+	grant_lds(conv_col_fwd<L>, Cfg::LDS);
 	hipLaunchKernelGGL(conv_col_fwd<L>, dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
 }
 
 template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hipStream_t st)
 {
 	using Cfg = ColCfg<L, PPS>;
-	static bool granted[3] = { false, false, false };
 	const int groups = (p.pairs_per_stream + PPS - 1) / PPS;
 	const dim3 grid((unsigned) (p.N2 / Cfg::TW), (unsigned) (p.n_streams_launch * groups)), block(Cfg::THREADS);
 	if (PPS == 4 && p.nph == 2 && p.up == 2 && p.down == 1 && !p.round_f32 && !p.ring_out_round_f32) {
 		if constexpr (PPS == 4) {
-			if (!granted[2]) { grant_lds(conv_col_inv<L, PPS, 2>, Cfg::LDS); granted[2] = true; }
+			grant_lds(conv_col_inv<L, PPS, 2>, Cfg::LDS);
 			hipLaunchKernelGGL((conv_col_inv<L, PPS, 2>), grid, block, Cfg::LDS, st, p);
 			return;
 		}
 	}
 	if (p.nph == 1 && p.up == 1 && p.down == 1) {
-		if (!granted[0]) { grant_lds(conv_col_inv<L, PPS, 0>, Cfg::LDS); granted[0] = true; }
+		grant_lds(conv_col_inv<L, PPS, 0>, Cfg::LDS);
 		hipLaunchKernelGGL((conv_col_inv<L, PPS, 0>), grid, block, Cfg::LDS, st, p);
 		return;
 	}
-	if (!granted[1]) { grant_lds(conv_col_inv<L, PPS, 1>, Cfg::LDS); granted[1] = true; }
+	grant_lds(conv_col_inv<L, PPS, 1>, Cfg::LDS);
 	hipLaunchKernelGGL((conv_col_inv<L, PPS, 1>), grid, block, Cfg::LDS, st, p);
 }
 
@@ -742,11 +742,7 @@ void launch_conv_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t
 template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
 	using Cfg = RowCfg<L2>;
-	static bool granted[3] = { false, false, false };
-	if (!granted[mode]) {
-		if (mode == 1) grant_lds(conv_row<L2, 1>, Cfg::LDS); else if (mode == 2) grant_lds(conv_row<L2, 2>, Cfg::LDS); else grant_lds(conv_row<L2, 0>, Cfg::LDS);
-		granted[mode] = true;
-	}
+	if (mode == 1) grant_lds(conv_row<L2, 1>, Cfg::LDS); else if (mode == 2) grant_lds(conv_row<L2, 2>, Cfg::LDS); else grant_lds(conv_row<L2, 0>, Cfg::LDS);
 	dim3 grid((unsigned) (p.N1 / Cfg::RPW), n_pairs), block(NT);
 	if (mode == 1) hipLaunchKernelGGL((conv_row<L2, 1>), grid, block, Cfg::LDS, st, p);
 	else if (mode == 2) hipLaunchKernelGGL((conv_row<L2, 2>), grid, block, Cfg::LDS, st, p);
@@ -756,11 +752,7 @@ template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pa
 template <int WV> static void launch_row_big(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
 	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + 256 + 4 * 64 + 4 * 16) * sizeof(cplx);
-	static bool granted[2] = { false, false };
-	if (!granted[mode]) {
-		if (mode) grant_lds(conv_row_big<WV, 1>, LDS); else grant_lds(conv_row_big<WV, 0>, LDS);
-		granted[mode] = true;
-	}
+	if (mode) grant_lds(conv_row_big<WV, 1>, LDS); else grant_lds(conv_row_big<WV, 0>, LDS);
 	dim3 grid((unsigned) (p.N1 / (4 / WV)), n_pairs), block(NT);
 	if (mode == 1) hipLaunchKernelGGL((conv_row_big<WV, 1>), grid, block, LDS, st, p);
 	else hipLaunchKernelGGL((conv_row_big<WV, 0>), grid, block, LDS, st, p);
@@ -768,8 +760,7 @@ template <int WV> static void launch_row_big(const ConvParams &p, int mode, int 
 
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	static int big_env = -1;
-	if (big_env < 0) { const char *e = getenv("DSP_AMD_ROW_BIG"); big_env = e ? atoi(e) : 1; }
+	static const int big_env = [] { const char *e = getenv("DSP_AMD_ROW_BIG"); return e ? atoi(e) : 1; }();
 	int big = big_env;
 	// (H is stored in the row kernel's own order: a multi-phase plan uses the generic kernel for preparation too)
 	if (p.nph > 1) big = 0;

@@ -6,8 +6,9 @@
 //   delay_kernel  : align_channel_run                 align.c:35-44   (per-channel delay of len frames, state carried)
 //   sgen_kernel   : sgen_run_generator (sine)         sgen.c:55-67
 //   digest_kernel : the `stats` quantities            stats.c:47-76
-// All arithmetic that must match the CPU bit for bit uses the explicitly rounded intrinsics
-// (__dadd_rn / __dmul_rn) so that the compiler can never contract it into an FMA.
+// All arithmetic that must match the CPU bit for bit is written with plain operators under `#pragma clang fp contract(off)`:
+// hipcc fuses a * b + c by default, and it does so THROUGH __dmul_rn / __dadd_rn (inlined helpers keep the translation
+// unit's contraction flag) -- only the pragma, applied to operators in its own scope, guarantees one rounding per operation.
 #include <hip/hip_runtime.h>
 #include "kparams.h"
 
@@ -15,6 +16,7 @@ namespace dspamd {
 
 __global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
 {
+#pragma clang fp contract(off)
 	const int s = blockIdx.y;
 	const long n = p.frames * p.Cout;
 	const double *in = p.in + (size_t) s * p.in_stride_frames * p.Cin;
@@ -28,19 +30,20 @@ __global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
 		if (p.w) {
 			// weighted form (st2ms.c:34-38, crossfeed.c:41-46): the first product starts the sum, every operation rounds once
 			const double *w = p.w + (size_t) k * p.max_n;
-			if (idx[0] >= 0) acc = __dmul_rn(fr[idx[0]], w[0]);
+			if (idx[0] >= 0) acc = fr[idx[0]] * w[0];
 			for (int j = 1; j < p.max_n; ++j) {
 				const int c = idx[j];
 				if (c < 0) break;
-				acc = __dadd_rn(acc, __dmul_rn(fr[c], w[j]));
+				const double prod = fr[c] * w[j];
+				acc = acc + prod;
 			}
-			if (p.post) acc = __dmul_rn(acc, p.post[k]);
+			if (p.post) acc = acc * p.post[k];
 		}
 		else {
 			for (int j = 0; j < p.max_n; ++j) {
 				const int c = idx[j];
 				if (c < 0) break;
-				acc = __dadd_rn(acc, fr[c]);
+				acc = acc + fr[c];
 			}
 		}
 		out[e] = acc;
@@ -184,18 +187,20 @@ void launch_digest(const double *buf, int n_streams, long frames, long stride, i
 	hipLaunchKernelGGL(digest_kernel, dim3(n_streams), dim3(256), 0, stream, buf, frames, stride, channels, out);
 }
 
-// 16 B per lane streaming copy: the measured HBM ceiling quoted next to the 8 TB/s spec
-__global__ __launch_bounds__(256) void copy_probe_kernel(const double2 *src, double2 *dst, size_t n)
+// 16 B per lane streaming copy: the measured HBM ceiling quoted next to the 8 TB/s spec.  One 4-KiB tile per workgroup,
+// one access in flight per lane: the fastest of the variants in scripts/ubench/hbmprobe.hip on this chip (6.2-6.3 TB/s;
+// round 1's 2048-workgroup grid-stride loop read 4.7-4.9, and more accesses in flight per lane read LESS: 16 per lane 5.3-5.6)
+__global__ __launch_bounds__(256) void copy_probe_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
 {
-	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
-		dst[i] = src[i];
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (i < n) dst[i] = src[i];
 }
 
 void launch_copy_probe(const void *src, void *dst, size_t bytes, hipStream_t stream)
 {
 	const size_t n = bytes / 16;
 	if (!n) return;
-	hipLaunchKernelGGL(copy_probe_kernel, dim3(2048), dim3(256), 0, stream, (const double2 *) src, (double2 *) dst, n);
+	hipLaunchKernelGGL(copy_probe_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, stream, (const double2 *) src, (double2 *) dst, n);
 }
 
 }  // namespace dspamd

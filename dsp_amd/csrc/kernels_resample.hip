@@ -15,6 +15,7 @@
 // (all channels), every thread owns one output frame and CPT channels of it.
 #include <hip/hip_runtime.h>
 #include "resample_params.h"
+#include "kparams.h"
 
 namespace dspamd {
 
@@ -196,8 +197,7 @@ void launch_resample_gemm(const ResampleGemmParams &p, int n_streams, hipStream_
 	dim3 grid((unsigned) tiles, n_streams), block(256);
 #define RSG_LAUNCH(N_)                                                                                                       \
 	{                                                                                                                        \
-		static size_t granted = 0;                                                                                           \
-		if (lds > granted) { (void) hipFuncSetAttribute(reinterpret_cast<const void *>(resample_gemm_kernel<N_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds); granted = lds; } \
+		grant_dynamic_lds(reinterpret_cast<const void *>(resample_gemm_kernel<N_>), lds);                                  \
 		hipLaunchKernelGGL(resample_gemm_kernel<N_>, grid, block, lds, st, p);                                                \
 	}
 	if (PT <= 1) RSG_LAUNCH(1) else if (PT == 2) RSG_LAUNCH(2) else if (PT == 3) RSG_LAUNCH(3) else if (PT == 4) RSG_LAUNCH(4) else if (PT == 5) RSG_LAUNCH(5) else RSG_LAUNCH(6)
@@ -217,11 +217,7 @@ void launch_resample(const ResampleParams &p, int n_streams, hipStream_t st)
 	const long tiles = (p.m_count + p.KT - 1) / p.KT;
 	const long span_max = ((long) p.KT * p.d) / p.n + p.J + 2;
 	const size_t lds = (size_t) span_max * p.C * sizeof(double);
-	static size_t granted = 0;
-	if (lds > granted) {
-		(void) hipFuncSetAttribute(reinterpret_cast<const void *>(resample_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-		granted = lds;
-	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(resample_kernel<4>), lds);
 	hipLaunchKernelGGL(resample_kernel<4>, dim3((unsigned) tiles, n_streams), dim3(256), lds, st, p);
 }
 

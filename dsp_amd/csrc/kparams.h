@@ -108,6 +108,11 @@ struct ConvGeom {
 	long N, N1, N2;
 };
 
+// Dynamic LDS above 64 KiB must be requested per kernel -- and the grant belongs to the DEVICE the attribute was set on.
+// Thread-safe, keyed by (kernel, current device): chains live on several host threads (LADSPA multi-instance, the
+// `watch` poller) and a process may drive several GPUs (engine.cpp).
+void grant_dynamic_lds(const void *kernel, size_t bytes);
+
 #ifdef __HIPCC__
 // streaming (non-temporal) 16-byte accesses: data touched once per launch should not displace what the L2 keeps
 typedef double dspamd_v2d __attribute__((ext_vector_type(2)));

@@ -57,16 +57,21 @@ static bool ensure_segment(struct effect *e, Node *n)
 	std::vector<const Spec *> specs;
 	for (struct effect *m = first;; m = m->next) {
 		Node *mn = node_of(m);
-		if (mn->spec->riir_pending && !riir_prepare(*mn->spec)) return false;    // a host that skipped prepare()
 		seg->members.push_back(m);
 		specs.push_back(mn->spec.get());
 		if (mn->spec->kind == Kind::Remix || mn->spec->kind == Kind::Resample) seg->in_place = false;
 		if (m == last) break;
 	}
+	// every member knows its segment BEFORE the first step that can fail: a failed segment (pipe == nullptr) is final --
+	// no rebuild, no second FIR design and no second error line per block on what may be a real-time thread
+	for (struct effect *m : seg->members) node_of(m)->seg = seg;
+	for (struct effect *m : seg->members) {
+		Node *mn = node_of(m);
+		if (mn->spec->riir_pending && !riir_prepare(*mn->spec)) return false;    // a host that skipped prepare()
+	}
 	const Spec &s0 = *specs.front(), &s1 = *specs.back();
 	const ssize_t cap = 1 << 16;
 	seg->ch_in = s0.ch_in; seg->ch_out = s1.ch_out;
-	for (struct effect *m : seg->members) node_of(m)->seg = seg;     // even on failure: do not retry every block
 	seg->pipe = Pipeline::compile(specs, s0.fs_in, s0.ch_in, 1, cap);
 	if (!seg->pipe) return false;
 	seg->pipe_frames = cap;

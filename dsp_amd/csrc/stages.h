@@ -27,10 +27,14 @@ private:
 	// few channels, long calls: the time axis is cut into K chunks that run as independent zero-state "streams" (kernels_chunk.hip)
 	std::vector<OpDesc> host_ops;            // [C][n_ops]
 	bool chunk_linear = false;               // sections and gains only (an `add` is not linear in the state)
-	struct ChunkPlan { long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X; } chunk;
-	long last_frames = 0;                    // a plan is built for a call size seen twice in a row, or big enough to pay at once
+	// Whether a call runs chunked is a pure function of (frames, S, the sections) -- never of earlier calls: run / reset / run
+	// and two instances with different histories give bit-identical output (the chunked path agrees with the direct kernels
+	// only to rounding, ~1e-15).  Plans (tables + buffers, about a millisecond each) are kept for the last few call sizes.
+	struct ChunkPlan { long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X; };
+	std::vector<std::unique_ptr<ChunkPlan>> chunk_plans;   // most recently used first, at most 4
 	bool choose_chunks(long frames, int *K, long *len) const;
-	bool build_chunk_plan(long frames, int K, long len);
+	ChunkPlan *chunk_plan_for(long frames, int K, long len);
+	bool build_chunk_plan(ChunkPlan &chunk, long frames, int K, long len);
 };
 
 class RemixStage : public Stage {

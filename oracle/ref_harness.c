@@ -184,6 +184,82 @@ ssize_t refh_chain_process(void *hp, const double *in, ssize_t frames, ssize_t b
 	return opos;
 }
 
+/*
+ * Two chains alive at once, interleaved on the SAME buffers -- the rebuild-with-crossfade of the CLI (dsp.c:1351-1366,
+ * 1423-1430) and of `watch`: chain A runs alone for `switch_block` blocks; then chain B is built while A is still alive
+ * and effects_chain_xfade_run (effects_chain.c:1241-1274) drives both on every block until the fade (xfade_frames) is
+ * over; A is destroyed (finish_xfade, dsp.c:702-707), B runs on and is drained.  Both chains must keep rate and channels.
+ * Returns output frames written, or -1.
+ */
+ssize_t refh_xfade_process(const char *chain_a, const char *chain_b, int fs, int channels, const char *dir,
+                           const double *in, ssize_t frames, ssize_t block_frames, ssize_t switch_block, ssize_t xfade_frames,
+                           double *out, ssize_t out_cap)
+{
+	struct effects_chain chain = EFFECTS_CHAIN_INITIALIZER;
+	struct effects_chain_xfade_state xf = EFFECTS_CHAIN_XFADE_STATE_INITIALIZER;
+	struct stream_info sa = { .fs = fs, .channels = channels }, sb = sa;
+	if (build_effects_chain_from_string(chain_a, NULL, &chain, &sa, NULL, dir)) return -1;
+	ssize_t len = get_effects_chain_buffer_len(&chain, block_frames, channels);
+	sample_t *buf1 = calloc(len, sizeof(sample_t)), *buf2 = calloc(len, sizeof(sample_t));
+	ssize_t pos = 0, opos = 0, blk = 0;
+	const int oc = sa.channels;
+	while (pos < frames) {
+		if (blk == switch_block) {
+			xf.chain[0] = chain;
+			if (build_effects_chain_from_string(chain_b, NULL, &xf.chain[1], &sb, NULL, dir) || sb.fs != sa.fs || sb.channels != sa.channels) {
+				destroy_effects_chain(&chain);
+				if (sb.fs != sa.fs || sb.channels != sa.channels) destroy_effects_chain(&xf.chain[1]);
+				free(buf1); free(buf2);
+				return -1;
+			}
+			xf.frames = xf.pos = xfade_frames;
+			const ssize_t len_b = get_effects_chain_buffer_len(&xf.chain[1], block_frames, channels);
+			if (len_b > len) {
+				len = len_b;
+				free(buf1); free(buf2);
+				buf1 = calloc(len, sizeof(sample_t)); buf2 = calloc(len, sizeof(sample_t));
+			}
+			xf.buf = calloc(len, sizeof(sample_t));
+			if (xf.pos == 0) { destroy_effects_chain(&chain); chain = xf.chain[1]; effects_chain_xfade_reset(&xf); }
+		}
+		const ssize_t n = (frames - pos < block_frames) ? frames - pos : block_frames;
+		memcpy(buf1, in + pos * channels, (size_t) n * channels * sizeof(sample_t));
+		ssize_t w = n;
+		sample_t *r;
+		if (xf.pos > 0) {
+			r = effects_chain_xfade_run(&xf, &w, buf1, buf2);
+			if (xf.pos == 0) {
+				destroy_effects_chain(&chain);
+				chain = xf.chain[1];
+				sample_t *b = xf.buf;
+				effects_chain_xfade_reset(&xf);
+				xf.buf = b;
+			}
+		}
+		else r = run_effects_chain(&chain, &w, buf1, buf2);
+		const ssize_t c = (opos + w <= out_cap) ? w : out_cap - opos;
+		if (c > 0) memcpy(out + opos * oc, r, (size_t) c * oc * sizeof(sample_t));
+		opos += (c > 0) ? c : 0;
+		pos += n;
+		++blk;
+	}
+	if (xf.pos > 0) {   /* input ended inside the fade: the new chain takes over, as finish_xfade() does */
+		destroy_effects_chain(&chain);
+		chain = xf.chain[1];
+	}
+	for (;;) {
+		ssize_t f = block_frames;
+		sample_t *r = drain_effects_chain(&chain, &f, buf1, buf2);
+		if (f < 0) break;
+		const ssize_t c = (opos + f <= out_cap) ? f : out_cap - opos;
+		if (c > 0) memcpy(out + opos * oc, r, (size_t) c * oc * sizeof(sample_t));
+		opos += (c > 0) ? c : 0;
+	}
+	destroy_effects_chain(&chain);
+	free(buf1); free(buf2); free(xf.buf);
+	return opos;
+}
+
 /* ---- CPU baseline (SURVEY.md section 8(d) "CPU baseline timing") ---- */
 
 struct bench_arg {

@@ -408,23 +408,27 @@ def test_wav_filter_files(amd, tmp_path, fmt, ch, ext, extra):
     T = 300 if fmt != "u8" else 40
     h = rng.standard_normal((T, ch)) * np.exp(-np.arange(T) / 50.0)[:, None]
     h = h / np.max(np.abs(h)) * 0.5
-    data, dec = _wav_bytes(h, fmt, fs=44100 if fmt == "s16" else 48000, extensible=ext, extra_chunk=extra)   # (rate mismatch ignored without -r)
+    mism = fmt == "s16"                                          # a 44.1 kHz file on a 48 kHz stream: needs `-r any` (fir_util.c:103-109)
+    any_fs = "-r any " if mism else ""
+    data, dec = _wav_bytes(h, fmt, fs=44100 if mism else 48000, extensible=ext, extra_chunk=extra)
     path = os.path.join(str(tmp_path), "filt_%s.WAV" % fmt)
     open(path, "wb").write(data)
     lit = "coefs:" + "/".join(",".join("%.17g" % v for v in dec[:, c]) for c in range(ch))
     x = noise(5000, 2, 81)
     sel = ":0,1 " if ch == 2 else ""
-    y = amd.EffectsChain(f"{sel}fir_p {path}", 48000, 2).process(x, block=1024)
+    y = amd.EffectsChain(f"{sel}fir_p {any_fs}{path}", 48000, 2).process(x, block=1024)
     y_lit = amd.EffectsChain(f"{sel}fir_p {lit}", 48000, 2).process(x, block=1024)
     assert np.array_equal(y, y_lit)
     ref = RefChain(f"{sel}fir_p {lit}", 48000, 2).process(x, block=2048)
     assert y.shape == ref.shape and rms(y - ref) < 1e-12
     # explicit type, and the error paths: -r with another rate than the file's, not a WAVE file
-    y2 = amd.EffectsChain(f"{sel}fir -t wav {path}", 48000, 2).process(x, block=1024)
+    y2 = amd.EffectsChain(f"{sel}fir {any_fs}-t wav {path}", 48000, 2).process(x, block=1024)
     assert rms(y2 - RefChain(f"{sel}fir {lit}", 48000, 2).process(x, block=2048)) < 1e-12
-    if fmt == "s16":
+    if mism:
         with pytest.raises(ValueError):
             amd.EffectsChain(f"fir_p -r 48k {path}", 48000, 2)
+        with pytest.raises(ValueError):                          # the default is the stream's rate, not "any" (fir_util.c:130)
+            amd.EffectsChain(f"fir_p {path}", 48000, 2)
     bad = os.path.join(str(tmp_path), "bad.wav"); open(bad, "wb").write(b"RIFX" + data[4:])
     with pytest.raises(ValueError):
         amd.EffectsChain(f"fir_p {bad}", 48000, 2)

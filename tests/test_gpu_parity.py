@@ -18,7 +18,7 @@ CASES = {c["name"]: c for c in META["cases"]}
 
 # bit-exact class (gain / remix / integer delay); everything else <= 1e-6 RMS by contract,
 # and in practice ~1e-15 (fp64 throughout)
-BITEXACT = {"gain_sel", "remix", "remix_up", "delay", "midside"}
+BITEXACT = {"gain_sel", "remix", "remix_up", "delay", "midside", "fir_direct"}
 TOL = 1e-12
 
 

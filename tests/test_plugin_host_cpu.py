@@ -211,3 +211,13 @@ def test_wav_filter_file_init_cpu(tmp_path):
     trunc = tmp_path / "trunc.wav"; trunc.write_bytes(wav[:30])
     assert not Obj(A, A.dspamd_get_effect_info, "fir", [str(trunc)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok()
     assert not Obj(A, A.dspamd_get_effect_info, "fir", ["-r", "48k", str(good).replace("h.wav", "missing.wav")], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok()
+    # a container whose rate differs from the stream's: refused (fir_util.c:103-109, config->p.fs = istream->fs by default, :130)
+    # unless `-r any` was given (:148-150) -- for every consumer of fir_read_filter
+    body441 = struct.pack("<HHIIHH", 1, 1, 44100, 88200, 2, 16)
+    wav441 = b"RIFF" + struct.pack("<I", 4 + 8 + len(body441) + 8 + q.nbytes) + b"WAVE" + b"fmt " + struct.pack("<I", len(body441)) + body441 + b"data" + struct.pack("<I", q.nbytes) + q.tobytes()
+    f441 = tmp_path / "h441.wav"; f441.write_bytes(wav441)
+    for eff in ("fir", "fir_p", "zita_convolver"):
+        assert not Obj(A, A.dspamd_get_effect_info, eff, [str(f441)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
+        assert not Obj(A, A.dspamd_get_effect_info, eff, ["-r", "48k", str(f441)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
+        assert Obj(A, A.dspamd_get_effect_info, eff, ["-r", "any", str(f441)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
+        assert Obj(A, A.dspamd_get_effect_info, eff, [str(f441)], 44100, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
