@@ -39,14 +39,19 @@ static void make_twiddles(long n, long count, long stride, std::vector<double2> 
 
 class ConvStage : public Stage {
 public:
-	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev);
+	// ring_parent (tail child of a small-call stage): work on that stage's rings instead of own ones; force_N: transform size
+	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev, ConvStage *ring_parent = nullptr, long force_N = 0);
 	const char *type() const override { return "conv"; }
 	std::string describe() const override;
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	ssize_t max_out_frames(ssize_t in_frames) const override { return ((long long) in_frames * up + down - 1) / down; }
 	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
-	size_t device_bytes() const override { return ring.bytes + W.bytes + H.bytes + H_plain.bytes + tail_z.bytes + tail_scratch.bytes + tail_out.bytes; }
+	size_t device_bytes() const override
+	{
+		return (is_tail_child ? 0 : ring.bytes) + W.bytes + H.bytes + H_plain.bytes + tail_z.bytes + tail_scratch.bytes + tail_out.bytes
+		       + fdl_buf.bytes + fdl_H.bytes + tail_buf.bytes + (tail_conv ? tail_conv->device_bytes() : 0);
+	}
 private:
 	bool prepare_filters(const Spec &sp);
 	void push(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st);
@@ -92,6 +97,21 @@ private:
 	int feed_round = 0;
 	ConvStage *feeds = nullptr, *fed_by = nullptr;
 	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_h, pair_out_ch, slot_of_channel;
+	double2 *ring_dev = nullptr;         // ring.p, or the parent's rings (tail child)
+	// ---- small-call regime (calls much shorter than the filter; the reference's own block is 2048 frames, dsp.h:38) ----
+	// head: the first fD = fP1 x fB taps as a uniformly partitioned convolution with a frequency-domain delay line
+	// (kernels_fft.hip conv_fdl; partition = fB frames, the largest power of two <= 2048 that divides the call size);
+	// tail: the taps from fD on through a child overlap-save convolver on the SAME rings, run once per fD frames: at a
+	// boundary n0 it computes (h_tail * x)[n0 - fD .. n0), which is the tail's share of the outputs n0 .. n0 + fD (tail_buf).
+	// The rings of samples stay the state of truth: a call that does not fit the grid (other size, unaligned position)
+	// simply continues on the one-transform-per-call path from the same rings, for the rest of the stream.
+	bool fdl = false, fdl_live = false, is_tail_child = false;
+	long fB = 0, fD = 0, fNF = 0;
+	int fP1 = 0, f_slot = 0;
+	DevBuf fdl_buf, fdl_H, fdl_tw, tail_buf;
+	std::unique_ptr<ConvStage> tail_conv;
+	bool init_fdl(const Spec &sp, ssize_t max_frames);
+	void run_fdl(ssize_t frames, double *out, long out_stride, hipStream_t st);
 };
 
 std::string ConvStage::describe() const
@@ -101,7 +121,12 @@ std::string ConvStage::describe() const
 	if (resampler) o << " " << fs_in << "->" << fs_out << " " << up << "/" << down << " delay=" << out_delay;
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
-	  << (round_f32 ? " f32-io" : "") << ((direct && !fed) ? " slab-direct" : "") << "]";
+	  << (round_f32 ? " f32-io" : "") << ((direct && !fed) ? " slab-direct" : "");
+	if (fdl) {
+		o << " small-calls: head " << fP1 << "x" << fB << " taps delay line";
+		if (tail_conv) o << " + tail T=" << tail_conv->T << " N=" << tail_conv->N << " per " << fD << " frames";
+	}
+	o << "]";
 	return o.str();
 }
 
@@ -111,9 +136,10 @@ ConvParams ConvStage::base_params() const
 	memset(&p, 0, sizeof(p));
 	p.log2N1 = log2N1; p.log2N2 = log2N2; p.log2_lo = log2_lo;
 	p.N = N; p.N1 = N1; p.N2 = N2;
-	p.ring = ring.as<double2>();
+	p.ring = ring_dev;
 	p.ring_row_stride = ring_len; p.ring_mask = ring_len - 1;
 	p.pair_h = pair_h.as<int>();
+	p.shared_h = (n_filters == 1) ? 1 : 0;
 	p.W = W.as<double2>();
 	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>();
 	p.tw_hi = tw_hi.as<double2>(); p.tw_lo = tw_lo.as<double2>();
@@ -156,8 +182,9 @@ long conv_plan(long T, long max_frames, bool resampler, double *cost_out)
 	return N;
 }
 
-bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev)
+bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev, ConvStage *ring_parent, long force_N)
 {
+	is_tail_child = ring_parent != nullptr;
 	name = sp.name;
 	T = sp.T;
 	lat = sp.latency;
@@ -203,7 +230,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	N = conv_plan(T, max_frames, resampler, nullptr);
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
-	if (env) N = std::max(lo, 1L << atoi(env));
+	if (env && !is_tail_child) N = std::max(lo, 1L << atoi(env));
+	if (force_N) N = force_N;
 	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
 	// N = N1 x N2: columns (strided) 16..256 points (one LDS exchange), rows (contiguous) 512..4096 points
 	// 1024-point rows where possible: one wave owns a row there and K2 needs no workgroup barrier (the best-tuned geometry)
@@ -223,7 +251,15 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	log2_lo = (ilog2(N) + 1) / 2;
 
 	// rings: one row of complex samples (x_a[n], x_b[n]) per channel pair per stream -- the sequence K1 transforms
-	if (!ring.alloc((size_t) S * pps * ring_len * sizeof(double2))) return false;
+	if (ring_parent) {
+		if (ring_parent->ring_len < ring_len || ring_parent->pps != pps) { set_error("%s: BUG: tail convolver does not fit its parent's rings", name.c_str()); return false; }
+		ring_len = ring_parent->ring_len;
+		ring_dev = ring_parent->ring_dev;
+	}
+	else {
+		if (!ring.alloc((size_t) S * pps * ring_len * sizeof(double2))) return false;
+		ring_dev = ring.as<double2>();
+	}
 	std::vector<int> soc(ch_in, -1);
 	std::vector<int> sel_ch;
 	for (int c = 0; c < ch_in; ++c) if (resampler || sp.sel[c]) sel_ch.push_back(c);
@@ -278,10 +314,10 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
 	// another FFT convolver right before, on the same channel pairs: its K3 writes (re, im) = this ring's elements
-	if (ConvStage *pc = dynamic_cast<ConvStage *>(prev)) {
+	if (ConvStage *pc = ring_parent ? nullptr : dynamic_cast<ConvStage *>(prev)) {
 		if (all_selected && n_filters == 1 && pc->all_selected && pc->n_filters == 1 && pc->ch_out == ch_in && pc->pps == pps && !pc->feeds
 		    && !pc->merged_pre && !getenv("DSP_AMD_NO_FEED")) {
-			pc->feed_ring = ring.as<double2>();
+			pc->feed_ring = ring_dev;
 			pc->feed_stride = ring_len;
 			pc->feed_mask = ring_len - 1;
 			pc->feed_pos = 0;
@@ -292,7 +328,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		}
 	}
 	if (feeder && all_selected && !round_f32 && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
-		feeder->ring.base = ring.as<double>();
+		feeder->ring.base = reinterpret_cast<double *>(ring_dev);
 		feeder->ring.row_stride = ring_len;
 		feeder->ring.mask = ring_len - 1;
 		feeder->ring.pos = 0;
@@ -303,7 +339,95 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		feeder_ = feeder;
 		fed = true;
 	}
+	if (!ring_parent && !init_fdl(sp, max_frames)) return false;
 	return true;
+}
+
+// ---- small-call regime: see the member comment.  Chosen when the calls are at most an eighth of the filter.
+bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
+{
+	static const int env = [] { const char *e = getenv("DSP_AMD_CONV_FDL"); return e ? atoi(e) : -1; }();   // 0 = never, P1 = force that many head partitions
+	if (env == 0 || resampler || nph != 1 || lat != 0 || round_f32 || n_filters != 1 || merged_pre) return true;
+	if (max_frames < 256 || (long) max_frames * 8 > T) return true;
+	long b = 2048;
+	while (b >= 256 && (max_frames % b)) b >>= 1;
+	if (b < 256) return true;
+	fB = b; fNF = 2 * b;
+	const long parts = (T + fB - 1) / fB;
+	fP1 = (int) std::min<long>(parts, (env > 0) ? env : 8);
+	if (parts <= 16 && env <= 0) fP1 = (int) parts;            // short enough: the whole filter in the delay line, no tail
+	fD = (long) fP1 * fB;
+	const long n_pairs = (long) S * pps;
+	if (!fdl_buf.alloc((size_t) fP1 * n_pairs * fNF * sizeof(double2)) || !fdl_H.alloc((size_t) fP1 * fNF * sizeof(double2), false)) return false;
+	std::vector<double2> t;
+	make_twiddles(fNF, fNF, 1, t);
+	if (!fdl_tw.upload(t.data(), t.size() * sizeof(double2))) return false;
+	{
+		// head partition spectra: partition q = taps [q B, q B + B), zero-padded to 2 B, through the kernel's own forward transform
+		std::vector<double2> rows((size_t) fP1 * fNF, make_double2(0.0, 0.0));
+		for (int q = 0; q < fP1; ++q)
+			for (long i = 0; i < fB && q * fB + i < T; ++i) rows[(size_t) q * fNF + i].x = sp.taps[(size_t) (q * fB + i) * sp.fch];
+		DevBuf d_rows;
+		if (!d_rows.upload(rows.data(), rows.size() * sizeof(double2))) return false;
+		FdlParams fp;
+		memset(&fp, 0, sizeof(fp));
+		fp.log2NF = ilog2(fNF); fp.P1 = fP1; fp.NF = fNF; fp.B = fB;
+		fp.ring = d_rows.as<double2>(); fp.ring_row_stride = fNF; fp.ring_mask = fNF - 1; fp.win_base = 0;
+		fp.n_sub = 1;
+		fp.spec_out = fdl_H.as<double2>(); fp.h_scale = 1.0 / (double) fNF;
+		fp.tw_nf = fdl_tw.as<double2>();
+		fp.n_pairs = fP1; fp.C = ch_in; fp.pairs_per_stream = 1;
+		launch_conv_fdl(fp, nullptr);
+		if (!hip_ok(hipDeviceSynchronize(), "head partition spectra")) return false;
+	}
+	if (fD < T) {
+		Spec ts(sp);
+		ts.T = T - fD;
+		ts.taps.assign(sp.taps.begin() + (size_t) fD * sp.fch, sp.taps.end());
+		ts.name = sp.name + ":tail";
+		tail_conv.reset(new ConvStage);
+		tail_conv->S = S; tail_conv->ch_in = ch_in; tail_conv->ch_out = ch_out; tail_conv->fs_in = fs_in; tail_conv->fs_out = fs_out;
+		const long fn = (ts.T - 1 + 7) & ~7L;
+		if (!tail_conv->init(ts, fD, nullptr, nullptr, this, std::max<long>(next_pow2(fn + fD), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)))) return false;
+		if (!tail_buf.alloc((size_t) S * fD * ch_in * sizeof(double))) return false;
+	}
+	fdl = fdl_live = true;
+	return true;
+}
+
+// the call's frames are already in the rings (pos .. pos + frames); frames and q_abs are multiples of fB
+void ConvStage::run_fdl(ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	const long n = frames / fB;
+	long done = 0;
+	while (done < n) {
+		const long q_now = q_abs + done * fB;
+		const long seg = std::min<long>(n - done, (fD - q_now % fD) / fB);
+		FdlParams fp;
+		memset(&fp, 0, sizeof(fp));
+		fp.log2NF = ilog2(fNF); fp.P1 = fP1; fp.NF = fNF; fp.B = fB;
+		fp.ring = ring_dev; fp.ring_row_stride = ring_len; fp.ring_mask = ring_len - 1;
+		fp.win_base = (pos + done * fB - fB) & (ring_len - 1);
+		fp.n_sub = (int) seg;
+		fp.slot0 = f_slot;
+		fp.fdl = fdl_buf.as<double2>();
+		fp.Hf = fdl_H.as<double2>();
+		fp.tw_nf = fdl_tw.as<double2>();
+		fp.n_pairs = (long) S * pps;
+		fp.C = ch_in; fp.pairs_per_stream = pps;
+		fp.pair_out_ch = pair_out_ch.as<int>();
+		fp.out = out + (size_t) done * fB * ch_in;
+		fp.out_stride_frames = out_stride;
+		if (tail_conv) { fp.tail = tail_buf.as<double>(); fp.tail_stride_frames = fD; fp.tail_off = q_now % fD; }
+		{ ProfScope ps("conv_fdl", st); launch_conv_fdl(fp, st); }
+		f_slot = (int) ((f_slot + seg) % fP1);
+		done += seg;
+		const long n0 = q_abs + done * fB;
+		if (tail_conv && n0 % fD == 0) {
+			// the tail's share of the NEXT fD outputs: (h_tail * x)[n0 - fD .. n0), every input it needs is in the rings by now
+			tail_conv->convolve(n0 - fD, n0 - 1, n0 - fD, fD, tail_buf.as<double>(), fD, st);
+		}
+	}
 }
 
 // filter spectra: run the forward half of the pipeline on the taps themselves (exactly what the
@@ -361,7 +485,7 @@ void ConvStage::push(const double *in, long in_stride, ssize_t frames, double *o
 	d.C = ch_in;
 	d.slot_of_channel = slot_of_channel.as<int>();
 	d.rows_per_stream = pps;
-	d.ring = ring.as<double2>();
+	d.ring = ring_dev;
 	d.ring_row_stride = ring_len; d.ring_mask = ring_len - 1; d.pos = pos;
 	d.round_f32 = round_f32;
 	{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
@@ -433,6 +557,17 @@ ssize_t ConvStage::emit(long count, double *out, long out_stride, hipStream_t st
 
 ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
+	if (fdl && fdl_live) {
+		if (!feeds && frames % fB == 0 && q_abs % fB == 0) {
+			cur_slab = nullptr;
+			if (!fed) push(in, in_stride, frames, out, out_stride, st);
+			run_fdl(frames, out, out_stride, st);
+			q_abs += frames;
+			pos = (pos + frames) & (ring_len - 1);
+			return frames;
+		}
+		fdl_live = false;      // off the grid: the rings carry on with one transform per call (the delay line is a cache of them)
+	}
 	const bool use_direct = direct && !fed && ((((size_t) in) & 15) == 0) && (double) in_stride * ch_in * 8 < 1.0e18;
 	cur_slab = use_direct ? in : nullptr;
 	cur_slab_stride = in_stride;
@@ -521,12 +656,18 @@ bool ConvStage::compute_tail(hipStream_t st)
 
 void ConvStage::reset(hipStream_t st)
 {
-	(void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
+	if (ring.p) (void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
 	pos = 0;
 	q_total = emitted = q_abs = 0;
 	tail_frames = -1; tail_served = 0;
 	feed_pos = 0;
 	if (feeder_) feeder_->ring.pos = 0;
+	if (fdl) {
+		(void) hipMemsetAsync(fdl_buf.p, 0, fdl_buf.bytes, st);
+		if (tail_buf.p) (void) hipMemsetAsync(tail_buf.p, 0, tail_buf.bytes, st);
+		f_slot = 0;
+		fdl_live = true;
+	}
 }
 
 // -------------------------------------------------------------- FirDirectStage

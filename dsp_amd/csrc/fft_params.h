@@ -23,6 +23,7 @@ struct ConvParams {
 	long slab_stride_frames, slab_frame0;   // slab frame of window element first_n (negative: the window starts in older calls)
 	int slab_store;                         // 1: K1 files the history itself (plain convolution); 0: the host pushes the tail of the call
 	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
+	int shared_h;                       // every pair uses filter 0 (pair_h is all zeros)
 	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
 	double2 *W;                         // [pairs in chunk][N] work spectrum / time buffer
 	const double2 *tw_n1, *tw_n2;       // exp(-2 pi i k / N1), exp(-2 pi i k / N2)
@@ -48,6 +49,32 @@ struct ConvParams {
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)
 	int round_f32;
 };
+
+// Small-call regime (calls much shorter than the filter): the head of the filter as a uniformly partitioned convolution with a
+// frequency-domain delay line -- what fft_part_group_compute does on the CPU (fir_p.c:64-103) -- with the partition = the
+// call's block B, transform size NF = 2 B; the rest of the filter is served by the overlap-save convolver once per P1 B frames.
+struct FdlParams {
+	int log2NF, P1;                     // NF = 2 B points per transform (512 .. 4096), P1 partitions of B taps
+	long NF, B;
+	const double2 *ring;                // the pair rings (complex samples), as in ConvParams
+	long ring_row_stride, ring_mask;
+	long win_base;                      // ring index of the first window element of sub-block 0 (= first new frame - B)
+	int n_sub;                          // sub-blocks of B frames handled by this launch, one after the other
+	int slot0;                          // delay-line slot written by sub-block 0; sub-block b writes (slot0 + b) % P1
+	double2 *fdl;                       // [P1][n_pairs][NF] spectra of the last P1 windows, in the transform's own (natural) order
+	const double2 *Hf;                  // [P1][NF] spectra of the zero-padded head partitions, pre-scaled by 1 / NF
+	double2 *spec_out;                  // preparation mode: write h_scale x forward transform here ([n_pairs][NF]) and stop
+	double h_scale;
+	const double2 *tw_nf;               // exp(-2 pi i k / NF)
+	long n_pairs;
+	int C, pairs_per_stream;
+	const int *pair_out_ch;             // [pairs_per_stream][2]
+	double *out;                        // [S][out_stride_frames][C]
+	long out_stride_frames;
+	const double *tail;                 // [S][tail_stride_frames][C]: contribution of the taps from P1 B on, or nullptr
+	long tail_stride_frames, tail_off;  // frame tail_off + f of `tail` belongs to output frame f of this launch
+};
+void launch_conv_fdl(const FdlParams &p, hipStream_t st);
 
 struct DeintParams {
 	const double *in;

@@ -29,6 +29,7 @@
 //        one workgroup so that whole 64-byte frames leave in 512-byte runs.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstdint>
 #include "kparams.h"
 #include "fft_params.h"
 
@@ -524,6 +525,89 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	for (int m = 0; m < 16; ++m) st16(W + P * m, cmulc(v[m], cmul(twb, steps[m])), p.nt & 8);
 }
 
+// K2, persistent form (plain convolution, one filter shared by every pair): a workgroup keeps ITS rows k1 and walks over the
+// pairs.  What the one-shot kernel above redoes per row and pair happens once per workgroup: the filter rows and the
+// inter-pass twiddles live in registers, the pass twiddles in LDS.  The next pair's rows come in by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass) while the current ones are transformed, so the HBM
+// stream never waits for a compute phase -- at 244 VGPRs the one-shot kernel holds two workgroups per CU whose load, compute
+// and store phases overlap only by chance (2.0 ms for 8.6 GB where the bare access pattern moves them in 1.55,
+// scripts/ubench/hbmprobe.hip).  Rows of 2048 / 4096 points take the same path (three radix-16 passes with workgroup
+// barriers): the extra barriers hide behind the stream instead of adding to it.
+// LDS: landing zone [16][256] points (thread t's point m at m * 256 + t: what every wave fetches is contiguous, as LDS-DMA
+// requires, and what a thread reads back is its own wave's) + the padded exchange rows + tables = 139 KB: one workgroup per CU.
+// vmcnt runs in order on this chip (loads and stores share it): at the top of an iteration the 16 stores of the previous
+// pair are the youngest operations, so `vmcnt(16)` means "this pair's rows have landed".
+template <int LOG2N2>
+__global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_wg, int n_pairs)
+{
+	using Cfg = RowCfg<LOG2N2>;
+	constexpr int N2 = Cfg::N2, P = Cfg::P, RPW = Cfg::RPW;
+	constexpr bool WL = Cfg::WAVE_LOCAL;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	cplx *land = reinterpret_cast<cplx *>(smem_raw);                    // [16][NT]
+	cplx *data = land + 16 * NT;                                         // [RPW][PITCH]
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + 256, *thi = tlo + 64;
+	const int tid = threadIdx.x;
+	const int rw = tid / P, j = tid % P;
+	const long k1 = (long) blockIdx.x * RPW + rw;
+	const long q0 = (long) blockIdx.y * pairs_per_wg;
+	const long q1 = (q0 + pairs_per_wg < n_pairs) ? q0 + pairs_per_wg : n_pairs;
+	if (q0 >= q1) return;
+	cplx *W = p.W + k1 * N2 + j;                                         // + pair * N
+	// LDS-DMA by hand: through the builtin the compiler books the transfer as an LDS write and parks an `s_waitcnt vmcnt(0)` in
+	// front of the next exchange-buffer access -- which would wait for the prefetch it is meant to overlap.  M0 = destination
+	// (wave-uniform LDS byte address; the hardware adds lane * 16), saved and restored around the instruction.
+	const unsigned land_wave = __builtin_amdgcn_readfirstlane((unsigned) (uintptr_t) (land + (tid & ~63)));
+	auto fetch = [&](long q) {
+		const cplx *src = W + q * p.N;                                   // (q counts from the launch's first pair, like W)
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			unsigned keep;
+			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+			             : "=&s"(keep) : "v"(src + P * m), "s"(land_wave + (unsigned) (NT * m * sizeof(cplx))) : "memory");
+		}
+	};
+	fetch(q0);
+	t256[tid] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) tlo[tid] = p.tw_n2[tid];
+	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
+	cplx *steps = thi + 64 + rw * 16;
+	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
+	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
+	cplx h[16], twd[16];
+	{
+		const cplx *H = p.H + k1 * N2 + j;                               // (one shared filter: pair_h is all zeros)
+#pragma unroll
+		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first fetch (the compiler does not know about it)
+	__syncthreads();                                                     // tables visible
+#pragma unroll
+	for (int m = 0; m < 16; ++m) twd[m] = cmul(twb, steps[m]);
+	const TwRow<N2> tw{ t256, tlo, thi };
+	const RowMap map{ rw * Cfg::PITCH };
+	for (long q = q0; q < q1; ++q) {
+		if (q > q0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");    // this pair's rows have landed (see above)
+		cplx v[16];
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m] = land[NT * m + tid];
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own landing slots read: they may be overwritten
+		if (q + 1 < q1) fetch(q + 1);
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], twd[m]);
+		row_fft<LOG2N2, false>(v, j, data, map, tw);
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], h[m]);
+		row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
+		row_fft<LOG2N2, true>(v, j, data, map, tw);
+		cplx *out = W + q * p.N;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) out[P * m] = cmulc(v[m], twd[m]);
+		if (q + 1 == q1) break;
+		row_sync<WL>();      // the last gather of the inverse transform is done before the next forward pass writes the row
+	}
+}
+
 // K2 for rows of N2 = WV * 1024 points (WV = 2, 4): the row FFT is itself split 4-step style so that all but one
 // exchange per direction stay inside a wave.  With n2 = a + 1024 b and k2 = WV ka + kb:
 //   forward   Z_kb[a] = w_N2^(a kb) sum_b x[a + 1024 b] w_WV^(b kb)      radix-WV butterflies on registers (a thread
@@ -617,6 +701,133 @@ __global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
 		dftR<WV, true>(u);
 #pragma unroll
 		for (int b = 0; b < WV; ++b) W[a + 1024 * b] = cmulc(u[b], cmul(twb, steps[i * WV + b]));
+	}
+}
+
+// ------------------------------------------------------------------ small calls: partitioned head with a delay line
+//
+// One row of NF = 2 B points per pair: window = [previous block | this block] of the pair's ring, forward transform (kept:
+// it is the newest entry of the pair's delay line), Y = sum_p X[now - p] H_p over the P1 head partitions, inverse transform,
+// the last B points are this block's outputs; the overlap-save convolver's share of the filter (taps from P1 B on, computed
+// once per P1 blocks: conv.cpp) is added from `tail` on the way out.  Every thread owns the same 16 bins in every
+// transform, so the delay line is only ever re-read by the thread that wrote it: consecutive sub-blocks of one call run in
+// ONE launch without any global synchronisation.  Traffic per pair and block: 16 B x NF in, 16 B x NF x P1 delay line,
+// 16 B x B out -- the reference's plan for 65536 taps re-reads 59 partitions' worth per block, this one P1 = 8.
+template <int LOG2NF>
+__global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
+{
+	using Cfg = RowCfg<LOG2NF>;
+	constexpr int NF = Cfg::N2, P = Cfg::P, RPW = Cfg::RPW, B = NF / 2;
+	constexpr bool WL = Cfg::WAVE_LOCAL;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	cplx *data = reinterpret_cast<cplx *>(smem_raw);
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + 256, *thi = tlo + 64;
+	const int tid = threadIdx.x;
+	const int rw = tid / P, j = tid % P;
+	// XCD-aware order: the pairs of one stream write neighbouring 16-byte pieces of the same output lines, so they should
+	// share an L2: workgroup ids that differ by a multiple of 8 land on the same XCD
+	long pair = (long) blockIdx.x * RPW + rw;
+	if (RPW == 1 && !p.spec_out && p.pairs_per_stream > 1 && (p.n_pairs % (8L * p.pairs_per_stream)) == 0) {
+		const long per = 8L * p.pairs_per_stream, blk = blockIdx.x / per, r = blockIdx.x % per;
+		pair = (blk * 8 + r % 8) * p.pairs_per_stream + r / 8;
+	}
+	t256[tid] = p.tw_nf[tid * (NF / 256)];
+	if (tid < 64) tlo[tid] = p.tw_nf[tid];
+	else if (tid < 64 + NF / 64) thi[tid - 64] = p.tw_nf[(tid - 64) * 64];
+	const bool active = pair < p.n_pairs;
+	const cplx *ring = p.ring + (active ? pair : 0) * p.ring_row_stride;
+	const TwRow<NF> tw{ t256, tlo, thi };
+	const RowMap map{ rw * Cfg::PITCH };
+	const long s = (active ? pair : 0) / p.pairs_per_stream;
+	const int qs = (int) ((active ? pair : 0) % p.pairs_per_stream);
+	const int cha = p.pair_out_ch ? p.pair_out_ch[2 * qs] : -1, chb = p.pair_out_ch ? p.pair_out_ch[2 * qs + 1] : -1;
+	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	const double *tail = p.tail ? p.tail + ((size_t) s * p.tail_stride_frames + p.tail_off) * p.C : nullptr;
+	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0) && (!tail || (((size_t) tail) & 15) == 0);
+	const size_t slot_stride = (size_t) p.n_pairs * NF;
+	__syncthreads();
+	for (int b = 0; b < p.n_sub; ++b) {
+		cplx v[16];
+		const long w0 = p.win_base + (long) b * B;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m] = active ? ring[(w0 + j + P * m) & p.ring_mask] : make_double2(0.0, 0.0);
+		if (b > 0) row_sync<WL>();       // the previous sub-block's last gather is done
+		row_fft<LOG2NF, false>(v, j, data, map, tw);
+		if (p.spec_out) {
+			if (active) {
+#pragma unroll
+				for (int m = 0; m < 16; ++m) p.spec_out[(size_t) pair * NF + j + P * m] = make_double2(v[m].x * p.h_scale, v[m].y * p.h_scale);
+			}
+			return;
+		}
+		const int slot = (p.slot0 + b) % p.P1;
+		cplx *line = p.fdl + (size_t) pair * NF + j;
+		if (active) {
+#pragma unroll
+			for (int m = 0; m < 16; ++m) line[(size_t) slot * slot_stride + P * m] = v[m];
+		}
+		{
+			const cplx *H = p.Hf + j;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], H[P * m]);
+		}
+		if (active) {
+			for (int q = 1; q < p.P1; ++q) {
+				const int sl = (slot + p.P1 - q) % p.P1;
+				const cplx *X = line + (size_t) sl * slot_stride;
+				const cplx *H = p.Hf + (size_t) q * NF + j;
+				// (eight bins at a time: two workgroups per CU need the kernel inside 256 registers)
+#pragma unroll
+				for (int half = 0; half < 2; ++half) {
+					cplx x[8];
+#pragma unroll
+					for (int m = 0; m < 8; ++m) x[m] = X[P * (8 * half + m)];
+#pragma unroll
+					for (int m = 0; m < 8; ++m) {
+						const cplx h = H[P * (8 * half + m)];
+						cplx &a = v[8 * half + m];
+						a.x = fma(x[m].x, h.x, fma(-x[m].y, h.y, a.x));
+						a.y = fma(x[m].x, h.y, fma(x[m].y, h.x, a.y));
+					}
+				}
+			}
+		}
+		row_sync<WL>();
+		row_fft<LOG2NF, true>(v, j, data, map, tw);
+		if (!active) continue;
+		// outputs: positions B .. NF - 1 of the row = frames b B .. b B + B - 1 of this launch
+#pragma unroll
+		for (int m = 8; m < 16; ++m) {
+			const long f = (long) b * B + (j + P * m - B);
+			cplx y = v[m];
+			if (wide) {
+				if (tail) { const cplx t = *reinterpret_cast<const cplx *>(tail + f * p.C + cha); y.x += t.x; y.y += t.y; }
+				*reinterpret_cast<cplx *>(out + f * p.C + cha) = y;
+			}
+			else {
+				if (cha >= 0) out[f * p.C + cha] = y.x + (tail ? tail[f * p.C + cha] : 0.0);
+				if (chb >= 0) out[f * p.C + chb] = y.y + (tail ? tail[f * p.C + chb] : 0.0);
+			}
+		}
+	}
+}
+
+template <int L> static void launch_fdl_t(const FdlParams &p, hipStream_t st)
+{
+	using Cfg = RowCfg<L>;
+	grant_lds(conv_fdl<L>, Cfg::LDS);
+	const long wgs = (p.n_pairs + Cfg::RPW - 1) / Cfg::RPW;
+	hipLaunchKernelGGL(conv_fdl<L>, dim3((unsigned) wgs), dim3(NT), Cfg::LDS, st, p);
+}
+
+void launch_conv_fdl(const FdlParams &p, hipStream_t st)
+{
+	switch (p.log2NF) {
+	case 9: launch_fdl_t<9>(p, st); break;
+	case 10: launch_fdl_t<10>(p, st); break;
+	case 11: launch_fdl_t<11>(p, st); break;
+	case 12: launch_fdl_t<12>(p, st); break;
+	default: break;
 	}
 }
 
@@ -758,8 +969,34 @@ template <int WV> static void launch_row_big(const ConvParams &p, int mode, int 
 	else hipLaunchKernelGGL((conv_row_big<WV, 0>), grid, block, LDS, st, p);
 }
 
+template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, hipStream_t st)
+{
+	using Cfg = RowCfg<L2>;
+	constexpr size_t LDS = ((size_t) 16 * NT + (size_t) Cfg::RPW * Cfg::PITCH + Cfg::NTW) * sizeof(cplx);
+	grant_lds(conv_row_pipe<L2>, LDS);
+	// one workgroup per CU (LDS) x 256 CUs: the row groups times as many pair ranges as that takes
+	const int groups = (int) (p.N1 / Cfg::RPW);
+	static const int wgs = [] { const char *e = getenv("DSP_AMD_ROW_PIPE_WGS"); return e ? atoi(e) : 512; }();
+	int ranges = (wgs + groups - 1) / groups;
+	if (ranges > n_pairs) ranges = n_pairs;
+	if (ranges < 1) ranges = 1;
+	const int per = (n_pairs + ranges - 1) / ranges;
+	ranges = (n_pairs + per - 1) / per;
+	hipLaunchKernelGGL(conv_row_pipe<L2>, dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
+}
+
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
+	static const int pipe_env = [] { const char *e = getenv("DSP_AMD_ROW_PIPE"); return e ? atoi(e) : 1; }();
+	if (pipe_env && mode == 0 && p.nph == 1 && p.shared_h && n_pairs >= 8) {
+		switch (p.log2N2) {
+		case 9: launch_row_pipe<9>(p, n_pairs, st); return;
+		case 10: launch_row_pipe<10>(p, n_pairs, st); return;
+		case 11: launch_row_pipe<11>(p, n_pairs, st); return;
+		case 12: launch_row_pipe<12>(p, n_pairs, st); return;
+		default: break;
+		}
+	}
 	static const int big_env = [] { const char *e = getenv("DSP_AMD_ROW_BIG"); return e ? atoi(e) : 1; }();
 	int big = big_env;
 	// (H is stored in the row kernel's own order: a multi-phase plan uses the generic kernel for preparation too)

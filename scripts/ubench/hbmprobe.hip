@@ -185,6 +185,17 @@ int main(int argc, char **argv)
 		const double t1 = time_ms([&] { k_row<<<dim3(64, pairs), 256>>>(a, b, pitch, pair); }, reps);
 		printf("pitch 1024+%-3ld  in place %8.2f   a->b %8.2f\n", pad, 2 * colbytes / t0 / 1e9, 2 * colbytes / t1 / 1e9);
 	}
+	// K3's read pattern: 128-byte runs (8 columns) of 256 rows at the row pitch of the transform, 4 pairs per 512-thread workgroup
+	// (pairs 4 MiB x pitch / 1024 apart); load only
+	printf("# K3 read pattern: 128 B runs x 256 rows, pitch = N2 (+pad) points; TB/s\n");
+	for (long n2 : { 1024L, 2048L, 4096L })
+		for (long pad : { 0L, 16L, 32L }) {
+			const long pitch = n2 + pad, pair = 256 * pitch;
+			const int np = (int) (bytes / ((size_t) pair * 16));
+			const double t = time_ms([&] { k_col<128, 256><<<dim3((unsigned) (n2 / 8), np), 128>>>(a, b, pitch, pitch, pair, pair, 1, 0); }, reps);
+			const double t2 = time_ms([&] { k_col<256, 256><<<dim3((unsigned) (n2 / 16), np), 256>>>(a, b, pitch, pitch, pair, pair, 1, 0); }, reps);
+			printf("N2 %5ld pad %3ld : 128 B runs %6.2f   256 B runs %6.2f\n", n2, pad, (double) np * 256 * n2 * 16 / t / 1e9, (double) np * 256 * n2 * 16 / t2 / 1e9);
+		}
 	// does the rate depend on how many workgroups (= bytes in flight) a CU holds?  dynamic LDS caps the residency
 	printf("# residency sweep: workgroups per CU capped through dynamic LDS (copy TB/s)\n");
 	printf("%-10s %12s %12s %12s %12s\n", "LDS/wg", "stream U=16", "stream U=4", "col 256thr", "row in place");

@@ -1,0 +1,98 @@
+"""GPU parity of the small-call regime of the FFT convolver (calls much shorter than the filter: the reference's own
+block is 2048 frames, dsp.h:38; its fir_p serves them with a partitioned delay line, fir_p.c:64-103): head partitions
+through the delay-line kernel + the rest of the filter through the overlap-save convolver once per 8 blocks, against the
+real reference at the same block size, across the boundaries where the tail hands over, off-grid calls, reset, drain."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_api import RefChain, rms
+
+pytestmark = pytest.mark.gpu
+
+
+def noise(frames, ch, seed, amp=0.5):
+    return np.random.Generator(np.random.PCG64(seed)).uniform(-amp, amp, size=(frames, ch))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import dsp_amd
+    assert dsp_amd.load_library().dspamd_device_count() >= 1, "no HIP device: GPU tests must fail loudly, not fall back"
+    return dsp_amd
+
+
+def filt(tmp_path, taps, seed=7, name="h.raw"):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 8.0))
+    h = h / np.sqrt(np.sum(h * h)) / 4.0
+    p = os.path.join(str(tmp_path), name)
+    np.asarray(h, dtype="<f8").tofile(p)
+    return p, h
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("taps,block,S,C,chain_head", [
+    (65536, 2048, 3, 8, "lowpass 1k 0.707 eq 400 2.0 1.5 "),      # the headline chain's shape at the reference's block size: head 8 x 2048 + tail
+    (65536, 2048, 2, 2, ""),                                       # convolver first in the chain (de-interleaving pass feeds the rings)
+    (20000, 1024, 2, 4, "gain -3 "),                               # 1024-frame partitions, tail of 11808 taps
+    (9000, 512, 3, 2, ""),                                         # short enough for the delay line alone (18 partitions -> no: 9000/512 = 18 > 16, tail)
+    (7000, 512, 2, 3, "highpass 50 0.707 "),                       # 14 partitions, no tail; odd channel count (a half-empty pair)
+    (40000, 4096, 2, 2, ""),                                       # calls of two partitions each
+])
+def test_small_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chain_head):
+    import torch
+    p, h = filt(tmp_path, taps)
+    chain = f"{chain_head}fir_p -t pcm -e double -c 1 {p}"
+    n_blocks = 2 * 8 + 3 if taps > 16 * min(block, 2048) else 12      # across two tail hand-overs
+    N = n_blocks * block
+    x = np.stack([noise(N, C, 300 + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    assert "small-calls" in b.plan(), b.plan()
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    for s in range(S):
+        ref = RefChain(chain, 48000, C).process(x[s], block=block)
+        assert y[s].shape == ref.shape, (y[s].shape, ref.shape)
+        assert rms(y[s] - ref) < 1e-12, (s, rms(y[s] - ref))
+
+
+def test_small_calls_equal_one_transform_per_call(amd, tmp_path):
+    """the same stream through the small-call path and through the one-transform-per-call path (a batch created for large
+    calls), and a stream that leaves the grid half way (an odd call size) and continues on the rings"""
+    import torch
+    p, h = filt(tmp_path, 30000)
+    chain = f"eq 300 1.0 3 fir_p -t pcm -e double -c 1 {p}"
+    S, C, block = 2, 4, 1024
+    x = torch.from_numpy(np.stack([noise(24 * block + 700, C, 20 + s) for s in range(S)])).cuda()
+    small = amd.BatchChain(chain, 48000, C, S, block)
+    big = amd.BatchChain(chain, 48000, C, S, 1 << 16)
+    assert "small-calls" in small.plan() and "small-calls" not in big.plan()
+    y_big = big.run(x).clone()
+    outs = [small.run(x[:, q:q + block, :].contiguous()).clone() for q in range(0, 11 * block, block)]
+    outs.append(small.run(x[:, 11 * block:11 * block + 700, :].contiguous()).clone())          # off the grid: 700 frames
+    pos = 11 * block + 700
+    while pos < x.shape[1]:
+        n = min(block, x.shape[1] - pos)
+        outs.append(small.run(x[:, pos:pos + n, :].contiguous()).clone())
+        pos += n
+    y = torch.cat(outs, dim=1)
+    assert y.shape == y_big.shape
+    assert float((y - y_big).abs().max()) < 1e-12
+
+
+def test_small_calls_reset(amd, tmp_path):
+    import torch
+    p, h = filt(tmp_path, 40000)
+    chain = f"fir_p -t pcm -e double -c 1 {p}"
+    S, C, block = 2, 2, 2048
+    x1 = torch.from_numpy(np.stack([noise(11 * block, C, 1 + s) for s in range(S)])).cuda()
+    x2 = torch.from_numpy(np.stack([noise(11 * block, C, 9 + s) for s in range(S)])).cuda()
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    for q in range(0, 11 * block, block):
+        b.run(x1[:, q:q + block, :].contiguous())
+    b.reset()
+    y = torch.cat([b.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, 11 * block, block)], dim=1)
+    f = amd.BatchChain(chain, 48000, C, S, block)
+    yf = torch.cat([f.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, 11 * block, block)], dim=1)
+    assert torch.equal(y, yf)
