@@ -136,9 +136,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--channels", type=int, default=8)
-    ap.add_argument("--block", type=int, default=196608, help="frames per step per stream")
+    ap.add_argument("--block", type=int, default=983040, help="frames per step per stream (default: the hop of a 2^20-point transform for 65536 taps, 15 x 65536: the valid fraction of every transform is 15/16)")
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab-pad", type=int, default=68, help="frames of padding between the slabs of two streams (input and output buffers): "
+                    "at exactly block x C x 8 bytes apart -- a multiple of 4 MiB at the default block -- every stream's frame t sits on the same "
+                    "memory channels (0 = contiguous [S][block][C] tensors)")
     ap.add_argument("--chain", default=None, help="override the chain (use {F} for the filter file)")
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="one of BASELINE.json's other configs (sets streams / channels / block / taps / chain); the default run is the headline workload")
     args = ap.parse_args()
@@ -187,10 +190,21 @@ def main():
     plan = batch.plan()
     stream = torch.cuda.current_stream().cuda_stream
     # synthetic sgen input resident in HBM: stream i = sine at (100 + 90 i) Hz, amplitude 1
-    x = [torch.empty((S, args.block, C), dtype=torch.float64, device="cuda") for _ in range(2)]
+    xc = [torch.empty((S, args.block, C), dtype=torch.float64, device="cuda") for _ in range(2)]
     for k in range(2):
-        L.dspamd_sgen_sine(x[k].data_ptr(), S, args.block, C, fs, 100.0 + 90.0 * s_lo, 90.0, k * args.block, stream)
-    out = torch.empty((S, batch.max_out_frames(args.block), batch.ochannels), dtype=torch.float64, device="cuda")
+        L.dspamd_sgen_sine(xc[k].data_ptr(), S, args.block, C, fs, 100.0 + 90.0 * s_lo, 90.0, k * args.block, stream)
+    if args.slab_pad > 0:
+        # the same slabs, args.slab_pad frames apart: [S][block + pad][C] buffers of which the engine sees [:, :block, :]
+        x = []
+        for k in range(2):
+            buf = torch.zeros((S, args.block + args.slab_pad, C), dtype=torch.float64, device="cuda")
+            buf[:, :args.block, :] = xc[k]
+            x.append(buf[:, :args.block, :])
+        del xc
+        out = torch.empty((S, batch.max_out_frames(args.block) + args.slab_pad, batch.ochannels), dtype=torch.float64, device="cuda")
+    else:
+        x = xc
+        out = torch.empty((S, batch.max_out_frames(args.block), batch.ochannels), dtype=torch.float64, device="cuda")
 
     def barrier():
         torch.cuda.synchronize()
@@ -242,7 +256,7 @@ def main():
 
     # digest: keeps the output observable and gives the judge a cheap checksum
     dig = torch.empty((S, 3), dtype=torch.float64, device="cuda")
-    L.dspamd_digest(out.data_ptr(), S, args.block, out.shape[1], batch.ochannels, dig.data_ptr(), stream)
+    L.dspamd_digest(out.data_ptr(), S, min(args.block, out.shape[1]), out.shape[1], batch.ochannels, dig.data_ptr(), stream)
     torch.cuda.synchronize()
     dig = job.gather_digests(dig, S_total)       # [S_total, 3]: sum, sum of squares, peak per stream
     finite = bool(torch.isfinite(dig).all().item())
@@ -283,7 +297,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic (device sgen sine, 100+90*i Hz per stream; seeded random 65536-tap filter)",
             "config": {"workload": (f"{S_total} streams x {C} ch @ {fs} Hz, chain = 10 biquads + fir_p({args.taps} taps), {args.block} frames/step/stream" if not (args.config or args.chain)
                                     else f"{S_total} streams x {C} ch @ {fs} Hz, chain = {chain_t}, {args.block} frames/step/stream"),
-                       "streams": S_total, "channels": C, "block_frames": args.block, "taps": args.taps,
+                       "streams": S_total, "channels": C, "block_frames": args.block, "taps": args.taps, "slab_pad_frames": args.slab_pad,
                        "parallelism": f"streams sharded {S_total // world}/GPU, no data-plane collective", "plan": plan},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,

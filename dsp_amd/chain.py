@@ -113,15 +113,21 @@ class BatchChain:
         return self.torch.cuda.current_stream().cuda_stream
 
     def run(self, x, out=None):
-        """x: [S, frames, C] cuda float64.  Returns a view [S, oframes, C_out] of `out` (allocated if None)."""
+        """x: [S, frames, C] cuda float64 -- contiguous, or a view x = buf[:, :frames, :] of a contiguous [S, stride, C] buffer
+        (padded slabs: see dspamd_batch_run_strided).  Returns a view [S, oframes, C_out] of `out` (allocated if None);
+        `out` may be such a view too."""
         t = self.torch
-        assert x.is_cuda and x.dtype == t.float64 and x.is_contiguous() and x.shape[0] == self.S and x.shape[2] == self.channels
+        assert x.is_cuda and x.dtype == t.float64 and x.shape[0] == self.S and x.shape[2] == self.channels
         frames = x.shape[1]
+        assert x.stride(2) == 1 and x.stride(1) == self.channels and x.stride(0) % self.channels == 0 and x.stride(0) >= frames * self.channels
+        in_stride = x.stride(0) // self.channels if self.S > 1 else frames
         cap = max(self.max_out_frames(frames), 1)
         if out is None:
             out = t.empty((self.S, cap, self.ochannels), dtype=t.float64, device=x.device)
-        assert out.is_contiguous() and out.shape[0] == self.S and out.shape[2] == self.ochannels and out.shape[1] >= cap
-        f = self.L.dspamd_batch_run(self.h, x.data_ptr(), frames, out.data_ptr(), out.shape[1], self._stream())
+        assert out.shape[0] == self.S and out.shape[2] == self.ochannels and out.shape[1] >= cap
+        assert out.stride(2) == 1 and out.stride(1) == self.ochannels and out.stride(0) % self.ochannels == 0
+        out_stride = out.stride(0) // self.ochannels if self.S > 1 else out.shape[1]
+        f = self.L.dspamd_batch_run_strided(self.h, x.data_ptr(), in_stride, frames, out.data_ptr(), out_stride, self._stream())
         if f < 0:
             raise RuntimeError(f"dsp_amd: batch_run failed: {last_error()}")
         return out[:, :f, :]
@@ -131,7 +137,8 @@ class BatchChain:
         cap = max(self.max_out_frames(block), 1)
         if out is None:
             out = t.empty((self.S, cap, self.ochannels), dtype=t.float64, device="cuda")
-        f = self.L.dspamd_batch_drain(self.h, block, out.data_ptr(), out.shape[1], self._stream())
+        out_stride = out.stride(0) // self.ochannels if self.S > 1 else out.shape[1]
+        f = self.L.dspamd_batch_drain(self.h, block, out.data_ptr(), out_stride, self._stream())
         if f == -1:
             return None
         if f < 0:

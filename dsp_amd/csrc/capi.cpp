@@ -93,6 +93,13 @@ ssize_t dspamd_batch_run(dspamd_batch *b, const void *d_in, ssize_t frames, void
 	return b->pipe->run(static_cast<const double *>(d_in), frames, static_cast<double *>(d_out), (long) out_stride_frames, static_cast<hipStream_t>(stream));
 }
 
+ssize_t dspamd_batch_run_strided(dspamd_batch *b, const void *d_in, ssize_t in_stride_frames, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream)
+{
+	if (frames < 1) return 0;
+	b->iframes += frames;
+	return b->pipe->run(static_cast<const double *>(d_in), frames, static_cast<double *>(d_out), (long) out_stride_frames, static_cast<hipStream_t>(stream), (long) in_stride_frames);
+}
+
 ssize_t dspamd_batch_drain(dspamd_batch *b, ssize_t block_frames, void *d_out, ssize_t out_stride_frames, void *stream)
 {
 	// drain_effects_chain(), effects_chain.c:1186-1218

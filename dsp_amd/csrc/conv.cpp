@@ -76,7 +76,7 @@ private:
 	bool spectrum_of(const std::vector<double> &taps_1ch, long n_taps, int stride, int offset, double2 *dst, int row_nph);
 	bool compute_tail(hipStream_t st);
 	ConvParams base_params() const;
-	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, first_n = 0, lat = 0, ring_len = 0, pos = 0;
+	long T = 0, N = 0, N1 = 0, N2 = 0, B = 0, first_n = 0, lat = 0, ring_len = 0, pos = 0, w_stride = 0, ring_stride = 0;   // ring_stride: distance between the rings of two pairs (ring_len + padding, see w_stride)
 	int log2N1 = 0, log2N2 = 0, log2_lo = 0, nsel = 0, pps = 0, n_filters = 1, round_f32 = 0;
 	bool fed = false, all_selected = false;
 	// plain zero-latency convolution of all channels straight from the interleaved slab: K1 reads the new frames there and
@@ -137,7 +137,7 @@ ConvParams ConvStage::base_params() const
 	p.log2N1 = log2N1; p.log2N2 = log2N2; p.log2_lo = log2_lo;
 	p.N = N; p.N1 = N1; p.N2 = N2;
 	p.ring = ring_dev;
-	p.ring_row_stride = ring_len; p.ring_mask = ring_len - 1;
+	p.ring_row_stride = ring_stride; p.ring_mask = ring_len - 1;
 	p.pair_h = pair_h.as<int>();
 	p.shared_h = (n_filters == 1) ? 1 : 0;
 	p.W = W.as<double2>();
@@ -150,7 +150,8 @@ ConvParams ConvStage::base_params() const
 	p.pair_out_ch = pair_out_ch.as<int>();
 	p.round_f32 = round_f32;
 	p.nph = nph; p.up = up; p.down = down;
-	p.phase_stride = pairs_per_chunk * N;
+	p.w_stride = w_stride;
+	p.phase_stride = pairs_per_chunk * w_stride;
 	p.ring_out = feed_ring;
 	p.ring_out_stride = feed_stride; p.ring_out_mask = feed_mask; p.ring_out_pos = feed_pos;
 	p.ring_out_round_f32 = feed_round;
@@ -160,8 +161,9 @@ ConvParams ConvStage::base_params() const
 
 // Transform size for a T-tap filter and calls of max_frames frames: at least 2T (overlap <= 1/2), up to 16x the
 // filter when calls are long (valid fraction (N - T + 1) / N: 1/2 at 2T, 15/16 at 16T); among the admissible sizes
-// the cheapest for such a call: blocks x points x relative cost per point of the row kernel (measured: 1024-point
-// rows 1.0, 2048 ~1.25, 4096 ~1.3).  *cost (optional) = that figure, comparable between plans.
+// the cheapest for such a call: blocks x points x relative cost per point of the three kernels together (measured with the
+// persistent row kernel, round 2: K1 + K2 + K3 = 1.55 + 1.83 + 1.47 per 2^28 points at 1024-point rows; K2 2.2 at 2048- and
+// 4096-point rows -> 1.08).  *cost (optional) = that figure, comparable between plans.
 long conv_plan(long T, long max_frames, bool resampler, double *cost_out)
 {
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
@@ -174,7 +176,7 @@ long conv_plan(long T, long max_frames, bool resampler, double *cost_out)
 		const long hop = (n - fn) & ~7L;
 		if (hop <= 0) continue;
 		const long n2 = n / std::min<long>(1L << FFT_MAX_LOG2_N1, ((n >> 10) >= (1L << FFT_MIN_LOG2_N1)) ? (n >> 10) : (n >> FFT_MIN_LOG2_N2));
-		const double c = (n2 >= 4096) ? 1.3 : (n2 >= 2048) ? 1.25 : 1.0;
+		const double c = (n2 >= 2048) ? 1.08 : 1.0;
 		const double cost = (double) ((F + hop - 1) / hop) * ((double) n * c + 16384.0);   // + per-block launch / tail overhead
 		if (best == 0.0 || cost < best) { best = cost; N = n; }
 	}
@@ -254,10 +256,12 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	if (ring_parent) {
 		if (ring_parent->ring_len < ring_len || ring_parent->pps != pps) { set_error("%s: BUG: tail convolver does not fit its parent's rings", name.c_str()); return false; }
 		ring_len = ring_parent->ring_len;
+		ring_stride = ring_parent->ring_stride;
 		ring_dev = ring_parent->ring_dev;
 	}
 	else {
-		if (!ring.alloc((size_t) S * pps * ring_len * sizeof(double2))) return false;
+		{ static const long pad = [] { const char *e = getenv("DSP_AMD_CONV_RPAD"); return e ? atol(e) : 272L; }(); ring_stride = ring_len + pad; }
+		if (!ring.alloc((size_t) S * pps * ring_stride * sizeof(double2))) return false;
 		ring_dev = ring.as<double2>();
 	}
 	std::vector<int> soc(ch_in, -1);
@@ -300,7 +304,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	const char *senv = getenv("DSP_AMD_CONV_SUBSTREAMS");
 	n_sub = (senv && chunk_streams < S) ? std::max(1, std::min(8, atoi(senv))) : 1;
 	if (nph > 1) n_sub = 1;
-	if (!W.alloc((size_t) n_sub * nph * pairs_per_chunk * N * sizeof(double2), false)) return false;
+	{ static const long pad = [] { const char *e = getenv("DSP_AMD_CONV_WPAD"); return e ? atol(e) : 272L; }(); w_stride = N + pad; }
+	if (!W.alloc((size_t) n_sub * nph * pairs_per_chunk * w_stride * sizeof(double2), false)) return false;
 	if (n_sub > 1) {
 		sub.resize(n_sub); sub_done.resize(n_sub);
 		for (int k = 0; k < n_sub; ++k) {
@@ -318,7 +323,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		if (all_selected && n_filters == 1 && pc->all_selected && pc->n_filters == 1 && pc->ch_out == ch_in && pc->pps == pps && !pc->feeds
 		    && !pc->merged_pre && !getenv("DSP_AMD_NO_FEED")) {
 			pc->feed_ring = ring_dev;
-			pc->feed_stride = ring_len;
+			pc->feed_stride = ring_stride;
 			pc->feed_mask = ring_len - 1;
 			pc->feed_pos = 0;
 			pc->feed_round = round_f32;
@@ -329,7 +334,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	}
 	if (feeder && all_selected && !round_f32 && feeder->Cg == ch_in && !getenv("DSP_AMD_NO_FEED")) {
 		feeder->ring.base = reinterpret_cast<double *>(ring_dev);
-		feeder->ring.row_stride = ring_len;
+		feeder->ring.row_stride = ring_stride;
 		feeder->ring.mask = ring_len - 1;
 		feeder->ring.pos = 0;
 		feeder->ring.pair_ch = pair_out_ch.as<int>();
@@ -406,7 +411,7 @@ void ConvStage::run_fdl(ssize_t frames, double *out, long out_stride, hipStream_
 		FdlParams fp;
 		memset(&fp, 0, sizeof(fp));
 		fp.log2NF = ilog2(fNF); fp.P1 = fP1; fp.NF = fNF; fp.B = fB;
-		fp.ring = ring_dev; fp.ring_row_stride = ring_len; fp.ring_mask = ring_len - 1;
+		fp.ring = ring_dev; fp.ring_row_stride = ring_stride; fp.ring_mask = ring_len - 1;
 		fp.win_base = (pos + done * fB - fB) & (ring_len - 1);
 		fp.n_sub = (int) seg;
 		fp.slot0 = f_slot;
@@ -486,7 +491,7 @@ void ConvStage::push(const double *in, long in_stride, ssize_t frames, double *o
 	d.slot_of_channel = slot_of_channel.as<int>();
 	d.rows_per_stream = pps;
 	d.ring = ring_dev;
-	d.ring_row_stride = ring_len; d.ring_mask = ring_len - 1; d.pos = pos;
+	d.ring_row_stride = ring_stride; d.ring_mask = ring_len - 1; d.pos = pos;
 	d.round_f32 = round_f32;
 	{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
 }
@@ -523,7 +528,7 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 				p.pair0 = s0 * pps;
 				p.stream0 = s0;
 				p.n_streams_launch = ns;
-				p.W = W.as<double2>() + (size_t) k * pairs_per_chunk * N;
+				p.W = W.as<double2>() + (size_t) k * pairs_per_chunk * w_stride;
 				launch_conv_col(p, false, (int) (ns * pps), sub[k]);
 				launch_conv_row(p, row_mode, (int) (ns * pps), sub[k]);
 				launch_conv_col(p, true, (int) (ns * pps), sub[k]);

@@ -726,17 +726,19 @@ ssize_t Pipeline::max_out_frames(ssize_t in_frames) const
 	return f;
 }
 
-ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st)
+ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st, long in_stride)
 {
+	if (in_stride <= 0) in_stride = frames;
+	if (in_stride < frames) { set_error("pipeline: input stride %ld shorter than the call (%zd frames)", in_stride, frames); return -1; }
 	if (frames > max_frames) { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return -1; }
 	if (out_stride <= 0) out_stride = max_out_frames(frames);
 	if (frames <= 0) return 0;
 	if (stages.empty()) {
-		launch_copy_slab(d_in, frames, d_out, out_stride, frames, 0, ch_in, S, st);
+		launch_copy_slab(d_in, in_stride, d_out, out_stride, frames, 0, ch_in, S, st);
 		return hip_ok(hipGetLastError(), "copy_slab") ? frames : -1;
 	}
 	const double *cur = d_in;
-	long cur_stride = frames;
+	long cur_stride = in_stride;
 	ssize_t F = frames;
 	int which = 0;
 	for (size_t i = 0; i < stages.size(); ++i) {

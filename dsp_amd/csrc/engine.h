@@ -90,7 +90,8 @@ public:
 	int S, fs_in, ch_in, fs_out, ch_out;
 	ssize_t max_frames;
 	ssize_t max_out_frames(ssize_t in_frames) const;
-	ssize_t run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st);
+	// in_stride: frames between the slabs of two streams in d_in (0 = frames: contiguous)
+	ssize_t run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st, long in_stride = 0);
 	ssize_t drain2(ssize_t block_frames, double *d_out, long out_stride, hipStream_t st);   // rate-changer flush
 	void reset(hipStream_t st);
 	std::string plan() const;

@@ -25,7 +25,9 @@ struct ConvParams {
 	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
 	int shared_h;                       // every pair uses filter 0 (pair_h is all zeros)
 	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
-	double2 *W;                         // [pairs in chunk][N] work spectrum / time buffer
+	double2 *W;                         // [pairs in chunk][w_stride] work spectrum / time buffer
+	long w_stride;                      // N + a few KB: K3 reads the 4 pairs of a stream at once, and at a power-of-two distance they
+	                                    // queue up on the same memory channels (scripts/ubench/hbmprobe.hip: 4.7 -> 5.1 TB/s for its pattern)
 	const double2 *tw_n1, *tw_n2;       // exp(-2 pi i k / N1), exp(-2 pi i k / N2)
 	const double2 *tw_hi, *tw_lo;       // w_N^(hi << log2_lo), w_N^lo
 	const double2 *H;                   // [n_filters][N] filter spectra in [k1][k2] order, pre-scaled by 1/N

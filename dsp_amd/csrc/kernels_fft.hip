@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 	lds_barrier();   // twiddle table visible (the data loads stay in flight)
 	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });
 	// the inter-pass twiddle w_N^(n2 k1) is applied by K2 when it reads the row (per row it is a geometric sequence in n2)
-	cplx *W = p.W + (pair - p.pair0) * p.N;
+	cplx *W = p.W + (pair - p.pair0) * p.w_stride;
 #pragma unroll
 	for (int m = 0; m < 16; ++m) st16(W + (long) (j + P * m) * p.N2 + n2, v[m], p.nt & 2);
 }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	if constexpr (HOLD2) {
 		cplx v0[16], v[16];
 		if (active) {
-			const cplx *W = p.W + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
+			const cplx *W = p.W + (s * p.pairs_per_stream + qs - p.pair0) * p.w_stride + n2;
 #pragma unroll
 			for (int m = 0; m < 16; ++m) v0[m] = ld16(W + (long) (j + P * m) * p.N2, p.nt & 16);
 #pragma unroll
@@ -363,7 +363,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	for (int ph = 0; ph < nph; ++ph) {
 		cplx v[16];
 		if (active) {
-			const cplx *W = p.W + (PLAIN ? 0 : ph * p.phase_stride) + (s * p.pairs_per_stream + qs - p.pair0) * p.N + n2;
+			const cplx *W = p.W + (PLAIN ? 0 : ph * p.phase_stride) + (s * p.pairs_per_stream + qs - p.pair0) * p.w_stride + n2;
 #pragma unroll
 			for (int m = 0; m < 16; ++m) v[m] = ld16(W + (long) (j + P * m) * p.N2, p.nt & 16);
 		}
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	const int rw = tid / P, j = tid % P;
 	const long k1 = (long) blockIdx.x * RPW + rw;
 	const long pair = p.pair0 + blockIdx.y;
-	cplx *W = p.W + (pair - p.pair0) * p.N + k1 * N2 + j;
+	cplx *W = p.W + (pair - p.pair0) * p.w_stride + k1 * N2 + j;
 	cplx v[16];
 #pragma unroll
 	for (int m = 0; m < 16; ++m) v[m] = ld16(W + P * m, p.nt & 4);
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	// (wave-uniform LDS byte address; the hardware adds lane * 16), saved and restored around the instruction.
 	const unsigned land_wave = __builtin_amdgcn_readfirstlane((unsigned) (uintptr_t) (land + (tid & ~63)));
 	auto fetch = [&](long q) {
-		const cplx *src = W + q * p.N;                                   // (q counts from the launch's first pair, like W)
+		const cplx *src = W + q * p.w_stride;                                   // (q counts from the launch's first pair, like W)
 #pragma unroll
 		for (int m = 0; m < 16; ++m) {
 			unsigned keep;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], h[m]);
 		row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
 		row_fft<LOG2N2, true>(v, j, data, map, tw);
-		cplx *out = W + q * p.N;
+		cplx *out = W + q * p.w_stride;
 #pragma unroll
 		for (int m = 0; m < 16; ++m) out[P * m] = cmulc(v[m], twd[m]);
 		if (q + 1 == q1) break;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
 	const int rw = wq / WV, w = wq % WV, tr = w * 64 + lane;
 	const long k1 = (long) blockIdx.x * ROWS + rw;
 	const long pair = p.pair0 + blockIdx.y;
-	cplx *W = p.W + (pair - p.pair0) * p.N + k1 * N2;
+	cplx *W = p.W + (pair - p.pair0) * p.w_stride + k1 * N2;
 	cplx v[16];
 #pragma unroll
 	for (int i = 0; i < AV; ++i)
@@ -969,26 +969,51 @@ template <int WV> static void launch_row_big(const ConvParams &p, int mode, int 
 	else hipLaunchKernelGGL((conv_row_big<WV, 0>), grid, block, LDS, st, p);
 }
 
+static void pipe_grid(int groups, int n_pairs, int *ranges, int *per)
+{
+	// one workgroup per CU (LDS): the row groups times as many pair ranges as it takes to give every CU two workgroups in turn
+	static const int wgs = [] { const char *e = getenv("DSP_AMD_ROW_PIPE_WGS"); return e ? atoi(e) : 512; }();
+	int r = (wgs + groups - 1) / groups;
+	if (r > n_pairs) r = n_pairs;
+	if (r < 1) r = 1;
+	*per = (n_pairs + r - 1) / r;
+	*ranges = (n_pairs + *per - 1) / *per;
+}
+
 template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, hipStream_t st)
 {
 	using Cfg = RowCfg<L2>;
 	constexpr size_t LDS = ((size_t) 16 * NT + (size_t) Cfg::RPW * Cfg::PITCH + Cfg::NTW) * sizeof(cplx);
 	grant_lds(conv_row_pipe<L2>, LDS);
-	// one workgroup per CU (LDS) x 256 CUs: the row groups times as many pair ranges as that takes
 	const int groups = (int) (p.N1 / Cfg::RPW);
-	static const int wgs = [] { const char *e = getenv("DSP_AMD_ROW_PIPE_WGS"); return e ? atoi(e) : 512; }();
-	int ranges = (wgs + groups - 1) / groups;
-	if (ranges > n_pairs) ranges = n_pairs;
-	if (ranges < 1) ranges = 1;
-	const int per = (n_pairs + ranges - 1) / ranges;
-	ranges = (n_pairs + per - 1) / per;
+	int ranges, per;
+	pipe_grid(groups, n_pairs, &ranges, &per);
 	hipLaunchKernelGGL(conv_row_pipe<L2>, dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
+}
+
+// Which row-kernel family serves a plan -- decided from the plan alone (never from the number of pairs in a launch): the
+// filter spectra are stored in the family's own order by its preparation mode.
+//   persistent three-pass kernel (conv_row_pipe; conv_row for launches of a few pairs): single-phase plans with one shared filter;
+//   split rows (conv_row_big: the row FFT itself four-step, all but one exchange inside a wave): the other 2048-point plans
+//   (a persistent form of it was measured: 5.4 against 4.4 ms at 2048-point rows, 11.1 against 8.9 at 4096 -- its two extra
+//   exchanges per row are exposed when a SIMD holds a single wave);
+//   everything else the generic three-pass kernel
+static const int g_pipe_env = [] { const char *e = getenv("DSP_AMD_ROW_PIPE"); return e ? atoi(e) : 1; }();
+static bool plan_is_pipe(const ConvParams &p) { return g_pipe_env && p.nph == 1 && p.shared_h; }
+static bool rows_are_split(const ConvParams &p)
+{
+	static const int big_env = [] { const char *e = getenv("DSP_AMD_ROW_BIG"); return e ? atoi(e) : 1; }();
+	if (!big_env || p.nph > 1 || plan_is_pipe(p)) return false;          // (a multi-phase plan uses the generic kernel for preparation too)
+	return p.log2N2 == 11 || (big_env > 1 && p.log2N2 == 12);            // (measured: the 3-pass kernel is ahead at 4096)
 }
 
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	static const int pipe_env = [] { const char *e = getenv("DSP_AMD_ROW_PIPE"); return e ? atoi(e) : 1; }();
-	if (pipe_env && mode == 0 && p.nph == 1 && p.shared_h && n_pairs >= 8) {
+	if (rows_are_split(p)) {
+		if (p.log2N2 == 11) launch_row_big<2>(p, mode, n_pairs, st); else launch_row_big<4>(p, mode, n_pairs, st);
+		return;
+	}
+	if (plan_is_pipe(p) && mode == 0 && n_pairs >= 8) {
 		switch (p.log2N2) {
 		case 9: launch_row_pipe<9>(p, n_pairs, st); return;
 		case 10: launch_row_pipe<10>(p, n_pairs, st); return;
@@ -997,12 +1022,6 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 		default: break;
 		}
 	}
-	static const int big_env = [] { const char *e = getenv("DSP_AMD_ROW_BIG"); return e ? atoi(e) : 1; }();
-	int big = big_env;
-	// (H is stored in the row kernel's own order: a multi-phase plan uses the generic kernel for preparation too)
-	if (p.nph > 1) big = 0;
-	if (big && p.log2N2 == 11) { launch_row_big<2>(p, mode, n_pairs, st); return; }
-	if (big > 1 && p.log2N2 == 12) { launch_row_big<4>(p, mode, n_pairs, st); return; }   // measured: the 3-pass kernel is ahead at 4096
 	switch (p.log2N2) {
 	case 9: launch_row<9>(p, mode, n_pairs, st); break;
 	case 10: launch_row<10>(p, mode, n_pairs, st); break;

@@ -53,7 +53,7 @@ API_SYMBOLS = [
     "dspamd_get_effect_info", "dspamd_plan_fir", "dspamd_chain_build", "dspamd_chain_run", "dspamd_chain_drain",
     "dspamd_chain_max_out_frames", "dspamd_chain_drain_frames", "dspamd_chain_reset", "dspamd_chain_destroy",
     "dspamd_chain_n_effects", "dspamd_chain_effect_name", "dspamd_batch_create", "dspamd_batch_out_fs",
-    "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run",
+    "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run", "dspamd_batch_run_strided",
     "dspamd_batch_drain", "dspamd_batch_reset", "dspamd_batch_destroy", "dspamd_batch_plan", "dspamd_batch_n_stages",
     "dspamd_sgen_sine", "dspamd_digest", "dspamd_copy_probe", "dspamd_pcm_sample_bytes", "dspamd_pcm_read", "dspamd_pcm_write", "dspamd_profile_enable", "dspamd_profile_collect",
 ]
@@ -103,6 +103,7 @@ def load_library():
         "dspamd_batch_out_fs": (i, [vp]), "dspamd_batch_out_channels": (i, [vp]),
         "dspamd_batch_max_out_frames": (ssize_t, [vp, ssize_t]), "dspamd_batch_drain_frames": (ssize_t, [vp]),
         "dspamd_batch_run": (ssize_t, [vp, vp, ssize_t, vp, ssize_t, vp]),
+        "dspamd_batch_run_strided": (ssize_t, [vp, vp, ssize_t, ssize_t, vp, ssize_t, vp]),
         "dspamd_batch_drain": (ssize_t, [vp, ssize_t, vp, ssize_t, vp]),
         "dspamd_batch_reset": (None, [vp, vp]), "dspamd_batch_destroy": (None, [vp]),
         "dspamd_batch_plan": (cp, [vp]), "dspamd_batch_n_stages": (i, [vp]),

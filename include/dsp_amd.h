@@ -84,6 +84,10 @@ ssize_t dspamd_batch_drain_frames(dspamd_batch *);
  * Returns frames produced per stream, or <0.
  */
 ssize_t dspamd_batch_run(dspamd_batch *, const void *d_in, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream);
+/* the same with the streams' input slabs in_stride_frames apart (>= frames): d_in is [S][in_stride_frames][C_in].  Slabs
+ * whose distance is a large power of two (or a multiple of one: 196608 frames x 64 B = 3 x 4 MiB) put the same frame of every
+ * stream on the same memory channels; a few hundred bytes of padding per stream avoid that. */
+ssize_t dspamd_batch_run_strided(dspamd_batch *, const void *d_in, ssize_t in_stride_frames, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream);
 /* end of stream: push zeros / flush rate changers; returns frames produced, -1 when dry */
 ssize_t dspamd_batch_drain(dspamd_batch *, ssize_t block_frames, void *d_out, ssize_t out_stride_frames, void *stream);
 void dspamd_batch_reset(dspamd_batch *, void *stream);

@@ -79,6 +79,29 @@ __global__ __launch_bounds__(THREADS) void k_col(const e16 *__restrict__ src, e1
 	}
 }
 
+// K3 as it is launched: 512 threads = 4 pairs (lane-fastest) x 8 columns x 16 row slots; reads 16 rows j + 16 m of every pair
+// (128 B runs per pair), writes 8 consecutive 64-byte frames per row (512 B runs) into an interleaved slab
+__global__ __launch_bounds__(512) void k_k3(const e16 *__restrict__ W, e16 *__restrict__ out, long n2_total, long pitch, long pair_stride, int do_store)
+{
+	const int q = threadIdx.x & 3, t = (threadIdx.x >> 2) & 7, j = threadIdx.x >> 5;
+	const long n2 = (long) blockIdx.x * 8 + t;
+	const e16 *s = W + ((long) blockIdx.y * 4 + q) * pair_stride + n2;
+	e16 v[16];
+#pragma unroll
+	for (int m = 0; m < 16; ++m) v[m] = s[(long) (j + 16 * m) * pitch];
+	if (do_store) {
+		e16 *d = out + (long) blockIdx.y * 4 * 256 * n2_total + q;       // [stream][frame][4 pairs]
+#pragma unroll
+		for (int m = 0; m < 16; ++m) d[((long) (j + 16 * m) * n2_total + n2) * 4] = v[m];
+	}
+	else {
+		e16 a = make_double2(0, 0);
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { a.x += v[m].x; a.y += v[m].y; }
+		if (a.x == 1.2345) out[0] = a;
+	}
+}
+
 // row pattern: grid (N1 / 4, pairs): 4 rows of 1024 points per workgroup, one per wave; lane moves j + 64 m
 __global__ __launch_bounds__(256) void k_row(const e16 *__restrict__ src, e16 *__restrict__ dst, long pitch, long pair_stride)
 {
@@ -196,6 +219,17 @@ int main(int argc, char **argv)
 			const double t2 = time_ms([&] { k_col<256, 256><<<dim3((unsigned) (n2 / 16), np), 256>>>(a, b, pitch, pitch, pair, pair, 1, 0); }, reps);
 			printf("N2 %5ld pad %3ld : 128 B runs %6.2f   256 B runs %6.2f\n", n2, pad, (double) np * 256 * n2 * 16 / t / 1e9, (double) np * 256 * n2 * 16 / t2 / 1e9);
 		}
+	printf("# K3 as launched (512 threads, 4 pairs, 128 B read runs, 512 B write runs): TB/s of bytes moved\n");
+	for (long n2 : { 1024L, 2048L, 4096L })
+		for (long pad : { 0L, 16L })
+			for (long ppad : { 0L, 272L }) {
+				const long pitch = n2 + pad, pair = 256 * pitch + ppad;
+				const int ns = (int) (bytes / ((size_t) pair * 16 * 4));
+				const double tl = time_ms([&] { k_k3<<<dim3((unsigned) (n2 / 8), ns), 512>>>(a, b, n2, pitch, pair, 0); }, reps);
+				const double tc = time_ms([&] { k_k3<<<dim3((unsigned) (n2 / 8), ns), 512>>>(a, b, n2, pitch, pair, 1); }, reps);
+				const double by = (double) ns * 4 * 256 * n2 * 16;
+				printf("N2 %5ld pitch pad %3ld pair pad %4ld : load %6.2f   copy %6.2f\n", n2, pad, ppad, by / tl / 1e9, 2 * by / tc / 1e9);
+			}
 	// does the rate depend on how many workgroups (= bytes in flight) a CU holds?  dynamic LDS caps the residency
 	printf("# residency sweep: workgroups per CU capped through dynamic LDS (copy TB/s)\n");
 	printf("%-10s %12s %12s %12s %12s\n", "LDS/wg", "stream U=16", "stream U=4", "col 256thr", "row in place");
