@@ -721,7 +721,7 @@ template <int G> __device__ __forceinline__ int rw_row_base(int r) { return (G =
 
 template <int G>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P)
+void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P, int p2p)
 {
 	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
 	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
@@ -740,6 +740,12 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	double *st = smem;                                          // [G][n_ops][2]
 	double *qt = st + G * n_ops * 2;                            // [n_ops][16][4] (G <= 2 only)
 	double *tb = qt + ((G <= 2) ? n_ops * FQ_DOUBLES : 0) + (size_t) w * RW_TB;       // this wave's transposer
+	// point-to-point ordering instead of a workgroup barrier per step (p2p): prog[v] = section steps wave v has completed.
+	// Section j of tile t only needs section j of tile t - 1 -- the neighbouring wave's work of one step earlier -- so a wave
+	// waits for exactly that, and a long step of one wave (its tile traffic) no longer stops the other P - 1: with a barrier
+	// per step a tile costs 7 section steps + 4 steps as long as the slowest wave's, without 10 + 1 of its own
+	volatile int *prog = reinterpret_cast<volatile int *>(qt + ((G <= 2) ? n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB);
+	if (tid < 16) prog[tid] = 0;
 
 	const int n_st = G * n_ops * 2;
 	double *gstate = p.state + ((size_t) s * p.C + c0) * n_ops * 2;
@@ -778,8 +784,10 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	// settle the first head BEFORE any loop: s_waitcnt cannot tell scalar loads apart, so a wait for `cur` placed behind the
 	// loads of the next head and of the scan matrices would expose a scalar-load round trip in every section
 	if (cur.kind == OP_BIQUAD || cur.kind == OP_SKIP) {
-		for (int i = 0; i < w; ++i) lds_barrier();              // the skew: wave w starts at step w
+		if (!p2p) for (int i = 0; i < w; ++i) lds_barrier();    // the skew: wave w starts at step w
 		steps = w;
+		const int wprev = (w + P - 1) % P;
+		int done_steps = 0;                                     // section steps this wave has completed
 		if (w < n_full) {
 			double2 raw[K];                                         // G = 1: 32 eight-byte elements, element k in raw[k >> 1]
 			double x[L];
@@ -883,6 +891,13 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 					// the kind is looked at BEFORE the next head is requested: a wait for `cur` behind that request (s_waitcnt cannot
 					// tell scalar loads apart) would expose a scalar-load round trip in every step
 					const bool section = (cur.kind == OP_BIQUAD);
+					if (p2p) {
+						// the predecessor's section j of the tile before this one: wave w - 1's step of the same index, or -- for
+						// wave 0 -- wave P - 1's step of one tile period earlier
+						const int need = done_steps + 1 - ((w == 0) ? n_ops : 0);
+						while (__builtin_amdgcn_readfirstlane(prog[wprev]) < need) __builtin_amdgcn_s_sleep(1);
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+					}
 					__builtin_amdgcn_sched_barrier(0);
 					const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
 					if (section) run_op_rows<L, G>(x, cur, cf + j * FOP_DOUBLES, st_row, qt + j * FQ_DOUBLES, j, pos, lane, fix, pending);
@@ -898,7 +913,12 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 							for (int i = 0; i < L; ++i) x[i] *= post;
 						}
 					}
-					lds_barrier();       // (two sections per barrier were measured: no gain)
+					if (p2p) {
+						++done_steps;
+						__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // the section state is in LDS before the count
+						if (lane == 0) prog[w] = done_steps;
+					}
+					else lds_barrier();       // (two sections per barrier were measured: no gain)
 				};
 				// The next tile's loads: unconditional (the last one re-reads this tile) -- a conditional load has to select between
 				// old and new registers, which costs a wait right behind the loads -- and at the boundary (issuing them one step
@@ -907,7 +927,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// The tile traffic is a step of its own: inside a section step it made that step (which every wave of the group
 				// waits for) up to 1.8 x as long, and with P waves skewed by one step almost every step had one such wave.  As an
 				// (n_ops + 1)-th step it runs beside the other waves' sections and costs one step in n_ops + 1.
-				lds_barrier();
+				if (!p2p) lds_barrier();
 				for (int j = 0; j < n_ops; ++j) step(j);
 				steps += n_ops + IO_STEPS;
 			}
@@ -921,7 +941,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				store_out(y, t_last);
 			}
 		}
-		for (; steps < n_steps; ++steps) lds_barrier();
+		if (!p2p) for (; steps < n_steps; ++steps) lds_barrier();
 	}
 	__syncthreads();
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
@@ -933,11 +953,12 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	const long n_full = p.frames / TILE;
 	if (n_full < 1 || (p.C % G)) return 0;
 	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
-	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB) * sizeof(double);
+	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB + 8) * sizeof(double);
 	if (lds > 160 * 1024) return 0;
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G>), lds);
+	static const int p2p = [] { const char *e = getenv("DSP_AMD_CASCADE_P2P"); return e ? atoi(e) : 1; }();   // 0: one workgroup barrier per step (round 1)
 	dim3 grid(n_streams, p.C / G), block(64 * P);
-	hipLaunchKernelGGL(cascade_rows<G>, grid, block, lds, stream, p, p.frows, p.frq, P);
+	hipLaunchKernelGGL(cascade_rows<G>, grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
 	return n_full * TILE;
 }
 
