@@ -155,7 +155,9 @@ ConvParams ConvStage::base_params() const
 	p.ring_out = feed_ring;
 	p.ring_out_stride = feed_stride; p.ring_out_mask = feed_mask; p.ring_out_pos = feed_pos;
 	p.ring_out_round_f32 = feed_round;
-	{ static const char *e = getenv("DSP_AMD_CONV_NT"); p.nt = e ? atoi(e) : 0; }
+	// non-temporal hints: K1's ring loads and W stores (data touched once per launch): 5.95 -> 5.55 ms at the headline shape; on
+	// K2 and K3 they measured nothing (scripts/exp_nt.sh)
+	{ static const char *e = getenv("DSP_AMD_CONV_NT"); p.nt = e ? atoi(e) : 3; }
 	return p;
 }
 

@@ -417,7 +417,6 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
-	{ static const char *dbg = getenv("DSP_AMD_CASCADE_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
 	int K = 0;
 	long len = 0;
 	if (!ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) {

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * CG) void cascade_fast(CascadeParams p, const d
 		if (tl < n_full) {                                                                                                 \
 			_Pragma("unroll") for (int k = 0; k < K; ++k) { tile[la[k]] = PF[k].x; tile[la[k] + CHS] = PF[k].y; }        \
 		}                                                                                                                  \
-		if (tl > 0 && !(p.debug & 1)) {                                                                                    \
+		if (tl > 0) {                                                                                    \
 			const long t0 = (tl - 1) * TILE;                                                                               \
 			if (p.write_interleaved) {                                                                                     \
 				_Pragma("unroll") for (int k = 0; k < K; ++k)                                                             \
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(64 * CG) void cascade_fast(CascadeParams p, const d
 				_Pragma("unroll") for (int k = 0; k < K; ++k) ring[(p.ring.pos + t0 + tk[k]) & p.ring.mask] = r[k];      \
 			}                                                                                                              \
 		}                                                                                                                  \
-		if (tl + 1 < n_full && !(p.debug & 2)) {                                                                           \
+		if (tl + 1 < n_full) {                                                                           \
 			const double *nx = in + (size_t) (tl + 1) * TILE * p.C;                                                        \
 			_Pragma("unroll") for (int k = 0; k < K; ++k)                                                                 \
 				PF[k] = *reinterpret_cast<const double2 *>(nx + (size_t) tk[k] * p.C + 2 * cp);                           \
@@ -836,7 +836,6 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto store_out = [&](const double2 (&y)[K], long t_out) {
-				if (p.debug & 1) return;
 				if constexpr (G == 1) {
 					typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 					const int tbb = (int) t_out * tile_bytes;
@@ -923,7 +922,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				// The next tile's loads: unconditional (the last one re-reads this tile) -- a conditional load has to select between
 				// old and new registers, which costs a wait right behind the loads -- and at the boundary (issuing them one step
 				// later, to shorten the boundary step everybody waits for, was measured: slower for G = 1 and 2, no gain for 4)
-				if (!(p.debug & 2)) load_raw((t + P < n_full) ? t + P : t);
+				load_raw((t + P < n_full) ? t + P : t);
 				// The tile traffic is a step of its own: inside a section step it made that step (which every wave of the group
 				// waits for) up to 1.8 x as long, and with P waves skewed by one step almost every step had one such wave.  As an
 				// (n_ops + 1)-th step it runs beside the other waves' sections and costs one step in n_ops + 1.
@@ -1049,7 +1048,7 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 			const long long kind = cur.kind;                 // before the next head is requested (see run_ops_fast)
 			__builtin_amdgcn_sched_barrier(0);
 			const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
-			if (!(p.debug & 4)) run_op_fast<L>(x, kind, cur, cf + j * FOP_DOUBLES, wq, j, cst, lane, fix, pending);
+			run_op_fast<L>(x, kind, cur, cf + j * FOP_DOUBLES, wq, j, cst, lane, fix, pending);
 			cur = nxt;
 			if (j + 1 == n_ops) {
 				if (pending) apply_fix<L>(x, fix);
@@ -1057,7 +1056,7 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 				for (int i = 0; i < L; ++i) tb[lm_off + i] = x[i];
 #pragma unroll
 				for (int i = 0; i < L; ++i) x[i] = tb[fm_off + (64 + 64 / L) * i];
-				if (!(p.debug & 1)) {
+				{
 					const size_t f0 = (size_t) t * TILE;
 					if (p.write_interleaved) {
 #pragma unroll
@@ -1088,7 +1087,7 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 			for (int i = 0; i < L; ++i) x[i] = tb[lm_off + i];
 			// unconditional (the last one re-reads this tile): a conditional load would have to select between old and new
 			// registers, which costs a wait right behind the loads
-			if (!(p.debug & 2)) load_raw(raw, (t + P < n_full) ? t + P : t);
+			load_raw(raw, (t + P < n_full) ? t + P : t);
 			process(x, t);
 		}
 	}

@@ -537,6 +537,11 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 // requires, and what a thread reads back is its own wave's) + the padded exchange rows + tables = 139 KB: one workgroup per CU.
 // vmcnt runs in order on this chip (loads and stores share it): at the top of an iteration the 16 stores of the previous
 // pair are the youngest operations, so `vmcnt(16)` means "this pair's rows have landed".
+// Measured at the headline shape (1024-point rows, 8.6 GB per launch): 2.05 -> 1.82 ms.  Without the transforms the same loop
+// takes 1.71 ms, without waiting for the landing 1.87: neither the arithmetic nor the read latency is what is left -- a
+// second prefetch stage in the accumulation registers (pairs two ahead, 128 KB of reads in flight per CU) changed nothing
+// (9.3 against 9.0 ms at 4096-point rows).  5.0 TB/s is what this in-place read-modify-write stream gets from the memory
+// system; the bare pattern reads 5.3-5.45 TB/s in scripts/ubench/hbmprobe.hip, a plain copy 6.3.
 template <int LOG2N2>
 __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_wg, int n_pairs)
 {

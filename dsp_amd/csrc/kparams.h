@@ -64,7 +64,6 @@ struct CascadeParams {
 	double *state;                       // [S][C][n_ops][2]
 	PlanarRing ring;                     // optional second destination (ring.base != nullptr)
 	int write_interleaved;               // 0: only the ring is written
-	int debug;                           // experiment switches (DSP_AMD_CASCADE_DEBUG): 1 = no stores, 2 = no reloads
 };
 
 // chunked cascade (kernels_chunk.hip): a call of K * len frames run as K zero-state chunks + carry + correction
