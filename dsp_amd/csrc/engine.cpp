@@ -568,6 +568,69 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 	std::vector<std::unique_ptr<Spec>> merged;   // specs synthesised here (LTI merges)
 	for (size_t si = 0; si < specs.size(); ++si) {
 		const Spec *sp = specs[si];
+		// OPT-IN (DSP_AMD_MERGE_IIR=1, off by default): biquad sections and gains on every channel directly in front of a zero-latency
+		// convolution are LTI stages like the two cases below, and once their joint impulse response has decayed below 2^-70 of
+		// its peak it IS a finite filter as far as fp64 can tell: g * h (T + L - 1 taps) through the convolver alone, no cascade
+		// pass at all.  Exactness is the decay criterion's (checked per chain: a 20 Hz high-pass needs 26000 taps, a 2 Hz one
+		// does not merge); the price is L frames less hop per transform.  Off by default because the headline workload is
+		// DEFINED as a biquad cascade + fir_p and is measured as such; bench.py --chain runs report the merged plan as a side figure.
+		if ((sp->kind == Kind::Biquad || sp->kind == Kind::Gain) && !casc && getenv("DSP_AMD_MERGE_IIR") && atoi(getenv("DSP_AMD_MERGE_IIR")) > 0) {
+			auto uniform = [](const Spec *q) {
+				if (num_set(q->sel) != q->ch_in || q->ch_in != q->ch_out || q->frac_delay || !q->bq_more.empty() || !q->riir.empty()) return false;
+				if (q->kind == Kind::Biquad) { for (int c = 1; c < q->ch_in; ++c) if (q->bq[c] != q->bq[0]) return false; return true; }
+				if (q->kind == Kind::Gain) { for (int c = 1; c < q->ch_in; ++c) if (q->vec[c] != q->vec[0]) return false; return true; }
+				return false;
+			};
+			size_t k = si;
+			while (k < specs.size() && uniform(specs[k])) ++k;
+			const Spec *cv = (k > si && k < specs.size()) ? specs[k] : nullptr;
+			if (cv && cv->kind == Kind::Conv && cv->conv_mode == CONV_ZERO_LATENCY && cv->latency == 0 && cv->fch == 1 && num_set(cv->sel) == cv->ch_in
+			    && cv->ch_in == sp->ch_in && cv->riir.empty()) {
+				// joint impulse response of the sections, in extended precision, until a 256-sample block stays below 2^-70 of the peak
+				const long Lmax = std::max<long>(cv->T, 1L << 16);
+				std::vector<long double> g;
+				std::vector<std::array<long double, 2>> st(k - si, std::array<long double, 2>{ { 0.0L, 0.0L } });
+				long double peak = 0.0L, blk = 0.0L;
+				bool decayed = false;
+				for (long n = 0; n < Lmax && !decayed; ++n) {
+					long double v = (n == 0) ? 1.0L : 0.0L;
+					for (size_t q = si; q < k; ++q) {
+						const Spec *b = specs[q];
+						if (b->kind == Kind::Gain) { v *= (long double) b->vec[0]; continue; }
+						const std::array<double, 5> &c = b->bq[0];             // TDF-II, biquad.h:76-92
+						std::array<long double, 2> &m = st[q - si];
+						const long double r = (long double) c[0] * v + m[0];
+						m[0] = (long double) c[1] * v + m[1] - (long double) c[3] * r;
+						m[1] = (long double) c[2] * v - (long double) c[4] * r;
+						v = r;
+					}
+					g.push_back(v);
+					peak = std::max(peak, fabsl(v));
+					blk = std::max(blk, fabsl(v));
+					if ((n & 255) == 255) { if (n >= 511 && blk < ldexpl(peak, -70)) decayed = true; blk = 0.0L; }
+				}
+				if (decayed) {
+					const long L = (long) g.size();
+					merged.emplace_back(new Spec(*cv));
+					Spec &m = *merged.back();
+					m.T = cv->T + L - 1;
+					m.taps.assign((size_t) m.T, 0.0);
+					std::vector<double> gd(g.begin(), g.end());
+					for (ssize_t i = 0; i < cv->T; ++i) {
+						const double a = cv->taps[i];
+						if (a == 0.0) continue;
+						double *dst = &m.taps[i];
+						for (long j = 0; j < L; ++j) dst[j] += a * gd[j];
+					}
+					m.name.clear();
+					for (size_t q = si; q < k; ++q) m.name += specs[q]->name + "+";
+					m.name += cv->name;
+					log_msg(LL_VERBOSE, "info: %zu sections and gains folded into %s: %ld taps of joint impulse response, %zd taps in all", k - si, cv->name.c_str(), L, m.T);
+					sp = &m;
+					si = k;
+				}
+			}
+		}
 		// fir_p -> fir_p (hilbert -p -> fir_p, ...): two zero-latency convolutions of every channel with one-channel
 		// filters = ONE convolution with h1 * h2 (T1 + T2 - 1 taps; the chain's drain length is the same sum)
 		while (sp->kind == Kind::Conv && si + 1 < specs.size() && specs[si + 1]->kind == Kind::Conv && !getenv("DSP_AMD_NO_LTI_MERGE")) {

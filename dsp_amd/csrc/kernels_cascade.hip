@@ -976,7 +976,12 @@ static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream
 	const long channels = (long) n_streams * p.C;
 	int G = (channels >= 1024 && p.rows4_ok) ? 4 : (channels >= 512) ? 2 : 1, P;
 	if (env > 0) { G = env / 100; P = env % 100; if ((G == 4 && !p.rows4_ok) || (G != 4 && G != 2 && G != 1)) return 0; }
-	else P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
+	else {
+		P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
+		// with point-to-point ordering more waves per group pay even when the chip is full anyway: 8 waves in one workgroup per
+		// CU against 2 x 4 (9.48 against 9.67 ms at 256 streams, scripts/exp_rowsP.sh)
+		if (G == 4 && P < 8 && p.n_ops >= 8) P = 8;
+	}
 	if (P > 8) P = 8;
 	if (P < 1) P = 1;
 	return (G == 4) ? try_launch_rows<4>(p, n_streams, P, stream) : (G == 2) ? try_launch_rows<2>(p, n_streams, P, stream) : try_launch_rows<1>(p, n_streams, P, stream);

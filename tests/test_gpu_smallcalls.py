@@ -96,3 +96,28 @@ def test_small_calls_reset(amd, tmp_path):
     f = amd.BatchChain(chain, 48000, C, S, block)
     yf = torch.cat([f.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, 11 * block, block)], dim=1)
     assert torch.equal(y, yf)
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_opt_in_iir_merge_vs_real_reference(amd, tmp_path, monkeypatch):
+    """DSP_AMD_MERGE_IIR=1 (off by default): sections and gains on every channel in front of a zero-latency convolution are folded
+    into the filter once their joint impulse response has decayed below 2^-70 of its peak -- same stream as the reference's
+    biquads + fir_p (<= 1e-12 RMS incl. the drain), no cascade stage in the plan; a chain whose poles sit too close to the
+    unit circle (2 Hz high-pass) keeps its cascade."""
+    import torch
+    p, h = filt(tmp_path, 6000)
+    biquads = "gain -2 lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 800 1.0 -1 highpass 20 0.707"
+    chain = f"{biquads} fir_p -t pcm -e double -c 1 {p}"
+    S, C, block = 2, 4, 8192
+    x = np.stack([noise(5 * block, C, 60 + s) for s in range(S)])
+    monkeypatch.setenv("DSP_AMD_MERGE_IIR", "1")
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    assert "cascade[" not in b.plan() and "highpass+fir_p" in b.plan(), b.plan()
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    for s in range(S):
+        ref = RefChain(chain, 48000, C).process(x[s], block=2048)
+        assert y[s].shape == ref.shape and rms(y[s] - ref) < 1e-12, rms(y[s] - ref)
+    slow = amd.BatchChain(f"highpass 2 0.707 fir_p -t pcm -e double -c 1 {p}", 48000, C, S, block)
+    assert "cascade[" in slow.plan()
+    monkeypatch.delenv("DSP_AMD_MERGE_IIR")
+    assert "cascade[" in amd.BatchChain(chain, 48000, C, S, block).plan()
