@@ -123,9 +123,9 @@ def cpu_baseline(chain, filt_dir, fs, channels, seconds_target=6.0):
 # BASELINE.json's other configs as presets (parity-test cases; the bench line of record is the default run)
 CONFIGS = {
     "2": dict(streams=1, channels=8, block=1 << 20, chain=BIQUADS),                    # 1 stream x 8 ch, 10 biquads
-    "3": dict(streams=256, channels=8, block=196608, taps=65536, chain="fir_p -t pcm -e double -c 1 {F}"),
-    "4": dict(streams=256, channels=8, block=195584, taps=65536, chain=BIQUADS + " fir_p -t pcm -e double -c 1 {F} resample 96k"),
-    "5": dict(streams=1024, channels=2, block=131072, taps=131072, chain="hilbert -p 4095 fir_p -t pcm -e double -c 1 {F}"),
+    "3": dict(streams=256, channels=8, block=983040, taps=65536, chain="fir_p -t pcm -e double -c 1 {F}"),
+    "4": dict(streams=256, channels=8, block=978944, taps=65536, chain=BIQUADS + " fir_p -t pcm -e double -c 1 {F} resample 96k"),
+    "5": dict(streams=1024, channels=2, block=917504, taps=131072, chain="hilbert -p 4095 fir_p -t pcm -e double -c 1 {F}"),
 }
 
 

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 			const long fr = n - p.first_n;                        // slab frame relative to slab_frame0 (folded into `slab`)
 			if (n >= p.valid) v[m] = make_double2(0.0, 0.0);
 			else if (fr + p.slab_frame0 >= 0) {
-				v[m] = ld16(slab + fr * hp, p.nt & 1);
+				v[m] = slab[fr * hp];             // (never non-temporal: the frames of a slab are read by the workgroups of all its pairs)
 				if (n >= keep_from) ringw[(p.win_base + n) & p.ring_mask] = v[m];
 			}
 			else v[m] = ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1);
