@@ -185,7 +185,7 @@ template <int LOG2N1, int PPS> struct ColCfg {
 	static constexpr int N1 = 1 << LOG2N1, P = N1 / 16;
 	static constexpr int THREADS = (PPS == 4) ? 2 * NT : NT;
 	static constexpr int TW = THREADS / (P * PPS);
-	static constexpr bool SPLIT = false;   // (a half-size real / imaginary exchange was measured: no occupancy gain at 143 VGPRs, two more barriers)
+	static constexpr bool SPLIT = false;   // (a half-size real / imaginary exchange was measured twice: round 1 no occupancy gain at 143 VGPRs; round 2 capped at 128 VGPRs for two workgroups per CU: 6.73 against 6.34 ms, 22 spills and two more barriers)
 	static constexpr int QS = N1 * TW + (PPS == 4 ? 4 : PPS == 2 ? 8 : 0);
 	static constexpr size_t LDS = (LOG2N1 > 4 ? (size_t) PPS * QS * (SPLIT ? sizeof(double) : sizeof(cplx)) : 0) + (size_t) N1 * sizeof(cplx);
 };
