@@ -542,7 +542,9 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 // second prefetch stage in the accumulation registers (pairs two ahead, 128 KB of reads in flight per CU) changed nothing
 // (9.3 against 9.0 ms at 4096-point rows).  5.0 TB/s is what this in-place read-modify-write stream gets from the memory
 // system; the bare pattern reads 5.3-5.45 TB/s in scripts/ubench/hbmprobe.hip, a plain copy 6.3.
-template <int LOG2N2>
+// NPH = 2: the two polyphase branches of a 2x upsampler (one forward transform, one multiply + inverse transform per
+// branch, each into its own W: conv_row<., 2> in persistent form)
+template <int LOG2N2, int NPH>
 __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_wg, int n_pairs)
 {
 	using Cfg = RowCfg<LOG2N2>;
@@ -579,11 +581,12 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	cplx *steps = thi + 64 + rw * 16;
 	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
 	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
-	cplx h[16], twd[16];
-	{
-		const cplx *H = p.H + k1 * N2 + j;                               // (one shared filter: pair_h is all zeros)
+	cplx h[NPH][16], twd[16];
 #pragma unroll
-		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
+	for (int ph = 0; ph < NPH; ++ph) {
+		const cplx *H = p.H + (long) ph * p.N + k1 * N2 + j;             // (one shared filter set: pair_h is all zeros)
+#pragma unroll
+		for (int m = 0; m < 16; ++m) h[ph][m] = H[P * m];
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first fetch (the compiler does not know about it)
 	__syncthreads();                                                     // tables visible
@@ -592,7 +595,9 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	for (long q = q0; q < q1; ++q) {
-		if (q > q0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");    // this pair's rows have landed (see above)
+		if (q > q0) {                                                    // this pair's rows have landed (see above)
+			if (NPH == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+		}
 		cplx v[16];
 #pragma unroll
 		for (int m = 0; m < 16; ++m) v[m] = land[NT * m + tid];
@@ -602,12 +607,16 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], twd[m]);
 		row_fft<LOG2N2, false>(v, j, data, map, tw);
 #pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], h[m]);
-		row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
-		row_fft<LOG2N2, true>(v, j, data, map, tw);
-		cplx *out = W + q * p.w_stride;
+		for (int ph = 0; ph < NPH; ++ph) {
+			cplx u[16];
 #pragma unroll
-		for (int m = 0; m < 16; ++m) out[P * m] = cmulc(v[m], twd[m]);
+			for (int m = 0; m < 16; ++m) u[m] = cmul(v[m], h[ph][m]);
+			row_sync<WL>();      // every gather of the transform before has completed before the inverse passes overwrite the row
+			row_fft<LOG2N2, true>(u, j, data, map, tw);
+			cplx *out = W + (long) ph * p.phase_stride + q * p.w_stride;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) out[P * m] = cmulc(u[m], twd[m]);
+		}
 		if (q + 1 == q1) break;
 		row_sync<WL>();      // the last gather of the inverse transform is done before the next forward pass writes the row
 	}
@@ -989,11 +998,16 @@ template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, 
 {
 	using Cfg = RowCfg<L2>;
 	constexpr size_t LDS = ((size_t) 16 * NT + (size_t) Cfg::RPW * Cfg::PITCH + Cfg::NTW) * sizeof(cplx);
-	grant_lds(conv_row_pipe<L2>, LDS);
 	const int groups = (int) (p.N1 / Cfg::RPW);
 	int ranges, per;
 	pipe_grid(groups, n_pairs, &ranges, &per);
-	hipLaunchKernelGGL(conv_row_pipe<L2>, dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
+	if (p.nph == 2) {
+		grant_lds((conv_row_pipe<L2, 2>), LDS);
+		hipLaunchKernelGGL((conv_row_pipe<L2, 2>), dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
+		return;
+	}
+	grant_lds((conv_row_pipe<L2, 1>), LDS);
+	hipLaunchKernelGGL((conv_row_pipe<L2, 1>), dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
 }
 
 // Which row-kernel family serves a plan -- decided from the plan alone (never from the number of pairs in a launch): the
@@ -1004,7 +1018,7 @@ template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, 
 //   exchanges per row are exposed when a SIMD holds a single wave);
 //   everything else the generic three-pass kernel
 static const int g_pipe_env = [] { const char *e = getenv("DSP_AMD_ROW_PIPE"); return e ? atoi(e) : 1; }();
-static bool plan_is_pipe(const ConvParams &p) { return g_pipe_env && p.nph == 1 && p.shared_h; }
+static bool plan_is_pipe(const ConvParams &p) { return g_pipe_env && p.nph <= 2 && p.shared_h; }
 static bool rows_are_split(const ConvParams &p)
 {
 	static const int big_env = [] { const char *e = getenv("DSP_AMD_ROW_BIG"); return e ? atoi(e) : 1; }();
@@ -1018,7 +1032,9 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 		if (p.log2N2 == 11) launch_row_big<2>(p, mode, n_pairs, st); else launch_row_big<4>(p, mode, n_pairs, st);
 		return;
 	}
-	if (plan_is_pipe(p) && mode == 0 && n_pairs >= 8) {
+	// (the two-branch form holds both filter rows in registers: at 2048- / 4096-point rows it spills 100 VGPRs and is behind the
+	// one-shot kernel, 16.7 against 15.0 ms; at 1024-point rows ahead, 3.26 against 3.53)
+	if (plan_is_pipe(p) && (mode == 0 || (mode == 2 && p.nph == 2 && p.log2N2 <= 10)) && n_pairs >= 8) {
 		switch (p.log2N2) {
 		case 9: launch_row_pipe<9>(p, n_pairs, st); return;
 		case 10: launch_row_pipe<10>(p, n_pairs, st); return;
