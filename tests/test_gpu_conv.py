@@ -297,6 +297,36 @@ def test_headline_workload_full_size_vs_real_reference(amd, tmp_path):
 
 
 @pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_bench_default_configuration_full_size_vs_real_reference(amd, tmp_path):
+    """bench.py's default step itself (round 2): 256 streams x 8 ch, 10 biquads + fir_p(65536), one step of 983040 frames through
+    N = 2^20 transforms (256 x 4096: the persistent row kernel at 4096-point rows, padded pair distances), input and output
+    slabs padded 68 frames apart exactly as bench.py allocates them -- then a second, short call so that the carried state and
+    the ring history cross a call boundary -- against the REAL reference on whole streams picked across the batch."""
+    import torch
+    taps, S, C, B, B2, PAD = 65536, 256, 8, 983040, 16384, 68
+    h = make_filter(taps)
+    p = write(tmp_path, h)
+    biq = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 eq 800 1.0 -1 "
+           "eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    chain = f"{biq} fir_p -t pcm -e double -c 1 {p}"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    assert "N=1048576=256x4096" in b.plan() and "fed-by-cascade" in b.plan(), b.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(13)
+    xbuf = torch.rand((S, B + PAD, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    obuf = torch.empty((S, B + PAD, C), dtype=torch.float64, device="cuda")
+    y1 = b.run(xbuf[:, :B, :], obuf).clone()                      # strided views: dspamd_batch_run_strided
+    x2 = torch.rand((S, B2, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y2 = b.run(x2).clone()
+    assert y1.shape == (S, B, C) and y2.shape == (S, B2, C)
+    for s in (0, 77, 255):
+        xs = torch.cat([xbuf[s, :B, :], x2[s]], dim=0).cpu().numpy()
+        ref = RefChain(chain, 48000, C).run(xs)
+        got = torch.cat([y1[s], y2[s]], dim=0).cpu().numpy()
+        assert ref.shape == got.shape
+        assert rms(ref - got) < 1e-12, (s, rms(ref - got))
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
 def test_config4_full_size_vs_real_reference(amd, tmp_path):
     """BASELINE config 4 at full size: 256 streams x 8 ch, 10 biquads + fir_p(65536) + resample 48k -> 96k, complete streams
     (run + drain) against the real reference on streams picked across the batch."""
