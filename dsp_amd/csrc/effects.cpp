@@ -1,6 +1,7 @@
 // effects.cpp -- init-time parsing and filter design (host only; libm on the host so that
 // coefficients agree with the reference's to the last bit -- SURVEY.md section 8 a4).
 #include "effects.h"
+#include <dlfcn.h>
 #include <cfloat>
 #include <algorithm>
 #include <cmath>
@@ -668,7 +669,7 @@ struct FirOpts {
 	ssize_t offset = 0;
 	const char *type = nullptr, *enc = nullptr;
 	int channels = 0;
-	bool big_endian = false;
+	bool big_endian = false, endian_given = false, endian_native = false;
 	bool any_fs = false;             // `-r any` (fir_util.c:148-150: p.fs = 0); otherwise p.fs = the stream's rate (:130) and a container's own rate must match (:103-109)
 };
 
@@ -689,8 +690,9 @@ static bool parse_fir_opts(const char *name, const stream_info *is, GetOpt &g, i
 			break;
 		case 't': o.type = g.arg; break;
 		case 'e': o.enc = g.arg; break;
-		case 'B': o.big_endian = true; break;
-		case 'L': case 'N': o.big_endian = false; break;
+		case 'B': o.big_endian = true; o.endian_given = true; o.endian_native = false; break;
+		case 'L': o.big_endian = false; o.endian_given = true; o.endian_native = false; break;
+		case 'N': o.big_endian = false; o.endian_given = true; o.endian_native = true; break;
 		case 'r':
 			if (strcmp(g.arg, "any") == 0) o.any_fs = true;
 			else {
@@ -823,11 +825,40 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 		*T = frames;
 		return true;
 	}
+	const char *spec_as_given = spec;
 	if (strncmp(spec, "file:", 5) == 0) spec += 5;
 	std::string path = full_path(dir, spec, is->fs, num_set(copy_sel(sel, is->channels)));   // fir_util.c:85
 	const bool wav = o.type ? (!strcmp(o.type, "wav") || !strcmp(o.type, "wavex") || !strcmp(o.type, "sndfile")) : has_wav_ext(path);
-	if (!wav && (!o.type || strcmp(o.type, "pcm") != 0)) {
-		set_error("%s: error: filter files are read as raw PCM (-t pcm -e double -c N) or RIFF/WAVE (.wav): %s", name, spec);
+	const char *enc_own = o.enc ? o.enc : "s16";
+	const bool pcm_own = o.type && !strcmp(o.type, "pcm") && (!strcmp(enc_own, "double") || !strcmp(enc_own, "float") || !strcmp(enc_own, "s32") || !strcmp(enc_own, "s24") || !strcmp(enc_own, "s16"));
+	if (!wav && !pcm_own) {
+		// not one of the formats decoded here: when this library sits in the reference host, the host's own fir_read_filter
+		// (fir_util.c:25-120) reads the file through its codec layer -- whatever containers and encodings it was built with
+		static const dspamd_host_fir_read_filter_fn host_read = reinterpret_cast<dspamd_host_fir_read_filter_fn>(dlsym(RTLD_DEFAULT, "fir_read_filter"));
+		if (host_read) {
+			effect_info ei;
+			memset(&ei, 0, sizeof(ei));
+			ei.name = name;
+			dspamd_codec_params cp;
+			memset(&cp, 0, sizeof(cp));
+			cp.path = spec_as_given; cp.type = o.type; cp.enc = o.enc;
+			cp.fs = o.any_fs ? 0 : is->fs;                       // fir_util.c:130, 148-150
+			cp.channels = o.channels;
+			cp.endian = o.endian_given ? (o.big_endian ? DSPAMD_CODEC_ENDIAN_BIG : o.endian_native ? DSPAMD_CODEC_ENDIAN_NATIVE : DSPAMD_CODEC_ENDIAN_LITTLE) : DSPAMD_CODEC_ENDIAN_DEFAULT;
+			cp.mode = DSPAMD_CODEC_MODE_READ;
+			cp.block_frames = 2048; cp.buf_ratio = 64;           // CODEC_PARAMS_AUTO, codec.h:62-68
+			const std::vector<char> selc = copy_sel(sel, is->channels);
+			int ch = 0;
+			ssize_t fr = 0;
+			sample_t *d = host_read(&ei, is, selc.data(), dir, &cp, &ch, &fr);
+			if (!d) { set_error("%s: error: the host's fir_read_filter could not read: %s", name, spec); return false; }   // (the host has logged why)
+			data.assign(d, d + (size_t) fr * ch);
+			free(d);
+			*fch = ch; *T = fr;
+			if (*T < 1) { set_error("%s: error: filter length must be >= 1", name); return false; }
+			return true;
+		}
+		set_error("%s: error: filter files are read as raw PCM (-t pcm -e double|float|s32|s24|s16 -c N) or RIFF/WAVE (.wav) here; other formats need the reference host's codec layer: %s", name, spec);
 		return false;
 	}
 	FILE *f = fopen(path.c_str(), "rb");

@@ -116,6 +116,23 @@ enum {   /* effect_info.effect_number for st2ms_effect_init (st2ms.h:25-28) */
 	DSPAMD_ST2MS_ST2MS = 1, DSPAMD_ST2MS_MS2ST,
 };
 
+/*
+ * Optional import from the host ("symbols the shim may import"): when the process exports the
+ * reference's fir_read_filter (fir_util.h:36, fir_util.c:25-120) -- i.e. when this library is linked into the reference
+ * host -- filter files this library does not decode itself (anything but coefs: literals, raw PCM in double / float / s32 /
+ * s24 / s16 and RIFF/WAVE) are read through it, i.e. through the host's own codec layer (init_codec, codec.h:72): every
+ * container and encoding the host was built with.  Looked up with dlsym(RTLD_DEFAULT, "fir_read_filter"); absent (the
+ * stand-alone hosts) such files are refused.  struct codec_params mirrors codec.h:57-60, the enums codec.h:24-34.
+ */
+struct dspamd_codec_params {
+	const char *path, *type, *enc;
+	int fs, channels, endian, mode, block_frames, buf_ratio;
+};
+enum { DSPAMD_CODEC_MODE_READ = 1 << 0 };
+enum { DSPAMD_CODEC_ENDIAN_DEFAULT = 0, DSPAMD_CODEC_ENDIAN_BIG, DSPAMD_CODEC_ENDIAN_LITTLE, DSPAMD_CODEC_ENDIAN_NATIVE };
+typedef sample_t *(*dspamd_host_fir_read_filter_fn)(const struct effect_info *, const struct stream_info *, const char *channel_selector,
+                                                    const char *dir, const struct dspamd_codec_params *, int *channels, ssize_t *frames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,3 +271,32 @@ def test_direct_fir_bit_exact(amd, effect, taps, block):
     ref = RefChain(chain, 48000, 2).process(x, block=block)
     y = amd.EffectsChain(chain, 48000, 2).process(x, block=block)
     assert y.shape == ref.shape and np.array_equal(y, ref)
+
+
+# ------------------------------------------------------------------ filter files through the host's codec layer (a14)
+
+@pytest.mark.skipif(not (RefChain.available("_gpu") and RefChain.available()), reason="oracle/_ref harness libraries not present")
+@pytest.mark.parametrize("enc,dt,scale", [("s24_3", None, 8388608.0), ("u8", "u1", 128.0), ("s8", "i1", 128.0)])
+def test_filter_file_through_the_hosts_codec_layer(amd, tmp_path, enc, dt, scale):
+    """Encodings this library's own raw-PCM reader does not decode: inside the reference host the host's fir_read_filter
+    (fir_util.c:25-120 -> init_codec) reads them -- same stream as the all-reference build."""
+    rng = np.random.default_rng(21)
+    q = np.clip(np.round(rng.standard_normal(90) * np.exp(-np.arange(90) / 20.0) * 0.3 * scale), -scale, scale - 1).astype(np.int64)
+    p = os.path.join(str(tmp_path), "h." + enc)
+    if enc == "s24_3":
+        raw = b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in q)
+    elif enc == "u8":
+        raw = (q + 128).astype("u1").tobytes()
+    else:
+        raw = q.astype("i1").tobytes()
+    open(p, "wb").write(raw)
+    chain = f"gain -2 fir -t pcm -e {enc} -c 1 {p} lowpass 5k 0.707"
+    x = noise(4000, 2, 91)
+    outs = {}
+    for variant in ("_gpu", ""):
+        rc = RefChain(chain, 48000, 2, variant=variant)
+        outs[variant] = rc.process(x, block=512)
+        rc.close()
+    assert outs["_gpu"].shape == outs[""].shape and rms(outs["_gpu"] - outs[""]) < 1e-12
+    # (a stand-alone host has no codec layer behind it and refuses the same file: tests/test_host_cpu.py, in a process of its own --
+    # here the reference runtime's symbols are in scope)

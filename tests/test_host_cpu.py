@@ -51,3 +51,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in src and "oracle_api" not in src and "dsp_oracle" not in src and "libdspref" not in src, f
+
+
+def test_filter_encodings_without_a_host_codec_layer_are_refused(tmp_path):
+    """Raw PCM in an encoding this library does not decode itself (s24_3, u8 ...) is read through the reference host's
+    fir_read_filter when the library sits inside that host (tests/test_gpu_endpoints.py); a stand-alone host has no codec
+    layer and must refuse it with a message -- checked in a process of its own (no reference symbols in scope)."""
+    import subprocess
+    import sys
+    f = tmp_path / "h.s24_3"
+    f.write_bytes(bytes(range(90)))
+    code = "\n".join([
+        "import sys; sys.path.insert(0, %r)" % ROOT,
+        "import ctypes, dsp_amd",
+        "L = dsp_amd.load_library()",            # host-side planning needs no device (include/dsp_amd.h: dspamd_plan_fir)
+        "d = ctypes.c_ssize_t()",
+        "n = L.dspamd_plan_fir(b'fir -t pcm -e s24_3 -c 1 %s', 48000, 2, None, 0, 0, None, 0, ctypes.byref(d))" % str(f),
+        "print('planned %d taps' % n if n >= 0 else 'refused: ' + L.dspamd_last_error().decode())",
+    ])
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "refused" in r.stdout and "codec layer" in r.stdout, r.stdout
