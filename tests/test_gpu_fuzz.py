@@ -231,3 +231,32 @@ def test_random_chain_ragged_calls(amd, seed):
     y = np.concatenate([o for o in outs if o.shape[0]]) if any(o.shape[0] for o in outs) else np.zeros((0, ec.ochannels))
     assert y.shape == yr.shape, (chain[:300], y.shape, yr.shape)
     assert rms(y - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain[:300], rms(y - yr))
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_chain_small_calls_vs_real_reference(amd, tmp_path, seed):
+    # the convolver's small-call regime (delay-line head + overlap-save tail) inside random chains: a long
+    # zero-latency filter on every channel between randomly drawn cascade effects, fed in calls of 256 ... 2048 frames that
+    # cross several tail hand-overs, with a ragged last call (which takes the stream off the grid) and the drain
+    import torch
+    rng = np.random.Generator(np.random.PCG64(17000 + seed))
+    channels = int(rng.choice([1, 2, 3, 4, 8]))
+    S = int(rng.choice([1, 5, 64]))
+    block = int(rng.choice([256, 512, 1024, 2048]))
+    taps = int(rng.integers(8 * block, 24 * block))
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 7.0))
+    h = h / np.sqrt(np.sum(h * h)) / 3.0
+    p = str(tmp_path / "h.raw")
+    np.asarray(h, dtype="<f8").tofile(p)
+    head = gen_chain(rng, channels, cascade_only=True) if rng.integers(3) else ""
+    tail = gen_chain(rng, channels, cascade_only=True) if rng.integers(3) == 0 else ""
+    chain = f"{head} : fir_p -t pcm -e double -c 1 {p} {tail}".strip()
+    n = block * int(rng.integers(9, 26)) + int(rng.integers(0, block))
+    x = rng.uniform(-0.5, 0.5, size=(S, n, channels))
+    b = amd.BatchChain(chain, 48000, channels, S, block)
+    assert "small-calls" in b.plan(), b.plan()
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    for s in sorted({0, S - 1}):
+        yr = RefChain(chain, 48000, channels).process(x[s], block=2048)
+        assert y[s].shape == yr.shape, (chain, s, y[s].shape, yr.shape)
+        assert rms(y[s] - yr) <= 1e-10 * max(rms(yr), 1e-3), (chain, s, rms(y[s] - yr))
