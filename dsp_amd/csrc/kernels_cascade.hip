@@ -955,7 +955,10 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB + 8) * sizeof(double);
 	if (lds > 160 * 1024) return 0;
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G>), lds);
-	static const int p2p = [] { const char *e = getenv("DSP_AMD_CASCADE_P2P"); return e ? atoi(e) : 1; }();   // 0: one workgroup barrier per step (round 1)
+	// point-to-point ordering for long calls (at least 16 tiles per wave); short ones keep the workgroup barrier per step: the
+	// polling costs more than it saves there (config 2's chunks of 8 tiles: 0.052 against 0.064 ms; 2048-frame calls 0.031 / 0.035)
+	static const int p2p_env = [] { const char *e = getenv("DSP_AMD_CASCADE_P2P"); return e ? atoi(e) : -1; }();
+	const int p2p = (p2p_env >= 0) ? p2p_env : (n_full / P >= 16 ? 1 : 0);
 	dim3 grid(n_streams, p.C / G), block(64 * P);
 	hipLaunchKernelGGL(cascade_rows<G>, grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
 	return n_full * TILE;
@@ -980,7 +983,7 @@ static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream
 		P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
 		// with point-to-point ordering more waves per group pay even when the chip is full anyway: 8 waves in one workgroup per
 		// CU against 2 x 4 (9.48 against 9.67 ms at 256 streams, scripts/exp_rowsP.sh)
-		if (G == 4 && P < 8 && p.n_ops >= 8) P = 8;
+		if (G == 4 && P < 8 && p.n_ops >= 8 && p.frames / 512 >= 64) P = 8;   // (long calls only: the skewed start costs P steps per launch)
 	}
 	if (P > 8) P = 8;
 	if (P < 1) P = 1;
