@@ -834,7 +834,8 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 	if (!wav && !pcm_own) {
 		// not one of the formats decoded here: when this library sits in the reference host, the host's own fir_read_filter
 		// (fir_util.c:25-120) reads the file through its codec layer -- whatever containers and encodings it was built with
-		static const dspamd_host_fir_read_filter_fn host_read = reinterpret_cast<dspamd_host_fir_read_filter_fn>(dlsym(RTLD_DEFAULT, "fir_read_filter"));
+		// (looked up per call, init time only: the host may come into scope after this library's first use in the process)
+		const dspamd_host_fir_read_filter_fn host_read = reinterpret_cast<dspamd_host_fir_read_filter_fn>(dlsym(RTLD_DEFAULT, "fir_read_filter"));
 		if (host_read) {
 			effect_info ei;
 			memset(&ei, 0, sizeof(ei));

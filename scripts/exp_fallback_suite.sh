@@ -1,6 +1,6 @@
 # the GPU suite once per fallback path (each switch removes one fast path; results must not change).  Tests that assert on
 # the plan text of the path that was switched off are left out.
-SKIP="not chunked and not slab_direct and not registered_host and not chained_convolvers_feed and not headline_workload_full_size and not convolver_configs_full_size and not small_calls"
+SKIP="not chunked and not slab_direct and not registered_host and not chained_convolvers_feed and not headline_workload_full_size and not bench_default_configuration and not convolver_configs_full_size and not small_calls"
 # round 2 switches: the one-shot K2, no small-call regime, a barrier per cascade step, no pair padding, no nt hints
 # (ROUND=2 runs only those)
 R1="DSP_AMD_CASCADE_ROWS=0|DSP_AMD_CASCADE_ROWS=0 DSP_AMD_CASCADE_WAVE=0|DSP_AMD_CASCADE_CHUNKS=0|DSP_AMD_CONV_NO_DIRECT=1|DSP_AMD_PLUGIN_MAPPED_KB=0|DSP_AMD_NO_LTI_MERGE=1|DSP_AMD_NO_FEED=1"
