@@ -79,7 +79,12 @@ ssize_t dspamd_batch_max_out_frames(dspamd_batch *, ssize_t in_frames);
 ssize_t dspamd_batch_drain_frames(dspamd_batch *);
 /*
  * One block for all streams, asynchronously on `stream`; no host sync, no
- * allocation, graph-capturable.  d_in: [S][frames][C_in]; d_out: [S][out_stride_frames][C_out]
+ * allocation (after the first call of a size: plans and LDS grants are made on
+ * first use), capturable into a hipGraph.  A captured call carries its position
+ * in the streams (ring offsets of convolvers, delays and resamplers are launch
+ * parameters): replaying it continues the streams only for chains whose state
+ * lives entirely in device memory (gains, biquad sections, remix); for the others
+ * capture a whole period of calls, or re-capture per call.  d_in: [S][frames][C_in]; d_out: [S][out_stride_frames][C_out]
  * (out_stride_frames >= returned frame count; pass 0 for "= max_out_frames(frames)").
  * Returns frames produced per stream, or <0.
  */

@@ -300,3 +300,35 @@ def test_filter_file_through_the_hosts_codec_layer(amd, tmp_path, enc, dt, scale
     assert outs["_gpu"].shape == outs[""].shape and rms(outs["_gpu"] - outs[""]) < 1e-12
     # (a stand-alone host has no codec layer behind it and refuses the same file: tests/test_host_cpu.py, in a process of its own --
     # here the reference runtime's symbols are in scope)
+
+
+# ------------------------------------------------------------------ hipGraph capture of a batch step (include/dsp_amd.h)
+
+def test_batch_step_captured_into_a_graph(amd, tmp_path):
+    """dspamd_batch_run makes no host synchronisation and no allocation after the first call of a size: a step can be captured
+    into a hipGraph.  Cascade-only chains keep their whole state in device memory, so replays continue the streams; a chain
+    with a convolver bakes its ring positions into the captured launches, so ONE replay is the next step."""
+    import torch
+    h = np.random.default_rng(1).standard_normal(5000) / 70
+    p = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(h, dtype="<f8").tofile(p)
+    S, Cn, B = 16, 8, 8192
+    x = torch.rand((S, B, Cn), dtype=torch.float64, device="cuda") - 0.5
+    for chain, replays in (("lowpass 1k 0.707 eq 300 1.0 3 highpass 30 0.707", 3),
+                           (f"lowpass 1k 0.707 eq 300 1.0 3 fir_p -t pcm -e double -c 1 {p}", 1)):
+        eager = amd.BatchChain(chain, 48000, Cn, S, B)
+        ref = [eager.run(x).clone() for _ in range(1 + replays)]
+        g = amd.BatchChain(chain, 48000, Cn, S, B)
+        out = torch.empty((S, B, Cn), dtype=torch.float64, device="cuda")
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            assert torch.equal(g.run(x, out), ref[0])              # first call eager: plans, LDS grants
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                g.run(x, out)
+        torch.cuda.synchronize()
+        for k in range(replays):
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref[1 + k]), (chain, k)
