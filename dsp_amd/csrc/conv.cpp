@@ -395,8 +395,14 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 		tail_conv.reset(new ConvStage);
 		tail_conv->S = S; tail_conv->ch_in = ch_in; tail_conv->ch_out = ch_out; tail_conv->fs_in = fs_in; tail_conv->fs_out = fs_out;
 		const long fn = (ts.T - 1 + 7) & ~7L;
-		if (!tail_conv->init(ts, fD, nullptr, nullptr, this, std::max<long>(next_pow2(fn + fD), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)))) return false;
-		if (!tail_buf.alloc((size_t) S * fD * ch_in * sizeof(double))) return false;
+		if (!tail_conv->init(ts, fD, nullptr, nullptr, this, std::max<long>(next_pow2(fn + fD), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)))
+		    || !tail_buf.alloc((size_t) S * fD * ch_in * sizeof(double))) {
+			// the regime is an optimisation: without it the stage runs one transform per call as before
+			log_msg(LL_VERBOSE, "%s: info: small-call regime not available (%s)", name.c_str(), last_error());
+			tail_conv.reset();
+			fdl_buf.release(); fdl_H.release(); fdl_tw.release(); tail_buf.release();
+			return true;
+		}
 	}
 	fdl = fdl_live = true;
 	return true;
