@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--block", type=int, default=983040, help="frames per step per stream (default: the hop of a 2^20-point transform for 65536 taps, 15 x 65536: the valid fraction of every transform is 15/16)")
     ap.add_argument("--taps", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the side figures (merged-IIR plan) reported next to the headline")
     ap.add_argument("--slab-pad", type=int, default=68, help="frames of padding between the slabs of two streams (input and output buffers): "
                     "at exactly block x C x 8 bytes apart -- a multiple of 4 MiB at the default block -- every stream's frame t sits on the same "
                     "memory channels (0 = contiguous [S][block][C] tensors)")
@@ -314,6 +315,34 @@ def main():
             "output_finite": finite, "env": env_set,
             "digest": {"streams": int(dig.shape[0]), "sum_of_squares": float(dig[:, 1].sum().item()), "peak": float(dig[:, 2].max().item())},
         }
+        if world == 1 and not (args.config or args.chain) and not args.no_side_runs and not args.no_cpu_baseline:
+            # SIDE FIGURE, never `value`: the same chain with the planner's opt-in LTI merge of the sections into the filter
+            # (DSP_AMD_MERGE_IIR=1): no cascade pass at all, exact to the decay criterion (2^-70).  The headline
+            # above is measured with the cascade kernel in place, as the workload is defined.
+            try:
+                del batch, x, out
+                torch.cuda.empty_cache()
+                os.environ["DSP_AMD_MERGE_IIR"] = "1"
+                sb = 958208                                        # the hop of N = 2^20 for the merged filter (65536 + 24832 - 1 taps)
+                mb = dsp_amd.BatchChain(chain, fs, C, S, sb, directory=filt_dir)
+                os.environ.pop("DSP_AMD_MERGE_IIR")
+                mx = torch.zeros((S, sb + args.slab_pad, C), dtype=torch.float64, device="cuda")
+                L.dspamd_sgen_sine(mx.data_ptr(), S, sb + args.slab_pad, C, fs, 100.0 + 90.0 * s_lo, 90.0, 0, stream)
+                mo = torch.empty((S, sb + args.slab_pad, C), dtype=torch.float64, device="cuda")
+                for _ in range(2):
+                    mb.run(mx[:, :sb, :], mo)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(6):
+                    mb.run(mx[:, :sb, :], mo)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 6
+                res["side_runs"] = {"merged_iir": {"what": "sections folded into the filter by the planner (opt-in DSP_AMD_MERGE_IIR=1); not the headline",
+                                                   "value": S * C * sb / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "block_frames": sb, "plan": mb.plan()}}
+                del mb, mx, mo
+            except Exception as e:  # pragma: no cover
+                os.environ.pop("DSP_AMD_MERGE_IIR", None)
+                res["side_runs"] = {"merged_iir": {"error": str(e)[:300]}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(chain, filt_dir, fs, C)
             if res["cpu_baseline"].get("value"):
