@@ -590,8 +590,14 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first fetch (the compiler does not know about it)
 	__syncthreads();                                                     // tables visible
+	// (two branches: the inter-pass twiddles are rebuilt from their LDS steps at every use instead of living in 64 registers --
+	// with both filter rows resident the kernel would spill a hundred VGPRs to scratch)
+	constexpr bool TWD_REGS = (NPH == 1);
+	auto twiddle = [&](int m) { return TWD_REGS ? twd[m] : cmul(twb, steps[m]); };
+	if (TWD_REGS) {
 #pragma unroll
-	for (int m = 0; m < 16; ++m) twd[m] = cmul(twb, steps[m]);
+		for (int m = 0; m < 16; ++m) twd[m] = cmul(twb, steps[m]);
+	}
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	for (long q = q0; q < q1; ++q) {
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own landing slots read: they may be overwritten
 		if (q + 1 < q1) fetch(q + 1);
 #pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], twd[m]);
+		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], twiddle(m));
 		row_fft<LOG2N2, false>(v, j, data, map, tw);
 #pragma unroll
 		for (int ph = 0; ph < NPH; ++ph) {
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 			row_fft<LOG2N2, true>(u, j, data, map, tw);
 			cplx *out = W + (long) ph * p.phase_stride + q * p.w_stride;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) out[P * m] = cmulc(u[m], twd[m]);
+			for (int m = 0; m < 16; ++m) out[P * m] = cmulc(u[m], twiddle(m));
 		}
 		if (q + 1 == q1) break;
 		row_sync<WL>();      // the last gather of the inverse transform is done before the next forward pass writes the row
@@ -1034,7 +1040,7 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 	}
 	// (the two-branch form holds both filter rows in registers: at 2048- / 4096-point rows it spills 100 VGPRs and is behind the
 	// one-shot kernel, 16.7 against 15.0 ms; at 1024-point rows ahead, 3.26 against 3.53)
-	if (plan_is_pipe(p) && (mode == 0 || (mode == 2 && p.nph == 2 && p.log2N2 <= 10)) && n_pairs >= 8) {
+	if (plan_is_pipe(p) && (mode == 0 || (mode == 2 && p.nph == 2)) && n_pairs >= 8) {
 		switch (p.log2N2) {
 		case 9: launch_row_pipe<9>(p, n_pairs, st); return;
 		case 10: launch_row_pipe<10>(p, n_pairs, st); return;
