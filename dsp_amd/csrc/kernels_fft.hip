@@ -526,8 +526,8 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 }
 
 // K2, persistent form (plain convolution, one filter shared by every pair): a workgroup keeps ITS rows k1 and walks over the
-// pairs.  What the one-shot kernel above redoes per row and pair happens once per workgroup: the filter rows and the
-// inter-pass twiddles live in registers, the pass twiddles in LDS.  The next pair's rows come in by LDS-DMA
+// pairs.  What the one-shot kernel above redoes per row and pair happens once per workgroup: the filter rows live in
+// registers, the pass twiddles and the 16 steps of each row's inter-pass twiddle in LDS.  The next pair's rows come in by LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, no ds_write pass) while the current ones are transformed, so the HBM
 // stream never waits for a compute phase -- at 244 VGPRs the one-shot kernel holds two workgroups per CU whose load, compute
 // and store phases overlap only by chance (2.0 ms for 8.6 GB where the bare access pattern moves them in 1.55,
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	cplx *steps = thi + 64 + rw * 16;
 	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
 	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
-	cplx h[NPH][16], twd[16];
+	cplx h[NPH][16];
 #pragma unroll
 	for (int ph = 0; ph < NPH; ++ph) {
 		const cplx *H = p.H + (long) ph * p.N + k1 * N2 + j;             // (one shared filter set: pair_h is all zeros)
@@ -590,14 +590,10 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first fetch (the compiler does not know about it)
 	__syncthreads();                                                     // tables visible
-	// (two branches: the inter-pass twiddles are rebuilt from their LDS steps at every use instead of living in 64 registers --
-	// with both filter rows resident the kernel would spill a hundred VGPRs to scratch)
-	constexpr bool TWD_REGS = (NPH == 1);
-	auto twiddle = [&](int m) { return TWD_REGS ? twd[m] : cmul(twb, steps[m]); };
-	if (TWD_REGS) {
-#pragma unroll
-		for (int m = 0; m < 16; ++m) twd[m] = cmul(twb, steps[m]);
-	}
+	// the inter-pass twiddles w_N^(k1 n2) are rebuilt from their 16 per-row steps in LDS at both uses instead of living in 64
+	// registers: with them resident the kernel needs ~110 AGPRs of spill space and as many copies per pair (9.0 -> 8.7 ms at
+	// 4096-point rows; the two-branch form would spill a hundred VGPRs to scratch)
+	auto twiddle = [&](int m) { return cmul(twb, steps[m]); };
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	for (long q = q0; q < q1; ++q) {
