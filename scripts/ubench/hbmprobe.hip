@@ -102,6 +102,23 @@ __global__ __launch_bounds__(512) void k_k3(const e16 *__restrict__ W, e16 *__re
 	}
 }
 
+// K1 reading an INTERLEAVED slab (frames of 64 bytes = 4 pairs) directly: PPS pairs per workgroup, lanes pair-fastest, so a
+// frame contributes PPS * 16 contiguous bytes; 16 columns x 256 rows per pair, W-like destination (256-byte runs per pair)
+template <int PPS>
+__global__ __launch_bounds__(256 * PPS) void k_slab(const e16 *__restrict__ slab, e16 *__restrict__ W, long n2_total)
+{
+	const int q = threadIdx.x % PPS, t = (threadIdx.x / PPS) % 16, j = threadIdx.x / (16 * PPS);
+	const long n2 = (long) blockIdx.x * 16 + t;
+	const long stream = blockIdx.y / (4 / PPS), pq = (blockIdx.y % (4 / PPS)) * PPS + q;
+	const e16 *s = slab + stream * 256 * n2_total * 4 + pq;
+	e16 *d = W + (stream * 4 + pq) * (256 * n2_total + 272) + n2;
+	e16 v[16];
+#pragma unroll
+	for (int m = 0; m < 16; ++m) v[m] = s[((long) (j + 16 * m) * n2_total + n2) * 4];
+#pragma unroll
+	for (int m = 0; m < 16; ++m) d[(long) (j + 16 * m) * n2_total] = v[m];
+}
+
 // row pattern: grid (N1 / 4, pairs): 4 rows of 1024 points per workgroup, one per wave; lane moves j + 64 m
 __global__ __launch_bounds__(256) void k_row(const e16 *__restrict__ src, e16 *__restrict__ dst, long pitch, long pair_stride)
 {
@@ -230,6 +247,15 @@ int main(int argc, char **argv)
 				const double by = (double) ns * 4 * 256 * n2 * 16;
 				printf("N2 %5ld pitch pad %3ld pair pad %4ld : load %6.2f   copy %6.2f\n", n2, pad, ppad, by / tl / 1e9, 2 * by / tc / 1e9);
 			}
+	printf("# K1 reading an interleaved slab directly (4 pairs per 64-byte frame): pairs per workgroup; TB/s of bytes moved\n");
+	for (long n2 : { 1024L, 4096L }) {
+		const int ns = (int) (bytes / ((size_t) 256 * n2 * 64));
+		const double by = 2.0 * ns * 256 * n2 * 64;
+		const double t1 = time_ms([&] { k_slab<1><<<dim3((unsigned) (n2 / 16), ns * 4), 256>>>(a, b, n2); }, reps);
+		const double t2 = time_ms([&] { k_slab<2><<<dim3((unsigned) (n2 / 16), ns * 2), 512>>>(a, b, n2); }, reps);
+		const double t4 = time_ms([&] { k_slab<4><<<dim3((unsigned) (n2 / 16), ns), 1024>>>(a, b, n2); }, reps);
+		printf("N2 %5ld : 1 pair / wg (16 B pieces) %6.2f   2 pairs (32 B) %6.2f   4 pairs (whole frames, 1024 threads) %6.2f\n", n2, by / t1 / 1e9, by / t2 / 1e9, by / t4 / 1e9);
+	}
 	// does the rate depend on how many workgroups (= bytes in flight) a CU holds?  dynamic LDS caps the residency
 	printf("# residency sweep: workgroups per CU capped through dynamic LDS (copy TB/s)\n");
 	printf("%-10s %12s %12s %12s %12s\n", "LDS/wg", "stream U=16", "stream U=4", "col 256thr", "row in place");
