@@ -11,6 +11,12 @@ import numpy as np
 from .lib import load_library, last_error
 
 
+# DSPAMD_PCM_* (include/dsp_amd.h) and the torch dtype / elements per sample that carry each format
+PCM_FORMATS = {"u8": 0, "s8": 1, "s16": 2, "s24": 3, "s32": 4, "s24_3": 5, "float": 6, "double": 7}
+WIRE_DTYPES = {"u8": ("uint8", 1), "s8": ("int8", 1), "s16": ("int16", 1), "s24": ("int32", 1), "s32": ("int32", 1),
+               "s24_3": ("uint8", 3), "float": ("float32", 1), "double": ("float64", 1)}
+
+
 class EffectsChain:
     def __init__(self, chain, fs, channels, directory=None):
         import ctypes as C
@@ -147,6 +153,65 @@ class BatchChain:
 
     def reset(self):
         self.L.dspamd_batch_reset(self.h, self._stream())
+
+    # ---- wire format to wire format (the file -> file path: read_buf_<fmt>, the chain, dither / clip / write_buf_<fmt>) ----
+    def _wire_out(self, fmt, cap, device):
+        t = self.torch
+        dt, mult = WIRE_DTYPES[fmt]
+        return t.empty((self.S, cap, self.ochannels * mult), dtype=getattr(t, dt), device=device)
+
+    def run_wire(self, x, in_fmt, out_fmt, dither_prec=0, stats=None, out=None):
+        """x: [S, frames, C] cuda tensor of the wire dtype of in_fmt (WIRE_DTYPES; s24_3: uint8 [S, frames, 3 C]), contiguous or a
+        view of a padded [S, stride, C] buffer.  Returns a view [S, oframes, C_out] of `out` in the dtype of out_fmt.  The batch
+        keeps the position in the dither sequences; stats: optional zero-initialised [S, 2] float64 (clip count bits, peak)."""
+        t = self.torch
+        dt, mult = WIRE_DTYPES[in_fmt]
+        assert x.is_cuda and x.dtype == getattr(t, dt) and x.shape[0] == self.S and x.shape[2] == self.channels * mult
+        frames, row = x.shape[1], self.channels * mult
+        assert x.stride(2) == 1 and x.stride(1) == row and x.stride(0) % row == 0
+        in_stride = x.stride(0) // row if self.S > 1 else frames
+        cap = max(self.max_out_frames(frames), 1)
+        if out is None:
+            out = self._wire_out(out_fmt, cap, x.device)
+        orow = out.shape[2]
+        assert out.shape[0] == self.S and out.shape[1] >= cap and orow == self.ochannels * WIRE_DTYPES[out_fmt][1]
+        out_stride = out.stride(0) // orow if self.S > 1 else out.shape[1]
+        f = self.L.dspamd_batch_run_wire(self.h, PCM_FORMATS[in_fmt], x.data_ptr(), in_stride, frames, PCM_FORMATS[out_fmt], out.data_ptr(), out_stride,
+                                         dither_prec, stats.data_ptr() if stats is not None else None, self._stream())
+        if f < 0:
+            raise RuntimeError(f"dsp_amd: batch_run_wire failed: {last_error()}")
+        return out[:, :f, :]
+
+    def drain_wire(self, block, out_fmt, dither_prec=0, stats=None, out=None):
+        cap = max(self.max_out_frames(block), 1)
+        if out is None:
+            out = self._wire_out(out_fmt, cap, "cuda")
+        out_stride = out.stride(0) // out.shape[2] if self.S > 1 else out.shape[1]
+        f = self.L.dspamd_batch_drain_wire(self.h, block, PCM_FORMATS[out_fmt], out.data_ptr(), out_stride, dither_prec,
+                                           stats.data_ptr() if stats is not None else None, self._stream())
+        if f == -1:
+            return None
+        if f < 0:
+            raise RuntimeError(f"dsp_amd: batch_drain_wire failed: {last_error()}")
+        return out[:, :f, :]
+
+    def wire_fused(self):
+        """what the last run_wire / drain_wire did: bit 0 = input converted by the first kernel, bit 1 = sink applied by the last"""
+        return self.L.dspamd_batch_wire_fused(self.h)
+
+    def process_wire(self, x, block, in_fmt, out_fmt, dither_prec=0, stats=None):
+        """Whole streams incl. drain, wire format to wire format."""
+        t = self.torch
+        outs = []
+        for p in range(0, x.shape[1], block):
+            outs.append(self.run_wire(x[:, p:p + block, :].contiguous(), in_fmt, out_fmt, dither_prec, stats).clone())
+        while True:
+            o = self.drain_wire(block, out_fmt, dither_prec, stats)
+            if o is None:
+                break
+            outs.append(o.clone())
+        outs = [o for o in outs if o.shape[1]]
+        return t.cat(outs, dim=1) if outs else self._wire_out(out_fmt, 1, x.device)[:, :0, :]
 
     def process(self, x, block):
         """Whole streams incl. drain: x [S, N, C] cuda -> [S, M, C_out] cuda."""

@@ -16,6 +16,8 @@ struct dspamd_batch {
 	ssize_t iframes = 0;
 	DevBuf zeros;
 	ssize_t zeros_frames = 0;
+	ssize_t wire_frames_out = 0;      // frames of each stream written through the sink so far (position in the dither sequences)
+	int wire_fused = 0;
 };
 
 struct dspamd_chain {
@@ -120,11 +122,57 @@ ssize_t dspamd_batch_drain(dspamd_batch *b, ssize_t block_frames, void *d_out, s
 	return b->pipe->drain2(block_frames, static_cast<double *>(d_out), stride, st);
 }
 
+static WireSink make_sink(dspamd_batch *b, int out_fmt, int dither_prec, void *d_stats)
+{
+	WireSink k;
+	k.on = 1; k.fmt = out_fmt;
+	// tpdf_dither_get_mult(), util.h:157-163
+	k.dither_mult = (dither_prec >= 1 && dither_prec <= 32) ? 1.0 / ((double) 0x7fffffff * (double) (1u << (dither_prec - 1))) : 0.0;
+	k.samples_before = (long) b->wire_frames_out * b->pipe->ch_out;
+	k.stats = static_cast<double *>(d_stats);
+	return k;
+}
+
+ssize_t dspamd_batch_run_wire(dspamd_batch *b, int in_fmt, const void *d_in, ssize_t in_stride_frames, ssize_t frames,
+                              int out_fmt, void *d_out, ssize_t out_stride_frames, int dither_prec, void *d_stats, void *stream)
+{
+	if (frames < 1) return 0;
+	if (!d_in) { set_error("batch_run_wire: no input"); return -1; }
+	b->iframes += frames;
+	const ssize_t f = b->pipe->run_wire(in_fmt, d_in, (long) in_stride_frames, frames, make_sink(b, out_fmt, dither_prec, d_stats), d_out, (long) out_stride_frames,
+	                                    static_cast<hipStream_t>(stream), &b->wire_fused);
+	if (f > 0) b->wire_frames_out += f;
+	return f;
+}
+
+ssize_t dspamd_batch_drain_wire(dspamd_batch *b, ssize_t block_frames, int out_fmt, void *d_out, ssize_t out_stride_frames, int dither_prec, void *d_stats, void *stream)
+{
+	if (b->iframes < 1 || block_frames < 1) return -1;
+	block_frames = std::min<ssize_t>(block_frames, b->pipe->max_frames);
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	ssize_t f;
+	if (b->drain_left > 0) {
+		const ssize_t n = std::min(block_frames, b->drain_left);
+		if (b->zeros_frames < n) {
+			if (!b->zeros.alloc((size_t) b->pipe->S * block_frames * b->pipe->ch_in * sizeof(double), true)) return -2;
+			b->zeros_frames = block_frames;
+		}
+		b->drain_left -= n;
+		f = b->pipe->run_wire(PCM_DOUBLE, b->zeros.p, 0, n, make_sink(b, out_fmt, dither_prec, d_stats), d_out, (long) out_stride_frames, st, &b->wire_fused);
+	}
+	else f = b->pipe->run_wire(PCM_DOUBLE, nullptr, 0, block_frames, make_sink(b, out_fmt, dither_prec, d_stats), d_out, (long) out_stride_frames, st, &b->wire_fused);
+	if (f > 0) b->wire_frames_out += f;
+	return f;
+}
+
+int dspamd_batch_wire_fused(dspamd_batch *b) { return b->wire_fused; }
+
 void dspamd_batch_reset(dspamd_batch *b, void *stream)
 {
 	b->pipe->reset(static_cast<hipStream_t>(stream));
 	b->drain_left = b->plan.drain_frames;
 	b->iframes = 0;
+	b->wire_frames_out = 0;
 }
 
 void dspamd_batch_destroy(dspamd_batch *b)
@@ -254,11 +302,7 @@ int dspamd_digest(const void *d_buf, int n_streams, ssize_t frames, ssize_t stri
 
 // ---------------------------------------------------------------- wire formats on the device
 
-static size_t pcm_bytes(int fmt)
-{
-	static const size_t b[PCM_N_FORMATS] = { 1, 1, 2, 4, 4, 3, 4, 8 };
-	return (fmt >= 0 && fmt < PCM_N_FORMATS) ? b[fmt] : 0;
-}
+static size_t pcm_bytes(int fmt) { return pcm_sample_bytes(fmt); }
 
 size_t dspamd_pcm_sample_bytes(int fmt) { return pcm_bytes(fmt); }
 
@@ -266,8 +310,8 @@ int dspamd_pcm_read(int fmt, const void *d_in, void *d_out, ssize_t n_samples, v
 {
 	if (!pcm_bytes(fmt)) { set_error("pcm_read: unknown format %d", fmt); return -1; }
 	if (device_count() < 1) { set_error("pcm_read: no HIP device available"); return -1; }
-	PcmReadParams p{ d_in, static_cast<double *>(d_out), (long) n_samples, fmt };
-	launch_pcm_read(p, static_cast<hipStream_t>(stream));
+	PcmReadParams p{ d_in, static_cast<double *>(d_out), (long) n_samples, (long) n_samples, (long) n_samples, 1, fmt };
+	launch_pcm_read(p, 1, static_cast<hipStream_t>(stream));
 	return hip_ok(hipGetLastError(), "pcm_read") ? 0 : -1;
 }
 
@@ -279,7 +323,7 @@ int dspamd_pcm_write(int fmt, const void *d_in, ssize_t in_stride_frames, void *
 	PcmWriteParams p;
 	p.in = static_cast<const double *>(d_in);
 	p.out = d_out;
-	p.in_stride_frames = in_stride_frames; p.frames = frames;
+	p.in_stride_frames = in_stride_frames; p.out_stride_frames = frames; p.frames = frames;
 	p.C = channels; p.fmt = fmt;
 	// tpdf_dither_get_mult(), util.h:157-163
 	p.dither_mult = (dither_prec >= 1 && dither_prec <= 32) ? 1.0 / ((double) 0x7fffffff * (double) (1u << (dither_prec - 1))) : 0.0;

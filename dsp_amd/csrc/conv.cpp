@@ -47,6 +47,22 @@ public:
 	ssize_t max_out_frames(ssize_t in_frames) const override { return ((long long) in_frames * up + down - 1) / down; }
 	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
+	// first stage of a pipeline fed in a wire format: the de-interleaving pass converts any format, K1 in direct mode the ones
+	// whose channel pairs are naturally aligned
+	bool wire_in_ok(int fmt, const void *in, long in_stride, ssize_t frames, bool also_out, int out_fmt) const override
+	{
+		(void) in; (void) in_stride; (void) frames; (void) out_fmt; (void) also_out;   // (K1 and K3 are different kernels: the ends are independent)
+		if (!wire_fusion_on() || fed) return false;
+		return !direct || (pcm_fusable(fmt) && fmt != PCM_DOUBLE);
+	}
+	// a plain convolution of every channel at the end of a pipeline: K3 applies the sink (dither, clip, wire format) in its stores
+	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override
+	{
+		(void) out; (void) out_stride; (void) in_fmt; (void) also_in;
+		if (!wire_fusion_on() || !pcm_fusable(fmt) || resampler || nph != 1 || up != 1 || down != 1 || !all_selected || feeds) return false;
+		if (fdl && fdl_live && frames % fB == 0 && q_abs % fB == 0) return false;      // the small-call regime writes through conv_fdl
+		return true;
+	}
 	size_t device_bytes() const override
 	{
 		return (is_tail_child ? 0 : ring.bytes) + W.bytes + H.bytes + H_plain.bytes + tail_z.bytes + tail_scratch.bytes + tail_out.bytes
@@ -149,6 +165,8 @@ ConvParams ConvStage::base_params() const
 	p.pairs_per_stream = pps;
 	p.pair_out_ch = pair_out_ch.as<int>();
 	p.round_f32 = round_f32;
+	p.sink = { 0, PCM_DOUBLE, 0.0, 0, nullptr };
+	p.slab_fmt = PCM_DOUBLE;
 	p.nph = nph; p.up = up; p.down = down;
 	p.w_stride = w_stride;
 	p.phase_stride = pairs_per_chunk * w_stride;
@@ -501,6 +519,7 @@ void ConvStage::push(const double *in, long in_stride, ssize_t frames, double *o
 	d.ring = ring_dev;
 	d.ring_row_stride = ring_stride; d.ring_mask = ring_len - 1; d.pos = pos;
 	d.round_f32 = round_f32;
+	d.in_fmt = wire_in_fmt;
 	{ ProfScope ps("conv_deinterleave", st); launch_deinterleave(d, S, st); }
 }
 
@@ -518,11 +537,12 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 		p.valid = std::max<long>(0, std::min<long>(first_n + f, first_n + q_end - q_blk));
 		p.out = out;
 		p.out_stride_frames = out_stride;
+		p.sink = wire_sink;
 		p.in_count = f;
 		p.q_blk = q_blk;
 		p.k_origin = k_origin;
 		p.out_count = out_count;
-		if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; p.slab_store = resampler ? 0 : 1; }
+		if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; p.slab_store = resampler ? 0 : 1; p.slab_fmt = wire_in_fmt; }
 		const int row_mode = (nph > 1) ? 2 : 0;
 		if (n_sub > 1) {
 			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
@@ -602,7 +622,7 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 			if (off < frames) {
 				const long sv = pos;
 				pos = (pos0 + off) & (ring_len - 1);
-				push(in + (size_t) off * ch_in, in_stride, frames - off, out, out_stride, st);
+				push(reinterpret_cast<const double *>(reinterpret_cast<const char *>(in) + (size_t) off * ch_in * pcm_sample_bytes(wire_in_fmt)), in_stride, frames - off, out, out_stride, st);
 				pos = sv;
 			}
 			cur_slab = nullptr;

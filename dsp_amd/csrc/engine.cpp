@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include "stages.h"
+#include "pcm_params.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -400,10 +401,12 @@ bool CascadeStage::build_chunk_plan(ChunkPlan &chunk, long frames, int K, long l
 	return true;
 }
 
-ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+CascadeParams CascadeStage::params(const double *in, long in_stride, ssize_t frames, double *out, long out_stride) const
 {
 	CascadeParams p;
 	p.in = in; p.out = out;
+	p.in_fmt = wire_in_fmt;
+	p.sink = wire_sink;
 	p.in_stride_frames = in_stride; p.out_stride_frames = out_stride;
 	p.frames = frames;
 	p.C = ch_in; p.cg0 = 0; p.Cg = Cg;
@@ -417,9 +420,41 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
+	return p;
+}
+
+// the wire formats are spoken by cascade_rows (+ the generic kernel on what is left of the block behind its tiles)
+bool CascadeStage::wire_ok(int in_fmt, bool sink_on, int out_fmt, const void *in, long in_stride, const void *out, long out_stride, ssize_t frames) const
+{
+	if (!wire_fusion_on()) return false;
 	int K = 0;
 	long len = 0;
-	if (!ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) {
+	if (!ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) return false;
+	CascadeParams p = params(static_cast<const double *>(in), in_stride, frames, static_cast<double *>(const_cast<void *>(out)), out_stride);
+	p.in_fmt = in_fmt;
+	p.sink.on = sink_on ? 1 : 0;
+	p.sink.fmt = out_fmt;
+	return cascade_rows_takes(p, S);
+}
+
+bool CascadeStage::wire_in_ok(int fmt, const void *in, long in_stride, ssize_t frames, bool also_out, int out_fmt) const
+{
+	// (the destination of a first-but-not-last stage is one of the pipeline's own aligned buffers, or the ring)
+	return wire_ok(fmt, also_out, out_fmt, in, in_stride, nullptr, in_stride, frames);
+}
+
+bool CascadeStage::wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const
+{
+	return wire_ok(also_in ? in_fmt : PCM_DOUBLE, true, fmt, nullptr, out_stride, out, out_stride, frames);
+}
+
+ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	CascadeParams p = params(in, in_stride, frames, out, out_stride);
+	int K = 0;
+	long len = 0;
+	const bool wire = wire_in_fmt != PCM_DOUBLE || wire_sink.on;
+	if (!wire && !ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) {
 		ChunkPlan *cpl = chunk_plan_for(frames, K, len);
 		if (!cpl) return -1;
 		ChunkPlan &chunk = *cpl;
@@ -475,7 +510,7 @@ bool RemixStage::init(const Spec &sp)
 ssize_t RemixStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
 	RemixParams p{ in, out, in_stride, out_stride, frames, ch_in, ch_out, d_idx.as<int>(), max_n,
-	               weighted ? d_w.as<double>() : nullptr, (weighted && d_post.p) ? d_post.as<double>() : nullptr };
+	               weighted ? d_w.as<double>() : nullptr, (weighted && d_post.p) ? d_post.as<double>() : nullptr, wire_in_fmt, wire_sink };
 	{ ProfScope ps("remix_kernel", st); launch_remix(p, S, st); }
 	return frames;
 }
@@ -524,6 +559,8 @@ ssize_t DelayStage::run(const double *in, long in_stride, ssize_t frames, double
 	p.ring = ring.as<double>() + (size_t) (phase ? half : 0);
 	p.ring_per_stream = ring_per_stream;
 	p.pos = pos;
+	p.in_fmt = wire_in_fmt;
+	p.sink = wire_sink;
 	const long skip = std::min<long>(remaining_discard, frames);
 	{ ProfScope ps("delay_kernel", st); launch_delay_ex(p, phase ? -half : half, skip, max_len, S, st); }
 	phase ^= 1;
@@ -830,6 +867,108 @@ ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long ou
 	return F;
 }
 
+ssize_t Pipeline::run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t frames, const WireSink &sink_in, void *d_out, long out_stride, hipStream_t st, int *fused)
+{
+	if (fused) *fused = 0;
+	if (!pcm_sample_bytes(in_fmt) || !pcm_sample_bytes(sink_in.fmt)) { set_error("pipeline: unknown wire format %d / %d", in_fmt, sink_in.fmt); return -1; }
+	const bool drain = (d_in == nullptr);
+	if (frames <= 0) return drain ? -1 : 0;
+	if (frames > max_frames) { if (drain) frames = max_frames; else { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return -1; } }
+	if (in_stride <= 0) in_stride = frames;
+	if (in_stride < frames) { set_error("pipeline: input stride %ld shorter than the call (%zd frames)", in_stride, frames); return -1; }
+	if (out_stride <= 0) out_stride = std::max<long>(1, max_out_frames(frames));
+	WireSink sink = sink_in;
+	sink.on = 1;
+	// the stand-alone sink pass over a plain fp64 slab of this pipeline (what a last stage that cannot fuse leaves behind)
+	auto own_out = [&](long *stride) -> double * {
+		const long need = std::max<long>(1, max_out_frames(max_frames));
+		if (!wire_tmp_out.p && !wire_tmp_out.alloc((size_t) S * need * ch_out * sizeof(double), false)) return nullptr;
+		*stride = need;
+		return wire_tmp_out.as<double>();
+	};
+	auto sink_pass = [&](const double *src, long src_stride, ssize_t F) -> bool {
+		PcmWriteParams w;
+		w.in = src; w.out = d_out;
+		w.in_stride_frames = src_stride; w.out_stride_frames = out_stride; w.frames = F;
+		w.C = ch_out; w.fmt = sink.fmt;
+		w.dither_mult = sink.dither_mult; w.samples_before = sink.samples_before; w.stats = sink.stats;
+		ProfScope ps("pcm_write", st);
+		launch_pcm_write(w, S, st);
+		return hip_ok(hipGetLastError(), "pcm_write");
+	};
+	if (drain) {
+		// the rate changers' flush is a few frames at the end of a stream: plain drain2, then the sink pass
+		long stride = 0;
+		double *buf = own_out(&stride);
+		if (!buf) return -2;
+		const ssize_t F = drain2(frames, buf, stride, st);
+		if (F <= 0) return F;
+		if (F > out_stride) { set_error("pipeline: %zd drained frames exceed the output stride %ld", F, out_stride); return -2; }
+		return sink_pass(buf, stride, F) ? F : -2;
+	}
+	// ---- input side: the first stage's own loads, or read_buf_<fmt> as a pass of its own
+	Stage *first = stages.empty() ? nullptr : stages.front().get();
+	const bool single = stages.size() == 1;
+	const double *cur = static_cast<const double *>(d_in);
+	long cur_stride = in_stride;
+	bool fin = false, fout_single = false;
+	if (in_fmt != PCM_DOUBLE) {
+		if (first && single && first->wire_in_ok(in_fmt, d_in, in_stride, frames, true, sink.fmt) && first->wire_out_ok(sink.fmt, d_out, out_stride, frames, true, in_fmt)) fin = fout_single = true;
+		else if (first && !single && first->wire_in_ok(in_fmt, d_in, in_stride, frames, false, PCM_DOUBLE)) fin = true;
+		else if (first && single && !first->wire_out_ok(sink.fmt, d_out, out_stride, frames, false, PCM_DOUBLE) && first->wire_in_ok(in_fmt, d_in, in_stride, frames, false, PCM_DOUBLE)) fin = true;
+		if (!fin) {
+			if (!wire_tmp_in.p && !wire_tmp_in.alloc((size_t) S * max_frames * ch_in * sizeof(double), false)) return -1;
+			PcmReadParams r{ d_in, wire_tmp_in.as<double>(), in_stride, (long) frames, (long) frames, ch_in, in_fmt };
+			{ ProfScope ps("pcm_read", st); launch_pcm_read(r, S, st); }
+			if (!hip_ok(hipGetLastError(), "pcm_read")) return -1;
+			cur = wire_tmp_in.as<double>();
+			cur_stride = frames;
+		}
+	}
+	if (stages.empty()) return sink_pass(cur, cur_stride, frames) ? frames : -1;
+	ssize_t F = frames;
+	int which = 0;
+	int did = fin ? 1 : 0;
+	for (size_t i = 0; i < stages.size(); ++i) {
+		Stage *s = stages[i].get();
+		const bool last = (i + 1 == stages.size());
+		const bool wired_in = (i == 0 && fin);
+		double *dst;
+		long dst_stride;
+		bool fout = false;
+		if (last) {
+			// decided with the frame count that actually reaches the last stage
+			fout = single ? (fout_single || (!fin && s->wire_out_ok(sink.fmt, d_out, out_stride, F, false, PCM_DOUBLE)))
+			              : s->wire_out_ok(sink.fmt, d_out, out_stride, F, false, PCM_DOUBLE);
+			if (fout) { dst = static_cast<double *>(d_out); dst_stride = out_stride; }
+			else { dst = own_out(&dst_stride); if (!dst) return -1; }
+		}
+		else if (s->in_place_ok() && cur != d_in && !wired_in) { dst = const_cast<double *>(cur); dst_stride = cur_stride; }
+		else {
+			dst = tmp[which].as<double>();
+			dst_stride = (long) (tmp[which].bytes / sizeof(double) / S / s->ch_out);
+			which ^= 1;
+		}
+		if (wired_in) s->wire_in_fmt = in_fmt;
+		if (fout) s->wire_sink = sink;
+		F = s->run(cur, cur_stride, F, dst, dst_stride, st);
+		s->wire_in_fmt = PCM_DOUBLE;
+		s->wire_sink.on = 0;
+		if (F < 0) return F;
+		if (!hip_ok(hipGetLastError(), s->type())) return -1;
+		cur = dst;
+		cur_stride = dst_stride;
+		if (F == 0) return 0;
+		if (last) {
+			if (F > out_stride) { set_error("pipeline: %zd frames exceed the output stride %ld", F, out_stride); return -1; }
+			if (fout) did |= 2;
+			else if (!sink_pass(cur, cur_stride, F)) return -1;
+		}
+	}
+	if (fused) *fused = did;
+	return F;
+}
+
 ssize_t Pipeline::drain2(ssize_t block_frames, double *d_out, long out_stride, hipStream_t st)
 {
 	// mirror of effects_chain.c:1199-1217: give each stage with a drain2 a turn, feed what comes out to the rest
@@ -877,7 +1016,7 @@ std::string Pipeline::plan() const
 
 size_t Pipeline::device_bytes() const
 {
-	size_t b = tmp[0].bytes + tmp[1].bytes;
+	size_t b = tmp[0].bytes + tmp[1].bytes + wire_tmp_in.bytes + wire_tmp_out.bytes;
 	for (auto &s : stages) b += s->device_bytes();
 	return b;
 }

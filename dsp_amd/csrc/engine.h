@@ -78,6 +78,14 @@ public:
 	virtual ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) { (void) max_frames; (void) out; (void) out_stride; (void) st; return -1; }
 	virtual void reset(hipStream_t st) = 0;
 	virtual size_t device_bytes() const { return 0; }
+	// Wire formats at the ends of a pipeline (Pipeline::run_wire): a first stage that answers wire_in_ok() reads samples of
+	// `wire_in_fmt` through its `in` pointer for this one call, a last stage that answers wire_out_ok() applies `wire_sink` (dither,
+	// clip, conversion: kparams.h) in its stores and writes samples of that format through `out`.  Both answers are pure
+	// functions of the call; the strides stay in frames.  The pipeline sets the two members around run() and clears them after.
+	virtual bool wire_in_ok(int fmt, const void *in, long in_stride, ssize_t frames, bool also_out, int out_fmt) const { (void) fmt; (void) in; (void) in_stride; (void) frames; (void) also_out; (void) out_fmt; return false; }
+	virtual bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const { (void) fmt; (void) out; (void) out_stride; (void) frames; (void) also_in; (void) in_fmt; return false; }
+	int wire_in_fmt = PCM_DOUBLE;
+	WireSink wire_sink = { 0, PCM_DOUBLE, 0.0, 0, nullptr };
 };
 
 class ConvStage;
@@ -93,6 +101,13 @@ public:
 	// in_stride: frames between the slabs of two streams in d_in (0 = frames: contiguous)
 	ssize_t run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st, long in_stride = 0);
 	ssize_t drain2(ssize_t block_frames, double *d_out, long out_stride, hipStream_t st);   // rate-changer flush
+	// The same from wire format to wire format (the file -> file path of dsp.c: read_buf_<fmt>, the chain, then dither / clip /
+	// write_buf_<fmt>): d_in holds [S][in_stride][C_in] samples of in_fmt, d_out receives [S][out_stride][C_out] samples of
+	// sink.fmt (sink.samples_before = samples of each stream written by earlier calls).  The first / last stage does the
+	// conversion in its own loads / stores where it can (cascade_rows, K3 of a plain convolution); otherwise the stand-alone
+	// conversion kernels run before / after on buffers of this pipeline.  Same samples either way, bit for bit.
+	// d_in == nullptr: drain2() of the rate changers into the sink.  *fused (optional): bit 0 = input fused, bit 1 = output.
+	ssize_t run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t frames, const WireSink &sink, void *d_out, long out_stride, hipStream_t st, int *fused = nullptr);
 	void reset(hipStream_t st);
 	std::string plan() const;
 	int n_stages() const { return (int) stages.size(); }
@@ -101,6 +116,7 @@ private:
 	Pipeline() {}
 	std::vector<std::unique_ptr<Stage>> stages;
 	DevBuf tmp[2];
+	DevBuf wire_tmp_in, wire_tmp_out;   // fp64 slabs either side when a wire format cannot be fused (allocated on first use)
 	long tmp_stride[2] = { 0, 0 };   // frames
 	int tmp_ch = 0;
 	int drain_stage = 0;
@@ -109,6 +125,7 @@ private:
 // kernel launchers (kernels_*.hip)
 size_t cascade_lds_bytes(int Cg, int n_ops);
 const char *launch_cascade(const CascadeParams &p, int n_streams, hipStream_t stream);   // returns the name of the kernel that took the block
+bool cascade_rows_takes(const CascadeParams &p, int n_streams);   // cascade_rows (the kernel that speaks the wire formats) would take this call
 void launch_chunk_carry(const ChunkParams &p, int n_streams, hipStream_t stream);
 void launch_chunk_fix(const ChunkParams &p, int n_streams, hipStream_t stream);
 void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream);

@@ -1,6 +1,7 @@
 // fft_params.h -- launch parameters of the FFT convolver kernels (kernels_fft.hip) shared with conv.cpp
 #pragma once
 #include <hip/hip_runtime.h>
+#include "kparams.h"
 
 namespace dspamd {
 
@@ -22,6 +23,7 @@ struct ConvParams {
 	const double *slab;
 	long slab_stride_frames, slab_frame0;   // slab frame of window element first_n (negative: the window starts in older calls)
 	int slab_store;                         // 1: K1 files the history itself (plain convolution); 0: the host pushes the tail of the call
+	int slab_fmt;                           // PCM_DOUBLE, or the fusable wire format the slab holds (first kernel of a pipeline run in wire formats)
 	const int *pair_h;                  // [n_pairs] index of the filter spectrum used by the pair
 	int shared_h;                       // every pair uses filter 0 (pair_h is all zeros)
 	long pair0;                         // first pair handled by this launch (W is indexed relative to it)
@@ -50,6 +52,7 @@ struct ConvParams {
 	long stream0, n_streams_launch;
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)
 	int round_f32;
+	WireSink sink;                      // K3 of a plain convolution at the end of a pipeline: `out` holds samples of sink.fmt (kparams.h)
 };
 
 // Small-call regime (calls much shorter than the filter): the head of the filter as a uniformly partitioned convolution with a
@@ -88,6 +91,7 @@ struct DeintParams {
 	double2 *ring;
 	long ring_row_stride, ring_mask, pos;
 	int round_f32;
+	int in_fmt;                         // PCM_DOUBLE, or the wire format `in` holds
 };
 
 struct FirDirectParams {

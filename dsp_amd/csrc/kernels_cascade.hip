@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "kparams.h"
+#include "pcm_device.h"
 
 namespace dspamd {
 
@@ -187,14 +188,19 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 		lops[i] = v;
 	}
 
-	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
-	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	// wire formats (in_fmt / sink): the element-wise paths below convert (pcm_device.h); `in` / `out` are then only bases
+	const bool wire_in = p.in_fmt != PCM_DOUBLE, sink_on = p.sink.on != 0;
+	const long in0 = (long) s * p.in_stride_frames * p.C, out0 = (long) s * p.out_stride_frames * p.C;
+	const double *in = p.in + (wire_in ? 0 : in0);
+	double *out = p.out + (sink_on ? 0 : out0);
+	double peak = 0.0;
+	unsigned long long clipped = 0;
 	const long n_full = p.frames / CASCADE_TILE;
 	const int rem = (int) (p.frames - n_full * CASCADE_TILE);
 	const long n_tiles = n_full + (rem ? 1 : 0);
 	// full tiles of a group that spans whole frames can be fetched 16 B per lane and prefetched into registers
 	const bool vec = (cgn == p.C) && (cgn == cgp) && (cgn >= 2) && ((CASCADE_TILE * cgn) / 2 <= nth * (MAX_PF / 2))
-	                 && ((((size_t) in) & 15) == 0) && ((((size_t) out) & 15) == 0);
+	                 && ((((size_t) in) & 15) == 0) && ((((size_t) out) & 15) == 0) && !wire_in && !sink_on;
 	const int npf = vec ? (CASCADE_TILE * cgn / 2 + nth - 1) / nth : 0;   // double2 loads per thread per tile
 	double2 pf[MAX_PF / 2];
 	if (vec && n_full > 0) {
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 			for (int e = tid; e < (nfr << cgs); e += nth) {
 				const int t = e >> cgs, cc = e & (cgp - 1);
 				if (cc < cgn)
-					tile[cc * CH_STRIDE + lds_index(t)] = in[(t0 + t) * p.C + c0 + cc];
+					tile[cc * CH_STRIDE + lds_index(t)] = wire_in ? pcm_load(p.in, p.in_fmt, in0 + (t0 + t) * p.C + c0 + cc) : in[(t0 + t) * p.C + c0 + cc];
 			}
 		}
 		__syncthreads();
@@ -283,8 +289,18 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 			else {
 				for (int e = tid; e < (nfr << cgs); e += nth) {
 					const int t = e >> cgs, cc = e & (cgp - 1);
-					if (cc < cgn)
-						out[(t0 + t) * p.C + c0 + cc] = tile[cc * CH_STRIDE + lds_index(t)];
+					if (cc >= cgn) continue;
+					const double v = tile[cc * CH_STRIDE + lds_index(t)];
+					if (sink_on) {
+						// the pipeline's last kernel: dither, clip and convert on the way out (dsp.c:685-699); remainders only, so the
+						// generator values are simply computed per sample
+						const long n = (t0 + t) * p.C + c0 + cc;
+						const bool dither = p.sink.dither_mult != 0.0;
+						uint32_t u0 = 0, u1 = 0;
+						if (dither) { u0 = pm_pow(PM_A0, (uint64_t) (p.sink.samples_before + n) + 1); u1 = pm_pow(PM_A1, (uint64_t) (p.sink.samples_before + n) + 1); }
+						pcm_store(p.out, p.sink.fmt, out0 + n, sink_sample(v, dither, u0, u1, p.sink.dither_mult, peak, clipped));
+					}
+					else out[(t0 + t) * p.C + c0 + cc] = v;
 				}
 			}
 		}
@@ -303,6 +319,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 		}
 		__syncthreads();
 	}
+	if (sink_on && p.sink.stats) sink_stats_wave(p.sink.stats, s, peak, clipped);
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
 }
 
@@ -719,10 +736,14 @@ constexpr int RW_TB = 4 * RW_ROW + 16;                          // doubles per w
 // G = 4: rows of 16 x 33 doubles at 0, 528, 1072, 1600;  G = 2: rows of 32 x 33 doubles at 0, 1056
 template <int G> __device__ __forceinline__ int rw_row_base(int r) { return (G == 4) ? r * RW_ROW + ((r >> 1) << 4) : r * 2 * RW_ROW; }
 
-template <int G>
+// WIRE (G = 4, 2): the instance that also speaks the wire formats -- p.in_fmt samples converted in the tile loads (read_buf_<fmt>),
+// and / or the sink of dsp.c:685-699 (dither, clip, write_buf_<fmt>) applied in the tile stores (p.sink).  The plain fp64
+// instance stays as it is.
+template <int G, bool WIRE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P, int p2p)
 {
+	static_assert(!WIRE || G >= 2, "wire formats: channel pairs");
 	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
 	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
 	constexpr int PARTNER = (G == 4) ? RW_ROW : 2 * RW_ROW;            // LDS distance between the two channels of a pair
@@ -754,8 +775,15 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 
 	const long n_full = p.frames / TILE;
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
-	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.in + (size_t) s * p.in_stride_frames * p.C + c0), 0, 0x7fffffff, RSRC_FLAGS);
-	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t) s * p.out_stride_frames * p.C + c0, 0, 0x7fffffff, RSRC_FLAGS);
+	// bytes per sample either side: 8 (fp64), 4 (s24 / s32 / float) or 2 (s16)
+	const int in_fmt = WIRE ? p.in_fmt : PCM_DOUBLE, out_fmt = (WIRE && p.sink.on) ? p.sink.fmt : PCM_DOUBLE;
+	const int in_bs = !WIRE ? 8 : (in_fmt == PCM_DOUBLE) ? 8 : (in_fmt == PCM_S16) ? 2 : 4;
+	const int out_bs = !WIRE ? 8 : (out_fmt == PCM_DOUBLE) ? 8 : (out_fmt == PCM_S16) ? 2 : 4;
+	const bool sink_on = WIRE && p.sink.on;
+	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<char *>(reinterpret_cast<const char *>(p.in) + ((size_t) s * p.in_stride_frames * p.C + c0) * in_bs), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+		reinterpret_cast<char *>(p.out) + ((size_t) s * p.out_stride_frames * p.C + c0) * out_bs, 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(
 		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) + ((G == 1) ? (c0 & 1) : 0) : p.out, 0, 0x7fffffff, RSRC_FLAGS);
 	const bool has_ring = p.ring.base != nullptr;
@@ -764,6 +792,8 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	// bytes per frame); G = 2: 64 frames of the one pair
 	const int pr = (G == 4) ? (lane & 1) : 0, f0 = (G == 4) ? (lane >> 1) : lane;
 	const int vo_slab = (f0 * p.C + 2 * pr) * 8, so_slab = FPS * p.C * 8, tile_bytes = TILE * p.C * 8;
+	const int vo_in = (f0 * p.C + 2 * pr) * in_bs, so_in = FPS * p.C * in_bs, tile_bytes_in = TILE * p.C * in_bs;
+	const int vo_out = (f0 * p.C + 2 * pr) * out_bs, so_out = FPS * p.C * out_bs, tile_bytes_out = TILE * p.C * out_bs;
 	// LDS position of slot k: G = 4: row 2 pr, frame f0 + 32 k at + 33 k;  G = 2: frame lane + 64 k at lane + lane / 32 + 66 k
 	double *tb_slab = tb + ((G == 4) ? rw_row_base<G>(2 * pr) + f0 : lane + (lane >> 5));
 	constexpr int SLAB_K = (G == 4) ? (L + 1) : 2 * (L + 1);
@@ -791,9 +821,47 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 		if (w < n_full) {
 			double2 raw[K];                                         // G = 1: 32 eight-byte elements, element k in raw[k >> 1]
 			double x[L];
+			// the sink's state of this lane: generator values of the next sample it writes, statistics (WIRE only)
+			typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+			const bool dither = sink_on && p.sink.dither_mult != 0.0;
+			uint32_t u0 = 0, u1 = 0, js0 = 1, js1 = 1, jt0 = 1, jt1 = 1;
+			double peak = 0.0;
+			unsigned long long clipped = 0;
+			if constexpr (WIRE) {
+				if (dither) {
+					// sample n of the stream (interleaved order) uses A^(n + 1): this lane starts at slot 0 of tile w, walks the
+					// slots of a tile FPS frames apart and the tiles of its wave P tiles apart
+					const uint64_t n0 = (uint64_t) p.sink.samples_before + (uint64_t) (((long) w * TILE + f0) * p.C + c0 + 2 * pr);
+					u0 = pm_pow(PM_A0, n0 + 1); u1 = pm_pow(PM_A1, n0 + 1);
+					js0 = pm_pow(PM_A0, (uint64_t) FPS * p.C); js1 = pm_pow(PM_A1, (uint64_t) FPS * p.C);
+					jt0 = pm_pow(PM_A0, (uint64_t) (P - 1) * TILE * p.C); jt1 = pm_pow(PM_A1, (uint64_t) (P - 1) * TILE * p.C);
+				}
+			}
 			auto load_raw = [&](long t) {
 				const int tbb = (int) t * tile_bytes;
-				if constexpr (G == 1) {
+				if constexpr (WIRE) {
+					// raw[k] holds the slot as it comes: 16 / 8 / 4 bytes of it
+					const int tbi = (int) t * tile_bytes_in;
+					if (in_bs == 8) {
+#pragma unroll
+						for (int k = 0; k < K; ++k) raw[k] = rw_as_d2(__builtin_amdgcn_raw_buffer_load_b128(r_in, vo_in, tbi + k * so_in, 0));
+					}
+					else if (in_bs == 4) {
+#pragma unroll
+						for (int k = 0; k < K; ++k) {
+							const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r_in, vo_in, tbi + k * so_in, 0);
+							raw[k].x = __builtin_bit_cast(double, v);
+						}
+					}
+					else {
+#pragma unroll
+						for (int k = 0; k < K; ++k) {
+							const u32x2 v = { __builtin_amdgcn_raw_buffer_load_b32(r_in, vo_in, tbi + k * so_in, 0), 0u };
+							raw[k].x = __builtin_bit_cast(double, v);
+						}
+					}
+				}
+				else if constexpr (G == 1) {
 #pragma unroll
 					for (int k = 0; k < 2 * K; ++k) {
 						const double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r_in, vo_slab, tbb + k * so_slab, 0));
@@ -806,7 +874,19 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto raw_to_tb = [&]() {
-				if constexpr (G == 1) {
+				if constexpr (WIRE) {
+#pragma unroll
+					for (int k = 0; k < K; ++k) {
+						double a = raw[k].x, b = raw[k].y;
+						if (in_bs != 8) {
+							const u32x2 v = __builtin_bit_cast(u32x2, raw[k].x);
+							if (in_bs == 4) { a = pcm_from_word(v.x, in_fmt); b = pcm_from_word(v.y, in_fmt); }
+							else { a = pcm_from_s16(v.x & 0xffffu); b = pcm_from_s16(v.x >> 16); }
+						}
+						tb_slab[SLAB_K * k] = a; tb_slab[SLAB_K * k + PARTNER] = b;
+					}
+				}
+				else if constexpr (G == 1) {
 #pragma unroll
 					for (int k = 0; k < 2 * K; ++k) tb_rows[(64 + 64 / L) * k] = (k & 1) ? raw[k >> 1].y : raw[k >> 1].x;
 				}
@@ -836,6 +916,28 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto store_out = [&](const double2 (&y)[K], long t_out) {
+				if constexpr (WIRE) {
+					if (sink_on) {
+						// the last kernel of the pipeline: dither, clip and convert on the way out (slab order; no ring behind a sink)
+						const int tbo = (int) t_out * tile_bytes_out;
+#pragma unroll
+						for (int k = 0; k < K; ++k) {
+							uint32_t b0 = 0, b1 = 0;
+							if (dither) { b0 = pm_mul(u0, PM_A0); b1 = pm_mul(u1, PM_A1); }
+							const double a = sink_sample(y[k].x, dither, u0, u1, p.sink.dither_mult, peak, clipped);
+							const double b = sink_sample(y[k].y, dither, b0, b1, p.sink.dither_mult, peak, clipped);
+							if (dither) { u0 = pm_mul(u0, js0); u1 = pm_mul(u1, js1); }
+							if (out_bs == 8) rw_store_b128(rw_as_u4(make_double2(a, b)), r_out, vo_out, tbo + k * so_out);
+							else if (out_bs == 4) {
+								const u32x2 v = { pcm_to_word(a, out_fmt), pcm_to_word(b, out_fmt) };
+								__builtin_amdgcn_raw_buffer_store_b64(v, r_out, vo_out + tbo + k * so_out, 0, 0);
+							}
+							else __builtin_amdgcn_raw_buffer_store_b32(pcm_to_s16(a) | (pcm_to_s16(b) << 16), r_out, vo_out + tbo + k * so_out, 0, 0);
+						}
+						if (dither) { u0 = pm_mul(u0, jt0); u1 = pm_mul(u1, jt1); }   // 16 slots = one tile on: the wave's next tile is P - 1 further
+						return;
+					}
+				}
 				if constexpr (G == 1) {
 					typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 					const int tbb = (int) t_out * tile_bytes;
@@ -939,6 +1041,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				fetch_out(y);
 				store_out(y, t_last);
 			}
+			if constexpr (WIRE) { if (sink_on && p.sink.stats) sink_stats_wave(p.sink.stats, s, peak, clipped); }
 		}
 		if (!p2p) for (; steps < n_steps; ++steps) lds_barrier();
 	}
@@ -954,31 +1057,40 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	P = (int) std::min<long>(std::min(P, p.n_ops), n_full);
 	const size_t lds = ((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) P * RW_TB + 8) * sizeof(double);
 	if (lds > 160 * 1024) return 0;
-	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G>), lds);
 	// point-to-point ordering for long calls (at least 16 tiles per wave); short ones keep the workgroup barrier per step: the
 	// polling costs more than it saves there (config 2's chunks of 8 tiles: 0.052 against 0.064 ms; 2048-frame calls 0.031 / 0.035)
 	static const int p2p_env = [] { const char *e = getenv("DSP_AMD_CASCADE_P2P"); return e ? atoi(e) : -1; }();
 	const int p2p = (p2p_env >= 0) ? p2p_env : (n_full / P >= 16 ? 1 : 0);
 	dim3 grid(n_streams, p.C / G), block(64 * P);
-	hipLaunchKernelGGL(cascade_rows<G>, grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
+	if (p.in_fmt != PCM_DOUBLE || p.sink.on) {
+		if constexpr (G >= 2) {
+			grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G, true>), lds);
+			hipLaunchKernelGGL((cascade_rows<G, true>), grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
+			return n_full * TILE;
+		}
+		return 0;
+	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G, false>), lds);
+	hipLaunchKernelGGL((cascade_rows<G, false>), grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
 	return n_full * TILE;
 }
 
-// 0 = not eligible; otherwise the number of leading frames taken
-static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream_t stream)
+// whether cascade_rows takes (the leading tiles of) this call, and in which shape: a pure function of the call
+static bool rows_choice(const CascadeParams &p, int n_streams, int *Gout, int *Pout)
 {
 	static const int env = [] { const char *e = getenv("DSP_AMD_CASCADE_ROWS"); return e ? atoi(e) : -1; }();   // 0 = never, G*100 + P = force
-	if (env == 0 || !p.frows || !p.frq || p.cg0 != 0) return 0;
-	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return 0;
-	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
+	if (env == 0 || !p.frows || !p.frq || p.cg0 != 0) return false;
+	if ((((size_t) p.in) | ((size_t) p.out)) & 15) return false;
+	if (p.ring.base && !p.ring.consecutive_pairs) return false;
 	// 32-bit byte offsets inside one stream's slab / ring rows
-	if ((double) std::max(p.in_stride_frames, p.out_stride_frames) * p.C * 8 >= 2.0e9 || (double) p.ring.row_stride * 16 * (p.C / 2) >= 2.0e9) return 0;
+	if ((double) std::max(p.in_stride_frames, p.out_stride_frames) * p.C * 8 >= 2.0e9 || (double) p.ring.row_stride * 16 * (p.C / 2) >= 2.0e9) return false;
 	// Four channels per wave when that still gives 2048 waves of at most 8 per group (what the LDS transposers allow), i.e.
 	// from 1024 channels; two per wave from 512 channels; one per wave (all four DPP rows, three sequential row carries,
 	// 8-byte elements) below that.  Measured, 10 sections, ms per launch at 32 / 64 / 128 / 256 streams x 8 ch: see DESIGN.md.
 	const long channels = (long) n_streams * p.C;
 	int G = (channels >= 1024 && p.rows4_ok) ? 4 : (channels >= 512) ? 2 : 1, P;
-	if (env > 0) { G = env / 100; P = env % 100; if ((G == 4 && !p.rows4_ok) || (G != 4 && G != 2 && G != 1)) return 0; }
+	const bool wire = p.in_fmt != PCM_DOUBLE || p.sink.on;
+	if (env > 0) { G = env / 100; P = env % 100; if ((G == 4 && !p.rows4_ok) || (G != 4 && G != 2 && G != 1)) return false; }
 	else {
 		P = (int) std::min<long>(8, std::max<long>(1, (2048 * G + channels - 1) / channels));
 		// with point-to-point ordering more waves per group pay even when the chip is full anyway: 8 waves in one workgroup per
@@ -987,6 +1099,28 @@ static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream
 	}
 	if (P > 8) P = 8;
 	if (P < 1) P = 1;
+	const int tile = (64 / G) * RW_L;
+	if (p.frames / tile < 1 || (p.C % G)) return false;
+	const int Pe = (int) std::min<long>(std::min(P, p.n_ops), p.frames / tile);
+	if (((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) Pe * RW_TB + 8) * sizeof(double) > 160 * 1024) return false;
+	// the wire formats are spoken by the instances that move channel pairs -- and only where the plain call would run the SAME
+	// instance shape: fused or not, a call gives the same samples bit for bit
+	if (wire && (G < 2 || !pcm_fusable(p.in_fmt) || (p.sink.on && (!pcm_fusable(p.sink.fmt) || p.ring.base || !p.write_interleaved)))) return false;
+	*Gout = G; *Pout = P;
+	return true;
+}
+
+bool cascade_rows_takes(const CascadeParams &p, int n_streams)
+{
+	int G, P;
+	return rows_choice(p, n_streams, &G, &P);
+}
+
+// 0 = not eligible; otherwise the number of leading frames taken
+static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream_t stream)
+{
+	int G, P;
+	if (!rows_choice(p, n_streams, &G, &P)) return 0;
 	return (G == 4) ? try_launch_rows<4>(p, n_streams, P, stream) : (G == 2) ? try_launch_rows<2>(p, n_streams, P, stream) : try_launch_rows<1>(p, n_streams, P, stream);
 }
 
@@ -1158,14 +1292,17 @@ const char *launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t s
 {
 	CascadeParams p = p0;
 	const char *name = "cascade_rows";
+	// a call in wire formats: cascade_rows and the generic kernel speak them (the host asks cascade_rows_takes() first)
+	const bool wire = p0.in_fmt != PCM_DOUBLE || p0.sink.on;
 	long done = launch_cascade_rows(p0, n_streams, stream);
-	if (done == 0) { name = "cascade_wave"; done = launch_cascade_wave(p0, n_streams, stream); }
-	if (done == 0) { name = "cascade_fast"; done = launch_cascade_fast(p0, n_streams, stream); }
+	if (done == 0 && !wire) { name = "cascade_wave"; done = launch_cascade_wave(p0, n_streams, stream); }
+	if (done == 0 && !wire) { name = "cascade_fast"; done = launch_cascade_fast(p0, n_streams, stream); }
 	if (done > 0) {
 		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block
 		if (done == p0.frames) return name;
-		p.in = p0.in + (size_t) done * p0.C;
-		p.out = p0.out + (size_t) done * p0.C;
+		p.in = reinterpret_cast<const double *>(reinterpret_cast<const char *>(p0.in) + (size_t) done * p0.C * pcm_sample_bytes(p0.in_fmt));
+		p.out = reinterpret_cast<double *>(reinterpret_cast<char *>(p0.out) + (size_t) done * p0.C * (p0.sink.on ? pcm_sample_bytes(p0.sink.fmt) : 8));
+		p.sink.samples_before += done * p0.C;
 		p.frames = p0.frames - done;
 		if (p.ring.base) p.ring.pos = (p0.ring.pos + done) & p0.ring.mask;
 	}

@@ -32,6 +32,7 @@
 #include <cstdint>
 #include "kparams.h"
 #include "fft_params.h"
+#include "pcm_device.h"
 
 namespace dspamd {
 
@@ -244,7 +245,9 @@ __device__ __forceinline__ void col_fft(cplx (&v)[16], int q, int t, int j, unsi
 }
 
 // K1: z (the pair's ring row: complex samples) --FFT over n1--> W[pair][k1][n2]
-template <int LOG2N1>
+// WIRE: direct mode at the START of a pipeline -- the slab holds samples of p.slab_fmt (s16 / s24 / s32 / float), converted
+// as they are read (read_buf_<fmt>, pcm_device.h); the ring keeps fp64 samples as always
+template <int LOG2N1, bool WIRE = false>
 __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 {
 	using Cfg = ColCfg<LOG2N1, 1>;
@@ -264,7 +267,9 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 		// on the way
 		cplx *ringw = const_cast<cplx *>(src);
 		const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
-		const cplx *slab = reinterpret_cast<const cplx *>(p.slab + ((size_t) s * p.slab_stride_frames + p.slab_frame0) * p.C) + qs;
+		const int bs = !WIRE ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
+		const char *wslab = reinterpret_cast<const char *>(p.slab) + (((size_t) s * p.slab_stride_frames + p.slab_frame0) * p.C + 2 * qs) * bs;
+		const cplx *slab = reinterpret_cast<const cplx *>(wslab);
 		const long hp = p.C >> 1;
 		const long keep_from = p.slab_store ? ((p.in_count > p.first_n) ? p.in_count : p.first_n) : p.N;
 #pragma unroll
@@ -273,7 +278,12 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 			const long fr = n - p.first_n;                        // slab frame relative to slab_frame0 (folded into `slab`)
 			if (n >= p.valid) v[m] = make_double2(0.0, 0.0);
 			else if (fr + p.slab_frame0 >= 0) {
-				v[m] = slab[fr * hp];             // (never non-temporal: the frames of a slab are read by the workgroups of all its pairs)
+				if constexpr (WIRE) {
+					const char *e = wslab + fr * p.C * bs;
+					if (bs == 4) { const uint2 w = *reinterpret_cast<const uint2 *>(e); v[m] = make_double2(pcm_from_word(w.x, p.slab_fmt), pcm_from_word(w.y, p.slab_fmt)); }
+					else { const uint32_t w = *reinterpret_cast<const uint32_t *>(e); v[m] = make_double2(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16)); }
+				}
+				else v[m] = slab[fr * hp];        // (never non-temporal: the frames of a slab are read by the workgroups of all its pairs)
 				if (n >= keep_from) ringw[(p.win_base + n) & p.ring_mask] = v[m];
 			}
 			else v[m] = ld16(src + ((p.win_base + n) & p.ring_mask), p.nt & 1);
@@ -299,7 +309,10 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 // that the 16-byte (re, im) = (channel 2q, 2q+1) pieces of one frame leave from adjacent lanes.
 // MODE 0: plain convolution (one phase, output index = input index: the headline path, no index arithmetic beyond an add);
 // MODE 1: any number of phases / up / down; MODE 2: the two interleaved phases of a 2x upsampler -- phase 0 is held in
-// registers and frames 2q, 2q+1 leave together
+// registers and frames 2q, 2q+1 leave together; MODE 3: MODE 0 at the END of a pipeline -- the sink of dsp.c:685-699 (TPDF
+// dither, clip() with its statistics, write_buf_<fmt>) applied in the stores (p.sink, pcm_device.h): a thread's 16 outputs
+// are P N2 frames apart, so it reaches its first sample's place in the two dither sequences by modular exponentiation and
+// the others by multiplying with A^(P N2 C)
 template <int LOG2N1, int PPS, int MODE>
 __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(ConvParams p)
 {
@@ -320,7 +333,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	const int cha = active ? p.pair_out_ch[2 * qs] : -1, chb = active ? p.pair_out_ch[2 * qs + 1] : -1;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
 	cplx *rout = p.ring_out ? p.ring_out + (s * p.pairs_per_stream + qs) * p.ring_out_stride : nullptr;
-	constexpr bool HOLD2 = (MODE == 2), PLAIN = (MODE == 0);
+	constexpr bool HOLD2 = (MODE == 2), PLAIN = (MODE == 0 || MODE == 3), SINK = (MODE == 3);
 	if constexpr (HOLD2) {
 		cplx v0[16], v[16];
 		if (active) {
@@ -373,6 +386,56 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 		}
 		if (ph > 0) lds_barrier();   // the previous phase's exchange has been read by everyone
 		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
+		if constexpr (SINK) {
+			// window sample of v[m]: f(m) = f0 + m P N2 -> output frame q_blk + f - k_origin; the valid m are a contiguous range
+			const long f0 = (long) j * p.N2 + n2 - p.first_n, dmo = (long) P * p.N2;
+			const long lo = (p.k_origin - p.q_blk > 0) ? p.k_origin - p.q_blk : 0;             // f >= lo  <=>  mo >= 0
+			const long hi = (p.in_count < p.out_count + p.k_origin - p.q_blk) ? p.in_count : p.out_count + p.k_origin - p.q_blk;   // f < hi
+			const bool dither = p.sink.dither_mult != 0.0;
+			const int bs = (p.sink.fmt == PCM_DOUBLE) ? 8 : (p.sink.fmt == PCM_S16) ? 2 : 4;
+			char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * bs;
+			const bool wpair = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) wout) & 15) == 0);
+			int m_first = 16;
+#pragma unroll
+			for (int m = 15; m >= 0; --m) { const long f = f0 + m * dmo; if (f >= lo && f < hi) m_first = m; }
+			uint32_t ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0, j0 = 1, j1 = 1;
+			if (active && dither && m_first < 16) {
+				const long mo = p.q_blk + f0 + m_first * dmo - p.k_origin;
+				const uint64_t na = (uint64_t) (p.sink.samples_before + mo * p.C + (cha >= 0 ? cha : 0)) + 1;
+				const uint64_t nb = (uint64_t) (p.sink.samples_before + mo * p.C + (chb >= 0 ? chb : 0)) + 1;
+				ua0 = pm_pow(PM_A0, na); ua1 = pm_pow(PM_A1, na);
+				if (chb == cha + 1) { ub0 = pm_mul(ua0, PM_A0); ub1 = pm_mul(ua1, PM_A1); }
+				else { ub0 = pm_pow(PM_A0, nb); ub1 = pm_pow(PM_A1, nb); }
+				j0 = pm_pow(PM_A0, (uint64_t) dmo * p.C); j1 = pm_pow(PM_A1, (uint64_t) dmo * p.C);
+			}
+			double peak = 0.0;
+			unsigned long long clipped = 0;
+			if (active) {
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					const long f = f0 + m * dmo;
+					if (f < lo || f >= hi) continue;
+					const long mo = p.q_blk + f - p.k_origin;
+					double ya = v[m].x, yb = v[m].y;
+					if (p.round_f32) { ya = (double) (float) ya; yb = (double) (float) yb; }
+					if (cha >= 0) ya = sink_sample(ya, dither, ua0, ua1, p.sink.dither_mult, peak, clipped);
+					if (chb >= 0) yb = sink_sample(yb, dither, ub0, ub1, p.sink.dither_mult, peak, clipped);
+					if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
+					if (wpair) {
+						char *dst = wout + (mo * p.C + cha) * bs;
+						if (bs == 8) st16(reinterpret_cast<cplx *>(dst), make_double2(ya, yb), p.nt & 32);
+						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, p.sink.fmt), pcm_to_word(yb, p.sink.fmt));
+						else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+					}
+					else {
+						if (cha >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + cha, ya);
+						if (chb >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + chb, yb);
+					}
+				}
+			}
+			if (p.sink.stats) sink_stats_wave(p.sink.stats, s, peak, clipped);
+			continue;
+		}
 		if (!active) continue;
 #pragma unroll
 		for (int m = 0; m < 16; ++m) {
@@ -852,15 +915,17 @@ void launch_conv_fdl(const FdlParams &p, hipStream_t st)
 __global__ __launch_bounds__(NT) void conv_deinterleave(DeintParams p)
 {
 	const int s = blockIdx.y;
-	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
+	const long in0 = (long) s * p.in_stride_frames * p.C;
+	const double *in = p.in + in0;
 	double *out = p.out ? p.out + (size_t) s * p.out_stride_frames * p.C : nullptr;
 	double *ring = reinterpret_cast<double *>(p.ring);
 	const long n = p.frames * p.C;
+	const bool wire_in = p.in_fmt != PCM_DOUBLE;     // the first kernel of a pipeline fed in a wire format (any of them)
 	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
 		const long t = e / p.C;
 		const int c = (int) (e - t * p.C);
 		const int slot = p.slot_of_channel[c];
-		double v = in[e];
+		double v = wire_in ? pcm_load(p.in, p.in_fmt, in0 + e) : in[e];
 		if (slot >= 0) {
 			if (p.round_f32) v = (double) (float) v;
 			ring[2 * (((size_t) s * p.rows_per_stream + (slot >> 1)) * p.ring_row_stride + ((p.pos + t) & p.ring_mask)) + (slot & 1)] = v;
@@ -922,8 +987,13 @@ template <class K> static void grant_lds(K kernel, size_t bytes) { grant_dynamic
 template <int L> static void launch_col_fwd(const ConvParams &p, int n_pairs, hipStream_t st)
 {
 	using Cfg = ColCfg<L, 1>;
-	grant_lds(conv_col_fwd<L>, Cfg::LDS);
-	hipLaunchKernelGGL(conv_col_fwd<L>, dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
+	if (p.slab && p.slab_fmt != PCM_DOUBLE) {
+		grant_lds(conv_col_fwd<L, true>, Cfg::LDS);
+		hipLaunchKernelGGL((conv_col_fwd<L, true>), dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
+		return;
+	}
+	grant_lds(conv_col_fwd<L, false>, Cfg::LDS);
+	hipLaunchKernelGGL((conv_col_fwd<L, false>), dim3((unsigned) (p.N2 / Cfg::TW), n_pairs), dim3(NT), Cfg::LDS, st, p);
 }
 
 template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hipStream_t st)
@@ -937,6 +1007,11 @@ template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hi
 			hipLaunchKernelGGL((conv_col_inv<L, PPS, 2>), grid, block, Cfg::LDS, st, p);
 			return;
 		}
+	}
+	if (p.nph == 1 && p.up == 1 && p.down == 1 && p.sink.on) {
+		grant_lds(conv_col_inv<L, PPS, 3>, Cfg::LDS);
+		hipLaunchKernelGGL((conv_col_inv<L, PPS, 3>), grid, block, Cfg::LDS, st, p);
+		return;
 	}
 	if (p.nph == 1 && p.up == 1 && p.down == 1) {
 		grant_lds(conv_col_inv<L, PPS, 0>, Cfg::LDS);

@@ -9,8 +9,11 @@
 // All arithmetic that must match the CPU bit for bit is written with plain operators under `#pragma clang fp contract(off)`:
 // hipcc fuses a * b + c by default, and it does so THROUGH __dmul_rn / __dadd_rn (inlined helpers keep the translation
 // unit's contraction flag) -- only the pragma, applied to operators in its own scope, guarantees one rounding per operation.
+// remix_kernel and delay_kernel also speak the wire formats (pcm_device.h) when they are the first / last kernel of a pipeline
+// run from wire format to wire format (engine.cpp Pipeline::run_wire): every format, element by element.
 #include <hip/hip_runtime.h>
 #include "kparams.h"
+#include "pcm_device.h"
 
 namespace dspamd {
 
@@ -19,22 +22,26 @@ __global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
 #pragma clang fp contract(off)
 	const int s = blockIdx.y;
 	const long n = p.frames * p.Cout;
-	const double *in = p.in + (size_t) s * p.in_stride_frames * p.Cin;
-	double *out = p.out + (size_t) s * p.out_stride_frames * p.Cout;
-	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
+	const long in0 = (long) s * p.in_stride_frames * p.Cin, out0 = (long) s * p.out_stride_frames * p.Cout;
+	const double *in = p.in + in0;
+	double *out = p.out + out0;
+	const bool wire_in = p.in_fmt != PCM_DOUBLE;
+	const long stride = (long) gridDim.x * blockDim.x;
+	SinkWalk walk;
+	auto x = [&](long t, int c) { return wire_in ? pcm_load(p.in, p.in_fmt, in0 + t * p.Cin + c) : in[t * p.Cin + c]; };
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
 		const long t = e / p.Cout;
 		const int k = (int) (e - t * p.Cout);
 		const int *idx = p.idx + (size_t) k * p.max_n;
-		const double *fr = in + t * p.Cin;
 		double acc = 0.0;
 		if (p.w) {
 			// weighted form (st2ms.c:34-38, crossfeed.c:41-46): the first product starts the sum, every operation rounds once
 			const double *w = p.w + (size_t) k * p.max_n;
-			if (idx[0] >= 0) acc = fr[idx[0]] * w[0];
+			if (idx[0] >= 0) acc = x(t, idx[0]) * w[0];
 			for (int j = 1; j < p.max_n; ++j) {
 				const int c = idx[j];
 				if (c < 0) break;
-				const double prod = fr[c] * w[j];
+				const double prod = x(t, c) * w[j];
 				acc = acc + prod;
 			}
 			if (p.post) acc = acc * p.post[k];
@@ -43,11 +50,13 @@ __global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
 			for (int j = 0; j < p.max_n; ++j) {
 				const int c = idx[j];
 				if (c < 0) break;
-				acc = acc + fr[c];
+				acc = acc + x(t, c);
 			}
 		}
-		out[e] = acc;
+		if (p.sink.on) pcm_store(p.out, p.sink.fmt, out0 + e, walk.next(p.sink, e, stride, acc));
+		else out[e] = acc;
 	}
+	if (p.sink.on && p.sink.stats) sink_stats_wave(p.sink.stats, s, walk.peak, walk.clipped);
 }
 
 void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream)
@@ -74,24 +83,34 @@ __global__ __launch_bounds__(256) void delay_kernel(DelayKArgs a)
 	const int s = blockIdx.y;
 	const long span = (p.frames > a.max_len) ? p.frames : a.max_len;
 	const long n = span * p.C;
-	const double *in = p.in + (size_t) s * p.in_stride_frames * p.C;
-	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	const long in0 = (long) s * p.in_stride_frames * p.C, out0 = (long) s * p.out_stride_frames * p.C;
+	const double *in = p.in + in0;
+	double *out = p.out + out0;
 	const double *rd = p.ring + (size_t) s * p.ring_per_stream;
 	double *wr = p.ring + (size_t) s * p.ring_per_stream + a.ring_alt_off;
-	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
+	const bool wire_in = p.in_fmt != PCM_DOUBLE;
+	const long stride = (long) gridDim.x * blockDim.x;
+	SinkWalk walk;
+	auto x = [&](long i) { return wire_in ? pcm_load(p.in, p.in_fmt, in0 + i) : in[i]; };
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
 		const long t = e / p.C;
 		const int c = (int) (e - t * p.C);
 		const long len = p.len[c];
 		if (t < p.frames) {
 			double v;
-			if (len == 0) v = in[t * p.C + c];
-			else if (t >= len) v = in[(t - len) * p.C + c];
+			if (len == 0) v = x(t * p.C + c);
+			else if (t >= len) v = x((t - len) * p.C + c);
 			else v = rd[p.ring_off[c] + (p.pos + t) % len];
-			if (t >= a.skip) out[(t - a.skip) * p.C + c] = v;
+			if (t >= a.skip) {
+				// (the outputs of a thread are its iterations from the first with t >= skip on: `stride` samples apart)
+				const long o = (t - a.skip) * p.C + c;
+				if (p.sink.on) pcm_store(p.out, p.sink.fmt, out0 + o, walk.next(p.sink, o, stride, v));
+				else out[o] = v;
+			}
 		}
 		if (len > 0 && t < span) {
 			if (t < p.frames) {
-				if (t >= p.frames - len) wr[p.ring_off[c] + (p.pos + t) % len] = in[t * p.C + c];
+				if (t >= p.frames - len) wr[p.ring_off[c] + (p.pos + t) % len] = x(t * p.C + c);
 			}
 			else if (t < len) {   // slot not overwritten this block: carry it over
 				const long slot = (p.pos + t) % len;
@@ -99,6 +118,7 @@ __global__ __launch_bounds__(256) void delay_kernel(DelayKArgs a)
 			}
 		}
 	}
+	if (p.sink.on && p.sink.stats) sink_stats_wave(p.sink.stats, s, walk.peak, walk.clipped);
 }
 
 void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream)

@@ -6,6 +6,27 @@
 
 namespace dspamd {
 
+// ---- wire formats at either end of a pipeline ----
+// same numbering as DSPAMD_PCM_* in include/dsp_amd.h
+enum { PCM_U8 = 0, PCM_S8, PCM_S16, PCM_S24, PCM_S32, PCM_S24_3, PCM_FLOAT, PCM_DOUBLE, PCM_N_FORMATS };
+inline size_t pcm_sample_bytes(int fmt)
+{
+	constexpr size_t b[PCM_N_FORMATS] = { 1, 1, 2, 4, 4, 3, 4, 8 };
+	return (fmt >= 0 && fmt < PCM_N_FORMATS) ? b[fmt] : 0;
+}
+// formats a kernel can take / leave in its own loads and stores: naturally aligned channel pairs (the others go through
+// the stand-alone conversion kernels)
+inline bool pcm_fusable(int fmt) { return fmt == PCM_S16 || fmt == PCM_S24 || fmt == PCM_S32 || fmt == PCM_FLOAT || fmt == PCM_DOUBLE; }
+
+// The output stage of dsp.c:685-699 done by the LAST kernel of a pipeline in its stores: [TPDF dither], clip() with its
+// statistics, write_buf_<fmt>.  `on` = 0: the kernel writes plain fp64 samples as usual.
+struct WireSink {
+	int on, fmt;
+	double dither_mult;        // 0 = no dither, else 1 / (PM_RAND_MAX 2^(prec-1))  (util.h:157-163)
+	long samples_before;       // samples of each stream written before frame 0 of the destination (position in the dither sequence)
+	double *stats;             // optional [S][2]: clipped samples (as a 64-bit count), peak |sample|
+};
+
 // ---- cascade (gain / add / biquad sections fused into one pass) ----
 
 enum : int { OP_MUL = 0, OP_ADD = 1, OP_BIQUAD = 2, OP_SKIP = 3 };
@@ -47,8 +68,10 @@ struct PlanarRing {
 };
 
 struct CascadeParams {
-	const double *in;                    // [S][frames][C]
-	double *out;                         // [S][out_stride][C] (may alias in)
+	const double *in;                    // [S][frames][C]  (samples of in_fmt when that is not PCM_DOUBLE)
+	double *out;                         // [S][out_stride][C] (may alias in)  (samples of sink.fmt when sink.on)
+	int in_fmt;                          // PCM_DOUBLE, or a fusable wire format read by the kernel's own loads
+	WireSink sink;
 	long in_stride_frames, out_stride_frames;
 	long frames;
 	int C;                               // channels per stream
@@ -88,6 +111,8 @@ struct RemixParams {
 	int max_n;
 	const double *w;                     // Mix: [Cout][max_n] weights (nullptr: plain remix sums from 0.0)
 	const double *post;                  // Mix: [Cout] post-scale or nullptr
+	int in_fmt;                          // `in` holds samples of this wire format (any of them; PCM_DOUBLE = plain)
+	WireSink sink;                       // `out` receives the sink's output (any format)
 };
 
 struct DelayParams {                     // integer per-channel delay with carried ring (align.c:35-44)
@@ -99,6 +124,8 @@ struct DelayParams {                     // integer per-channel delay with carri
 	double *ring;                        // [S][ring_per_stream]
 	long ring_per_stream;
 	long pos;                            // frames already pushed through (same for all channels)
+	int in_fmt;                          // as in RemixParams
+	WireSink sink;
 };
 
 // ---- FFT convolution (overlap-save on channel pairs) ----

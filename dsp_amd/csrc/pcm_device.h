@@ -1,0 +1,175 @@
+// pcm_device.h -- the wire formats either side of the chain as device functions, shared by the stand-alone conversion
+// kernels (kernels_pcm.hip) and by the kernels that do the conversion in their own loads / stores (cascade_rows,
+// cascade_kernel, conv_col_inv).
+//
+// Restates, per sample,
+//   read_buf_<fmt> / write_buf_<fmt>          sampleconv.c:25-149 with the BIT_PERFECT macros of sampleconv.h:35-56
+//   clip() + TPDF dither at the sink          dsp.c:673-694, util.h:127-178
+// All of it is bit-exact: the conversions are single IEEE operations (scaling by a power of two, nearbyint, a
+// saturating compare), and the dither noise is the difference of two Lehmer generators (multipliers 48271 and 16807
+// modulo 2^31 - 1, both seeded with 1) advanced once per sample in interleaved order -- sample n of a stream uses
+// A^(n+1) mod (2^31 - 1), which a thread reaches by modular exponentiation (pm_pow) and leaves by multiplying with a
+// precomputed power of A (its stride through the stream), never by walking the sequence.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "pcm_params.h"
+
+namespace dspamd {
+
+constexpr uint32_t PM = 0x7fffffffu;      // 2^31 - 1 (util.h:57)
+constexpr uint32_t PM_A0 = 48271u, PM_A1 = 16807u;    // util.h:151-152
+
+// (a * b) mod (2^31 - 1) the way PM_RAND_R_DEFINE_FUNC folds it (util.h:127-136); values stay in [1, 2^31 - 1]
+__device__ __forceinline__ uint32_t pm_mul(uint32_t a, uint32_t b)
+{
+	const uint64_t p = (uint64_t) a * b;
+	uint32_t r = (uint32_t) (p & PM) + (uint32_t) (p >> 31);
+	r = (r & PM) + (r >> 31);
+	return r;
+}
+
+__device__ __forceinline__ uint32_t pm_pow(uint32_t a, uint64_t e)
+{
+	uint32_t r = 1;
+	while (e) {
+		if (e & 1) r = pm_mul(r, a);
+		a = pm_mul(a, a);
+		e >>= 1;
+	}
+	return r;
+}
+
+__device__ __forceinline__ double pcm_load(const void *in, int fmt, long i)
+{
+	switch (fmt) {
+	case PCM_U8: return ((double) static_cast<const uint8_t *>(in)[i] - 128.0) / 128.0;          // U8_TO_SAMPLE
+	case PCM_S8: return (double) static_cast<const int8_t *>(in)[i] / 128.0;
+	case PCM_S16: return (double) static_cast<const int16_t *>(in)[i] / 32768.0;
+	case PCM_S24: {                                                                              // S24_SIGN_EXTEND
+		int32_t x = static_cast<const int32_t *>(in)[i];
+		x = (x & 0x800000) ? (x | ~0x7fffff) : x;
+		return (double) x / 8388608.0;
+	}
+	case PCM_S32: return (double) static_cast<const int32_t *>(in)[i] / 2147483648.0;
+	case PCM_S24_3: {                                                                            // sampleconv.c:108-118
+		const uint8_t *b = static_cast<const uint8_t *>(in) + 3 * i;
+		int32_t x = (int32_t) b[0] | ((int32_t) b[1] << 8) | ((int32_t) b[2] << 16);
+		x = (x & 0x800000) ? (x | ~0x7fffff) : x;
+		return (double) x / 8388608.0;
+	}
+	case PCM_FLOAT: return (double) static_cast<const float *>(in)[i];
+	default: return static_cast<const double *>(in)[i];
+	}
+}
+
+// one 32-bit word of a 4-byte format -> sample (the same operations as pcm_load)
+__device__ __forceinline__ double pcm_from_word(uint32_t w, int fmt)
+{
+	switch (fmt) {
+	case PCM_S24: {
+		int32_t x = (int32_t) w;
+		x = (x & 0x800000) ? (x | ~0x7fffff) : x;
+		return (double) x / 8388608.0;
+	}
+	case PCM_S32: return (double) (int32_t) w / 2147483648.0;
+	default: return (double) __uint_as_float(w);             // PCM_FLOAT
+	}
+}
+__device__ __forceinline__ double pcm_from_s16(uint32_t h) { return (double) (int16_t) (uint16_t) h / 32768.0; }
+
+// SAMPLE_TO_<fmt> with BIT_PERFECT = 1 (sampleconv.h:35-41): saturate at the positive end, nearbyint elsewhere
+// (round-half-even: the default rounding mode; negative overflow cannot occur after clip())
+__device__ __forceinline__ double quant(double x, double scale, double maxv)
+{
+	const double v = x * scale;
+	return (v > maxv) ? maxv : rint(v);
+}
+
+__device__ __forceinline__ void pcm_store(void *out, int fmt, long i, double x)
+{
+	switch (fmt) {
+	case PCM_U8: {
+		const double v = x * 128.0 + 128.0;
+		static_cast<uint8_t *>(out)[i] = (uint8_t) ((v > 255.0) ? 255.0 : rint(v));
+		break;
+	}
+	case PCM_S8: static_cast<int8_t *>(out)[i] = (int8_t) quant(x, 128.0, 127.0); break;
+	case PCM_S16: static_cast<int16_t *>(out)[i] = (int16_t) quant(x, 32768.0, 32767.0); break;
+	case PCM_S24: static_cast<int32_t *>(out)[i] = (int32_t) quant(x, 8388608.0, 8388607.0); break;
+	case PCM_S32: static_cast<int32_t *>(out)[i] = (int32_t) quant(x, 2147483648.0, 2147483647.0); break;
+	case PCM_S24_3: {
+		const int32_t v = (int32_t) quant(x, 8388608.0, 8388607.0);
+		uint8_t *b = static_cast<uint8_t *>(out) + 3 * i;
+		b[0] = (uint8_t) (v & 0xff); b[1] = (uint8_t) ((v >> 8) & 0xff); b[2] = (uint8_t) ((v >> 16) & 0xff);
+		break;
+	}
+	case PCM_FLOAT: static_cast<float *>(out)[i] = (float) x; break;
+	default: static_cast<double *>(out)[i] = x; break;
+	}
+}
+
+// sample -> the 32-bit word of a 4-byte format / the 16 bits of S16 (the same operations as pcm_store)
+__device__ __forceinline__ uint32_t pcm_to_word(double x, int fmt)
+{
+	switch (fmt) {
+	case PCM_S24: return (uint32_t) (int32_t) quant(x, 8388608.0, 8388607.0);
+	case PCM_S32: return (uint32_t) (int32_t) quant(x, 2147483648.0, 2147483647.0);
+	default: return __float_as_uint((float) x);              // PCM_FLOAT
+	}
+}
+__device__ __forceinline__ uint32_t pcm_to_s16(double x) { return (uint32_t) (uint16_t) (int16_t) quant(x, 32768.0, 32767.0); }
+
+// the sink of dsp.c:685-699 for one sample: [+ tpdf_noise (util.h:165-172) from the generator values u0, u1 of this sample],
+// clip() (dsp.c:673-682) with its peak / clip_count bookkeeping
+__device__ __forceinline__ double sink_sample(double x, bool dither, uint32_t u0, uint32_t u1, double dither_mult, double &peak, unsigned long long &clipped)
+{
+	if (dither) x = x + (double) ((int32_t) u0 - (int32_t) u1) * dither_mult;
+	const double a = fabs(x);
+	peak = fmax(peak, a);
+	if (a > 1.0) { ++clipped; x = signbit(x) ? -1.0 : 1.0; }
+	return x;
+}
+
+// A thread that walks a stream's samples at a constant stride (grid-stride loops): the generator values of its first sample by
+// modular exponentiation, every further one by one multiplication with A^stride
+struct SinkWalk {
+	uint32_t u0 = 0, u1 = 0, j0 = 1, j1 = 1;
+	double peak = 0.0;
+	unsigned long long clipped = 0;
+	bool started = false;
+	// sample n (0-based in this call's destination, interleaved order) -> what goes on the wire; consecutive calls of one thread
+	// must be `stride` samples apart
+	__device__ __forceinline__ double next(const WireSink &k, long n, long stride, double x)
+	{
+		const bool dither = k.dither_mult != 0.0;
+		if (dither) {
+			if (!started) {
+				const uint64_t e = (uint64_t) (k.samples_before + n) + 1;
+				u0 = pm_pow(PM_A0, e); u1 = pm_pow(PM_A1, e);
+				j0 = pm_pow(PM_A0, (uint64_t) stride); j1 = pm_pow(PM_A1, (uint64_t) stride);
+				started = true;
+			}
+			else { u0 = pm_mul(u0, j0); u1 = pm_mul(u1, j1); }
+		}
+		return sink_sample(x, dither, u0, u1, k.dither_mult, peak, clipped);
+	}
+};
+
+// per-stream statistics of the sink: stats[2 s] += clipped samples (64-bit count), stats[2 s + 1] = max(|sample|).
+// Every lane of the wave works on the SAME stream: one pair of atomics per wave.
+__device__ __forceinline__ void sink_stats_wave(double *stats, long s, double peak, unsigned long long clipped)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		peak = fmax(peak, __shfl_xor(peak, d, 64));
+		clipped += (unsigned long long) __shfl_xor((long long) clipped, d, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (clipped) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 2 * s, clipped);
+		// peak >= 0: its IEEE bit pattern orders like an unsigned integer
+		atomicMax(reinterpret_cast<unsigned long long *>(stats) + 2 * s + 1, (unsigned long long) __double_as_longlong(peak));
+	}
+}
+
+}  // namespace dspamd

@@ -1,8 +1,12 @@
 // stages.h -- concrete Stage classes
 #pragma once
 #include "engine.h"
+#include <cstdlib>
 
 namespace dspamd {
+
+// DSP_AMD_NO_WIRE_FUSION: the wire formats always as passes of their own (the fallback suite's switch)
+inline bool wire_fusion_on() { static const bool off = getenv("DSP_AMD_NO_WIRE_FUSION") != nullptr; return !off; }
 
 // gain / add / biquad sections on the same stream format, fused into one launch
 class CascadeStage : public Stage {
@@ -14,6 +18,8 @@ public:
 	bool in_place_ok() const override { return true; }
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
+	bool wire_in_ok(int fmt, const void *in, long in_stride, ssize_t frames, bool also_out, int out_fmt) const override;
+	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override;
 	size_t device_bytes() const override { return ops.bytes + state.bytes + fops.bytes + fq.bytes; }
 	// optional planar destination owned by the following FFT convolver
 	PlanarRing ring = { nullptr, 0, 0, 0, nullptr, 0, 0 };
@@ -33,6 +39,8 @@ private:
 	struct ChunkPlan { long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X; };
 	std::vector<std::unique_ptr<ChunkPlan>> chunk_plans;   // most recently used first, at most 4
 	bool choose_chunks(long frames, int *K, long *len) const;
+	CascadeParams params(const double *in, long in_stride, ssize_t frames, double *out, long out_stride) const;
+	bool wire_ok(int in_fmt, bool sink_on, int out_fmt, const void *in, long in_stride, const void *out, long out_stride, ssize_t frames) const;
 	ChunkPlan *chunk_plan_for(long frames, int K, long len);
 	bool build_chunk_plan(ChunkPlan &chunk, long frames, int K, long len);
 };
@@ -44,6 +52,9 @@ public:
 	std::string describe() const override { return std::string(type()) + "[" + std::to_string(ch_in) + "->" + std::to_string(ch_out) + "]"; }
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t) override {}
+	// element-wise kernels speak every wire format at either end
+	bool wire_in_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
+	bool wire_out_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
 	size_t device_bytes() const override { return d_idx.bytes + d_w.bytes + d_post.bytes; }
 private:
 	DevBuf d_idx, d_w, d_post;           // d_w / d_post: weighted rows (Kind::Mix)
@@ -59,6 +70,8 @@ public:
 	std::string describe() const override;
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
+	bool wire_in_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
+	bool wire_out_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
 	size_t device_bytes() const override { return ring.bytes; }
 private:
 	std::vector<ssize_t> len;

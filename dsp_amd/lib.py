@@ -56,6 +56,7 @@ API_SYMBOLS = [
     "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run", "dspamd_batch_run_strided",
     "dspamd_batch_drain", "dspamd_batch_reset", "dspamd_batch_destroy", "dspamd_batch_plan", "dspamd_batch_n_stages",
     "dspamd_sgen_sine", "dspamd_digest", "dspamd_copy_probe", "dspamd_pcm_sample_bytes", "dspamd_pcm_read", "dspamd_pcm_write", "dspamd_profile_enable", "dspamd_profile_collect",
+    "dspamd_batch_run_wire", "dspamd_batch_drain_wire", "dspamd_batch_wire_fused",
 ]
 
 
@@ -114,6 +115,9 @@ def load_library():
         "dspamd_pcm_read": (i, [i, vp, vp, ssize_t, vp]),
         "dspamd_pcm_write": (i, [i, vp, ssize_t, vp, i, ssize_t, i, i, ssize_t, vp, vp]),
         "dspamd_profile_enable": (None, [i]), "dspamd_profile_collect": (cp, []),
+        "dspamd_batch_run_wire": (ssize_t, [vp, i, vp, ssize_t, ssize_t, i, vp, ssize_t, i, vp, vp]),
+        "dspamd_batch_drain_wire": (ssize_t, [vp, ssize_t, i, vp, ssize_t, i, vp, vp]),
+        "dspamd_batch_wire_fused": (i, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -125,6 +125,21 @@ int dspamd_pcm_read(int fmt, const void *d_in, void *d_out, ssize_t n_samples, v
 int dspamd_pcm_write(int fmt, const void *d_in, ssize_t in_stride_frames, void *d_out, int n_streams, ssize_t frames, int channels,
                      int dither_prec, ssize_t frames_before, void *d_stats, void *stream);
 
+/*
+ * One block from wire format to wire format -- the file -> file path of dsp.c: read_buf_<in_fmt>, the chain, then the sink
+ * above at the position the batch has reached (frames written through run_wire / drain_wire since create / reset).
+ * d_in: [S][in_stride_frames][C_in] samples of in_fmt (0 = frames); d_out: [S][out_stride_frames][C_out] samples of out_fmt
+ * (0 = max_out_frames(frames)); d_stats as for dspamd_pcm_write.  Where the first / last kernel of the plan can, it converts in
+ * its own loads / stores -- no separate passes over the block: the biquad cascade kernel on either side, the inverse column
+ * transform of a plain convolution on the output side, for s16 / s24 / s32 / float / double -- otherwise the conversion
+ * kernels run before / after it on buffers of the batch.  The samples are the same either way, bit for bit.
+ */
+ssize_t dspamd_batch_run_wire(dspamd_batch *, int in_fmt, const void *d_in, ssize_t in_stride_frames, ssize_t frames,
+                              int out_fmt, void *d_out, ssize_t out_stride_frames, int dither_prec, void *d_stats, void *stream);
+ssize_t dspamd_batch_drain_wire(dspamd_batch *, ssize_t block_frames, int out_fmt, void *d_out, ssize_t out_stride_frames, int dither_prec, void *d_stats, void *stream);
+/* what the last run_wire / drain_wire did: bit 0 = input format read by the first kernel, bit 1 = sink applied by the last kernel */
+int dspamd_batch_wire_fused(dspamd_batch *);
+
 /* plain device copy kernel: measured HBM ceiling next to the 8 TB/s spec (bytes must be a multiple of 16) */
 int dspamd_copy_probe(const void *d_src, void *d_dst, size_t bytes, void *stream);
 

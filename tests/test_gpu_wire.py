@@ -1,0 +1,274 @@
+"""Wire format to wire format in ONE pipeline (fused): read_buf_<fmt> in the first kernel's loads,
+dither / clip() / write_buf_<fmt> (dsp.c:685-699) in the last kernel's stores, through dspamd_batch_run_wire.
+
+The bar is bit-exactness against the SAME conversions done as passes of their own (dspamd_pcm_read -> dspamd_batch_run ->
+dspamd_pcm_write, which tests/test_pcm.py pins bit for bit against the reference's functions and the stock CLI's bytes): the
+fused kernels do the same IEEE operations on the same values, so every byte, every clip count and every peak must agree --
+for every format, with and without dither, across calls of ragged sizes (the dither sequences run on through the stream) and
+through the drain.  One test compares with the bytes the reference CLI itself writes for an s16 -> s16 file run."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_api import REF_DIR
+
+pytestmark = pytest.mark.gpu
+
+DSP_REF = os.path.join(REF_DIR, "dsp_ref")
+NP_DT = {"u8": np.uint8, "s8": np.int8, "s16": np.int16, "s24": np.int32, "s32": np.int32, "s24_3": np.uint8, "float": np.float32, "double": np.float64}
+EQ10 = " ".join(f"eq {f} 1.2 {g}" for f, g in zip((60, 120, 250, 500, 1000, 2000, 4000, 8000, 12000, 16000), (1.5, -2, 1, -1, 2, -1.5, 1, -2, 1.5, -1)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import dsp_amd
+    L = dsp_amd.load_library()
+    assert L.dspamd_device_count() >= 1
+    return dsp_amd, L, torch
+
+
+def wire_input(torch, fmt, S, F, Cn, seed):
+    """[S, F, C] samples of the wire format (device), loud enough to clip after a boost"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.uniform(-0.9, 0.9, size=(S, F, Cn))
+    if fmt == "double":
+        return torch.from_numpy(x).cuda()
+    if fmt == "float":
+        return torch.from_numpy(x.astype(np.float32)).cuda()
+    if fmt == "s16":
+        return torch.from_numpy(np.round(x * 32767).astype(np.int16)).cuda()
+    if fmt == "s24":
+        return torch.from_numpy((np.round(x * 8388607).astype(np.int32)) & 0xffffff).to(torch.int32).cuda()   # junk-free upper byte not required: sign-extension is the kernel's job
+    if fmt == "s32":
+        return torch.from_numpy(np.round(x * 2147483647).astype(np.int64).astype(np.int32)).cuda()
+    if fmt == "u8":
+        return torch.from_numpy(np.round(x * 127 + 128).astype(np.uint8)).cuda()
+    if fmt == "s8":
+        return torch.from_numpy(np.round(x * 127).astype(np.int8)).cuda()
+    if fmt == "s24_3":
+        v = np.round(x * 8388607).astype(np.int32)
+        b = np.stack([(v & 0xff), ((v >> 8) & 0xff), ((v >> 16) & 0xff)], axis=-1).astype(np.uint8)
+        return torch.from_numpy(b.reshape(S, F, Cn * 3)).cuda()
+    raise ValueError(fmt)
+
+
+def separate_passes(mods, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec, filt_dir=None):
+    """the conversions as passes of their own around dspamd_batch_run: (bytes [S, M, ...], stats [S, 2])"""
+    dsp_amd, L, torch = mods
+    from dsp_amd.chain import PCM_FORMATS, WIRE_DTYPES
+    b = dsp_amd.BatchChain(chain, fs, Cn, S, max(blocks), directory=filt_dir)
+    stats = torch.zeros((S, 2), dtype=torch.float64, device="cuda")
+    outs, pos, written = [], 0, 0
+    mult_in = WIRE_DTYPES[in_fmt][1]
+
+    def sink(y):
+        nonlocal written
+        f = y.shape[1]
+        if f == 0:
+            return
+        yc = y.contiguous()
+        dt, mult = WIRE_DTYPES[out_fmt]
+        o = torch.empty((S, f, b.ochannels * mult), dtype=getattr(torch, dt), device="cuda")
+        assert L.dspamd_pcm_write(PCM_FORMATS[out_fmt], yc.data_ptr(), f, o.data_ptr(), S, f, b.ochannels, prec, written, stats.data_ptr(), None) == 0
+        written += f
+        outs.append(o)
+
+    for n in blocks:
+        seg = x[:, pos:pos + n, :].contiguous()
+        pos += n
+        d = torch.empty((S, n, Cn), dtype=torch.float64, device="cuda")
+        assert L.dspamd_pcm_read(PCM_FORMATS[in_fmt], seg.data_ptr(), d.data_ptr(), S * n * Cn, None) == 0
+        assert seg.shape[2] == Cn * mult_in
+        sink(b.run(d))
+    while True:
+        y = b.drain(max(blocks))
+        if y is None:
+            break
+        sink(y)
+    torch.cuda.synchronize()
+    plan = b.plan()
+    b.close()
+    return torch.cat(outs, dim=1).cpu().numpy(), stats.cpu().numpy(), plan
+
+
+def fused(mods, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec, filt_dir=None, pad=0):
+    dsp_amd, L, torch = mods
+    b = dsp_amd.BatchChain(chain, fs, Cn, S, max(blocks), directory=filt_dir)
+    stats = torch.zeros((S, 2), dtype=torch.float64, device="cuda")
+    outs, pos, bits = [], 0, []
+    for n in blocks:
+        seg = x[:, pos:pos + n, :]
+        pos += n
+        if pad:
+            buf = torch.zeros((S, n + pad, x.shape[2]), dtype=x.dtype, device="cuda")
+            buf[:, :n, :] = seg
+            seg = buf[:, :n, :]
+        else:
+            seg = seg.contiguous()
+        outs.append(b.run_wire(seg, in_fmt, out_fmt, prec, stats).clone())
+        bits.append(b.wire_fused())
+    while True:
+        y = b.drain_wire(max(blocks), out_fmt, prec, stats)
+        if y is None:
+            break
+        outs.append(y.clone())
+    torch.cuda.synchronize()
+    b.close()
+    outs = [o for o in outs if o.shape[1]]
+    return torch.cat(outs, dim=1).cpu().numpy(), stats.cpu().numpy(), bits
+
+
+def same(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def write_filter(tmp_path, taps, seed=3):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 6.0))
+    h = h / np.sqrt(np.sum(h * h)) / 2.0
+    path = os.path.join(str(tmp_path), f"h{taps}.raw")
+    np.asarray(h, dtype="<f8").tofile(path)
+    return path, h
+
+
+# the headline plan's shape in small: identical sections on every channel, >= 1024 channels (cascade_rows<4>), a zero-latency
+# convolution behind it (K3 writes the output)
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("s32", "s24", 24), ("float", "float", 0), ("s24", "s32", 0),
+                                                 ("double", "s16", 0), ("s16", "double", 0), ("float", "s16", 16)])
+def test_cascade_in_k3_out(gpu, tmp_path, in_fmt, out_fmt, prec):
+    path, _ = write_filter(tmp_path, 3000)
+    chain = f"gain 7 {EQ10} fir_p -t pcm -e double -c 1 {path}"
+    S, Cn, fs = 128, 8, 48000
+    blocks = [4096, 2600, 4096, 1111]
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 1)
+    want, wstats, plan = separate_passes(gpu, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    got, gstats, bits = fused(gpu, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert "cascade" in plan and "conv[" in plan
+    assert same(got, want)
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    assert wstats[:, 1].max() > 1.0 and wstats.view(np.uint64)[:, 0].min() > 0     # the boost clips: the statistics are exercised
+    # every long call: input converted by cascade_rows (unless it already is fp64), sink applied by K3
+    want_bits = (0 if in_fmt == "double" else 1) | 2
+    assert all(b == want_bits for b in bits), bits
+
+
+# a chain that is ONE cascade stage: both conversions in the same kernel; padded input slabs; the drain
+@pytest.mark.parametrize("S,Cn,bits_want", [(128, 8, 3), (64, 8, 3), (3, 2, 0), (40, 4, 0)])   # cascade_rows<4>, <2>; fewer channels run kernels that do not speak the formats
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("s32", "float", 0), ("float", "s24", 20)])
+def test_cascade_both_ends(gpu, S, Cn, bits_want, in_fmt, out_fmt, prec):
+    chain = f"gain 8 {EQ10}"
+    blocks = [5000, 2048, 3333]
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 2)
+    want, wstats, _ = separate_passes(gpu, chain, 44100, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    got, gstats, bits = fused(gpu, chain, 44100, Cn, S, x, blocks, in_fmt, out_fmt, prec, pad=17 * 4)
+    assert same(got, want)
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    assert all(b == bits_want for b in bits), bits
+
+
+# formats and plans the kernels do not speak themselves: the stand-alone passes run inside run_wire -- same bytes, bits say so
+@pytest.mark.parametrize("chain,S,Cn,in_fmt,out_fmt,prec,bits_want", [
+    (f"gain 8 {EQ10}", 64, 8, "s24_3", "u8", 8, 0),             # unaligned formats
+    (f"gain 8 {EQ10}", 64, 8, "s8", "s24_3", 24, 0),
+    (f"gain 8 {EQ10}", 64, 8, "s16", "s24_3", 0, 1),            # input fusable, output not
+    (f"gain 8 {EQ10}", 64, 8, "u8", "s16", 16, 2),              # and the other way round
+    (f"gain 8 {EQ10}", 16, 2, "s16", "s16", 16, 0),             # few channels: kernels that do not speak the formats
+    ("gain 3 resample 44.1k", 16, 2, "s16", "s16", 16, 0),      # rate changer last: its drain goes through the sink too
+    ("", 16, 2, "s16", "float", 0, 0),                          # no effects at all: conversion only
+])
+def test_unfused_paths_inside_run_wire(gpu, chain, S, Cn, in_fmt, out_fmt, prec, bits_want):
+    blocks = [4096, 1100, 4096]
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 3)
+    want, wstats, _ = separate_passes(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert same(got, want)
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    assert all(b == bits_want for b in bits), bits
+
+
+# the other first / last kernels: element-wise stages (remix, the alignment delay) speak every format; a convolver at the start
+# reads the wire format in K1 (all channels, aligned pairs) or in its de-interleaving pass; K3 at the end applies the sink, also
+# on single channels of a pair; `fir` ends in the alignment stage that discards its latency
+@pytest.mark.parametrize("chain,S,Cn,in_fmt,out_fmt,prec,bits_want", [
+    ("remix 1 0", 16, 2, "s24_3", "u8", 8, 3),
+    ("remix 0,1 0 1 gain 2", 16, 2, "s16", "s16", 16, 1),       # remix first, a 48-channel cascade last
+    ("delay 2m", 16, 2, "s16", "s24_3", 24, 3),                 # one alignment stage
+    ("fir_p -t pcm -e double -c 1 {F}", 128, 8, "s16", "s16", 16, 3),     # K1 direct in, K3 out
+    ("fir_p -t pcm -e double -c 1 {F}", 128, 8, "s24_3", "s16", 16, 2),   # K1 cannot: the read pass runs; K3 out
+    ("fir_p -t pcm -e double -c 1 {F}", 24, 3, "s8", "s32", 0, 3),        # odd channels: the de-interleaving pass in; K3 out (single channel of a pair)
+    (f"{EQ10} fir -t pcm -e double -c 1 {{F}}", 24, 3, "s16", "s16", 16, 2),   # cascade (few channels) ... fir, alignment stage out
+    ("gain 6 fir_p -t pcm -e double -c 1 {F}", 24, 5, "float", "float", 0, 2),
+    ("resample 96k", 32, 2, "s16", "s16", 16, 1),               # 2x upsampler first and last: K1 + its history pass in; two-phase K3 not
+    ("resample 44.1k", 32, 2, "s16", "s16", 16, 0),             # the general resampler speaks neither
+])
+def test_other_first_and_last_kernels(gpu, tmp_path, chain, S, Cn, in_fmt, out_fmt, prec, bits_want):
+    path, _ = write_filter(tmp_path, 700)
+    chain = chain.replace("{F}", path)
+    blocks = [3000, 3000, 500]
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 4)
+    want, wstats, plan = separate_passes(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert same(got, want), plan
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    assert all(b == bits_want for b in bits), (bits, plan)
+
+
+# reset: the dither sequences start again
+def test_reset_restarts_the_dither_sequences(gpu):
+    dsp_amd, L, torch = gpu
+    chain = f"gain 2 {EQ10}"
+    S, Cn, n = 128, 8, 4096
+    x = wire_input(torch, "s16", S, n, Cn, 5)
+    b = dsp_amd.BatchChain(chain, 48000, Cn, S, n)
+    a = b.run_wire(x, "s16", "s16", 16).clone()
+    c = b.run_wire(x, "s16", "s16", 16).clone()
+    b.reset()
+    d = b.run_wire(x, "s16", "s16", 16).clone()
+    assert torch.equal(a, d) and not torch.equal(a, c)
+
+
+# the switch that forces the stand-alone passes exists for the fallback suite; it must say so in the bits
+def test_no_fusion_switch_is_honoured_in_a_fresh_process(tmp_path):
+    code = "\n".join([
+        "import torch, dsp_amd",
+        "b = dsp_amd.BatchChain('gain 2 eq 1k 1 3 eq 2k 1 -3', 48000, 8, 128, 4096)",
+        "x = torch.zeros((128, 4096, 8), dtype=torch.int16, device='cuda')",
+        "b.run_wire(x, 's16', 's16', 16)",
+        "print('BITS', b.wire_fused())",
+    ])
+    env = dict(os.environ, DSP_AMD_NO_WIRE_FUSION="1")
+    r = subprocess.run(["python", "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "BITS 0" in r.stdout, r.stdout[-2000:]
+
+
+# the reference CLI, file to file: s16 in, ten sections, s16 out with dither.  The chain itself agrees with the reference to
+# ~1e-13 (not bit for bit: the sections run as a scan here), so a sample can land on the other side of a rounding boundary
+# once in ~1e8: the bytes are expected to be identical, and at most a handful of +-1 LSB differences are tolerated
+@pytest.mark.skipif(not os.path.exists(DSP_REF), reason="oracle/_ref/dsp_ref not built")
+def test_file_to_file_against_the_reference_cli(gpu, tmp_path):
+    dsp_amd, L, torch = gpu
+    Cn, F = 8, 60000
+    rng = np.random.Generator(np.random.PCG64(6))
+    pcm = np.round(rng.uniform(-0.5, 0.5, size=(F, Cn)) * 32767).astype("<i2")
+    xin = os.path.join(str(tmp_path), "in.raw"); pcm.tofile(xin)
+    out = os.path.join(str(tmp_path), "out.raw")
+    eff = f"gain 5 {EQ10}".split()
+    cmd = [DSP_REF, "-q", "-d", "-t", "pcm", "-e", "s16", "-r", "48k", "-c", str(Cn), xin, "-o", "-t", "pcm", "-e", "s16", out] + eff
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    want = np.fromfile(out, dtype="<i2").reshape(-1, Cn)
+    # 128 streams so that cascade_rows<4> takes it; stream 0 carries the file
+    S = 128
+    x = torch.zeros((S, F, Cn), dtype=torch.int16, device="cuda")
+    x[0] = torch.from_numpy(pcm.astype(np.int16)).cuda()
+    b = dsp_amd.BatchChain(" ".join(eff), 48000, Cn, S, 8192)
+    y = b.process_wire(x, 8192, "s16", "s16", 16)
+    assert b.wire_fused() in (0, 3)      # (the last call was a drain or a run)
+    got = y[0].cpu().numpy()
+    assert got.shape == want.shape
+    d = got.astype(np.int32) - want.astype(np.int32)
+    assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 4, (np.abs(d).max(), np.count_nonzero(d))
