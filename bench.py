@@ -319,8 +319,52 @@ def main():
             # SIDE FIGURE, never `value`: the same chain with the planner's opt-in LTI merge of the sections into the filter
             # (DSP_AMD_MERGE_IIR=1): no cascade pass at all, exact to the decay criterion (2^-70).  The headline
             # above is measured with the cascade kernel in place, as the workload is defined.
+            res["side_runs"] = {}
             try:
-                del batch, x, out
+                # SIDE FIGURE, never `value`: the same step from wire format to wire format (the reference's file -> file run: s16 in,
+                # the chain, TPDF dither at 16 bits + clip + s16 out, dsp.c:685-699) -- conversions in the first / last kernel
+                # (dspamd_batch_run_wire) against the same conversions as passes of their own around the fp64 step
+                del batch
+                wb = dsp_amd.BatchChain(chain, fs, C, S, args.block, directory=filt_dir)
+                x16 = torch.zeros((S, args.block + args.slab_pad, C), dtype=torch.int16, device="cuda")
+                x16[:, :args.block, :] = (x[0] * 20000.0).round().to(torch.int16)
+                och = wb.ochannels
+                o16 = torch.empty((S, out.shape[1], och), dtype=torch.int16, device="cuda")
+                wstats = torch.zeros((S, 2), dtype=torch.float64, device="cuda")
+
+                def t_of(fn, n=5):
+                    for _ in range(2):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / n
+
+                dt_f = t_of(lambda: wb.run_wire(x16[:, :args.block, :], "s16", "s16", 16, wstats, o16))
+                bits = wb.wire_fused()
+                xd = x[1]
+                written = [0]
+
+                def separate():
+                    # (x16 and x[1] are views of buffers with the same padded layout: one flat conversion over the whole buffer)
+                    L.dspamd_pcm_read(2, x16.data_ptr(), xd.data_ptr(), S * (args.block + args.slab_pad) * C, stream)
+                    f = wb.run(xd, out).shape[1]
+                    L.dspamd_pcm_write(2, out.data_ptr(), out.shape[1], o16.data_ptr(), S, f, och, 16, written[0], wstats.data_ptr(), stream)
+                    written[0] += f
+
+                dt_s = t_of(separate)
+                res["side_runs"]["file_to_file"] = {
+                    "what": "s16 -> chain -> dither(16) + clip + s16, per step; fused = conversions in the first / last kernel (dspamd_batch_run_wire), "
+                            "separate = dspamd_pcm_read + the fp64 step + dspamd_pcm_write; not the headline",
+                    "fused_ms_per_step": dt_f * 1e3, "separate_ms_per_step": dt_s * 1e3, "fused_bits": bits,
+                    "value_fused": S * C * args.block / dt_f / 1e6, "value_separate": S * C * args.block / dt_s / 1e6, "unit": "Msamples/s"}
+                del wb, x16, o16
+            except Exception as e:  # pragma: no cover
+                res["side_runs"]["file_to_file"] = {"error": str(e)[:300]}
+            try:
+                del x, out
                 torch.cuda.empty_cache()
                 os.environ["DSP_AMD_MERGE_IIR"] = "1"
                 sb = 958208                                        # the hop of N = 2^20 for the merged filter (65536 + 24832 - 1 taps)
@@ -337,12 +381,12 @@ def main():
                     mb.run(mx[:, :sb, :], mo)
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / 6
-                res["side_runs"] = {"merged_iir": {"what": "sections folded into the filter by the planner (opt-in DSP_AMD_MERGE_IIR=1); not the headline",
-                                                   "value": S * C * sb / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "block_frames": sb, "plan": mb.plan()}}
+                res["side_runs"]["merged_iir"] = {"what": "sections folded into the filter by the planner (opt-in DSP_AMD_MERGE_IIR=1); not the headline",
+                                                   "value": S * C * sb / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "block_frames": sb, "plan": mb.plan()}
                 del mb, mx, mo
             except Exception as e:  # pragma: no cover
                 os.environ.pop("DSP_AMD_MERGE_IIR", None)
-                res["side_runs"] = {"merged_iir": {"error": str(e)[:300]}}
+                res["side_runs"]["merged_iir"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(chain, filt_dir, fs, C)
             if res["cpu_baseline"].get("value"):

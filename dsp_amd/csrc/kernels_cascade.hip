@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 						const long n = (t0 + t) * p.C + c0 + cc;
 						const bool dither = p.sink.dither_mult != 0.0;
 						uint32_t u0 = 0, u1 = 0;
-						if (dither) { u0 = pm_pow(PM_A0, (uint64_t) (p.sink.samples_before + n) + 1); u1 = pm_pow(PM_A1, (uint64_t) (p.sink.samples_before + n) + 1); }
+						if (dither) { u0 = pm_pow<0>((uint64_t) (p.sink.samples_before + n) + 1); u1 = pm_pow<1>((uint64_t) (p.sink.samples_before + n) + 1); }
 						pcm_store(p.out, p.sink.fmt, out0 + n, sink_sample(v, dither, u0, u1, p.sink.dither_mult, peak, clipped));
 					}
 					else out[(t0 + t) * p.C + c0 + cc] = v;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpD
 		}
 		__syncthreads();
 	}
-	if (sink_on && p.sink.stats) sink_stats_wave(p.sink.stats, s, peak, clipped);
+	if (sink_on && p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
 }
 
@@ -744,6 +744,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P, int p2p)
 {
 	static_assert(!WIRE || G >= 2, "wire formats: channel pairs");
+	double sink_peak = 0.0;                                     // statistics of the sink (WIRE with p.sink.on)
+	unsigned long long sink_clipped = 0;
 	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
 	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
 	constexpr int PARTNER = (G == 4) ? RW_ROW : 2 * RW_ROW;            // LDS distance between the two channels of a pair
@@ -825,16 +827,16 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 			typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 			const bool dither = sink_on && p.sink.dither_mult != 0.0;
 			uint32_t u0 = 0, u1 = 0, js0 = 1, js1 = 1, jt0 = 1, jt1 = 1;
-			double peak = 0.0;
-			unsigned long long clipped = 0;
+			double &peak = sink_peak;
+			unsigned long long &clipped = sink_clipped;
 			if constexpr (WIRE) {
 				if (dither) {
 					// sample n of the stream (interleaved order) uses A^(n + 1): this lane starts at slot 0 of tile w, walks the
 					// slots of a tile FPS frames apart and the tiles of its wave P tiles apart
 					const uint64_t n0 = (uint64_t) p.sink.samples_before + (uint64_t) (((long) w * TILE + f0) * p.C + c0 + 2 * pr);
-					u0 = pm_pow(PM_A0, n0 + 1); u1 = pm_pow(PM_A1, n0 + 1);
-					js0 = pm_pow(PM_A0, (uint64_t) FPS * p.C); js1 = pm_pow(PM_A1, (uint64_t) FPS * p.C);
-					jt0 = pm_pow(PM_A0, (uint64_t) (P - 1) * TILE * p.C); jt1 = pm_pow(PM_A1, (uint64_t) (P - 1) * TILE * p.C);
+					u0 = pm_pow<0>(n0 + 1); u1 = pm_pow<1>(n0 + 1);
+					js0 = pm_pow<0>((uint64_t) FPS * p.C); js1 = pm_pow<1>((uint64_t) FPS * p.C);
+					jt0 = pm_pow<0>((uint64_t) (P - 1) * TILE * p.C); jt1 = pm_pow<1>((uint64_t) (P - 1) * TILE * p.C);
 				}
 			}
 			auto load_raw = [&](long t) {
@@ -1041,11 +1043,11 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				fetch_out(y);
 				store_out(y, t_last);
 			}
-			if constexpr (WIRE) { if (sink_on && p.sink.stats) sink_stats_wave(p.sink.stats, s, peak, clipped); }
 		}
 		if (!p2p) for (; steps < n_steps; ++steps) lds_barrier();
 	}
 	__syncthreads();
+	if constexpr (WIRE) { if (sink_on && p.sink.stats) sink_stats_block(p.sink.stats, s, sink_peak, sink_clipped); }
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
 }
 

@@ -403,10 +403,10 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 				const long mo = p.q_blk + f0 + m_first * dmo - p.k_origin;
 				const uint64_t na = (uint64_t) (p.sink.samples_before + mo * p.C + (cha >= 0 ? cha : 0)) + 1;
 				const uint64_t nb = (uint64_t) (p.sink.samples_before + mo * p.C + (chb >= 0 ? chb : 0)) + 1;
-				ua0 = pm_pow(PM_A0, na); ua1 = pm_pow(PM_A1, na);
+				ua0 = pm_pow<0>(na); ua1 = pm_pow<1>(na);
 				if (chb == cha + 1) { ub0 = pm_mul(ua0, PM_A0); ub1 = pm_mul(ua1, PM_A1); }
-				else { ub0 = pm_pow(PM_A0, nb); ub1 = pm_pow(PM_A1, nb); }
-				j0 = pm_pow(PM_A0, (uint64_t) dmo * p.C); j1 = pm_pow(PM_A1, (uint64_t) dmo * p.C);
+				else { ub0 = pm_pow<0>(nb); ub1 = pm_pow<1>(nb); }
+				j0 = pm_pow<0>((uint64_t) dmo * p.C); j1 = pm_pow<1>((uint64_t) dmo * p.C);
 			}
 			double peak = 0.0;
 			unsigned long long clipped = 0;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 					}
 				}
 			}
-			if (p.sink.stats) sink_stats_wave(p.sink.stats, s, peak, clipped);
+			if (p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
 			continue;
 		}
 		if (!active) continue;

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void pcm_write_kernel(PcmWriteParams p)
 		uint32_t s0 = 0, s1 = 0;
 		if (dither) {
 			const uint64_t k = (uint64_t) (p.samples_before + e0);   // samples already drawn for this stream
-			s0 = pm_pow(PM_A0, k);                                   // state after k draws from seed 1 (util.h:151-152)
-			s1 = pm_pow(PM_A1, k);
+			s0 = pm_pow<0>(k);                                   // state after k draws from seed 1 (util.h:151-152)
+			s1 = pm_pow<1>(k);
 		}
 		const long e1 = (e0 + PCM_RUN < n) ? e0 + PCM_RUN : n;
 		for (long e = e0; e < e1; ++e) {

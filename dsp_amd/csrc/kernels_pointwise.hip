@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void remix_kernel(RemixParams p)
 		if (p.sink.on) pcm_store(p.out, p.sink.fmt, out0 + e, walk.next(p.sink, e, stride, acc));
 		else out[e] = acc;
 	}
-	if (p.sink.on && p.sink.stats) sink_stats_wave(p.sink.stats, s, walk.peak, walk.clipped);
+	if (p.sink.on && p.sink.stats) sink_stats_block(p.sink.stats, s, walk.peak, walk.clipped);
 }
 
 void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream)
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void delay_kernel(DelayKArgs a)
 			}
 		}
 	}
-	if (p.sink.on && p.sink.stats) sink_stats_wave(p.sink.stats, s, walk.peak, walk.clipped);
+	if (p.sink.on && p.sink.stats) sink_stats_block(p.sink.stats, s, walk.peak, walk.clipped);
 }
 
 void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream)

@@ -29,15 +29,41 @@ __device__ __forceinline__ uint32_t pm_mul(uint32_t a, uint32_t b)
 	return r;
 }
 
-__device__ __forceinline__ uint32_t pm_pow(uint32_t a, uint64_t e)
+// A^e for the two multipliers from byte tables: the generators have period 2^31 - 2 (A^(2^31 - 2) = 1 modulo the prime 2^31 - 1),
+// so e is first reduced modulo that, and A^e = T[0][e & 255] T[1][(e >> 8) & 255] T[2][...] T[3][...] with T[k][b] = A^(b 256^k):
+// four look-ups and three multiplications where square-and-multiply takes about sixty (measured on K3 with dither at the
+// headline shape: 13.7 -> see DESIGN.md section 4.5).  The tables are computed by the compiler.
+struct PmTables { uint32_t t[2][4][256]; };
+constexpr uint32_t pm_mul_c(uint32_t a, uint32_t b)
 {
-	uint32_t r = 1;
-	while (e) {
-		if (e & 1) r = pm_mul(r, a);
-		a = pm_mul(a, a);
-		e >>= 1;
-	}
+	const uint64_t p = (uint64_t) a * b;
+	uint32_t r = (uint32_t) (p & PM) + (uint32_t) (p >> 31);
+	r = (r & PM) + (r >> 31);
 	return r;
+}
+constexpr PmTables pm_make_tables()
+{
+	PmTables T{};
+	for (int g = 0; g < 2; ++g) {
+		uint32_t base = g ? PM_A1 : PM_A0;
+		for (int k = 0; k < 4; ++k) {
+			uint32_t v = 1;
+			for (int b = 0; b < 256; ++b) { T.t[g][k][b] = v; v = pm_mul_c(v, base); }
+			base = v;                                  // base^256
+		}
+	}
+	return T;
+}
+static __device__ const PmTables PM_TAB = pm_make_tables();
+
+// G = 0: A = 48271, G = 1: A = 16807
+template <int G> __device__ __forceinline__ uint32_t pm_pow(uint64_t e)
+{
+	const uint32_t r = (uint32_t) (e % (uint64_t) (PM - 1));
+	uint32_t v = PM_TAB.t[G][0][r & 255];
+	v = pm_mul(v, PM_TAB.t[G][1][(r >> 8) & 255]);
+	v = pm_mul(v, PM_TAB.t[G][2][(r >> 16) & 255]);
+	return pm_mul(v, PM_TAB.t[G][3][r >> 24]);
 }
 
 __device__ __forceinline__ double pcm_load(const void *in, int fmt, long i)
@@ -146,8 +172,8 @@ struct SinkWalk {
 		if (dither) {
 			if (!started) {
 				const uint64_t e = (uint64_t) (k.samples_before + n) + 1;
-				u0 = pm_pow(PM_A0, e); u1 = pm_pow(PM_A1, e);
-				j0 = pm_pow(PM_A0, (uint64_t) stride); j1 = pm_pow(PM_A1, (uint64_t) stride);
+				u0 = pm_pow<0>(e); u1 = pm_pow<1>(e);
+				j0 = pm_pow<0>((uint64_t) stride); j1 = pm_pow<1>((uint64_t) stride);
 				started = true;
 			}
 			else { u0 = pm_mul(u0, j0); u1 = pm_mul(u1, j1); }
@@ -157,18 +183,30 @@ struct SinkWalk {
 };
 
 // per-stream statistics of the sink: stats[2 s] += clipped samples (64-bit count), stats[2 s + 1] = max(|sample|).
-// Every lane of the wave works on the SAME stream: one pair of atomics per wave.
-__device__ __forceinline__ void sink_stats_wave(double *stats, long s, double peak, unsigned long long clipped)
+// Every thread of the WORKGROUP works on the same stream and all of them get here: waves by shuffles, the workgroup through
+// LDS, then at most one pair of global atomics -- and the maximum only when it would change something (a million waves
+// hitting 256 addresses cost K3 a millisecond at the headline shape).
+__device__ __forceinline__ void sink_stats_block(double *stats, long s, double peak, unsigned long long clipped)
 {
+	__shared__ unsigned long long red[2];
+	if (threadIdx.x == 0) { red[0] = 0; red[1] = 0; }
+	__syncthreads();
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) {
 		peak = fmax(peak, __shfl_xor(peak, d, 64));
 		clipped += (unsigned long long) __shfl_xor((long long) clipped, d, 64);
 	}
+	// peak >= 0: its IEEE bit pattern orders like an unsigned integer
+	const unsigned long long pk = (unsigned long long) __double_as_longlong(peak);
 	if ((threadIdx.x & 63) == 0) {
-		if (clipped) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 2 * s, clipped);
-		// peak >= 0: its IEEE bit pattern orders like an unsigned integer
-		atomicMax(reinterpret_cast<unsigned long long *>(stats) + 2 * s + 1, (unsigned long long) __double_as_longlong(peak));
+		if (clipped) atomicAdd(&red[0], clipped);
+		if (pk) atomicMax(&red[1], pk);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long *g = reinterpret_cast<unsigned long long *>(stats) + 2 * s;
+		if (red[0]) atomicAdd(g, red[0]);
+		if (red[1] > __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g + 1, red[1]);
 	}
 }
 

@@ -121,6 +121,13 @@ def fused(mods, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec, filt_dir=Non
     return torch.cat(outs, dim=1).cpu().numpy(), stats.cpu().numpy(), bits
 
 
+def check_bits(bits, want, note=None):
+    """which ends were fused is asserted on the default plan only: the fallback suite's DSP_AMD_* switches change the kernels"""
+    if any(k.startswith("DSP_AMD_") for k in os.environ):
+        return
+    assert all(b == want for b in bits), (bits, want, note)
+
+
 def same(a, b):
     return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
@@ -152,7 +159,7 @@ def test_cascade_in_k3_out(gpu, tmp_path, in_fmt, out_fmt, prec):
     assert wstats[:, 1].max() > 1.0 and wstats.view(np.uint64)[:, 0].min() > 0     # the boost clips: the statistics are exercised
     # every long call: input converted by cascade_rows (unless it already is fp64), sink applied by K3
     want_bits = (0 if in_fmt == "double" else 1) | 2
-    assert all(b == want_bits for b in bits), bits
+    check_bits(bits, want_bits)
 
 
 # a chain that is ONE cascade stage: both conversions in the same kernel; padded input slabs; the drain
@@ -166,7 +173,7 @@ def test_cascade_both_ends(gpu, S, Cn, bits_want, in_fmt, out_fmt, prec):
     got, gstats, bits = fused(gpu, chain, 44100, Cn, S, x, blocks, in_fmt, out_fmt, prec, pad=17 * 4)
     assert same(got, want)
     assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
-    assert all(b == bits_want for b in bits), bits
+    check_bits(bits, bits_want)
 
 
 # formats and plans the kernels do not speak themselves: the stand-alone passes run inside run_wire -- same bytes, bits say so
@@ -186,7 +193,7 @@ def test_unfused_paths_inside_run_wire(gpu, chain, S, Cn, in_fmt, out_fmt, prec,
     got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
     assert same(got, want)
     assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
-    assert all(b == bits_want for b in bits), bits
+    check_bits(bits, bits_want)
 
 
 # the other first / last kernels: element-wise stages (remix, the alignment delay) speak every format; a convolver at the start
@@ -213,7 +220,7 @@ def test_other_first_and_last_kernels(gpu, tmp_path, chain, S, Cn, in_fmt, out_f
     got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
     assert same(got, want), plan
     assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
-    assert all(b == bits_want for b in bits), (bits, plan)
+    check_bits(bits, bits_want, plan)
 
 
 # reset: the dither sequences start again
