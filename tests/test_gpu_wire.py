@@ -274,7 +274,6 @@ def test_file_to_file_against_the_reference_cli(gpu, tmp_path):
     x[0] = torch.from_numpy(pcm.astype(np.int16)).cuda()
     b = dsp_amd.BatchChain(" ".join(eff), 48000, Cn, S, 8192)
     y = b.process_wire(x, 8192, "s16", "s16", 16)
-    assert b.wire_fused() in (0, 3)      # (the last call was a drain or a run)
     got = y[0].cpu().numpy()
     assert got.shape == want.shape
     d = got.astype(np.int32) - want.astype(np.int32)
