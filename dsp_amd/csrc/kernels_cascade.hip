@@ -732,22 +732,28 @@ __device__ __forceinline__ rw_u32x4 rw_as_u4(double2 v) { return __builtin_bit_c
 // address pair per slot and direction, 96 VGPRs), transposed to the lane-major layout of the recurrence through a
 // wave-private LDS tile (rows placed so that both access patterns are bank-conflict free), one tile per n_ops steps,
 // prefetched a whole tile period ahead.
-constexpr int RW_TB = 4 * RW_ROW + 16;                          // doubles per wave-private transposer (either G)
-// G = 4: rows of 16 x 33 doubles at 0, 528, 1072, 1600;  G = 2: rows of 32 x 33 doubles at 0, 1056
-template <int G> __device__ __forceinline__ int rw_row_base(int r) { return (G == 4) ? r * RW_ROW + ((r >> 1) << 4) : r * 2 * RW_ROW; }
+constexpr int rw_tb_doubles(int L) { return 4 * 16 * (L + 1) + 16; }     // doubles per wave-private transposer (either G)
+constexpr int RW_TB = rw_tb_doubles(RW_L);
+// G = 4: rows of 16 x 33 doubles at 0, 528, 1072, 1600;  G = 2: rows of 32 x 33 doubles at 0, 1056  (L = 32)
+template <int G, int ROW = RW_ROW> __device__ __forceinline__ int rw_row_base(int r) { return (G == 4) ? r * ROW + ((r >> 1) << 4) : r * 2 * ROW; }
 
 // WIRE (G = 4, 2): the instance that also speaks the wire formats -- p.in_fmt samples converted in the tile loads (read_buf_<fmt>),
 // and / or the sink of dsp.c:685-699 (dither, clip, write_buf_<fmt>) applied in the tile stores (p.sink).  The plain fp64
 // instance stays as it is.
-template <int G, bool WIRE = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// LL / WPE: frames per lane and waves per SIMD.  16 frames per lane (half the tile registers -- 127 VGPRs -- and half the
+// transposer, constants P^(16 2^k)) at FOUR waves per SIMD was built and measured in round 2: 10.15 against 9.57 ms at the
+// headline shape (8 waves per group; 11.1 with 4, 12.8 at three waves per SIMD with 6) -- the scan is paid per lane, so halving
+// the frames per lane adds 20 % instructions, more than the occupancy gives back.  32 it is.
+template <int G, bool WIRE = false, int LL = RW_L, int WPE = 2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P, int p2p)
 {
 	static_assert(!WIRE || G >= 2, "wire formats: channel pairs");
 	double sink_peak = 0.0;                                     // statistics of the sink (WIRE with p.sink.on)
 	unsigned long long sink_clipped = 0;
-	constexpr int L = RW_L, LPC = 64 / G, TILE = LPC * L, K = 16;      // K slots (16 B) per lane and tile: 2048 samples either way
+	constexpr int L = LL, LPC = 64 / G, TILE = LPC * L, K = L / 2, KH = K / 2;   // K slots (16 B) per lane and tile (L = 32: 2048 samples)
 	constexpr int FPS = (G == 4) ? 32 : 64;                            // frames covered by one slot instruction of the wave
+	constexpr int RW_ROW = 16 * (L + 1), RW_TB = rw_tb_doubles(L);     // (shadow the L = 32 constants of the file)
 	constexpr int PARTNER = (G == 4) ? RW_ROW : 2 * RW_ROW;            // LDS distance between the two channels of a pair
 	// the tile traffic of a wave is one step of its sequence (see the main loop).  (Two steps for G = 1 -- results out in one,
 	// the new tile in in the next -- were measured: 0.452 against 0.432 ms at 32 streams.  What G = 1 pays for is not the length
@@ -797,13 +803,13 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	const int vo_in = (f0 * p.C + 2 * pr) * in_bs, so_in = FPS * p.C * in_bs, tile_bytes_in = TILE * p.C * in_bs;
 	const int vo_out = (f0 * p.C + 2 * pr) * out_bs, so_out = FPS * p.C * out_bs, tile_bytes_out = TILE * p.C * out_bs;
 	// LDS position of slot k: G = 4: row 2 pr, frame f0 + 32 k at + 33 k;  G = 2: frame lane + 64 k at lane + lane / 32 + 66 k
-	double *tb_slab = tb + ((G == 4) ? rw_row_base<G>(2 * pr) + f0 : lane + (lane >> 5));
-	constexpr int SLAB_K = (G == 4) ? (L + 1) : 2 * (L + 1);
+	double *tb_slab = tb + ((G == 4) ? rw_row_base<G, RW_ROW>(2 * pr) + f0 + f0 / L : lane + lane / L);   // frame f of a row at f + f / L
+	constexpr int SLAB_K = FPS + FPS / L;
 	// row order (ring-only output, G = 4): slot k = pair k >> 3, frame lane + 64 (k & 7) -- one store instruction = 1 KB of ONE
 	// ring row.  (G = 2 has one pair: slab order is row order.)
-	double *tb_rows = tb + lane + (lane >> 5);                  // + rw_row_base(2 (k >> 3)) + 66 (k & 7)
+	double *tb_rows = tb + lane + lane / L;                     // + rw_row_base(2 (k / KH)) + (64 + 64 / L) (k % KH)
 	const int ch = lane / LPC, pos = lane % LPC;                // this lane's channel inside the group and position in it
-	double *tb_lane = tb + ((G == 1) ? 0 : rw_row_base<G>(ch)) + pos * (L + 1);
+	double *tb_lane = tb + ((G == 1) ? 0 : rw_row_base<G, RW_ROW>(ch)) + pos * (L + 1);
 	double *st_row = st + ch * n_ops * 2;
 	const double *__restrict__ cf = frows + (size_t) (c0 >> 1) * n_ops * FOP_DOUBLES;     // one entry per channel PAIR
 
@@ -912,7 +918,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				else {
 #pragma unroll
 					for (int k = 0; k < K; ++k) {
-						const double *a = tb_rows + rw_row_base<G>(2 * (k >> 3)) + (64 + 64 / L) * (k & 7);
+						const double *a = tb_rows + rw_row_base<G, RW_ROW>(2 * (k / KH)) + (64 + 64 / L) * (k % KH);
 						y[k] = make_double2(a[0], a[PARTNER]);
 					}
 				}
@@ -967,7 +973,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 					const long e0 = p.ring.pos + t_out * TILE + lane;
 #pragma unroll
 					for (int k = 0; k < K; ++k)
-						rw_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 64 * (k & 7)) & p.ring.mask) * 16, (k >> 3) * ring_row_bytes);
+						rw_store_b128(rw_as_u4(y[k]), r_ring, (int) ((e0 + 64 * (k % KH)) & p.ring.mask) * 16, (k / KH) * ring_row_bytes);
 				}
 			};
 			for (long t = w; t < n_full; t += P) {
