@@ -420,6 +420,7 @@ CascadeParams CascadeStage::params(const double *in, long in_stride, ssize_t fra
 	p.state = state.as<double>();
 	p.ring = ring;
 	p.write_interleaved = write_interleaved;
+	p.xcd_map = 1;
 	return p;
 }
 

@@ -51,6 +51,24 @@ constexpr int MAX_PF = 16;                 // prefetch registers (doubles) per t
 
 __device__ __forceinline__ int lds_index(int t) { return t + (t >> 4); }
 
+// Which (stream, channel group) a workgroup of a (streams, groups) grid works on.  The channel groups of a stream share every
+// 64-byte frame of its slabs (a group of 4 channels owns 32 bytes of it), so they should run at the same time on the same XCD:
+// its L2 then sees whole lines -- fetched once, written back whole.  Run a whole dispatch wave apart (the plain x-fastest
+// order), each group fetches the lines again and its half lines go to HBM as partial writes: a chain that ENDS in sections
+// (interleaved output) 18.9 -> 8.5 ms at 256 x 8 channels, the headline's cascade (ring output) 9.5 -> 8.6 ms.  Workgroups are
+// dispatched in linear id order (x fastest) and dealt to the 8 XCDs round robin: ids that differ by 8 meet in one L2, a few
+// dispatch slots apart -- blocks of 8 streams, group-major inside.
+__device__ __forceinline__ void stream_and_group_of_block(int xcd_map, int &s, int &grp)
+{
+	const int ns = gridDim.x, ng = gridDim.y;
+	if (xcd_map && ng > 1 && (ns & 7) == 0) {
+		const int id = blockIdx.x + blockIdx.y * ns, per = 8 * ng, blk = id / per, r = id % per;
+		s = blk * 8 + (r & 7);
+		grp = r >> 3;
+	}
+	else { s = blockIdx.x; grp = blockIdx.y; }
+}
+
 // ---- cross-lane helpers: DPP moves of fp64 values (two 32-bit DPP ops), no LDS traffic ----
 template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
 {
@@ -161,8 +179,9 @@ __device__ __forceinline__ void run_ops(double (&v)[L], const double *ops, int n
 __global__ __launch_bounds__(512) void cascade_kernel(CascadeParams p, const OpDesc *__restrict__ gops)
 {
 	extern __shared__ __attribute__((aligned(16))) double smem[];
-	const int s = blockIdx.x;
-	const int c0 = p.cg0 + blockIdx.y * p.Cg;
+	int s, grp;
+	stream_and_group_of_block(p.xcd_map, s, grp);
+	const int c0 = p.cg0 + grp * p.Cg;
 	const int cgn = min(p.Cg, p.C - c0);
 	const int tid = threadIdx.x, nth = blockDim.x;
 	const int lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
@@ -470,8 +489,9 @@ __global__ __launch_bounds__(64 * CG) void cascade_fast(CascadeParams p, const d
 	using Cfg = FastCfg<CG>;
 	constexpr int L = Cfg::L, TILE = Cfg::TILE, NTH = Cfg::NTH, K = Cfg::K, HP = Cfg::HP, CHS = Cfg::CHS;
 	extern __shared__ __attribute__((aligned(16))) double smem[];
-	const int s = blockIdx.x;
-	const int c0 = p.cg0 + blockIdx.y * CG;
+	int s, grp;
+	stream_and_group_of_block(p.xcd_map, s, grp);
+	const int c0 = p.cg0 + grp * CG;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	double *tile = smem;                                        // [CG][CHS]
@@ -761,8 +781,9 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	constexpr int IO_STEPS = 1;
 	// G = 1: one channel per wave -- 8-byte elements (32 per lane and tile), frame lane + 64 k at LDS lane + lane / 32 + 66 k
 	extern __shared__ __attribute__((aligned(16))) double smem[];
-	const int s = blockIdx.x;
-	const int c0 = p.cg0 + blockIdx.y * G;
+	int s, grp;
+	stream_and_group_of_block(p.xcd_map, s, grp);
+	const int c0 = p.cg0 + grp * G;
 	const int tid = threadIdx.x, lane = tid & 63, nth = 64 * P;
 	const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // position in the wavefront
 	const int n_ops = p.n_ops;
@@ -1152,8 +1173,9 @@ __global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, con
 {
 	constexpr int L = CASCADE_L, TILE = 64 * L, NTH = 64 * CG * P;
 	extern __shared__ __attribute__((aligned(16))) double smem[];
-	const int s = blockIdx.x;
-	const int c0 = p.cg0 + blockIdx.y * CG;
+	int s, grp;
+	stream_and_group_of_block(p.xcd_map, s, grp);
+	const int c0 = p.cg0 + grp * CG;
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int w = wave / CG, cc = wave % CG, c = c0 + cc;
@@ -1296,8 +1318,11 @@ size_t cascade_lds_bytes(int Cg, int n_ops)
 	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2 + (size_t) Cg * n_ops * OPL_DOUBLES) * sizeof(double);
 }
 
-const char *launch_cascade(const CascadeParams &p0, int n_streams, hipStream_t stream)
+const char *launch_cascade(const CascadeParams &p_in, int n_streams, hipStream_t stream)
 {
+	static const int xmap = [] { const char *e = getenv("DSP_AMD_CASCADE_XCDMAP"); return e ? atoi(e) : 1; }();   // 0: plain block order (for comparison)
+	CascadeParams p0 = p_in;
+	p0.xcd_map = xmap;
 	CascadeParams p = p0;
 	const char *name = "cascade_rows";
 	// a call in wire formats: cascade_rows and the generic kernel speak them (the host asks cascade_rows_takes() first)

@@ -87,6 +87,7 @@ struct CascadeParams {
 	double *state;                       // [S][C][n_ops][2]
 	PlanarRing ring;                     // optional second destination (ring.base != nullptr)
 	int write_interleaved;               // 0: only the ring is written
+	int xcd_map;                         // workgroup -> (stream, channel group) order that co-schedules a stream's groups on one XCD (set by launch_cascade)
 };
 
 // chunked cascade (kernels_chunk.hip): a call of K * len frames run as K zero-state chunks + carry + correction
