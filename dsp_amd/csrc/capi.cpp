@@ -111,8 +111,10 @@ ssize_t dspamd_batch_drain(dspamd_batch *b, ssize_t block_frames, void *d_out, s
 	if (b->drain_left > 0) {
 		const ssize_t n = std::min(block_frames, b->drain_left);
 		if (b->zeros_frames < n) {
-			if (!b->zeros.alloc((size_t) b->pipe->S * block_frames * b->pipe->ch_in * sizeof(double), true)) return -2;
-			b->zeros_frames = block_frames;
+			// (as much silence as one drain call pushes, not a whole block of it: 1 GB instead of 16 at the bench's step)
+			const ssize_t want = std::min(block_frames, b->plan.drain_frames);
+			if (!b->zeros.alloc((size_t) b->pipe->S * want * b->pipe->ch_in * sizeof(double), true)) return -2;
+			b->zeros_frames = want;
 		}
 		b->drain_left -= n;
 		return b->pipe->run(b->zeros.as<double>(), n, static_cast<double *>(d_out), (long) out_stride_frames, st);
@@ -154,8 +156,10 @@ ssize_t dspamd_batch_drain_wire(dspamd_batch *b, ssize_t block_frames, int out_f
 	if (b->drain_left > 0) {
 		const ssize_t n = std::min(block_frames, b->drain_left);
 		if (b->zeros_frames < n) {
-			if (!b->zeros.alloc((size_t) b->pipe->S * block_frames * b->pipe->ch_in * sizeof(double), true)) return -2;
-			b->zeros_frames = block_frames;
+			// (as much silence as one drain call pushes, not a whole block of it: 1 GB instead of 16 at the bench's step)
+			const ssize_t want = std::min(block_frames, b->plan.drain_frames);
+			if (!b->zeros.alloc((size_t) b->pipe->S * want * b->pipe->ch_in * sizeof(double), true)) return -2;
+			b->zeros_frames = want;
 		}
 		b->drain_left -= n;
 		f = b->pipe->run_wire(PCM_DOUBLE, b->zeros.p, 0, n, make_sink(b, out_fmt, dither_prec, d_stats), d_out, (long) out_stride_frames, st, &b->wire_fused);

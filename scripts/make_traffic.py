@@ -4,12 +4,16 @@
 usage: make_traffic.py gpurun_out/<tag> <tag>
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  Corrections (MI355X_MICROARCH.md "HBM", checked in the same run against
 copy_probe_kernel = 1 GiB read + 1 GiB write): FETCH_SIZE under-counts wide contiguous 16 B/lane loads by 2x on gfx950
-(factor taken from the probe); kernels whose loads are 32-byte pieces (the cascade reads half a frame per lane group) are
-taken 1:1 -- with x2 they would exceed what the kernel can request at all.  conv_col_fwd's average is diluted by the
+(factor taken from the probe).  The cascade reads half a 64-byte frame per lane group: as long as the two channel groups of a
+stream ran a dispatch wave apart (up to r02d) those 32-byte requests reached HBM as they were and the counter took them 1:1
+(14.7 GiB raw for 15 GiB read); since the groups are co-scheduled on one XCD (r02e) the L2 merges them into whole-line fetches,
+which the counter under-counts like any wide load: 7.35 GiB raw for the same 15 GiB -- the probe's factor applies (argument
+`cascade_factor`, default: the probe's).  conv_col_fwd's average is diluted by the
 one-pair filter-preparation launch: scaled by launches / (launches - 1)."""
 import json, sys, os
 
 src, tag = sys.argv[1], sys.argv[2]
+cascade_factor = float(sys.argv[3]) if len(sys.argv) > 3 else None
 raw = json.load(open(os.path.join(src, "pmc_hbm.json")))
 bench = json.load(open(os.path.join(src, "bench.json")))
 cfg = bench["config"]
@@ -28,7 +32,7 @@ probe_k, probe = find("copy_probe_kernel")
 fetch_factor = (1 << 20) / probe["FETCH_SIZE"]["per_launch_raw"] if probe else 2.0
 kernels = {}
 spec = {   # bench name -> (rocprof substring, fetch factor, designed bytes)
-    "cascade_rows": ("cascade_rows", 1.0, samples * 16),
+    "cascade_rows": ("cascade_rows", cascade_factor if cascade_factor else fetch_factor, samples * 16),
     "cascade_fast": ("cascade_fast", 1.0, samples * 16),
     "cascade_wave": ("cascade_wave", 1.0, samples * 16),
     "conv_col_fwd": ("conv_col_fwd", fetch_factor, pairs * N * 32),
