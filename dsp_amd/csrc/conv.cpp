@@ -59,7 +59,11 @@ public:
 	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override
 	{
 		(void) out; (void) out_stride; (void) in_fmt; (void) also_in;
-		if (!wire_fusion_on() || !pcm_fusable(fmt) || resampler || nph != 1 || up != 1 || down != 1 || !all_selected || feeds) return false;
+		if (!wire_fusion_on() || !pcm_fusable(fmt) || !all_selected || feeds) return false;
+		// K3 speaks the formats in its plain form and in its two-phase form (the 2x upsampler, at least 3 pairs per stream)
+		const bool plain = !resampler && nph == 1 && up == 1 && down == 1;
+		const bool twice = resampler && nph == 2 && up == 2 && down == 1 && pps >= 3 && !round_f32;
+		if (!plain && !twice) return false;
 		if (fdl && fdl_live && frames % fB == 0 && q_abs % fB == 0) return false;      // the small-call regime writes through conv_fdl
 		return true;
 	}

@@ -309,10 +309,13 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 // that the 16-byte (re, im) = (channel 2q, 2q+1) pieces of one frame leave from adjacent lanes.
 // MODE 0: plain convolution (one phase, output index = input index: the headline path, no index arithmetic beyond an add);
 // MODE 1: any number of phases / up / down; MODE 2: the two interleaved phases of a 2x upsampler -- phase 0 is held in
-// registers and frames 2q, 2q+1 leave together; MODE 3: MODE 0 at the END of a pipeline -- the sink of dsp.c:685-699 (TPDF
-// dither, clip() with its statistics, write_buf_<fmt>) applied in the stores (p.sink, pcm_device.h): a thread's 16 outputs
-// are P N2 frames apart, so it reaches its first sample's place in the two dither sequences by modular exponentiation and
-// the others by multiplying with A^(P N2 C)
+// registers and frames 2q, 2q+1 leave together.
+// At the END of a pipeline run from wire format to wire format (p.sink.on, MODE 0 and 2) the stores go through the sink of
+// dsp.c:685-699 (TPDF dither, clip() with its statistics, write_buf_<fmt>; pcm_device.h): a thread's 16 outputs are P N2 frames
+// apart, so it reaches its first sample's place in the two dither sequences from the byte tables and the others by multiplying
+// with A^(P N2 C).  A run-time branch of the SAME kernel, not an instance of its own: between two instances hipcc's choice of
+// fma against mul + add in the transform differed in the last bit of some outputs, and fused or not a call must give the same
+// samples (138 VGPRs either way; the headline's K3 measured the same 6.4 ms with the branch in place).
 template <int LOG2N1, int PPS, int MODE>
 __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(ConvParams p)
 {
@@ -333,7 +336,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	const int cha = active ? p.pair_out_ch[2 * qs] : -1, chb = active ? p.pair_out_ch[2 * qs + 1] : -1;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
 	cplx *rout = p.ring_out ? p.ring_out + (s * p.pairs_per_stream + qs) * p.ring_out_stride : nullptr;
-	constexpr bool HOLD2 = (MODE == 2), PLAIN = (MODE == 0 || MODE == 3), SINK = (MODE == 3);
+	constexpr bool HOLD2 = (MODE == 2), PLAIN = (MODE == 0);
 	if constexpr (HOLD2) {
 		cplx v0[16], v[16];
 		if (active) {
@@ -350,6 +353,60 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 		col_fft<LOG2N1, PPS, true>(v0, q, t, j, smem_raw, TwCol{ twt });
 		lds_barrier();
 		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
+		if (p.sink.on) {
+			// the 2x upsampler at the END of a pipeline: the sink on the four samples a thread holds per m -- frames mo and mo + 1 of its
+			// pair; from one m to the next the position in the dither sequences moves by 2 P N2 C samples
+			const long f0 = (long) j * p.N2 + n2 - p.first_n, dmo = (long) P * p.N2;
+			const bool dither = p.sink.dither_mult != 0.0;
+			const int bs = (p.sink.fmt == PCM_DOUBLE) ? 8 : (p.sink.fmt == PCM_S16) ? 2 : 4;
+			char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * bs;
+			const bool wpair = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) wout) & 15) == 0);
+			int m_first = 16;
+#pragma unroll
+			for (int m = 15; m >= 0; --m) { const long f = f0 + m * dmo; if (f >= 0 && f < p.in_count) m_first = m; }
+			uint32_t ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0, j0 = 1, j1 = 1, c0 = 1, c1 = 1;
+			if (active && dither && m_first < 16) {
+				const long mo = 2 * (p.q_blk + f0 + m_first * dmo) - p.k_origin;          // may lie before the block: signed exponents
+				const long na = p.sink.samples_before + mo * p.C + (cha >= 0 ? cha : 0) + 1, nb = p.sink.samples_before + mo * p.C + (chb >= 0 ? chb : 0) + 1;
+				ua0 = pm_pow_signed<0>(na); ua1 = pm_pow_signed<1>(na);
+				ub0 = pm_pow_signed<0>(nb); ub1 = pm_pow_signed<1>(nb);
+				j0 = pm_pow<0>((uint64_t) (2 * dmo * p.C)); j1 = pm_pow<1>((uint64_t) (2 * dmo * p.C));
+				c0 = pm_pow<0>((uint64_t) p.C); c1 = pm_pow<1>((uint64_t) p.C);
+			}
+			double peak = 0.0;
+			unsigned long long clipped = 0;
+			if (active) {
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					const long f = f0 + m * dmo;
+					if (f < 0 || f >= p.in_count) continue;
+					const long mo = 2 * (p.q_blk + f) - p.k_origin;
+#pragma unroll
+					for (int ph = 0; ph < 2; ++ph) {
+						const long fo = mo + ph;
+						// the generator values of frame mo + 1 are C samples on
+						const uint32_t a0 = ph ? pm_mul(ua0, c0) : ua0, a1 = ph ? pm_mul(ua1, c1) : ua1, b0 = ph ? pm_mul(ub0, c0) : ub0, b1 = ph ? pm_mul(ub1, c1) : ub1;
+						if (fo < 0 || fo >= p.out_count) continue;
+						double ya = ph ? v[m].x : v0[m].x, yb = ph ? v[m].y : v0[m].y;
+						if (cha >= 0) ya = sink_sample(ya, dither, a0, a1, p.sink.dither_mult, peak, clipped);
+						if (chb >= 0) yb = sink_sample(yb, dither, b0, b1, p.sink.dither_mult, peak, clipped);
+						if (wpair) {
+							char *dst = wout + (fo * p.C + cha) * bs;
+							if (bs == 8) *reinterpret_cast<cplx *>(dst) = make_double2(ya, yb);
+							else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, p.sink.fmt), pcm_to_word(yb, p.sink.fmt));
+							else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+						}
+						else {
+							if (cha >= 0) pcm_store(wout, p.sink.fmt, fo * p.C + cha, ya);
+							if (chb >= 0) pcm_store(wout, p.sink.fmt, fo * p.C + chb, yb);
+						}
+					}
+					if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
+				}
+			}
+			if (p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
+			return;
+		}
 		if (!active) return;
 #pragma unroll
 		for (int m = 0; m < 16; ++m) {
@@ -386,7 +443,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 		}
 		if (ph > 0) lds_barrier();   // the previous phase's exchange has been read by everyone
 		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
-		if constexpr (SINK) {
+		if (PLAIN && p.sink.on) {
 			// window sample of v[m]: f(m) = f0 + m P N2 -> output frame q_blk + f - k_origin; the valid m are a contiguous range
 			const long f0 = (long) j * p.N2 + n2 - p.first_n, dmo = (long) P * p.N2;
 			const long lo = (p.k_origin - p.q_blk > 0) ? p.k_origin - p.q_blk : 0;             // f >= lo  <=>  mo >= 0
@@ -1007,11 +1064,6 @@ template <int L, int PPS> static void launch_col_inv_pps(const ConvParams &p, hi
 			hipLaunchKernelGGL((conv_col_inv<L, PPS, 2>), grid, block, Cfg::LDS, st, p);
 			return;
 		}
-	}
-	if (p.nph == 1 && p.up == 1 && p.down == 1 && p.sink.on) {
-		grant_lds(conv_col_inv<L, PPS, 3>, Cfg::LDS);
-		hipLaunchKernelGGL((conv_col_inv<L, PPS, 3>), grid, block, Cfg::LDS, st, p);
-		return;
 	}
 	if (p.nph == 1 && p.up == 1 && p.down == 1) {
 		grant_lds(conv_col_inv<L, PPS, 0>, Cfg::LDS);

@@ -57,6 +57,15 @@ constexpr PmTables pm_make_tables()
 static __device__ const PmTables PM_TAB = pm_make_tables();
 
 // G = 0: A = 48271, G = 1: A = 16807
+template <int G> __device__ __forceinline__ uint32_t pm_pow(uint64_t e);
+// a signed exponent (A^-k is the inverse in the group): positions computed relative to a frame that lies before the block
+template <int G> __device__ __forceinline__ uint32_t pm_pow_signed(long e)
+{
+	const long m = (long) (PM - 1);
+	long r = e % m;
+	if (r < 0) r += m;
+	return pm_pow<G>((uint64_t) r);
+}
 template <int G> __device__ __forceinline__ uint32_t pm_pow(uint64_t e)
 {
 	const uint32_t r = (uint32_t) (e % (uint64_t) (PM - 1));
@@ -150,7 +159,14 @@ __device__ __forceinline__ uint32_t pcm_to_s16(double x) { return (uint32_t) (ui
 // clip() (dsp.c:673-682) with its peak / clip_count bookkeeping
 __device__ __forceinline__ double sink_sample(double x, bool dither, uint32_t u0, uint32_t u1, double dither_mult, double &peak, unsigned long long &clipped)
 {
-	if (dither) x = x + (double) ((int32_t) u0 - (int32_t) u1) * dither_mult;
+	// two roundings, as the reference's buf[i] + tpdf_noise(mult) has them (util.h:165-172 returns the rounded product): hipcc
+	// fuses a * b + c wherever it is allowed to, and whether it does depends on the calling kernel -- the peak it reports would
+	// differ in the last bit from one kernel to the next
+#pragma clang fp contract(off)
+	if (dither) {
+		const double noise = (double) ((int32_t) u0 - (int32_t) u1) * dither_mult;
+		x = x + noise;
+	}
 	const double a = fabs(x);
 	peak = fmax(peak, a);
 	if (a > 1.0) { ++clipped; x = signbit(x) ? -1.0 : 1.0; }
