@@ -227,6 +227,23 @@ def test_other_first_and_last_kernels(gpu, tmp_path, chain, S, Cn, in_fmt, out_f
     check_bits(bits, bits_want, plan)
 
 
+# ragged calls: whole tiles + a remainder (the generic kernel speaks the formats behind cascade_rows' tiles), calls shorter than a
+# tile (stand-alone passes inside the call), a single frame -- the dither sequences run on through all of them
+@pytest.mark.parametrize("chain_tail", ["", " fir_p -t pcm -e double -c 1 {F}"])
+def test_ragged_calls_keep_the_dither_sequences(gpu, tmp_path, chain_tail):
+    path, _ = write_filter(tmp_path, 900)
+    chain = f"gain 8 {EQ10}" + chain_tail.replace("{F}", path)
+    S, Cn = 128, 8
+    blocks = [4096, 100, 1, 4096, 700, 513, 511]
+    x = wire_input(gpu[2], "s16", S, sum(blocks), Cn, 7)
+    want, wstats, _ = separate_passes(gpu, chain, 48000, Cn, S, x, blocks, "s16", "s16", 16)
+    got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, "s16", "s16", 16)
+    assert same(got, want)
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    out_bit = 2                                                   # cascade_rows (chain of sections) or K3 (convolver last) ...
+    check_bits(bits, [3, 0 if not chain_tail else out_bit, 0 if not chain_tail else out_bit, 3, 3, 3, 0 if not chain_tail else out_bit])
+
+
 # reset: the dither sequences start again
 def test_reset_restarts_the_dither_sequences(gpu):
     dsp_amd, L, torch = gpu
