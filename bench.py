@@ -173,11 +173,15 @@ def main():
         if rank == 0:
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE\n")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; DSP_AMD_BENCH_BACKEND=gloo (a test switch) lets several ranks share the GPUs there are -- the sharding, setup
+    # broadcast, digest gathering and timing reductions run as they do over RCCL, on a box with one GPU
+    backend = os.environ.get("DSP_AMD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     L = dsp_amd.load_library()
-    L.dspamd_set_device(local_rank)
+    L.dspamd_set_device(dev_index)
     from dsp_amd.shard import Job, stream_range
-    job = Job(backend="nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL over xGMI on ROCm
+    job = Job(backend=backend, device=torch.device("cuda", dev_index))   # "nccl" is RCCL over xGMI on ROCm
 
     fs, C = 48000, args.channels
     S_total = args.streams

@@ -39,13 +39,16 @@ class Job:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
         self.dist = None
+        self.backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if self.backend == "gloo":
+            self.device = None              # gloo moves host tensors: the few bytes of setup / digests / timings go through the CPU
         if self.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
                 kw = {}
-                if backend == "nccl" and device is not None:
+                if self.backend == "nccl" and device is not None:
                     kw["device_id"] = device
-                dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), **kw)
+                dist.init_process_group(backend=self.backend, **kw)
             self.dist = dist
 
     def _dev(self):
@@ -87,10 +90,14 @@ class Job:
         if self.dist is None:
             return local
         width = max(stream_range(n_streams, r, self.world)[1] - stream_range(n_streams, r, self.world)[0] for r in range(self.world))
+        home = local.device
+        if self.backend == "gloo":
+            local = local.cpu()
         pad = t.zeros((width, 3), dtype=t.float64, device=local.device)
         pad[: local.shape[0]] = local
         parts = [t.zeros_like(pad) for _ in range(self.world)]
         self.dist.all_gather(parts, pad)
+        parts = [q.to(home) for q in parts]
         rows = []
         for r in range(self.world):
             lo, hi = stream_range(n_streams, r, self.world)

@@ -332,3 +332,26 @@ def test_batch_step_captured_into_a_graph(amd, tmp_path):
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(out, ref[1 + k]), (chain, k)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), with the test switch that lets
+    the ranks share the GPUs there are and talk over gloo: stream sharding, the setup broadcast, digest gathering and the max /
+    sum reductions run exactly as over RCCL; the line must describe the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSP_AMD_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "24", "--block", "16384", "--taps", "4096", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 prints the one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["output_finite"]
+    assert d["digest"]["streams"] == 24                       # every rank's streams are in the gathered digests
+    assert d["config"]["streams"] == 24 and "12/GPU" in d["config"]["parallelism"]
+    assert abs(d["value"] - 24 * 8 * 16384 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) < 1e-6 * d["value"]     # whole-job samples over the max-over-ranks time
