@@ -130,9 +130,12 @@ int dspamd_pcm_write(int fmt, const void *d_in, ssize_t in_stride_frames, void *
  * above at the position the batch has reached (frames written through run_wire / drain_wire since create / reset).
  * d_in: [S][in_stride_frames][C_in] samples of in_fmt (0 = frames); d_out: [S][out_stride_frames][C_out] samples of out_fmt
  * (0 = max_out_frames(frames)); d_stats as for dspamd_pcm_write.  Where the first / last kernel of the plan can, it converts in
- * its own loads / stores -- no separate passes over the block: the biquad cascade kernel on either side, the inverse column
- * transform of a plain convolution on the output side, for s16 / s24 / s32 / float / double -- otherwise the conversion
- * kernels run before / after it on buffers of the batch.  The samples are the same either way, bit for bit.
+ * its own loads / stores -- no separate passes over the block: the biquad cascade kernel on either side (512 channels and more,
+ * identical sections on the channels of a group), a convolver's first kernel on the input side, the inverse column transform of
+ * a plain convolution or of a 2x upsampler on the output side (s16 / s24 / s32 / float / double each), remix and the alignment
+ * delay on either side (every format) -- otherwise the conversion kernels run before / after it on buffers of the batch
+ * (DESIGN.md section 4.6 has the table).  The samples are the same either way, bit for bit; dspamd_batch_wire_fused() says
+ * what the last call did.
  */
 ssize_t dspamd_batch_run_wire(dspamd_batch *, int in_fmt, const void *d_in, ssize_t in_stride_frames, ssize_t frames,
                               int out_fmt, void *d_out, ssize_t out_stride_frames, int dither_prec, void *d_stats, void *stream);
