@@ -387,6 +387,8 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 	if (parts <= 16 && env <= 0) fP1 = (int) parts;            // short enough: the whole filter in the delay line, no tail
 	fD = (long) fP1 * fB;
 	const long n_pairs = (long) S * pps;
+	// conv_fdl addresses a pair's delay-line slots and its ring row with 32-bit byte offsets (buffer descriptors)
+	if ((double) fP1 * n_pairs * fNF * sizeof(double2) >= 2.0e9 || (double) ring_len * sizeof(double2) >= 2.0e9) return true;   // (regime off: one transform per call)
 	if (!fdl_buf.alloc((size_t) fP1 * n_pairs * fNF * sizeof(double2)) || !fdl_H.alloc((size_t) fP1 * fNF * sizeof(double2), false)) return false;
 	std::vector<double2> t;
 	make_twiddles(fNF, fNF, 1, t);

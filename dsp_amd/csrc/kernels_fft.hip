@@ -881,12 +881,37 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 	const double *tail = p.tail ? p.tail + ((size_t) s * p.tail_stride_frames + p.tail_off) * p.C : nullptr;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0) && (!tail || (((size_t) tail) & 15) == 0);
 	const size_t slot_stride = (size_t) p.n_pairs * NF;
+	// Rows of at least 1024 points belong to whole waves (P >= 64): the pair is wave-uniform and every array is addressed as
+	// SGPR base (buffer descriptor) + ONE per-lane offset register + a scalar offset per access.  With plain pointers the 16
+	// strided accesses per array (4 KB and more apart: beyond the instruction's immediate) each hold a 64-bit address pair:
+	// 87 scratch instructions at NF = 4096, two workgroups per CU.
+	constexpr bool BUF = (P >= 64);
+	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+	const long pair_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) ((active ? pair : 0) >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) (active ? pair : 0))) : 0;
+	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
+	const __amdgpu_buffer_rsrc_t r_fdl = __builtin_amdgcn_make_buffer_rsrc(p.fdl + (BUF ? pair_u * NF : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.Hf), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.ring) + (BUF ? pair_u * p.ring_row_stride : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	// (32-bit byte offsets: the host only enters this regime when the delay line of a pair's slots and a ring row stay below 2 GB)
+	const int jb = j * 16;
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (BUF ? (size_t) (pair_u / p.pairs_per_stream) * p.out_stride_frames * p.C : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_tail = __builtin_amdgcn_make_buffer_rsrc(
+		const_cast<double *>(p.tail ? p.tail + ((BUF ? (size_t) (pair_u / p.pairs_per_stream) : 0) * p.tail_stride_frames + p.tail_off) * p.C : p.out), 0, 0x7fffffff, RSRC_FLAGS);
+	const bool out_small = (double) p.out_stride_frames * p.C * 8 < 2.0e9 && (double) p.n_sub * B * p.C * 8 < 2.0e9;
+	const int vo_out = (j * p.C + cha) * 8;
 	__syncthreads();
 	for (int b = 0; b < p.n_sub; ++b) {
 		cplx v[16];
 		const long w0 = p.win_base + (long) b * B;
+		if constexpr (BUF) {
 #pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = active ? ring[(w0 + j + P * m) & p.ring_mask] : make_double2(0.0, 0.0);
+			for (int m = 0; m < 16; ++m)
+				v[m] = active ? __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_ring, (int) ((w0 + j + P * m) & p.ring_mask) * 16, 0, 0)) : make_double2(0.0, 0.0);
+		}
+		else {
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v[m] = active ? ring[(w0 + j + P * m) & p.ring_mask] : make_double2(0.0, 0.0);
+		}
 		if (b > 0) row_sync<WL>();       // the previous sub-block's last gather is done
 		row_fft<LOG2NF, false>(v, j, data, map, tw);
 		if (p.spec_out) {
@@ -897,33 +922,63 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 			return;
 		}
 		const int slot = (p.slot0 + b) % p.P1;
-		cplx *line = p.fdl + (size_t) pair * NF + j;
-		if (active) {
+		if constexpr (BUF) {
+			const int so = (int) ((size_t) slot * slot_stride * 16);
+			if (active) {
 #pragma unroll
-			for (int m = 0; m < 16; ++m) line[(size_t) slot * slot_stride + P * m] = v[m];
+				for (int m = 0; m < 16; ++m) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[m]), r_fdl, jb + so + P * m * 16, 0, 0);
+			}
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_H, jb, P * m * 16, 0)));
+			if (active) {
+				for (int q = 1; q < p.P1; ++q) {
+					const int sl = (slot + p.P1 - q) % p.P1;
+					const int sx = (int) ((size_t) sl * slot_stride * 16), sh = q * NF * 16;
+#pragma unroll
+					for (int half = 0; half < 2; ++half) {
+						cplx x[8];
+#pragma unroll
+						for (int m = 0; m < 8; ++m) x[m] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_fdl, jb, sx + P * (8 * half + m) * 16, 0));
+#pragma unroll
+						for (int m = 0; m < 8; ++m) {
+							const cplx h = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_H, jb, sh + P * (8 * half + m) * 16, 0));
+							cplx &a = v[8 * half + m];
+							a.x = fma(x[m].x, h.x, fma(-x[m].y, h.y, a.x));
+							a.y = fma(x[m].x, h.y, fma(x[m].y, h.x, a.y));
+						}
+					}
+				}
+			}
 		}
-		{
-			const cplx *H = p.Hf + j;
+		else {
+			cplx *line = p.fdl + (size_t) pair * NF + j;
+			if (active) {
 #pragma unroll
-			for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], H[P * m]);
-		}
-		if (active) {
-			for (int q = 1; q < p.P1; ++q) {
-				const int sl = (slot + p.P1 - q) % p.P1;
-				const cplx *X = line + (size_t) sl * slot_stride;
-				const cplx *H = p.Hf + (size_t) q * NF + j;
-				// (eight bins at a time: two workgroups per CU need the kernel inside 256 registers)
+				for (int m = 0; m < 16; ++m) line[(size_t) slot * slot_stride + P * m] = v[m];
+			}
+			{
+				const cplx *H = p.Hf + j;
 #pragma unroll
-				for (int half = 0; half < 2; ++half) {
-					cplx x[8];
+				for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], H[P * m]);
+			}
+			if (active) {
+				for (int q = 1; q < p.P1; ++q) {
+					const int sl = (slot + p.P1 - q) % p.P1;
+					const cplx *X = line + (size_t) sl * slot_stride;
+					const cplx *H = p.Hf + (size_t) q * NF + j;
+					// (eight bins at a time: two workgroups per CU need the kernel inside 256 registers)
 #pragma unroll
-					for (int m = 0; m < 8; ++m) x[m] = X[P * (8 * half + m)];
+					for (int half = 0; half < 2; ++half) {
+						cplx x[8];
 #pragma unroll
-					for (int m = 0; m < 8; ++m) {
-						const cplx h = H[P * (8 * half + m)];
-						cplx &a = v[8 * half + m];
-						a.x = fma(x[m].x, h.x, fma(-x[m].y, h.y, a.x));
-						a.y = fma(x[m].x, h.y, fma(x[m].y, h.x, a.y));
+						for (int m = 0; m < 8; ++m) x[m] = X[P * (8 * half + m)];
+#pragma unroll
+						for (int m = 0; m < 8; ++m) {
+							const cplx h = H[P * (8 * half + m)];
+							cplx &a = v[8 * half + m];
+							a.x = fma(x[m].x, h.x, fma(-x[m].y, h.y, a.x));
+							a.y = fma(x[m].x, h.y, fma(x[m].y, h.x, a.y));
+						}
 					}
 				}
 			}
@@ -936,6 +991,15 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 		for (int m = 8; m < 16; ++m) {
 			const long f = (long) b * B + (j + P * m - B);
 			cplx y = v[m];
+			if constexpr (BUF) {
+				if (wide && out_small) {
+					// frame f = (b - 1) B + j + P m: one per-lane offset (j, the pair's channels), the rest scalar
+					const int so = (int) ((((long) b - 1) * B + P * m) * p.C * 8);
+					if (tail) { const cplx t = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_tail, vo_out, so, 0)); y.x += t.x; y.y += t.y; }
+					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), r_out, vo_out + so, 0, 0);
+					continue;
+				}
+			}
 			if (wide) {
 				if (tail) { const cplx t = *reinterpret_cast<const cplx *>(tail + f * p.C + cha); y.x += t.x; y.y += t.y; }
 				*reinterpret_cast<cplx *>(out + f * p.C + cha) = y;
