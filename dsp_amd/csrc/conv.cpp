@@ -58,11 +58,12 @@ public:
 	// a plain convolution of every channel at the end of a pipeline: K3 applies the sink (dither, clip, wire format) in its stores
 	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override
 	{
-		(void) out; (void) out_stride; (void) in_fmt; (void) also_in;
+		(void) out_stride; (void) in_fmt; (void) also_in;
 		if (!wire_fusion_on() || !pcm_fusable(fmt) || !all_selected || feeds) return false;
 		// K3 speaks the formats in its plain form and in its two-phase form (the 2x upsampler, at least 3 pairs per stream)
 		const bool plain = !resampler && nph == 1 && up == 1 && down == 1;
-		const bool twice = resampler && nph == 2 && up == 2 && down == 1 && pps >= 3 && !round_f32;
+		// (the two-phase form writes whole pairs only: adjacent channels of an aligned slab)
+		const bool twice = resampler && nph == 2 && up == 2 && down == 1 && pps >= 3 && !round_f32 && n_filters == 1 && (ch_in % 2) == 0 && ((((size_t) out) & 15) == 0);
 		if (!plain && !twice) return false;
 		if (fdl && fdl_live && frames % fB == 0 && q_abs % fB == 0) return false;      // the small-call regime writes through conv_fdl
 		return true;

@@ -360,7 +360,6 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 			const bool dither = p.sink.dither_mult != 0.0;
 			const int bs = (p.sink.fmt == PCM_DOUBLE) ? 8 : (p.sink.fmt == PCM_S16) ? 2 : 4;
 			char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * bs;
-			const bool wpair = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) wout) & 15) == 0);
 			int m_first = 16;
 #pragma unroll
 			for (int m = 15; m >= 0; --m) { const long f = f0 + m * dmo; if (f >= 0 && f < p.in_count) m_first = m; }
@@ -381,26 +380,22 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 					const long f = f0 + m * dmo;
 					if (f < 0 || f >= p.in_count) continue;
 					const long mo = 2 * (p.q_blk + f) - p.k_origin;
-#pragma unroll
-					for (int ph = 0; ph < 2; ++ph) {
-						const long fo = mo + ph;
-						// the generator values of frame mo + 1 are C samples on
-						const uint32_t a0 = ph ? pm_mul(ua0, c0) : ua0, a1 = ph ? pm_mul(ua1, c1) : ua1, b0 = ph ? pm_mul(ub0, c0) : ub0, b1 = ph ? pm_mul(ub1, c1) : ub1;
-						if (fo < 0 || fo >= p.out_count) continue;
-						double ya = ph ? v[m].x : v0[m].x, yb = ph ? v[m].y : v0[m].y;
-						if (cha >= 0) ya = sink_sample(ya, dither, a0, a1, p.sink.dither_mult, peak, clipped);
-						if (chb >= 0) yb = sink_sample(yb, dither, b0, b1, p.sink.dither_mult, peak, clipped);
-						if (wpair) {
-							char *dst = wout + (fo * p.C + cha) * bs;
-							if (bs == 8) *reinterpret_cast<cplx *>(dst) = make_double2(ya, yb);
-							else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, p.sink.fmt), pcm_to_word(yb, p.sink.fmt));
-							else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
-						}
-						else {
-							if (cha >= 0) pcm_store(wout, p.sink.fmt, fo * p.C + cha, ya);
-							if (chb >= 0) pcm_store(wout, p.sink.fmt, fo * p.C + chb, yb);
-						}
-					}
+					// (both frames written out by hand: with a loop over the two phases in here the compiler left the loop over m rolled
+					// and moved v0 / v to scratch memory -- for the plain path of this kernel too)
+					auto emit = [&](long fo, double ya, double yb, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+						if (fo < 0 || fo >= p.out_count) return;
+						ya = sink_sample(ya, dither, a0, a1, p.sink.dither_mult, peak, clipped);
+						yb = sink_sample(yb, dither, b0, b1, p.sink.dither_mult, peak, clipped);
+						// (whole pairs only -- the host asks for the sink here only when every pair is two adjacent channels of an
+						// aligned slab: the element-wise stores of the plain form would make this loop too large to be unrolled)
+						char *dst = wout + (fo * p.C + cha) * bs;
+						if (bs == 8) *reinterpret_cast<cplx *>(dst) = make_double2(ya, yb);
+						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, p.sink.fmt), pcm_to_word(yb, p.sink.fmt));
+						else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+					};
+					emit(mo, v0[m].x, v0[m].y, ua0, ua1, ub0, ub1);
+					// the generator values of frame mo + 1 are C samples on
+					emit(mo + 1, v[m].x, v[m].y, dither ? pm_mul(ua0, c0) : 0u, dither ? pm_mul(ua1, c1) : 0u, dither ? pm_mul(ub0, c0) : 0u, dither ? pm_mul(ub1, c1) : 0u);
 					if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
 				}
 			}
