@@ -757,14 +757,14 @@ constexpr int RW_TB = rw_tb_doubles(RW_L);
 // G = 4: rows of 16 x 33 doubles at 0, 528, 1072, 1600;  G = 2: rows of 32 x 33 doubles at 0, 1056  (L = 32)
 template <int G, int ROW = RW_ROW> __device__ __forceinline__ int rw_row_base(int r) { return (G == 4) ? r * ROW + ((r >> 1) << 4) : r * 2 * ROW; }
 
-// WIRE (G = 4, 2): the instance that also speaks the wire formats -- p.in_fmt samples converted in the tile loads (read_buf_<fmt>),
+// WIRE (G = 4, 2; bit 0: input, bit 1: output): the instances that also speak the wire formats -- p.in_fmt samples converted in the tile loads (read_buf_<fmt>),
 // and / or the sink of dsp.c:685-699 (dither, clip, write_buf_<fmt>) applied in the tile stores (p.sink).  The plain fp64
 // instance stays as it is.
 // LL / WPE: frames per lane and waves per SIMD.  16 frames per lane (half the tile registers -- 127 VGPRs -- and half the
 // transposer, constants P^(16 2^k)) at FOUR waves per SIMD was built and measured in round 2: 10.15 against 9.57 ms at the
 // headline shape (8 waves per group; 11.1 with 4, 12.8 at three waves per SIMD with 6) -- the scan is paid per lane, so halving
 // the frames per lane adds 20 % instructions, more than the occupancy gives back.  32 it is.
-template <int G, bool WIRE = false, int LL = RW_L, int WPE = 2>
+template <int G, int WIRE = 0, int LL = RW_L, int WPE = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P, int p2p)
 {
@@ -805,10 +805,11 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	const long n_full = p.frames / TILE;
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
 	// bytes per sample either side: 8 (fp64), 4 (s24 / s32 / float) or 2 (s16)
-	const int in_fmt = WIRE ? p.in_fmt : PCM_DOUBLE, out_fmt = (WIRE && p.sink.on) ? p.sink.fmt : PCM_DOUBLE;
-	const int in_bs = !WIRE ? 8 : (in_fmt == PCM_DOUBLE) ? 8 : (in_fmt == PCM_S16) ? 2 : 4;
-	const int out_bs = !WIRE ? 8 : (out_fmt == PCM_DOUBLE) ? 8 : (out_fmt == PCM_S16) ? 2 : 4;
-	const bool sink_on = WIRE && p.sink.on;
+	constexpr bool WIN = (WIRE & 1) != 0, WOUT = (WIRE & 2) != 0;
+	const int in_fmt = WIN ? p.in_fmt : PCM_DOUBLE, out_fmt = WOUT ? p.sink.fmt : PCM_DOUBLE;
+	const int in_bs = !WIN ? 8 : (in_fmt == PCM_DOUBLE) ? 8 : (in_fmt == PCM_S16) ? 2 : 4;
+	const int out_bs = !WOUT ? 8 : (out_fmt == PCM_DOUBLE) ? 8 : (out_fmt == PCM_S16) ? 2 : 4;
+	const bool sink_on = WOUT;
 	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
 		const_cast<char *>(reinterpret_cast<const char *>(p.in) + ((size_t) s * p.in_stride_frames * p.C + c0) * in_bs), 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
@@ -856,7 +857,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 			uint32_t u0 = 0, u1 = 0, js0 = 1, js1 = 1, jt0 = 1, jt1 = 1;
 			double &peak = sink_peak;
 			unsigned long long &clipped = sink_clipped;
-			if constexpr (WIRE) {
+			if constexpr (WOUT) {
 				if (dither) {
 					// sample n of the stream (interleaved order) uses A^(n + 1): this lane starts at slot 0 of tile w, walks the
 					// slots of a tile FPS frames apart and the tiles of its wave P tiles apart
@@ -868,7 +869,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 			}
 			auto load_raw = [&](long t) {
 				const int tbb = (int) t * tile_bytes;
-				if constexpr (WIRE) {
+				if constexpr (WIN) {
 					// raw[k] holds the slot as it comes: 16 / 8 / 4 bytes of it
 					const int tbi = (int) t * tile_bytes_in;
 					if (in_bs == 8) {
@@ -903,7 +904,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto raw_to_tb = [&]() {
-				if constexpr (WIRE) {
+				if constexpr (WIN) {
 #pragma unroll
 					for (int k = 0; k < K; ++k) {
 						double a = raw[k].x, b = raw[k].y;
@@ -945,7 +946,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto store_out = [&](const double2 (&y)[K], long t_out) {
-				if constexpr (WIRE) {
+				if constexpr (WOUT) {
 					if (sink_on) {
 						// the last kernel of the pipeline: dither, clip and convert on the way out (slab order; no ring behind a sink)
 						const int tbo = (int) t_out * tile_bytes_out;
@@ -1074,7 +1075,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 		if (!p2p) for (; steps < n_steps; ++steps) lds_barrier();
 	}
 	__syncthreads();
-	if constexpr (WIRE) { if (sink_on && p.sink.stats) sink_stats_block(p.sink.stats, s, sink_peak, sink_clipped); }
+	if constexpr (WOUT) { if (p.sink.stats) sink_stats_block(p.sink.stats, s, sink_peak, sink_clipped); }
 	for (int i = tid; i < n_st; i += nth) gstate[i] = st[i];
 }
 
@@ -1091,16 +1092,21 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	static const int p2p_env = [] { const char *e = getenv("DSP_AMD_CASCADE_P2P"); return e ? atoi(e) : -1; }();
 	const int p2p = (p2p_env >= 0) ? p2p_env : (n_full / P >= 16 ? 1 : 0);
 	dim3 grid(n_streams, p.C / G), block(64 * P);
-	if (p.in_fmt != PCM_DOUBLE || p.sink.on) {
+	const int wire = (p.in_fmt != PCM_DOUBLE ? 1 : 0) | (p.sink.on ? 2 : 0);
+	if (wire) {
 		if constexpr (G >= 2) {
-			grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G, true>), lds);
-			hipLaunchKernelGGL((cascade_rows<G, true>), grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
+			// (an instance per end: the one that only reads a wire format -- the headline's file -> file run -- does not carry the sink)
+			auto go = [&](auto kernel) {
+				grant_dynamic_lds(reinterpret_cast<const void *>(kernel), lds);
+				hipLaunchKernelGGL(kernel, grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
+			};
+			if (wire == 1) go(cascade_rows<G, 1>); else if (wire == 2) go(cascade_rows<G, 2>); else go(cascade_rows<G, 3>);
 			return n_full * TILE;
 		}
 		return 0;
 	}
-	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G, false>), lds);
-	hipLaunchKernelGGL((cascade_rows<G, false>), grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G, 0>), lds);
+	hipLaunchKernelGGL((cascade_rows<G, 0>), grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
 	return n_full * TILE;
 }
 
