@@ -810,6 +810,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	const int in_bs = !WIN ? 8 : (in_fmt == PCM_DOUBLE) ? 8 : (in_fmt == PCM_S16) ? 2 : 4;
 	const int out_bs = !WOUT ? 8 : (out_fmt == PCM_DOUBLE) ? 8 : (out_fmt == PCM_S16) ? 2 : 4;
 	const bool sink_on = WOUT;
+	const WordFormat wf_in = word_format(in_fmt), wf_out = word_format(out_fmt);
 	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
 		const_cast<char *>(reinterpret_cast<const char *>(p.in) + ((size_t) s * p.in_stride_frames * p.C + c0) * in_bs), 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
@@ -905,15 +906,24 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 			};
 			auto raw_to_tb = [&]() {
 				if constexpr (WIN) {
+					// (one loop per sample size, the format of the 4-byte ones folded into constants: no branch per value)
+					if (in_bs == 8) {
 #pragma unroll
-					for (int k = 0; k < K; ++k) {
-						double a = raw[k].x, b = raw[k].y;
-						if (in_bs != 8) {
+						for (int k = 0; k < K; ++k) { tb_slab[SLAB_K * k] = raw[k].x; tb_slab[SLAB_K * k + PARTNER] = raw[k].y; }
+					}
+					else if (in_bs == 4) {
+#pragma unroll
+						for (int k = 0; k < K; ++k) {
 							const u32x2 v = __builtin_bit_cast(u32x2, raw[k].x);
-							if (in_bs == 4) { a = pcm_from_word(v.x, in_fmt); b = pcm_from_word(v.y, in_fmt); }
-							else { a = pcm_from_s16(v.x & 0xffffu); b = pcm_from_s16(v.x >> 16); }
+							tb_slab[SLAB_K * k] = pcm_from_word(v.x, wf_in); tb_slab[SLAB_K * k + PARTNER] = pcm_from_word(v.y, wf_in);
 						}
-						tb_slab[SLAB_K * k] = a; tb_slab[SLAB_K * k + PARTNER] = b;
+					}
+					else {
+#pragma unroll
+						for (int k = 0; k < K; ++k) {
+							const u32x2 v = __builtin_bit_cast(u32x2, raw[k].x);
+							tb_slab[SLAB_K * k] = pcm_from_s16(v.x & 0xffffu); tb_slab[SLAB_K * k + PARTNER] = pcm_from_s16(v.x >> 16);
+						}
 					}
 				}
 				else if constexpr (G == 1) {
@@ -959,7 +969,7 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 							if (dither) { u0 = pm_mul(u0, js0); u1 = pm_mul(u1, js1); }
 							if (out_bs == 8) rw_store_b128(rw_as_u4(make_double2(a, b)), r_out, vo_out, tbo + k * so_out);
 							else if (out_bs == 4) {
-								const u32x2 v = { pcm_to_word(a, out_fmt), pcm_to_word(b, out_fmt) };
+								const u32x2 v = { pcm_to_word(a, wf_out), pcm_to_word(b, wf_out) };
 								__builtin_amdgcn_raw_buffer_store_b64(v, r_out, vo_out + tbo + k * so_out, 0, 0);
 							}
 							else __builtin_amdgcn_raw_buffer_store_b32(pcm_to_s16(a) | (pcm_to_s16(b) << 16), r_out, vo_out + tbo + k * so_out, 0, 0);

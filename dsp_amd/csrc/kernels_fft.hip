@@ -268,6 +268,7 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 		cplx *ringw = const_cast<cplx *>(src);
 		const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
 		const int bs = !WIRE ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
+		const WordFormat wf_slab = word_format(p.slab_fmt);
 		const char *wslab = reinterpret_cast<const char *>(p.slab) + (((size_t) s * p.slab_stride_frames + p.slab_frame0) * p.C + 2 * qs) * bs;
 		const cplx *slab = reinterpret_cast<const cplx *>(wslab);
 		const long hp = p.C >> 1;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 			else if (fr + p.slab_frame0 >= 0) {
 				if constexpr (WIRE) {
 					const char *e = wslab + fr * p.C * bs;
-					if (bs == 4) { const uint2 w = *reinterpret_cast<const uint2 *>(e); v[m] = make_double2(pcm_from_word(w.x, p.slab_fmt), pcm_from_word(w.y, p.slab_fmt)); }
+					if (bs == 4) { const uint2 w = *reinterpret_cast<const uint2 *>(e); v[m] = make_double2(pcm_from_word(w.x, wf_slab), pcm_from_word(w.y, wf_slab)); }
 					else { const uint32_t w = *reinterpret_cast<const uint32_t *>(e); v[m] = make_double2(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16)); }
 				}
 				else v[m] = slab[fr * hp];        // (never non-temporal: the frames of a slab are read by the workgroups of all its pairs)
@@ -337,6 +338,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
 	cplx *rout = p.ring_out ? p.ring_out + (s * p.pairs_per_stream + qs) * p.ring_out_stride : nullptr;
 	constexpr bool HOLD2 = (MODE == 2), PLAIN = (MODE == 0);
+	const WordFormat wf_sink = word_format(p.sink.fmt);
 	if constexpr (HOLD2) {
 		cplx v0[16], v[16];
 		if (active) {
@@ -390,7 +392,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 						// aligned slab: the element-wise stores of the plain form would make this loop too large to be unrolled)
 						char *dst = wout + (fo * p.C + cha) * bs;
 						if (bs == 8) *reinterpret_cast<cplx *>(dst) = make_double2(ya, yb);
-						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, p.sink.fmt), pcm_to_word(yb, p.sink.fmt));
+						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, wf_sink), pcm_to_word(yb, wf_sink));
 						else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
 					};
 					emit(mo, v0[m].x, v0[m].y, ua0, ua1, ub0, ub1);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 					if (wpair) {
 						char *dst = wout + (mo * p.C + cha) * bs;
 						if (bs == 8) st16(reinterpret_cast<cplx *>(dst), make_double2(ya, yb), p.nt & 32);
-						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, p.sink.fmt), pcm_to_word(yb, p.sink.fmt));
+						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, wf_sink), pcm_to_word(yb, wf_sink));
 						else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
 					}
 					else {

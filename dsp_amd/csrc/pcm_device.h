@@ -98,20 +98,47 @@ __device__ __forceinline__ double pcm_load(const void *in, int fmt, long i)
 	}
 }
 
-// one 32-bit word of a 4-byte format -> sample (the same operations as pcm_load)
-__device__ __forceinline__ double pcm_from_word(uint32_t w, int fmt)
+__device__ __forceinline__ double quant_bf(double x, double scale, double maxv)
 {
-	switch (fmt) {
-	case PCM_S24: {
-		int32_t x = (int32_t) w;
-		x = (x & 0x800000) ? (x | ~0x7fffff) : x;
-		return (double) x / 8388608.0;
-	}
-	case PCM_S32: return (double) (int32_t) w / 2147483648.0;
-	default: return (double) __uint_as_float(w);             // PCM_FLOAT
-	}
+	const double v = x * scale;
+	return (v > maxv) ? maxv : rint(v);               // (a select: both arms are plain values)
 }
+
 __device__ __forceinline__ double pcm_from_s16(uint32_t h) { return (double) (int16_t) (uint16_t) h / 32768.0; }
+
+// The same conversions of the 4-byte formats WITHOUT a branch per value: inside the unrolled tile loops of the kernels that
+// convert in their own loads / stores a switch on the (wave-uniform) format became a scalar compare-and-branch per sample -- 15 %
+// of the cascade's time with float input.  The format is folded into constants once per kernel: the integer formats differ in
+// a mask (sign extension of s24) and a power of two, float in which of two results is kept (a bit mask, not a select).
+struct WordFormat {
+	uint32_t ext_mask;         // s24: the bits S24_SIGN_EXTEND sets when bit 23 is (sampleconv.h), else 0
+	double inv_scale, scale, maxv;
+	uint32_t float_mask;       // all ones for float
+};
+__device__ __forceinline__ WordFormat word_format(int fmt)
+{
+	WordFormat f;
+	f.ext_mask = (fmt == PCM_S24) ? 0xff800000u : 0u;
+	f.scale = (fmt == PCM_S24) ? 8388608.0 : 2147483648.0;
+	f.maxv = (fmt == PCM_S24) ? 8388607.0 : 2147483647.0;
+	f.inv_scale = 1.0 / f.scale;                     // exact: a power of two
+	f.float_mask = (fmt == PCM_FLOAT) ? 0xffffffffu : 0u;
+	return f;
+}
+__device__ __forceinline__ double pcm_from_word(uint32_t w, const WordFormat &f)
+{
+	const uint32_t x = w | ((0u - ((w >> 23) & 1u)) & f.ext_mask);      // (x & 0x800000) ? x | ~0x7fffff : x  -- the upper byte stays as it is otherwise
+	const double vi = (double) (int32_t) x * f.inv_scale;               // == (double) x / scale
+	const double vf = (double) __uint_as_float(w);
+	const unsigned long long m = ((unsigned long long) f.float_mask << 32) | f.float_mask;
+	return __longlong_as_double((long long) ((((unsigned long long) __double_as_longlong(vf)) & m) | (((unsigned long long) __double_as_longlong(vi)) & ~m)));
+}
+__device__ __forceinline__ uint32_t pcm_to_word(double x, const WordFormat &f)
+{
+	const uint32_t wi = (uint32_t) (int32_t) quant_bf(x, f.scale, f.maxv);
+	const uint32_t wf = __float_as_uint((float) x);
+	return (wf & f.float_mask) | (wi & ~f.float_mask);
+}
 
 // SAMPLE_TO_<fmt> with BIT_PERFECT = 1 (sampleconv.h:35-41): saturate at the positive end, nearbyint elsewhere
 // (round-half-even: the default rounding mode; negative overflow cannot occur after clip())
@@ -144,15 +171,7 @@ __device__ __forceinline__ void pcm_store(void *out, int fmt, long i, double x)
 	}
 }
 
-// sample -> the 32-bit word of a 4-byte format / the 16 bits of S16 (the same operations as pcm_store)
-__device__ __forceinline__ uint32_t pcm_to_word(double x, int fmt)
-{
-	switch (fmt) {
-	case PCM_S24: return (uint32_t) (int32_t) quant(x, 8388608.0, 8388607.0);
-	case PCM_S32: return (uint32_t) (int32_t) quant(x, 2147483648.0, 2147483647.0);
-	default: return __float_as_uint((float) x);              // PCM_FLOAT
-	}
-}
+// sample -> the 16 bits of S16 (the same operations as pcm_store)
 __device__ __forceinline__ uint32_t pcm_to_s16(double x) { return (uint32_t) (uint16_t) (int16_t) quant(x, 32768.0, 32767.0); }
 
 // the sink of dsp.c:685-699 for one sample: [+ tpdf_noise (util.h:165-172) from the generator values u0, u1 of this sample],
