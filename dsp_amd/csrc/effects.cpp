@@ -947,7 +947,56 @@ SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, con
 	ssize_t T;
 	if (!read_filter(name, is, sel, dir, o, argv[g.ind], data, &fch, &T)) return nullptr;
 	const ssize_t ref = filter_offset(o, data, T);
-	return make_fir_spec(name, is, sel, data.data(), fch, T, ref, partitioned ? CONV_ZERO_LATENCY : CONV_LATENCY_LEN, 0, 0);
+	SpecPtr s = make_fir_spec(name, is, sel, data.data(), fch, T, ref, partitioned ? CONV_ZERO_LATENCY : CONV_LATENCY_LEN, 0, 0);
+	if (s) s->max_part_len = max_part_len;
+	return s;
+}
+
+// How many filter terms the reference's fir_p carries: 32 direct taps, then up to four groups of equal partitions whose
+// length grows by a step of 4 (8, 16 ... when four groups do not reach), each group covering the filter up to `step` (x2 when
+// the group runs on a worker thread: filters of 4096 taps and more) times its partition length, the last group taking
+// the rest; then groups trade partitions for doubled lengths where that saves transforms (fir_p.c:242-289).  The GPU engine
+// plans its own transforms; this only fixes how many zero-padded terms `plot` prints.
+ssize_t fir_p_planned_len(ssize_t T, long max_part_len)
+{
+	if (T <= 32) return T;
+	const long cap = max_part_len ? max_part_len : (1L << 14);
+	const long reach = (T < 4096) ? 1 : 2;
+	struct Grp { long len, n; };
+	std::vector<Grp> grp;
+	for (long step = 4;; step *= 2) {
+		grp.clear();
+		bool fits = true;
+		long len = 32;
+		ssize_t covered = 32;
+		while (covered < T) {
+			if (grp.size() == 4) { fits = false; break; }
+			Grp g = { len, 1 };
+			covered += len;
+			while (covered < T && covered < len * step * reach) { ++g.n; covered += len; }
+			const long next = len * step;
+			const bool last = next > cap || covered + next * step > T;
+			if (last) while (covered < T) { ++g.n; covered += len; }
+			grp.push_back(g);
+			if (last) break;
+			len = next;
+		}
+		if (fits) break;
+	}
+	for (size_t k = grp.size(); k-- > 1;) {
+		Grp &g = grp[k], &before = grp[k - 1];
+		while (g.len * 2 <= cap) {
+			const long grown = before.n + g.len * reach / before.len;
+			if (g.n <= grown) break;
+			before.n = grown;
+			g.len *= 2;
+			g.n -= reach;
+			g.n = g.n / 2 + (g.n & 1);
+		}
+	}
+	ssize_t total = 32;
+	for (const Grp &g : grp) total += (ssize_t) g.len * g.n;
+	return total;
 }
 
 SpecPtr parse_zita(const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
@@ -1121,12 +1170,13 @@ bool riir_prepare(Spec &sp)
 	const int n = sp.ch_in;
 	std::vector<std::vector<double>> h(n);
 	sp.ch_latency.assign(n, 0);
+	sp.riir_plot.assign(n, std::string());
 	ssize_t T = 0;
 	int nsel = 0;
 	for (int k = 0; k < n; ++k) {
 		sp.sel[k] = sp.riir[k].empty() ? 0 : 1;
 		if (!sp.sel[k]) continue;
-		if (!riir_design(sp.name.c_str(), k, sp.riir[k], h[k], &sp.ch_latency[k])) return false;
+		if (!riir_design(sp.name.c_str(), k, sp.riir[k], h[k], &sp.ch_latency[k], &sp.riir_plot[k])) return false;
 		T = std::max<ssize_t>(T, (ssize_t) h[k].size());
 		++nsel;
 	}

@@ -68,6 +68,8 @@ struct Spec {
 	std::vector<std::vector<RiirSec>> riir;  // [ch_in]; non-empty = a reverse-IIR effect
 	bool riir_pending = false;
 	std::vector<ssize_t> ch_latency;         // [ch_in] when the channels' delays differ (reverse IIR)
+	std::vector<std::string> riir_plot;      // [ch_in] transfer function of the designed channel in gnuplot notation (for e->plot)
+	long max_part_len = 0;                   // fir_p: the host's partition-length cap -- only the number of terms `plot` prints depends on it
 
 	int rs_n = 1, rs_d = 1, rs_m = 0;        // Resample: ratio n/d, prototype order m
 	double rs_fc = 0.0;
@@ -107,10 +109,13 @@ void hilbert_design(ssize_t taps, double angle_rad, std::vector<double> &h);
 
 // reverse_iir.cpp
 void riir_sec_from_biquad(const std::array<double, 5> &c, double thresh, RiirSec *s);
-bool riir_design(const char *name, int channel, std::vector<RiirSec> secs, std::vector<double> &taps, ssize_t *latency);
+bool riir_design(const char *name, int channel, std::vector<RiirSec> secs, std::vector<double> &taps, ssize_t *latency, std::string *plot = nullptr);
 bool riir_prepare(Spec &sp);   // the effect's prepare(): section lists -> per-channel FIRs
 SpecPtr make_frac_delay_spec(const char *name, const stream_info *is, const char *sel, double samples_frac, int fd_ap_n, bool *noop);
 bool delay_prepare(Spec &sp, bool *noop);   // delay.c:149-204: integer part + Thiran all-pass section per channel
+
+// number of filter terms the reference's fir_p prints in its plot (32 direct taps + the zero-padded partition groups, fir_p.c:242-289)
+ssize_t fir_p_planned_len(ssize_t T, long max_part_len);
 
 const effect_info *registry_lookup(const char *name);
 const effect_info *registry_table(int *n);

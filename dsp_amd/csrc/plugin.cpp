@@ -153,6 +153,7 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	}
 	Segment &sg = *n->seg;
 	if (e != sg.members.front()) return ibuf;      // the head already produced the segment's output into this buffer
+	sg.touched = true;
 	sample_t *dst = sg.in_place ? ibuf : obuf;
 	ssize_t done = 0, produced = 0;
 	const ssize_t total = *frames;
@@ -214,9 +215,12 @@ static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1
 static void plugin_reset(struct effect *e)
 {
 	Node *n = node_of(e);
-	if (n && n->seg && n->seg->pipe && e == n->seg->members.front()) {
+	// stateless effects carry no reset callback (gain.c, remix.c, st2ms.c set none) and may head a segment: whichever
+	// member with state the host resets first clears the whole segment, the others find it clean
+	if (n && n->seg && n->seg->pipe && n->seg->touched) {
 		n->seg->pipe->reset(nullptr);
 		(void) hipStreamSynchronize(nullptr);
+		n->seg->touched = false;
 	}
 }
 
@@ -299,15 +303,97 @@ static void plugin_channel_deps(struct effect *e, char **deps)
 		memcpy(deps[k], n->spec->remix[k].data(), n->spec->ch_in);                              // remix.c:116-121
 }
 
+#define BQ_PLOT_FMT "%.15e+%.15e*exp(-j*w)+%.15e*exp(-2.0*j*w))/(1.0+%.15e*exp(-j*w)+%.15e*exp(-2.0*j*w)"   /* biquad.h:94 */
+#define BQ_PLOT_ARGS(c) (c)[0], (c)[1], (c)[2], (c)[3], (c)[4]
+
+// one FIR channel the way fir.c:72-89 / :163-178 / fir_p.c:209-233 print it: the reference walks its zero-padded working
+// length (a power of two, the FFT length, 32 + the partition groups), so the same number of terms is printed here
+static void plot_fir_channel(const Spec &sp, int k, int i, int f)
+{
+	ssize_t terms = sp.T;
+	if (sp.riir.empty()) {
+		if (sp.kind == Kind::FirDirect) { terms = 1; while (terms < sp.T) terms <<= 1; }           // fir.c:253-255
+		else if (sp.conv_mode == CONV_LATENCY_LEN) terms = next_fast_fftw_len(sp.T);              // fir.c:296
+		else terms = fir_p_planned_len(sp.T, sp.max_part_len);
+	}
+	printf("H%d_%d(w)=(abs(w)<=pi)?exp(-j*w*%zd)*(0.0", k, i, -sp.ref);
+	for (ssize_t n = 0; n < terms; ++n)
+		printf("+exp(-j*w*%zd)*%.15e", n, n < sp.T ? sp.taps[(size_t) n * sp.fch + f] : 0.0);
+	puts("):0/0");
+}
+
 static void plugin_plot(struct effect *e, int i)
 {
 	Node *n = node_of(e);
 	if (!n) return;
 	const Spec &sp = *n->spec;
+	const int fs = sp.fs_out;
+	switch (sp.kind) {
+	case Kind::Remix:                                                     // remix.c:103-114
+		for (int k = 0; k < sp.ch_out; ++k) {
+			printf("H%d_%d(w)=0.0", k, i);
+			for (int c = 0; c < sp.ch_in; ++c)
+				if (sp.remix[k][c]) printf("+Ht%d_%d(w*%d/2.0/pi)", c, i, fs);
+			putchar('\n');
+		}
+		return;
+	case Kind::Mix: {                                                     // st2ms.c:56-70: the pair is the two selected channels
+		int c0 = -1, c1 = -1;
+		for (int k = 0; k < sp.ch_in; ++k) if (sp.sel[k]) { if (c0 < 0) c0 = k; else if (c1 < 0) c1 = k; }
+		const double scale = (sp.name == "ms2st") ? 1.0 : 0.5;
+		for (int k = 0; k < sp.ch_out; ++k) {
+			if (k == c0 || k == c1)
+				printf("H%d_%d(w)=(Ht%d_%d(w*%d/2.0/pi)%cHt%d_%d(w*%d/2.0/pi))*%g\n", k, i, c0, i, fs, k == c0 ? '+' : '-', c1, i, fs, scale);
+			else printf("H%d_%d(w)=Ht%d_%d(w*%d/2.0/pi)\n", k, i, k, i, fs);
+		}
+		return;
+	}
+	case Kind::Crossfeed:                                                 // crossfeed.c:61-83
+		for (int k = 0; k < sp.ch_out; ++k) {
+			if (k == sp.xf_c0 || k == sp.xf_c1) {
+				const int other = (k == sp.xf_c0) ? sp.xf_c1 : sp.xf_c0;
+				printf("H%d_%d(w)=(abs(w)<=pi)?%.15e*Ht%d_%d(w*%d/2.0/pi)", k, i, sp.xf_direct, k, i, fs);
+				printf("+%.15e*Ht%d_%d(w*%d/2.0/pi)*(" BQ_PLOT_FMT ")", sp.xf_cross, other, i, fs, BQ_PLOT_ARGS(sp.xf_lp));
+				printf("+%.15e*Ht%d_%d(w*%d/2.0/pi)*(" BQ_PLOT_FMT ")", sp.xf_cross, k, i, fs, BQ_PLOT_ARGS(sp.xf_hp));
+				puts(":0/0");
+			}
+			else printf("H%d_%d(w)=Ht%d_%d(w*%d/2.0/pi)\n", k, i, k, i, fs);
+		}
+		return;
+	case Kind::Align: case Kind::Add:                                     // effect_plot_noop (effect.c:98-102; align.c:121, gain.c:122)
+		for (int k = 0; k < sp.ch_in; ++k) printf("H%d_%d(f)=1.0\n", k, i);
+		return;
+	case Kind::FirDirect: case Kind::Conv: {
+		int f = 0;
+		for (int k = 0; k < sp.ch_out; ++k) {
+			if (!sp.sel[k]) { printf("H%d_%d(w)=1.0\n", k, i); continue; }
+			if (!sp.riir.empty()) {
+				// reverse_iir.c:178-212: the pole / residue form of the designed channel (the host calls prepare() first; a
+				// channel still waiting for its design is printed from nothing better than the identity)
+				if (k < (int) sp.riir_plot.size() && !sp.riir_plot[k].empty())
+					printf("H%d_%d(w)=(abs(w)<=pi)?1.0%s*exp(%zd*j*w):0/0\n", k, i, sp.riir_plot[k].c_str(), sp.ch_latency[k]);
+				else printf("H%d_%d(w)=1.0\n", k, i);
+			}
+			else plot_fir_channel(sp, k, i, sp.fch > 1 ? f : 0);
+			++f;
+		}
+		return;
+	}
+	default: break;
+	}
 	for (int k = 0; k < sp.ch_out; ++k) {
-		if (sp.kind == Kind::Biquad && sp.sel[k])   // biquad.h:94-95, biquad.c:325-336
-			printf("H%d_%d(w)=(abs(w)<=pi)?(%.15e+%.15e*exp(-j*w)+%.15e*exp(-2.0*j*w))/(1.0+%.15e*exp(-j*w)+%.15e*exp(-2.0*j*w)):0/0\n",
-				k, i, sp.bq[k][0], sp.bq[k][1], sp.bq[k][2], sp.bq[k][3], sp.bq[k][4]);
+		if (sp.kind == Kind::Biquad && sp.frac_delay) {                   // delay.c:84-104 (orders above 2: the same all-pass as a product of sections)
+			printf("H%d_%d(w)=exp(-j*w*%zd)", k, i, sp.delay[k]);
+			if (sp.sel[k]) {
+				printf("*((abs(w)<=pi)?(" BQ_PLOT_FMT ")", BQ_PLOT_ARGS(sp.bq[k]));
+				for (size_t m = 0; m < sp.bq_more.size(); ++m)
+					if (sp.sel_more[m][k]) printf("*(" BQ_PLOT_FMT ")", BQ_PLOT_ARGS(sp.bq_more[m][k]));
+				printf(":0/0)");
+			}
+			putchar('\n');
+		}
+		else if (sp.kind == Kind::Biquad && sp.sel[k])                    // biquad.c:325-336
+			printf("H%d_%d(w)=(abs(w)<=pi)?(" BQ_PLOT_FMT "):0/0\n", k, i, BQ_PLOT_ARGS(sp.bq[k]));
 		else if (sp.kind == Kind::Gain) printf("H%d_%d(w)=%.15e\n", k, i, sp.vec[k]);           // gain.c:45-50
 		else if (sp.kind == Kind::Delay) printf("H%d_%d(w)=exp(-j*w*%zd)\n", k, i, sp.delay[k]);
 		else printf("H%d_%d(w)=1.0\n", k, i);
@@ -329,17 +415,18 @@ struct effect *make_effect(SpecPtr spec, bool noop)
 	e->data = n;
 	if (!noop) {
 		e->run = (sp.kind == Kind::Delay) ? plugin_run_noop : plugin_run;
-		e->reset = plugin_reset;
+		// reset only where the reference's effect has one (gain.c / remix.c / st2ms.c: none)
+		if (sp.kind != Kind::Gain && sp.kind != Kind::Add && sp.kind != Kind::Remix && sp.kind != Kind::Mix) e->reset = plugin_reset;
 		switch (sp.kind) {
 		case Kind::Gain: case Kind::Add: e->merge = plugin_merge; e->plot = plugin_plot; break;
 		case Kind::Biquad: e->merge = plugin_merge; e->plot = plugin_plot; break;
 		case Kind::Delay: e->merge = plugin_merge; e->plot = plugin_plot; e->channel_offsets = plugin_channel_offsets; e->prepare = plugin_prepare; break;
 		case Kind::Align: e->drain_samples = plugin_drain_samples; e->plot = plugin_plot; break;
-		case Kind::Remix: e->channel_deps = plugin_channel_deps; break;
-		case Kind::Mix: case Kind::Crossfeed: e->channel_deps = plugin_channel_deps; e->plot = plugin_plot; break;
+		case Kind::Remix: case Kind::Mix: case Kind::Crossfeed: e->channel_deps = plugin_channel_deps; e->plot = plugin_plot; break;
 		case Kind::FirDirect: case Kind::Conv:
 			e->drain_samples = plugin_drain_samples;
 			e->channel_offsets = plugin_channel_offsets;
+			if (sp.conv_mode != CONV_ZITA_EQUIV) e->plot = plugin_plot;       // zita_convolver.cpp sets none
 			if (sp.riir_pending) { e->merge = plugin_merge; e->prepare = plugin_prepare; }
 			break;
 		case Kind::Resample: e->drain2 = plugin_drain2; break;
@@ -465,8 +552,8 @@ struct effect *fir_effect_init_with_filter(const struct effect_info *ei, const s
 struct effect *fir_p_effect_init_with_filter(const struct effect_info *ei, const struct stream_info *is, const char *sel, sample_t *filter_data,
 	int filter_channels, ssize_t filter_frames, ssize_t ref, int max_part_len)
 {
-	(void) max_part_len;
 	SpecPtr s = make_fir_spec(ei->name, is, sel, filter_data, filter_channels, filter_frames, ref, CONV_ZERO_LATENCY, 0, 0);
+	if (s) s->max_part_len = max_part_len;
 	return s ? make_effect(std::move(s), false) : nullptr;
 }
 

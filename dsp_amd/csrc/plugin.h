@@ -19,6 +19,7 @@ struct Segment {
 	ssize_t pipe_frames = 0, out_cap_frames = 0;
 	int ch_in = 0, ch_out = 0;
 	bool in_place = true;
+	bool touched = false;                    // frames have gone through since the last reset
 	DevBuf d_in, d_out;
 	MappedPair mapped;                       // staging for small blocks (engine.h)
 	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the

@@ -15,7 +15,10 @@
 #include <cmath>
 #include <complex>
 #include <cfloat>
+#include <cstdarg>
+#include <cstdio>
 #include <cstring>
+#include <string>
 
 namespace dspamd {
 
@@ -128,7 +131,18 @@ static cd csquare(cd a)
 struct RiirStateFir { std::vector<long double> h; };    // equivalent FIR of one riir_state
 
 // The reference's per-channel prepare (reverse_iir.c:381-636), producing the equivalent FIR instead of comb stages.
-bool riir_design(const char *name, int channel, std::vector<RiirSec> v, std::vector<double> &taps, ssize_t *latency)
+static void appendf(std::string &s, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static void appendf(std::string &s, const char *fmt, ...)
+{
+	char buf[256];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	s += buf;
+}
+
+bool riir_design(const char *name, int channel, std::vector<RiirSec> v, std::vector<double> &taps, ssize_t *latency, std::string *plot)
 {
 	std::vector<RiirSec> cascade;
 	// sections with a repeated real pole are split, the second copy goes to a series state (:394-411)
@@ -276,6 +290,31 @@ bool riir_design(const char *name, int channel, std::vector<RiirSec> v, std::vec
 		for (int m = 0; m < fir_n; ++m) st.h[(size_t) L + m] += (long double) fir_c[m];
 		if (fir_n == 0) st.h.resize((size_t) L);
 		states.push_back(std::move(st));
+		if (plot) {
+			// the transfer function of this series state in the reference's gnuplot notation (reverse_iir.c:178-212): the FIR
+			// part behind its 2^N delay, then every pole as residue * prod_j (p^(2^j) + z^(-2^j))
+			std::string &o = *plot;
+			o += "*(0";
+			if (fir_n > 0) {
+				appendf(o, "+(%.15e", fir_c[0]);
+				for (int m = 1; m < fir_n; ++m) appendf(o, "+%.15e*exp(-%d*j*w)", fir_c[m], m);
+				appendf(o, ")*exp(-2**%ld*j*w)", N);
+			}
+			for (const RiirSec &sec : v) {
+				if (sec.pt == RIIR_CC) {
+					for (int half = 0; half < 2; ++half) {
+						const double sg = half ? -1.0 : 1.0;
+						appendf(o, "+{%.15e,%.15e}", sec.rc_re, sg * sec.rc_im);
+						for (long jj = 0; jj < N; ++jj) appendf(o, "*({%.15e,%.15e}**(2**%ld)+exp(-2**%ld*j*w))", sec.pc_re, sg * sec.pc_im, jj, jj);
+					}
+				}
+				else for (int l = 0; l < pq_n_eval(sec.pt); ++l) {
+					appendf(o, "+%.15e", sec.rr[l]);
+					for (long jj = 0; jj < N; ++jj) appendf(o, "*((%.15e)**(2**%ld)+exp(-2**%ld*j*w))", sec.pr[l], jj, jj);
+				}
+			}
+			o += ")";
+		}
 		*latency += L + fir_n - 1;                                 // reverse_iir.c:623-625
 		if (cascade.empty()) break;
 		v.swap(cascade);
