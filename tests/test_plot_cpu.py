@@ -1,0 +1,141 @@
+"""CPU-only: `plot` (effect.h:51, effects_chain.c:1124-1190).  `dsp -p` needs no device: the unmodified reference CLI linked
+against libdsp_amd.so (oracle/_ref/dsp_gpu) prints a gnuplot script from this library's `plot` callbacks, the stock CLI
+(oracle/_ref/dsp_ref) prints the reference's.  Both scripts are parsed into Python functions and the channel transfer functions
+Ht<k>(f) are compared at a grid of frequencies; where the reference prints stored numbers (biquad, gain, direct FIR, remix,
+st2ms, crossfeed, integer delay) the text itself must be identical.  The reference's FFT forms of fir / fir_p print their
+taps after a transform round trip (fir.c:163-178, fir_p.c:209-233): same number of terms, values to 1e-15 of the peak."""
+import cmath
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_api import REF_DIR
+
+REF = os.path.join(REF_DIR, "dsp_ref")
+GPU = os.path.join(REF_DIR, "dsp_gpu")
+pytestmark = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(GPU)), reason="oracle/_ref/dsp_gpu or dsp_ref not built")
+
+COEFS40 = "coefs:" + ",".join(f"{0.9 ** i * (1 if i % 3 else -1):.6f}" for i in range(40))
+COEFS12 = "coefs:" + ",".join(f"{(-0.7) ** i:.8f}" for i in range(12))
+COEFS2CH = "coefs:" + ",".join(f"{0.8 ** i:.6f}" for i in range(50)) + "/" + ",".join(f"{(-0.6) ** i:.6f}" for i in range(37))
+
+
+def script(exe, channels, chain, fs="48k"):
+    r = subprocess.run([exe, "-p", "-r", fs, "-c", str(channels), "-n"] + chain.split(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    return r.returncode, r.stdout, r.stderr
+
+
+DEF = re.compile(r"^([A-Za-z_][A-Za-z0-9_]*)\((\w)\)=(.*)$")
+
+
+class Plot:
+    """the function definitions of one gnuplot script, evaluated in Python"""
+
+    def __init__(self, text):
+        self.defs = {}
+        for line in text.splitlines():
+            m = DEF.match(line)
+            if m:
+                self.defs[m.group(1)] = (m.group(2), self._py(m.group(3)))
+        self.env = {"exp": cmath.exp, "abs": abs, "pi": math.pi, "j": 1j, "log10": math.log10, "arg": cmath.phase, "complex": complex}
+        for name in self.defs:
+            self.env[name] = (lambda nm: (lambda x: self.call(nm, x)))(name)
+
+    @staticmethod
+    def _py(expr):
+        expr = expr.replace("(abs(w)<=pi)?", "").replace(":0/0", "")
+        return re.sub(r"\{([^{},]+),([^{},]+)\}", r"complex(\1,\2)", expr)
+
+    def call(self, name, x):
+        arg, expr = self.defs[name]
+        return eval(expr, dict(self.env, **{arg: x}))            # noqa: S307 (test-only: both scripts come from our own binaries)
+
+
+def compare_scripts(channels_out, chain, channels_in=None, fs="48k", tol=1e-9, same_text=False):
+    ci = channels_in or channels_out
+    rc_r, ref, err_r = script(REF, ci, chain, fs)
+    rc_g, gpu, err_g = script(GPU, ci, chain, fs)
+    assert rc_r == rc_g == 0, (chain, err_r[-400:], err_g[-400:])
+    assert ("plot Ht0_mag_dB" in ref) and ("plot Ht0_mag_dB" in gpu), (chain, err_r[-300:], err_g[-300:])
+    lr, lg = ref.splitlines(), gpu.splitlines()
+    assert len(lr) == len(lg), chain
+    if same_text:
+        assert ref == gpu, chain
+    # same definitions in the same order (names and argument letters: `(f)=1.0` of the no-op plot included)
+    assert [l.split("=")[0] for l in lr] == [l.split("=")[0] for l in lg], chain
+    # the FIR forms: same number of terms per channel
+    assert [l.count("+exp(-j*w*") for l in lr] == [l.count("+exp(-j*w*") for l in lg], chain
+    pr, pg = Plot(ref), Plot(gpu)
+    fsn = pr_rate(ref)
+    worst = 0.0
+    for k in range(channels_out):
+        for f in (11.0, 97.3, 440.0, 1234.5, 5000.0, 0.23 * fsn, 0.41 * fsn, 0.499 * fsn):
+            a, b = pr.call(f"Ht{k}", f), pg.call(f"Ht{k}", f)
+            worst = max(worst, abs(a - b) / max(abs(a), 1e-3))
+    assert worst <= tol, (chain, worst)
+
+
+def pr_rate(text):
+    return float(re.search(r"set xrange \[10:(\d+)/2\]", text).group(1))
+
+
+@pytest.mark.parametrize("channels,chain", [
+    (2, "gain -6 lowpass 1k 0.707 eq 400 2.0 1.5 :1 highshelf 8k 6d -3"),
+    (2, f"fir {COEFS12} :0 fir -a {COEFS12}"),                                      # direct form (<= 16 taps), zero-padded to 16 terms
+    (3, "remix 0,1 2 . :0,2 st2ms"),
+    (4, ":1,3 ms2st :0,2 crossfeed 700 4.5 :2 add 0.01 : mult 0.5"),
+    (2, "delay 11S :1 delay -3S"),
+    (2, f"fir_p coefs:1,0.5,0.25,0.125 remix 1 0"),                                 # fir_p of <= 32 taps: the direct form again
+])
+def test_plot_text_identical(channels, chain):
+    compare_scripts(channels, chain, same_text=True)
+
+
+@pytest.mark.parametrize("channels,chain,cin", [
+    (2, f"fir {COEFS40}", None),                                                      # FFT form: next_fast_fftw_len(40) terms
+    (2, f"fir_p {COEFS40} :0 fir_p -a {COEFS40}", None),                              # 32 direct + one 32-tap partition
+    (2, f"fir_p {COEFS2CH}", None),                                                   # one filter per channel, ragged
+    (2, "hilbert 127 :1 hilbert -p -a 45 255", None),
+    (3, f"gain -3 remix 0 1,2 0,2 fir {COEFS40} :1,2 st2ms", 3),
+    (2, "delay -f 0.3S :1 delay -f1 2.7S", None),
+    (2, "delay -f5 2.3S :0 delay -f3 0.4S", None),                                    # the reference prints the ladder, this library its sections
+    (2, "lowpass -r 1k 0.707", None),
+    (2, "lowpass 2k 0.707 lowpass -r 2k 0.707 :0 highpass -r60 30 0.707", None),
+    (1, "eq -r 400 2.0 1.5 highshelf -r 8k 0.7 -3 lowpass_1 -r 300", None),
+    (2, "lowpass -r 2k 0.707 lowpass -r 2k 0.707", None),                             # repeated poles: series states
+])
+def test_plot_same_function(channels, chain, cin):
+    compare_scripts(channels, chain, channels_in=cin, tol=2e-8)
+
+
+def test_plot_long_partitioned_filter_term_counts(tmp_path):
+    # the number of terms fir_p prints follows its partition plan (fir_p.c:242-289): 32 + groups of zero-padded partitions
+    rng = np.random.Generator(np.random.PCG64(5))
+    for T, extra in ((100, ""), (1000, ""), (4095, ""), (4096, ""), (5000, "64"), (20000, ""), (70001, ""), (70001, "1024"), (140000, "32768")):
+        h = rng.standard_normal(T) * np.exp(-np.arange(T) / (T / 8.0))
+        f = os.path.join(str(tmp_path), f"h{T}.raw"); h.astype("<f8").tofile(f)
+        chain = f"fir_p -t pcm -e double -c 1 {extra} {f}"
+        rc_r, ref, _ = script(REF, 1, chain)
+        rc_g, gpu, _ = script(GPU, 1, chain)
+        assert rc_r == rc_g == 0
+        lr = [l for l in ref.splitlines() if l.startswith("H0_0(w)=")][0]
+        lg = [l for l in gpu.splitlines() if l.startswith("H0_0(w)=")][0]
+        nr, ng = lr.count("+exp(-j*w*"), lg.count("+exp(-j*w*")
+        assert nr == ng, (T, extra, nr, ng)
+        vr = np.array([float(t.split("*")[-1]) for t in lr[lr.index("(0.0") + 4:lr.rindex("):0/0")].split("+exp")[1:]])
+        vg = np.array([float(t.split("*")[-1]) for t in lg[lg.index("(0.0") + 4:lg.rindex("):0/0")].split("+exp")[1:]])
+        assert np.max(np.abs(vr - vg)) <= 1e-14 * np.max(np.abs(vr)), (T, extra)
+
+
+def test_effects_without_plot_are_refused_alike():
+    # resample and zita_convolver have no plot callback in the reference either: same verdict from plot_effects_chain
+    for chain in ("resample 96k", "gain -3 resample 44.1k"):
+        rc_r, ref, err_r = script(REF, 2, chain)
+        rc_g, gpu, err_g = script(GPU, 2, chain)
+        assert rc_r == rc_g
+        assert ("does not support plotting" in err_r) == ("does not support plotting" in err_g), (err_r, err_g)
+        assert ref == gpu
