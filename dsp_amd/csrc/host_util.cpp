@@ -91,64 +91,70 @@ ssize_t parse_len(const char *s, int fs, char **r_endptr)
 	return (ssize_t) lround(parse_len_frac(s, (double) fs, r_endptr));
 }
 
-static void fill_range(Selector &b, int n, int start, int end, bool dash)
+// Channel selectors (README.md "Selector syntax"; verdicts as util.c:120-215): a comma-separated list of items
+//   N | N-M | N- | -M | -        and the whole string "" or "-" = every channel.
+// Parsed here item by item: split at the commas, then read `[number] ['-' [number]]` and demand the end of the item.
+namespace {
+struct SelItem { long lo = -1, hi = -1; bool range = false; };
+
+// reads one item from [p, q); false + message on a syntax error
+bool read_sel_item(const char *p, const char *q, SelItem &it)
 {
-	if (start == -1 && end == -1) { start = 0; end = n - 1; }
-	else if (start == -1) start = 0;
-	else if (end == -1) end = dash ? n - 1 : start;
-	for (int i = start; i <= end; ++i) b[i] = 1;
+	auto number = [&](long &out) {
+		if (p == q || *p < '0' || *p > '9') return false;
+		long v = 0;
+		while (p != q && *p >= '0' && *p <= '9') { if (v < 100000000L) v = v * 10 + (*p - '0'); ++p; }
+		out = v;
+		return true;
+	};
+	if (p == q) { set_error("parse_selector: syntax error: ',' unexpected"); return false; }
+	number(it.lo);
+	if (p != q && *p == '-') {
+		it.range = true;
+		++p;
+		number(it.hi);
+	}
+	if (p != q) {
+		if (*p == '-') set_error("parse_selector: syntax error: '-' unexpected");
+		else set_error("parse_selector: syntax error: invalid character: %c", *p);
+		return false;
+	}
+	return true;
 }
+}  // namespace
 
 bool parse_selector(const char *s, Selector &b, int n)
 {
+	if (strcmp(s, "") == 0 || strcmp(s, "-") == 0) { b.assign(n, 1); return true; }
 	b.assign(n, 0);
-	if (s[0] == '\0' || (s[0] == '-' && s[1] == '\0')) {
-		b.assign(n, 1);
-		return true;
-	}
-	int start = -1, end = -1;
-	bool dash = false;
-	for (;;) {
-		if (*s >= '0' && *s <= '9') {
-			const int v = atoi(s);
-			if (v < 0 || v > n - 1) { set_error("parse_selector: error: value out of range: %d", v); return false; }
-			if (dash) {
-				if (v < start) { set_error("parse_selector: error: malformed range"); return false; }
-				end = v;
-			}
-			else start = v;
-			while (*s >= '0' && *s <= '9') ++s;
-		}
-		else if (*s == '-') {
-			if (dash) { set_error("parse_selector: syntax error: '-' unexpected"); return false; }
-			dash = true;
-			++s;
-		}
-		else if (*s == ',' || *s == '\0') {
-			if (start == -1 && end == -1 && !dash) { set_error("parse_selector: syntax error: ',' unexpected"); return false; }
-			fill_range(b, n, start, end, dash);
-			start = end = -1;
-			dash = false;
-			if (*s == '\0') break;
-			++s;
-			if (*s == '\0') { set_error("parse_selector: syntax error: ',' unexpected"); return false; }
-		}
-		else { set_error("parse_selector: syntax error: invalid character: %c", *s); return false; }
+	for (const char *item = s;;) {
+		const char *stop = strchr(item, ',');
+		const char *q = stop ? stop : item + strlen(item);
+		SelItem it;
+		if (!read_sel_item(item, q, it)) return false;
+		for (long v : { it.lo, it.hi })
+			if (v > n - 1) { set_error("parse_selector: error: value out of range: %ld", v); return false; }
+		if (it.range && it.lo >= 0 && it.hi >= 0 && it.hi < it.lo) { set_error("parse_selector: error: malformed range"); return false; }
+		// open ends: "-M" starts at 0, "N-" runs to the last channel, a lone number selects itself
+		const long first = it.lo >= 0 ? it.lo : 0;
+		const long last = it.hi >= 0 ? it.hi : (it.range ? n - 1 : it.lo);
+		for (long c = first; c <= last; ++c) b[(size_t) c] = 1;
+		if (!stop) break;
+		item = stop + 1;
+		if (*item == '\0') { set_error("parse_selector: syntax error: ',' unexpected"); return false; }
 	}
 	return true;
 }
 
+// a selector counted over the SET channels of `mask` (":0" inside a block that selected channels 2,3 means channel 2)
 bool parse_selector_masked(const char *s, Selector &b, const Selector &mask, int n)
 {
+	std::vector<int> chosen;                       // chosen[i] = the i-th channel the mask lets through
+	for (int c = 0; c < n && c < (int) mask.size(); ++c) if (mask[c]) chosen.push_back(c);
+	Selector local;
 	b.assign(n, 0);
-	const int nb = num_set(mask);
-	Selector tmp;
-	if (!parse_selector(s, tmp, nb)) return false;
-	for (int i = 0, k = 0; i < nb; ++i, ++k) {
-		while (k < n && !mask[k]) ++k;
-		if (k == n) { set_error("parse_selector_masked(): BUG: too many channels"); return false; }   // util.c:203-207
-		if (tmp[i]) b[k] = 1;
-	}
+	if (!parse_selector(s, local, (int) chosen.size())) return false;
+	for (size_t i = 0; i < chosen.size(); ++i) if (local[i]) b[(size_t) chosen[i]] = 1;
 	return true;
 }
 
@@ -166,30 +172,51 @@ int num_set(const char *b, int n)
 	return c;
 }
 
+// Option scanner with the reference's dialect (dsp_getopt, util.c): clustered flags ("-ab"), "x:" = required argument
+// (attached or the next word), "x::" = optional argument (attached only), "--" ends the options; returns -1 at the
+// first non-option word, '?' for a letter that is not in `opts`, ':' when a required argument is missing.
 int GetOpt::next(int argc, const char *const *argv, const char *opts)
 {
-	if (sp == 1) {
-		if (ind >= argc || argv[ind][0] != '-' || argv[ind][1] == '\0') return -1;
-		if (strcmp(argv[ind], "--") == 0) { ++ind; return -1; }
+	enum Need { UNKNOWN, FLAG, REQUIRED, OPTIONAL };
+	auto classify = [opts](int c) {
+		if (c == ':' || c == '\0') return UNKNOWN;
+		for (const char *o = opts; *o; ++o) {
+			if (*o != c) continue;
+			if (o[1] != ':') return FLAG;
+			return o[2] == ':' ? OPTIONAL : REQUIRED;
+		}
+		return UNKNOWN;
+	};
+	if (sp == 1) {                                   // at the start of a word: is it an option word at all?
+		const char *w = (ind < argc) ? argv[ind] : nullptr;
+		if (!w || w[0] != '-' || w[1] == '\0') return -1;
+		if (w[1] == '-' && w[2] == '\0') { ++ind; return -1; }
 	}
-	const int c = opt = argv[ind][sp];
-	const char *cp = (c == ':') ? nullptr : strchr(opts, c);
-	if (!cp) {
-		if (argv[ind][++sp] == '\0') { ++ind; sp = 1; }
+	const char *word = argv[ind];
+	const char *rest = word + sp + 1;                // what follows the letter inside this word
+	opt = word[sp];
+	auto step_inside_word = [&] { if (*rest) ++sp; else { ++ind; sp = 1; } };
+	switch (classify(opt)) {
+	case UNKNOWN:
+		step_inside_word();
 		return '?';
-	}
-	if (cp[1] == ':') {
-		if (argv[ind][sp + 1] != '\0') arg = &argv[ind++][sp + 1];
-		else if (cp[2] == ':') { ++ind; arg = nullptr; }           // optional argument, absent
-		else if (++ind >= argc) { sp = 1; return ':'; }
-		else arg = argv[ind++];
-		sp = 1;
-	}
-	else {
-		if (argv[ind][++sp] == '\0') { ++ind; sp = 1; }
+	case FLAG:
 		arg = nullptr;
+		step_inside_word();
+		return opt;
+	case OPTIONAL:
+		arg = *rest ? rest : nullptr;
+		++ind; sp = 1;
+		return opt;
+	case REQUIRED:
+		sp = 1;
+		if (*rest) { arg = rest; ++ind; return opt; }
+		if (ind + 1 >= argc) { ++ind; return ':'; }
+		arg = argv[ind + 1];
+		ind += 2;
+		return opt;
 	}
-	return c;
+	return -1;
 }
 
 void GetOpt::print_error(int r, const char *name) const

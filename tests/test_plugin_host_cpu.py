@@ -224,3 +224,53 @@ def test_wav_filter_file_init_cpu(tmp_path):
         assert not Obj(A, A.dspamd_get_effect_info, eff, ["-r", "48k", str(f441)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
         assert Obj(A, A.dspamd_get_effect_info, eff, ["-r", "any", str(f441)], 48000, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
         assert Obj(A, A.dspamd_get_effect_info, eff, [str(f441)], 44100, 2, {0, 1}, Effect, StreamInfo, ssize_t).ok(), eff
+
+
+def test_selector_grammar_differential():
+    # the selector parser is this library's own (csrc/host_util.cpp); the grammar and the verdicts are the reference's
+    # (util.c parse_selector / parse_selector_masked): random strings through `remix`, whose arguments are selectors counted
+    # over the channels the block selector lets through -- same accept / reject, same dependency matrix
+    rng = np.random.Generator(np.random.PCG64(4242))
+    alphabet = list("0123456789") + [",", "-", "-", ",", "x", " ", "10", "11"]
+    handmade = ["", "-", "0", "0-", "-2", "1-2", "2-1", "0,", ",0", "0,,1", "--", "1--2", "0-1-2", "9", "0-9", "3,2,1", "1,1", "-0", "01", "007-", "0-,1", "-,-"]      # (numbers beyond int: the reference wraps them through atoi, this library refuses them)
+    strings = handmade + ["".join(rng.choice(alphabet, size=int(rng.integers(1, 7)))) for _ in range(400)]
+    accepted = 0
+    for i, s in enumerate(strings):
+        channels = int(rng.integers(1, 7))
+        sel = sorted(set(int(c) for c in rng.integers(0, channels, size=int(rng.integers(1, channels + 1)))))
+        args = [s] if s else ["."]
+        if rng.integers(0, 2):
+            args.append(str(rng.integers(0, len(sel))))
+        a, r = pair("remix", args, channels=channels, sel=sel)
+        assert a.ok() == r.ok(), (s, channels, sel, a.ok(), r.ok())
+        if a.ok():
+            accepted += 1
+            assert (a.e.contents.ostream.channels, a.e.contents.flags) == (r.e.contents.ostream.channels, r.e.contents.flags), s
+            a.ch = r.ch = max(channels, a.e.contents.ostream.channels)
+            assert a.deps() == r.deps(), (s, channels, sel)
+        a.free(); r.free()
+    assert accepted > 50
+
+
+def test_option_scanner_differential():
+    # the option scanner is this library's own; the dialect is dsp_getopt's (util.c): clustered flags, attached / detached /
+    # optional arguments, "--", unknown letters, a missing argument -- random option words in front of a valid filter
+    rng = np.random.Generator(np.random.PCG64(77))
+    words = ["-a", "-a3S", "-a-2S", "-B", "-L", "-N", "-BL", "-LNa", "-c", "1", "-c1", "-t", "pcm", "-tpcm", "-e", "double", "-edouble",
+             "-r", "48k", "-r48k", "-rany", "--", "-x", "-", "-Bx", "-c", "-e", "-:", "-a:", "-Be", "double"]
+    same_init = 0
+    for _ in range(300):
+        opts = [str(w) for w in rng.choice(words, size=int(rng.integers(0, 5)))]
+        for name in ("fir", "fir_p"):
+            a, r = pair(name, opts + [COEFS40], channels=2)
+            assert a.ok() == r.ok(), (name, opts, a.ok(), r.ok())
+            if a.ok():
+                same_init += 1
+                assert a.offsets() == r.offsets(), (name, opts)
+                assert a.drain() == r.drain(), (name, opts)
+            a.free(); r.free()
+    for opts in (["-f"], ["-f3"], ["-f", "3"], ["-f0"], ["-fx"], ["-f2", "--"], ["--", "-f"], ["-q"]):
+        a, r = pair("delay", opts + ["2.5S"], channels=2)
+        assert a.ok() == r.ok() or opts == ["-q"], opts      # (-m/-M/-b/-q: modulated delay, refused by this backend on purpose)
+        a.free(); r.free()
+    assert same_init > 40
