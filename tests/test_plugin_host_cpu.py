@@ -233,7 +233,11 @@ def test_selector_grammar_differential():
     rng = np.random.Generator(np.random.PCG64(4242))
     alphabet = list("0123456789") + [",", "-", "-", ",", "x", " ", "10", "11"]
     handmade = ["", "-", "0", "0-", "-2", "1-2", "2-1", "0,", ",0", "0,,1", "--", "1--2", "0-1-2", "9", "0-9", "3,2,1", "1,1", "-0", "01", "007-", "0-,1", "-,-"]      # (numbers beyond int: the reference wraps them through atoi, this library refuses them)
-    strings = handmade + ["".join(rng.choice(alphabet, size=int(rng.integers(1, 7)))) for _ in range(400)]
+    def item():
+        a, b = int(rng.integers(0, 4)), int(rng.integers(0, 5))
+        return str(rng.choice([f"{a}", f"{a}-{b}", f"{a}-", f"-{b}", "-"]))
+    strings = handmade + ["".join(rng.choice(alphabet, size=int(rng.integers(1, 7)))) for _ in range(300)]
+    strings += [",".join(item() for _ in range(int(rng.integers(1, 4)))) for _ in range(300)]      # mostly well-formed
     accepted = 0
     for i, s in enumerate(strings):
         channels = int(rng.integers(1, 7))
