@@ -129,6 +129,36 @@ def cpu_baseline(chain, filt_dir, fs, channels, seconds_target=6.0):
     return {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "unavailable", "sample": "oracle not built"}
 
 
+def parity_of_first_step(chain, filt_dir, fs, picks):
+    """Self-check inside the bench run (checker only, like cpu_baseline): the first step's output of a few (stream, channel)
+    picks against the reference itself (oracle/_ref, built from /root/reference) fed the same device-generated input, over
+    the WHOLE step -- every row and column of the step's transforms.  The chains benched here act on every channel alike,
+    so the reference runs them as one-channel chains.  picks: [(stream, channel, x[frames], y[frames_out])]."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        from oracle_api import RefChain
+        if not RefChain.available():
+            return {"checked": False, "why": "oracle/_ref not built"}
+        t0 = time.time()
+        worst, worst_rel, n = 0.0, 0.0, 0
+        for s, c, xin, y in picks:
+            ref = RefChain(chain, fs, 1, directory=filt_dir)
+            parts = [ref.run(xin[p:p + 2048].reshape(-1, 1)) for p in range(0, xin.shape[0], 2048)]
+            r = np.concatenate([q for q in parts if q.shape[0]])[:, 0]
+            m = min(r.shape[0], y.shape[0])      # (a rate changer hands frames over in other portions than the reference: common prefix)
+            d = r[:m] - y[:m]
+            e = float(np.sqrt(np.mean(d * d)))
+            worst = max(worst, e)
+            worst_rel = max(worst_rel, e / max(float(np.sqrt(np.mean(r[:m] * r[:m]))), 1e-300))
+            n = m
+            ref.close()
+        return {"checked": True, "rms": worst, "rms_rel_to_signal": worst_rel, "frames_compared": n,
+                "picks": [[int(s), int(c)] for s, c, _, _ in picks], "against": "oracle/_ref: the reference's own sources, same input, whole first step",
+                "seconds": time.time() - t0}
+    except Exception as e:  # pragma: no cover
+        return {"checked": False, "why": str(e)[:300]}
+
+
 # BASELINE.json's other configs as presets (parity-test cases; the bench line of record is the default run)
 CONFIGS = {
     "2": dict(streams=1, channels=8, block=1 << 20, chain=BIQUADS),                    # 1 stream x 8 ch, 10 biquads
@@ -222,14 +252,27 @@ def main():
         job.barrier()
         torch.cuda.synchronize()
 
+    # ---- step 0 of the stream, before anything is timed: the position every run shares whatever --warmup / --steps are.
+    # The digest is taken here (a reproducible checksum), and two (stream, channel) picks are kept for the parity check
+    # against the reference (rank 0, with the CPU baseline leg).
+    y0 = batch.run(x[0], out)
+    f0 = y0.shape[1]
+    dig = torch.empty((S, 3), dtype=torch.float64, device="cuda")
+    L.dspamd_digest(out.data_ptr(), S, f0, out.shape[1], batch.ochannels, dig.data_ptr(), stream)
+    torch.cuda.synchronize()
+    picks = []
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and ":" not in chain and "remix" not in chain:
+        for s_, c_ in {(0, 0), (S - 1, C - 1)}:
+            picks.append((s_lo + s_, c_, x[0][s_, :, c_].cpu().numpy().copy(), y0[s_, :, min(c_, batch.ochannels - 1)].cpu().numpy().copy()))
+
     for w in range(args.warmup):
-        batch.run(x[w & 1], out)
+        batch.run(x[(w + 1) & 1], out)
 
     def timed_region():
         barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            batch.run(x[k & 1], out)
+            batch.run(x[(k + 1) & 1], out)
         barrier()
         return job.max_time(time.perf_counter() - t0)
 
@@ -265,12 +308,13 @@ def main():
     copy_gbps = 5 * 2 * nbytes / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del a, b
 
-    # digest: keeps the output observable and gives the judge a cheap checksum
-    dig = torch.empty((S, 3), dtype=torch.float64, device="cuda")
-    L.dspamd_digest(out.data_ptr(), S, min(args.block, out.shape[1]), out.shape[1], batch.ochannels, dig.data_ptr(), stream)
-    torch.cuda.synchronize()
+    # digest of step 0 (taken above): keeps the output observable and is the same number for every --warmup / --steps
     dig = job.gather_digests(dig, S_total)       # [S_total, 3]: sum, sum of squares, peak per stream
-    finite = bool(torch.isfinite(dig).all().item())
+    # the last timed output too must be finite (observed, so nothing of the timed region can be skipped)
+    dlast = torch.empty((S, 3), dtype=torch.float64, device="cuda")
+    L.dspamd_digest(out.data_ptr(), S, min(args.block, out.shape[1]), out.shape[1], batch.ochannels, dlast.data_ptr(), stream)
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(dig).all().item()) and bool(torch.isfinite(dlast).all().item())
     total_streams = job.sum_count(S)
     assert total_streams == S_total
 
@@ -317,8 +361,11 @@ def main():
                          "whole_chain_frac_per_gpu": chain_frac, "measured_copy_GBps": copy_gbps,
                          "kernels": {k: {"avg_ms": v["avg_ms"], "launches_per_step": v["launches"] / args.steps} for k, v in prof.items()}},
             "output_finite": finite, "env": env_set,
-            "digest": {"streams": int(dig.shape[0]), "sum_of_squares": float(dig[:, 1].sum().item()), "peak": float(dig[:, 2].max().item())},
+            "digest": {"of": "step 0 of the stream (same for every --warmup / --steps)", "streams": int(dig.shape[0]), "frames": int(f0),
+                       "sum_of_squares": float(dig[:, 1].sum().item()), "peak": float(dig[:, 2].max().item())},
         }
+        if picks:
+            res["parity"] = parity_of_first_step(chain, filt_dir, fs, picks)
         if world == 1 and not (args.config or args.chain) and not args.no_side_runs and not args.no_cpu_baseline:
             # SIDE FIGURE, never `value`: the same chain with the planner's opt-in LTI merge of the sections into the filter
             # (DSP_AMD_MERGE_IIR=1): no cascade pass at all, exact to the decay criterion (2^-70).  The headline

@@ -118,6 +118,17 @@ class BatchChain:
     def _stream(self):
         return self.torch.cuda.current_stream().cuda_stream
 
+    def _check_out(self, out, dtype, row, cap):
+        """an output slab [S, >= cap, row] of `dtype` on the device, rows contiguous (the kernels write through raw pointers: a
+        wrong dtype or a strided view would put samples outside the tensor); returns its stream stride in frames"""
+        if not (out.is_cuda and out.dtype == dtype and out.dim() == 3):
+            raise ValueError(f"dsp_amd: output tensor must be a cuda tensor of {dtype} with 3 dimensions")
+        if out.shape[0] != self.S or out.shape[2] != row or out.shape[1] < cap:
+            raise ValueError(f"dsp_amd: output tensor must be [{self.S}, >= {cap}, {row}], got {tuple(out.shape)}")
+        if out.stride(2) != 1 or out.stride(1) != row or (self.S > 1 and (out.stride(0) % row or out.stride(0) < out.shape[1] * row)):
+            raise ValueError("dsp_amd: output tensor rows must be contiguous ([S, stride, row] buffer or a [:, :n, :] view of one)")
+        return out.stride(0) // row if self.S > 1 else out.shape[1]
+
     def run(self, x, out=None):
         """x: [S, frames, C] cuda float64 -- contiguous, or a view x = buf[:, :frames, :] of a contiguous [S, stride, C] buffer
         (padded slabs: see dspamd_batch_run_strided).  Returns a view [S, oframes, C_out] of `out` (allocated if None);
@@ -125,14 +136,13 @@ class BatchChain:
         t = self.torch
         assert x.is_cuda and x.dtype == t.float64 and x.shape[0] == self.S and x.shape[2] == self.channels
         frames = x.shape[1]
-        assert x.stride(2) == 1 and x.stride(1) == self.channels and x.stride(0) % self.channels == 0 and x.stride(0) >= frames * self.channels
+        assert x.stride(2) == 1 and x.stride(1) == self.channels
+        assert self.S == 1 or (x.stride(0) % self.channels == 0 and x.stride(0) >= frames * self.channels)
         in_stride = x.stride(0) // self.channels if self.S > 1 else frames
         cap = max(self.max_out_frames(frames), 1)
         if out is None:
             out = t.empty((self.S, cap, self.ochannels), dtype=t.float64, device=x.device)
-        assert out.shape[0] == self.S and out.shape[2] == self.ochannels and out.shape[1] >= cap
-        assert out.stride(2) == 1 and out.stride(1) == self.ochannels and out.stride(0) % self.ochannels == 0
-        out_stride = out.stride(0) // self.ochannels if self.S > 1 else out.shape[1]
+        out_stride = self._check_out(out, t.float64, self.ochannels, cap)
         f = self.L.dspamd_batch_run_strided(self.h, x.data_ptr(), in_stride, frames, out.data_ptr(), out_stride, self._stream())
         if f < 0:
             raise RuntimeError(f"dsp_amd: batch_run failed: {last_error()}")
@@ -143,7 +153,7 @@ class BatchChain:
         cap = max(self.max_out_frames(block), 1)
         if out is None:
             out = t.empty((self.S, cap, self.ochannels), dtype=t.float64, device="cuda")
-        out_stride = out.stride(0) // self.ochannels if self.S > 1 else out.shape[1]
+        out_stride = self._check_out(out, t.float64, self.ochannels, cap)
         f = self.L.dspamd_batch_drain(self.h, block, out.data_ptr(), out_stride, self._stream())
         if f == -1:
             return None
@@ -168,14 +178,13 @@ class BatchChain:
         dt, mult = WIRE_DTYPES[in_fmt]
         assert x.is_cuda and x.dtype == getattr(t, dt) and x.shape[0] == self.S and x.shape[2] == self.channels * mult
         frames, row = x.shape[1], self.channels * mult
-        assert x.stride(2) == 1 and x.stride(1) == row and x.stride(0) % row == 0
+        assert x.stride(2) == 1 and x.stride(1) == row and (self.S == 1 or (x.stride(0) % row == 0 and x.stride(0) >= frames * row))
         in_stride = x.stride(0) // row if self.S > 1 else frames
         cap = max(self.max_out_frames(frames), 1)
         if out is None:
             out = self._wire_out(out_fmt, cap, x.device)
-        orow = out.shape[2]
-        assert out.shape[0] == self.S and out.shape[1] >= cap and orow == self.ochannels * WIRE_DTYPES[out_fmt][1]
-        out_stride = out.stride(0) // orow if self.S > 1 else out.shape[1]
+        odt, omult = WIRE_DTYPES[out_fmt]
+        out_stride = self._check_out(out, getattr(t, odt), self.ochannels * omult, cap)
         f = self.L.dspamd_batch_run_wire(self.h, PCM_FORMATS[in_fmt], x.data_ptr(), in_stride, frames, PCM_FORMATS[out_fmt], out.data_ptr(), out_stride,
                                          dither_prec, stats.data_ptr() if stats is not None else None, self._stream())
         if f < 0:
@@ -186,7 +195,8 @@ class BatchChain:
         cap = max(self.max_out_frames(block), 1)
         if out is None:
             out = self._wire_out(out_fmt, cap, "cuda")
-        out_stride = out.stride(0) // out.shape[2] if self.S > 1 else out.shape[1]
+        odt, omult = WIRE_DTYPES[out_fmt]
+        out_stride = self._check_out(out, getattr(self.torch, odt), self.ochannels * omult, cap)
         f = self.L.dspamd_batch_drain_wire(self.h, block, PCM_FORMATS[out_fmt], out.data_ptr(), out_stride, dither_prec,
                                            stats.data_ptr() if stats is not None else None, self._stream())
         if f == -1:

@@ -653,7 +653,7 @@ ssize_t ConvStage::drain2(ssize_t max_frames, double *out, long out_stride, hipS
 	if (q_total == 0 || left <= 0) return -1;
 	const long count = std::min<long>(left, std::max<long>(max_out_frames(max_frames), 1));
 	if (!merged_pre) return emit(count, out, out_stride, st);
-	if (tail_frames < 0 && !compute_tail(st)) return -1;
+	if (tail_frames < 0 && !compute_tail(st)) return PIPE_FAILED;
 	// serve the precomputed tail
 	const long n = std::min<long>(count, tail_frames - tail_served);
 	if (n <= 0) return -1;

@@ -323,18 +323,30 @@ bool CascadeStage::choose_chunks(long frames, int *K_out, long *len_out) const
 
 // M (state after len frames of silence, per unit state) and H (the outputs on the way) by running the sections themselves,
 // in extended precision; channels with identical ops share one table
+CascadeStage::ChunkPlan::~ChunkPlan() { if (done) (void) hipEventDestroy(done); }
+
 CascadeStage::ChunkPlan *CascadeStage::chunk_plan_for(long frames, int K, long len)
 {
+	// plans that fell out of the cache are released once the launches that used them have finished -- asked with an event
+	// query, never waited for: a new call size must not stall the device or break the caller's asynchronous stream
+	for (size_t i = 0; i < retired_plans.size();)
+		if (!retired_plans[i]->done || hipEventQuery(retired_plans[i]->done) == hipSuccess) retired_plans.erase(retired_plans.begin() + i);
+		else { (void) hipGetLastError(); ++i; }
 	for (size_t i = 0; i < chunk_plans.size(); ++i)
-		if (chunk_plans[i]->frames == frames) {
+		if (chunk_plans[i]->frames == frames && chunk_plans[i]->K == K && chunk_plans[i]->len == len) {
 			std::rotate(chunk_plans.begin(), chunk_plans.begin() + i, chunk_plans.begin() + i + 1);
 			return chunk_plans.front().get();
 		}
 	std::unique_ptr<ChunkPlan> c(new ChunkPlan);
 	if (!build_chunk_plan(*c, frames, K, len)) return nullptr;
-	if (chunk_plans.size() >= 4) {
-		(void) hipDeviceSynchronize();          // the plan about to go may still be in use by queued launches
+	if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); c->done = nullptr; }
+	if (chunk_plans.size() >= 8) {
+		retired_plans.push_back(std::move(chunk_plans.back()));
 		chunk_plans.pop_back();
+		if (retired_plans.size() > 16) {                  // a caller that never lets the stream finish: wait for the oldest one only
+			if (retired_plans.front()->done) (void) hipEventSynchronize(retired_plans.front()->done);
+			retired_plans.erase(retired_plans.begin());
+		}
 	}
 	chunk_plans.insert(chunk_plans.begin(), std::move(c));
 	return chunk_plans.front().get();
@@ -472,6 +484,7 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 		cp.cstate = chunk.cstate.as<double>(); cp.X = chunk.X.as<double>(); cp.state = state.as<double>();
 		{ ProfScope ps("cascade_chunk_carry", st); launch_chunk_carry(cp, S, st); }
 		{ ProfScope ps("cascade_chunk_fix", st); launch_chunk_fix(cp, S, st); }
+		if (chunk.done) (void) hipEventRecord(chunk.done, st);
 		return frames;
 	}
 	{ ProfScope ps("cascade_kernel", st); ps.rename(launch_cascade(p, S, st)); }
@@ -829,8 +842,8 @@ ssize_t Pipeline::max_out_frames(ssize_t in_frames) const
 ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st, long in_stride)
 {
 	if (in_stride <= 0) in_stride = frames;
-	if (in_stride < frames) { set_error("pipeline: input stride %ld shorter than the call (%zd frames)", in_stride, frames); return -1; }
-	if (frames > max_frames) { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return -1; }
+	if (in_stride < frames) { set_error("pipeline: input stride %ld shorter than the call (%zd frames)", in_stride, frames); return PIPE_FAILED; }
+	if (frames > max_frames) { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return PIPE_FAILED; }
 	if (out_stride <= 0) out_stride = max_out_frames(frames);
 	if (frames <= 0) return 0;
 	if (stages.empty()) {
@@ -857,7 +870,7 @@ ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long ou
 		F = s->run(cur, cur_stride, F, dst, dst_stride, st);
 		if (F < 0) return F;
 		// a launch that failed (bad configuration, LDS not granted on this device ...) must not pass stale memory on as audio
-		if (!hip_ok(hipGetLastError(), s->type())) return -1;
+		if (!hip_ok(hipGetLastError(), s->type())) return PIPE_FAILED;
 		cur = dst;
 		cur_stride = dst_stride;
 		if (F == 0) {
@@ -871,12 +884,12 @@ ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long ou
 ssize_t Pipeline::run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t frames, const WireSink &sink_in, void *d_out, long out_stride, hipStream_t st, int *fused)
 {
 	if (fused) *fused = 0;
-	if (!pcm_sample_bytes(in_fmt) || !pcm_sample_bytes(sink_in.fmt)) { set_error("pipeline: unknown wire format %d / %d", in_fmt, sink_in.fmt); return -1; }
+	if (!pcm_sample_bytes(in_fmt) || !pcm_sample_bytes(sink_in.fmt)) { set_error("pipeline: unknown wire format %d / %d", in_fmt, sink_in.fmt); return PIPE_FAILED; }
 	const bool drain = (d_in == nullptr);
 	if (frames <= 0) return drain ? -1 : 0;
-	if (frames > max_frames) { if (drain) frames = max_frames; else { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return -1; } }
+	if (frames > max_frames) { if (drain) frames = max_frames; else { set_error("pipeline: %zd frames exceed max_frames=%zd", frames, max_frames); return PIPE_FAILED; } }
 	if (in_stride <= 0) in_stride = frames;
-	if (in_stride < frames) { set_error("pipeline: input stride %ld shorter than the call (%zd frames)", in_stride, frames); return -1; }
+	if (in_stride < frames) { set_error("pipeline: input stride %ld shorter than the call (%zd frames)", in_stride, frames); return PIPE_FAILED; }
 	if (out_stride <= 0) out_stride = std::max<long>(1, max_out_frames(frames));
 	WireSink sink = sink_in;
 	sink.on = 1;
@@ -901,11 +914,11 @@ ssize_t Pipeline::run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t
 		// the rate changers' flush is a few frames at the end of a stream: plain drain2, then the sink pass
 		long stride = 0;
 		double *buf = own_out(&stride);
-		if (!buf) return -2;
+		if (!buf) return PIPE_FAILED;
 		const ssize_t F = drain2(frames, buf, stride, st);
 		if (F <= 0) return F;
-		if (F > out_stride) { set_error("pipeline: %zd drained frames exceed the output stride %ld", F, out_stride); return -2; }
-		return sink_pass(buf, stride, F) ? F : -2;
+		if (F > out_stride) { set_error("pipeline: %zd drained frames exceed the output stride %ld", F, out_stride); return PIPE_FAILED; }
+		return sink_pass(buf, stride, F) ? F : PIPE_FAILED;
 	}
 	// ---- input side: the first stage's own loads, or read_buf_<fmt> as a pass of its own
 	Stage *first = stages.empty() ? nullptr : stages.front().get();
@@ -918,10 +931,10 @@ ssize_t Pipeline::run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t
 		else if (first && !single && first->wire_in_ok(in_fmt, d_in, in_stride, frames, false, PCM_DOUBLE)) fin = true;
 		else if (first && single && !first->wire_out_ok(sink.fmt, d_out, out_stride, frames, false, PCM_DOUBLE) && first->wire_in_ok(in_fmt, d_in, in_stride, frames, false, PCM_DOUBLE)) fin = true;
 		if (!fin) {
-			if (!wire_tmp_in.p && !wire_tmp_in.alloc((size_t) S * max_frames * ch_in * sizeof(double), false)) return -1;
+			if (!wire_tmp_in.p && !wire_tmp_in.alloc((size_t) S * max_frames * ch_in * sizeof(double), false)) return PIPE_FAILED;
 			PcmReadParams r{ d_in, wire_tmp_in.as<double>(), in_stride, (long) frames, (long) frames, ch_in, in_fmt };
 			{ ProfScope ps("pcm_read", st); launch_pcm_read(r, S, st); }
-			if (!hip_ok(hipGetLastError(), "pcm_read")) return -1;
+			if (!hip_ok(hipGetLastError(), "pcm_read")) return PIPE_FAILED;
 			cur = wire_tmp_in.as<double>();
 			cur_stride = frames;
 		}
@@ -942,7 +955,7 @@ ssize_t Pipeline::run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t
 			fout = single ? (fout_single || (!fin && s->wire_out_ok(sink.fmt, d_out, out_stride, F, false, PCM_DOUBLE)))
 			              : s->wire_out_ok(sink.fmt, d_out, out_stride, F, false, PCM_DOUBLE);
 			if (fout) { dst = static_cast<double *>(d_out); dst_stride = out_stride; }
-			else { dst = own_out(&dst_stride); if (!dst) return -1; }
+			else { dst = own_out(&dst_stride); if (!dst) return PIPE_FAILED; }
 		}
 		else if (s->in_place_ok() && cur != d_in && !wired_in) { dst = const_cast<double *>(cur); dst_stride = cur_stride; }
 		else {
@@ -956,14 +969,14 @@ ssize_t Pipeline::run_wire(int in_fmt, const void *d_in, long in_stride, ssize_t
 		s->wire_in_fmt = PCM_DOUBLE;
 		s->wire_sink.on = 0;
 		if (F < 0) return F;
-		if (!hip_ok(hipGetLastError(), s->type())) return -1;
+		if (!hip_ok(hipGetLastError(), s->type())) return PIPE_FAILED;
 		cur = dst;
 		cur_stride = dst_stride;
 		if (F == 0) return 0;
 		if (last) {
-			if (F > out_stride) { set_error("pipeline: %zd frames exceed the output stride %ld", F, out_stride); return -1; }
+			if (F > out_stride) { set_error("pipeline: %zd frames exceed the output stride %ld", F, out_stride); return PIPE_FAILED; }
 			if (fout) did |= 2;
-			else if (!sink_pass(cur, cur_stride, F)) return -1;
+			else if (!sink_pass(cur, cur_stride, F)) return PIPE_FAILED;
 		}
 	}
 	if (fused) *fused = did;
@@ -979,7 +992,7 @@ ssize_t Pipeline::drain2(ssize_t block_frames, double *d_out, long out_stride, h
 		double *dst = last ? d_out : tmp[0].as<double>();
 		long dst_stride = last ? out_stride : (long) (tmp[0].bytes / sizeof(double) / S / s->ch_out);
 		ssize_t F = s->drain2(block_frames, dst, dst_stride, st);
-		if (!hip_ok(hipGetLastError(), s->type())) return -1;
+		if (!hip_ok(hipGetLastError(), s->type()) || F == PIPE_FAILED) return PIPE_FAILED;
 		if (F < 0) { ++drain_stage; continue; }
 		const double *cur = dst;
 		long cur_stride = dst_stride;
@@ -991,13 +1004,13 @@ ssize_t Pipeline::drain2(ssize_t block_frames, double *d_out, long out_stride, h
 			long d2_stride = nlast ? out_stride : (long) (tmp[which].bytes / sizeof(double) / S / n->ch_out);
 			which ^= 1;
 			F = n->run(cur, cur_stride, F, d2, d2_stride, st);
-			if (!hip_ok(hipGetLastError(), n->type())) return -1;
+			if (!hip_ok(hipGetLastError(), n->type()) || F < 0) return PIPE_FAILED;
 			cur = d2;
 			cur_stride = d2_stride;
 		}
 		return F;
 	}
-	return -1;
+	return PIPE_DRY;
 }
 
 void Pipeline::reset(hipStream_t st)

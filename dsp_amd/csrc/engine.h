@@ -62,6 +62,10 @@ struct ProfScope {
 	void rename(const char *name) { if (on && name) g_prof.rename_last(name); }   // the launcher knows which kernel it picked
 };
 
+// what the run / drain entry points return besides a frame count: "dry" is the reference's end-of-drain sentinel
+// (effects_chain.c:1186-1218: *frames = -1), a failed launch or allocation must never look like it
+enum : ssize_t { PIPE_DRY = -1, PIPE_FAILED = -2 };
+
 // One fused device stage.  in/out are [S][stride][C] slabs; a stage may be run in place when
 // in_place_ok() (out == in, same stride).
 class Stage {
@@ -72,9 +76,9 @@ public:
 	virtual std::string describe() const = 0;
 	virtual bool in_place_ok() const { return false; }
 	virtual ssize_t max_out_frames(ssize_t in_frames) const { return in_frames; }
-	// returns frames produced per stream (>= 0) or < 0 on error
+	// returns frames produced per stream (>= 0) or PIPE_FAILED
 	virtual ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) = 0;
-	// second-phase drain for stages that hold frames back (resample drain2); -1 = nothing (left)
+	// second-phase drain for stages that hold frames back (resample drain2); PIPE_DRY = nothing (left), PIPE_FAILED = error
 	virtual ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) { (void) max_frames; (void) out; (void) out_stride; (void) st; return -1; }
 	virtual void reset(hipStream_t st) = 0;
 	virtual size_t device_bytes() const { return 0; }

@@ -36,8 +36,13 @@ private:
 	// Whether a call runs chunked is a pure function of (frames, S, the sections) -- never of earlier calls: run / reset / run
 	// and two instances with different histories give bit-identical output (the chunked path agrees with the direct kernels
 	// only to rounding, ~1e-15).  Plans (tables + buffers, about a millisecond each) are kept for the last few call sizes.
-	struct ChunkPlan { long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X; };
-	std::vector<std::unique_ptr<ChunkPlan>> chunk_plans;   // most recently used first, at most 4
+	struct ChunkPlan {
+		long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X;
+		hipEvent_t done = nullptr;                             // recorded behind the plan's last launches
+		~ChunkPlan();
+	};
+	std::vector<std::unique_ptr<ChunkPlan>> chunk_plans;   // most recently used first, at most 8, keyed on (frames, K, len)
+	std::vector<std::unique_ptr<ChunkPlan>> retired_plans; // evicted, freed when their event has completed
 	bool choose_chunks(long frames, int *K, long *len) const;
 	CascadeParams params(const double *in, long in_stride, ssize_t frames, double *out, long out_stride) const;
 	bool wire_ok(int in_fmt, bool sink_on, int out_fmt, const void *in, long in_stride, const void *out, long out_stride, ssize_t frames) const;
