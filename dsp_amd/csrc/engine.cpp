@@ -718,7 +718,8 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 		// filters are h * h_p (one set of FFT passes instead of two, no slab between them)
 		if (sp->kind == Kind::Conv && si + 1 < specs.size() && specs[si + 1]->kind == Kind::Resample && !getenv("DSP_AMD_NO_LTI_MERGE")) {
 			const Spec *rs = specs[si + 1];
-			const bool int_ratio = (rs->rs_n == 1 || rs->rs_d == 1) && rs->rs_n <= 8 && rs->rs_d <= 8;
+			// (the same condition under which the resampler rides the FFT convolver, conv.cpp: a resampler on the polyphase kernels cannot take a filter in front)
+			const bool int_ratio = (rs->rs_n == 1 || rs->rs_d == 1) && rs->rs_n <= 8 && rs->rs_d <= 8 && !getenv("DSP_AMD_RESAMPLE_DIRECT");
 			bool cheaper = false;
 			if (int_ratio) {
 				// the branches of an n-fold upsampler cost about (1 + 2 n) / 3 of a plain convolution of the same size

@@ -33,6 +33,12 @@
 #include "kparams.h"
 #include "fft_params.h"
 #include "pcm_device.h"
+#ifndef DUO_EXP
+#define DUO_EXP 0
+#endif
+#ifndef DUO_LDS_EXTRA
+#define DUO_LDS_EXTRA 0
+#endif
 
 namespace dspamd {
 
@@ -116,12 +122,16 @@ struct TwCol {            // sequence length NSEQ <= 256: one table of W_NSEQ; t
 	const cplx *t;
 	template <int M> __device__ __forceinline__ cplx get(int e) const { return t[e]; }
 };
-template <int NSEQ> struct TwRow {   // rows: W_256 direct, W_NSEQ as hi[e >> 6] * lo[e & 63]
-	const cplx *t256, *lo, *hi;
+// rows: W_256 direct, W_NSEQ as hi[e >> 6] * lo[e & 63].  The lanes of a pass look these up at e = r k with k = the lane's
+// low bits: a stride of r slots, i.e. gcd(r, 16)-way bank conflicts on a plain table (8-way for r = 8).  One slot of padding
+// per 16 (twpad) makes every power-of-two stride conflict-free.
+__device__ __forceinline__ constexpr int twpad(int e) { return e + (e >> 4); }
+template <int NSEQ> struct TwRow {
+	const cplx *t256, *lo, *hi;             // t256: [twpad(256)], lo: [twpad(64)], hi: [64]
 	template <int M> __device__ __forceinline__ cplx get(int e) const
 	{
-		if constexpr (M == NSEQ && NSEQ > 256) return cmul(hi[e >> 6], lo[e & 63]);
-		else return t256[e * (256 / M)];
+		if constexpr (M == NSEQ && NSEQ > 256) return cmul(hi[e >> 6], lo[twpad(e & 63)]);
+		else return t256[twpad(e * (256 / M))];
 	}
 };
 
@@ -527,15 +537,23 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 template <int LOG2N2> struct RowCfg {
 	static constexpr int N2 = 1 << LOG2N2, P = N2 / 16, RPW = NT / P, R3 = N2 / 256;
 	static constexpr int PITCH = N2 + N2 / 16;
-	static constexpr int NTW = 256 + 64 + 64 + RPW * 16;   // W_256, W_N2 lo / hi, per-row inter-pass twiddle steps
+	static constexpr int T256 = 272, TLO = 68;            // padded table lengths (twpad)
+	static constexpr int NTW = T256 + TLO + 64 + RPW * 16;  // W_256, W_N2 lo / hi, per-row inter-pass twiddle steps
 	static constexpr size_t LDS = ((size_t) RPW * PITCH + NTW) * sizeof(cplx);
 	static constexpr bool WAVE_LOCAL = (P <= 64);
 };
 
+// Where point `pos` of a row lives: the low three bits of its 16-byte slot XORed with bits 4..6 of pos.  Conflict-free for
+// both access shapes of the exchanges on this LDS (MI355X_MICROARCH.md, LDS table): a Stockham store instruction writes
+// 16 j + r or 16 (j - k) + k + 16 r from 8 contiguous lanes (a ds_write_b128 is served in groups of 8 lanes x 4 banks of 32:
+// the slots must differ mod 8), a gather reads j + P m from the lane groups {0-3, 12-15, 20-27} ... of a ds_read_b128 (16
+// lanes x 4 banks of 64: the slots must differ mod 16).  Round 2's padding (pos + pos / 16) served the stores but left a
+// two-way conflict in every gather group -- lanes 12 and 27 -- and SQ_LDS_BANK_CONFLICT at 28 % of the LDS cycles of K2.
 struct RowMap {
 	int base;                                // row * PITCH
-	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + pos + (pos >> 4)] = v; }
-	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + pos + (pos >> 4)]; }
+	__device__ __forceinline__ static int slot(int pos) { return pos ^ ((pos >> 4) & 7); }
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + slot(pos)] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + slot(pos)]; }
 };
 
 template <bool WAVE_LOCAL> __device__ __forceinline__ void row_sync()
@@ -585,7 +603,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	constexpr bool WL = Cfg::WAVE_LOCAL;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + 256, *thi = tlo + 64;
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + Cfg::T256, *thi = tlo + Cfg::TLO;
 	const int tid = threadIdx.x;
 	const int rw = tid / P, j = tid % P;
 	const long k1 = (long) blockIdx.x * RPW + rw;
@@ -594,8 +612,8 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	cplx v[16];
 #pragma unroll
 	for (int m = 0; m < 16; ++m) v[m] = ld16(W + P * m, p.nt & 4);
-	t256[tid] = p.tw_n2[tid * (N2 / 256)];
-	if (tid < 64) tlo[tid] = p.tw_n2[tid];
+	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) tlo[twpad(tid)] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
 	cplx *steps = thi + 64 + rw * 16;
 	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
@@ -670,7 +688,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *land = reinterpret_cast<cplx *>(smem_raw);                    // [16][NT]
 	cplx *data = land + 16 * NT;                                         // [RPW][PITCH]
-	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + 256, *thi = tlo + 64;
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + Cfg::T256, *thi = tlo + Cfg::TLO;
 	const int tid = threadIdx.x;
 	const int rw = tid / P, j = tid % P;
 	const long k1 = (long) blockIdx.x * RPW + rw;
@@ -692,8 +710,8 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 		}
 	};
 	fetch(q0);
-	t256[tid] = p.tw_n2[tid * (N2 / 256)];
-	if (tid < 64) tlo[tid] = p.tw_n2[tid];
+	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) tlo[twpad(tid)] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
 	cplx *steps = thi + 64 + rw * 16;
 	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
@@ -741,6 +759,96 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	}
 }
 
+// K2, persistent form for rows of 2048 / 4096 points (round 3): TWO workgroups per CU instead of a landing zone.
+// Rows that span several waves meet at seven workgroup barriers per pair; with the 64 KB landing zone of conv_row_pipe a CU
+// holds one workgroup = one wave per SIMD, and butterflies (3.2 us of fp64 issue per 4096-point row pair), LDS exchanges
+// (2.2 us) and barriers run strictly one after the other: 8.5 us per row where its 128 KB of HBM traffic need 5.6
+// (profiles/r03_clock.json: 34 % VALU-busy).  Here a workgroup keeps only the exchange row and the tables (74 KB) and loads its
+// row straight into the registers it transforms; the second workgroup of the CU fills the gaps: while one waits at a barrier
+// or for its loads the other issues butterflies.  The filter row stays in registers; the wave's budget is 256 of them (2 waves
+// per SIMD), which holds because W is addressed through a buffer descriptor (no per-access address pairs).
+template <int LOG2N2>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_row_duo(ConvParams p, int pairs_per_wg, int n_pairs)
+{
+	using Cfg = RowCfg<LOG2N2>;
+	constexpr int N2 = Cfg::N2, P = Cfg::P, RPW = Cfg::RPW;
+	constexpr bool WL = Cfg::WAVE_LOCAL;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	cplx *data = reinterpret_cast<cplx *>(smem_raw);                    // [RPW][PITCH]
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + Cfg::T256, *thi = tlo + Cfg::TLO;
+	const int tid = threadIdx.x;
+	const int rw = tid / P, j = tid % P;
+	const long k1 = (long) blockIdx.x * RPW + rw;
+	const long q0 = (long) blockIdx.y * pairs_per_wg;
+	const long q1 = (q0 + pairs_per_wg < n_pairs) ? q0 + pairs_per_wg : n_pairs;
+	if (q0 >= q1) return;
+	// W of a pair through a buffer descriptor (SGPR base = the pair's W, one per-lane offset register, constant offsets per
+	// access): with plain pointers the 16 strided loads and 16 strided stores (4 KB and more apart: beyond the instruction's
+	// immediate) each hold a 64-bit address pair -- 64 registers that the two-workgroup budget does not have
+	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+	auto pair_rsrc = [&](long q) { return __builtin_amdgcn_make_buffer_rsrc(p.W + q * p.w_stride, 0, 0x7fffffff, 0x00020000); };
+	const int vo = (int) ((k1 * N2 + j) * (long) sizeof(cplx));
+	cplx v[16];
+	{
+		const __amdgpu_buffer_rsrc_t r = pair_rsrc(q0);
+#pragma unroll
+		for (int m = 0; m < 16; ++m) v[m] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r, vo, P * m * (int) sizeof(cplx), 0));
+	}
+	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) tlo[twpad(tid)] = p.tw_n2[tid];
+	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
+	cplx *steps = thi + 64 + rw * 16;
+	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
+	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
+	cplx h[16];
+	{
+		const cplx *H = p.H + k1 * N2 + j;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
+	}
+	auto filter = [&](int m) { return h[m]; };
+	lds_barrier();                                                       // tables visible
+	auto twiddle = [&](int m) { return cmul(twb, steps[m]); };
+	const TwRow<N2> tw{ t256, tlo, thi };
+	const RowMap map{ rw * Cfg::PITCH };
+	for (long q = q0; q < q1; ++q) {
+		// (the scheduling fences keep the unrolled element-wise loops from being turned into sixteen loads, then sixteen products ...:
+		// each of them would hold 64 more registers than the transforms need)
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], twiddle(m)); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+#if DUO_EXP != 1
+		row_fft<LOG2N2, false>(v, j, data, map, tw);
+#endif
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], filter(m)); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+#if DUO_EXP != 1
+		row_sync<WL>();      // every gather of the forward transform has completed before the inverse passes overwrite the row
+		row_fft<LOG2N2, true>(v, j, data, map, tw);
+#endif
+#if DUO_EXP == 2
+		if (q + 1 == q1)
+#endif
+		{
+			// (the offset of a 128-bit buffer store rides in the per-lane register, soffset = 0: DESIGN.md section 4.1, the gfx950 hazard)
+			const __amdgpu_buffer_rsrc_t r = pair_rsrc(q);
+#pragma unroll
+			for (int m = 0; m < 16; ++m) {
+				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cmulc(v[m], twiddle(m))), r, vo + P * m * (int) sizeof(cplx), 0, 0);
+				if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+			}
+		}
+		if (q + 1 == q1) break;
+#if DUO_EXP != 2
+		{
+			const __amdgpu_buffer_rsrc_t r = pair_rsrc(q + 1);
+#pragma unroll
+			for (int m = 0; m < 16; ++m) v[m] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r, vo, P * m * (int) sizeof(cplx), 0));
+		}
+#endif
+		row_sync<WL>();      // the last gather of the inverse transform is done before the next forward pass writes the row
+	}
+}
+
 // K2 for rows of N2 = WV * 1024 points (WV = 2, 4): the row FFT is itself split 4-step style so that all but one
 // exchange per direction stay inside a wave.  With n2 = a + 1024 b and k2 = WV ka + kb:
 //   forward   Z_kb[a] = w_N2^(a kb) sum_b x[a + 1024 b] w_WV^(b kb)      radix-WV butterflies on registers (a thread
@@ -758,7 +866,7 @@ __global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
 	constexpr int N2 = 1024 * WV, AV = 16 / WV, TR = 64 * WV, ROWS = 4 / WV, PITCH = C10::PITCH;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);                 // [4 sub-rows][PITCH]
-	cplx *t256 = data + 4 * PITCH, *tlo = t256 + 256, *thi = tlo + 64, *t1lo = thi + 64, *t1hi = t1lo + 64;
+	cplx *t256 = data + 4 * PITCH, *tlo = t256 + C10::T256, *thi = tlo + 64, *t1lo = thi + 64, *t1hi = t1lo + C10::TLO;   // t256, t1lo: padded (twpad)
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wq = tid >> 6;                        // wq: wave of the workgroup = sub-row buffer
 	const int rw = wq / WV, w = wq % WV, tr = w * 64 + lane;
@@ -771,8 +879,8 @@ __global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
 #pragma unroll
 		for (int b = 0; b < WV; ++b) v[i * WV + b] = W[tr + TR * i + 1024 * b];
 	// tables: W_256, W_N2 two-level (cross-wave twiddles), W_1024 two-level (in-wave FFT)
-	t256[tid] = p.tw_n2[tid * (N2 / 256)];
-	if (tid < 64) { tlo[tid] = p.tw_n2[tid]; t1lo[tid] = p.tw_n2[tid * WV]; }
+	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
+	if (tid < 64) { tlo[tid] = p.tw_n2[tid]; t1lo[twpad(tid)] = p.tw_n2[tid * WV]; }
 	else if (tid < 128) { thi[tid - 64] = (tid - 64 < N2 / 64) ? p.tw_n2[(tid - 64) * 64] : make_double2(0.0, 0.0); }
 	else if (tid < 144) t1hi[tid - 128] = p.tw_n2[(tid - 128) * 64 * WV];
 	cplx *steps = t1hi + 64 + rw * 16;
@@ -854,7 +962,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 	constexpr bool WL = Cfg::WAVE_LOCAL;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + 256, *thi = tlo + 64;
+	cplx *t256 = data + RPW * Cfg::PITCH, *tlo = t256 + Cfg::T256, *thi = tlo + Cfg::TLO;
 	const int tid = threadIdx.x;
 	const int rw = tid / P, j = tid % P;
 	// XCD-aware order: the pairs of one stream write neighbouring 16-byte pieces of the same output lines, so they should
@@ -864,8 +972,8 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 		const long per = 8L * p.pairs_per_stream, blk = blockIdx.x / per, r = blockIdx.x % per;
 		pair = (blk * 8 + r % 8) * p.pairs_per_stream + r / 8;
 	}
-	t256[tid] = p.tw_nf[tid * (NF / 256)];
-	if (tid < 64) tlo[tid] = p.tw_nf[tid];
+	t256[twpad(tid)] = p.tw_nf[tid * (NF / 256)];
+	if (tid < 64) tlo[twpad(tid)] = p.tw_nf[tid];
 	else if (tid < 64 + NF / 64) thi[tid - 64] = p.tw_nf[(tid - 64) * 64];
 	const bool active = pair < p.n_pairs;
 	const cplx *ring = p.ring + (active ? pair : 0) * p.ring_row_stride;
@@ -1166,7 +1274,7 @@ template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pa
 
 template <int WV> static void launch_row_big(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + 256 + 4 * 64 + 4 * 16) * sizeof(cplx);
+	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + RowCfg<10>::T256 + 3 * 64 + RowCfg<10>::TLO + 4 * 16) * sizeof(cplx);
 	if (mode) grant_lds(conv_row_big<WV, 1>, LDS); else grant_lds(conv_row_big<WV, 0>, LDS);
 	dim3 grid((unsigned) (p.N1 / (4 / WV)), n_pairs), block(NT);
 	if (mode == 1) hipLaunchKernelGGL((conv_row_big<WV, 1>), grid, block, LDS, st, p);
@@ -1200,6 +1308,20 @@ template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, 
 	hipLaunchKernelGGL((conv_row_pipe<L2, 1>), dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
 }
 
+template <int L2> static void launch_row_duo(const ConvParams &p, int n_pairs, hipStream_t st)
+{
+	using Cfg = RowCfg<L2>;
+	constexpr size_t LDS = ((size_t) Cfg::RPW * Cfg::PITCH + Cfg::NTW) * sizeof(cplx) + DUO_LDS_EXTRA;
+	const int groups = (int) (p.N1 / Cfg::RPW);
+	// two workgroups per CU: the row groups times as many pair ranges as it takes to fill 512 slots
+	int r = (512 + groups - 1) / groups;
+	if (r > n_pairs) r = n_pairs;
+	if (r < 1) r = 1;
+	const int per = (n_pairs + r - 1) / r, ranges = (n_pairs + per - 1) / per;
+	grant_lds((conv_row_duo<L2>), LDS);
+	hipLaunchKernelGGL((conv_row_duo<L2>), dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
+}
+
 // Which row-kernel family serves a plan -- decided from the plan alone (never from the number of pairs in a launch): the
 // filter spectra are stored in the family's own order by its preparation mode.
 //   persistent three-pass kernel (conv_row_pipe; conv_row for launches of a few pairs): single-phase plans with one shared filter;
@@ -1224,6 +1346,11 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 	}
 	// (the two-branch form holds both filter rows in registers: at 2048- / 4096-point rows it spills 100 VGPRs and is behind the
 	// one-shot kernel, 16.7 against 15.0 ms; at 1024-point rows ahead, 3.26 against 3.53)
+	static const int duo_env = [] { const char *e = getenv("DSP_AMD_ROW_DUO"); return e ? atoi(e) : 1; }();
+	if (duo_env && plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= (duo_env > 1 ? 11 : 12)) {
+		if (p.log2N2 == 11) launch_row_duo<11>(p, n_pairs, st); else launch_row_duo<12>(p, n_pairs, st);
+		return;
+	}
 	if (plan_is_pipe(p) && (mode == 0 || (mode == 2 && p.nph == 2)) && n_pairs >= 8) {
 		switch (p.log2N2) {
 		case 9: launch_row_pipe<9>(p, n_pairs, st); return;
