@@ -117,7 +117,7 @@ private:
 	long feed_stride = 0, feed_mask = 0, feed_pos = 0;
 	int feed_round = 0;
 	ConvStage *feeds = nullptr, *fed_by = nullptr;
-	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, pair_h, pair_out_ch, slot_of_channel;
+	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, tw_col, pair_h, pair_out_ch, slot_of_channel;
 	double2 *ring_dev = nullptr;         // ring.p, or the parent's rings (tail child)
 	// ---- small-call regime (calls much shorter than the filter; the reference's own block is 2048 frames, dsp.h:38) ----
 	// head: the first fD = fP1 x fB taps as a uniformly partitioned convolution with a frequency-domain delay line
@@ -163,7 +163,7 @@ ConvParams ConvStage::base_params() const
 	p.shared_h = (n_filters == 1) ? 1 : 0;
 	p.W = W.as<double2>();
 	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>();
-	p.tw_hi = tw_hi.as<double2>(); p.tw_lo = tw_lo.as<double2>();
+	p.tw_hi = tw_hi.as<double2>(); p.tw_lo = tw_lo.as<double2>(); p.tw_col = tw_col.as<double2>();
 	p.H = H.as<double2>();
 	p.h_scale = 1.0 / (double) N;
 	p.C = ch_in;
@@ -315,6 +315,18 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	if (!tw_lo.upload(t.data(), t.size() * sizeof(double2))) return false;
 	make_twiddles(N, N >> log2_lo, 1L << log2_lo, t);
 	if (!tw_hi.upload(t.data(), t.size() * sizeof(double2))) return false;
+	{
+		// the inter-pass twiddle as the column kernels read it (kernels_fft.hip, col_twiddle): row j < P = N1 / 16 holds
+		// w_N^(n2 j), row P holds w_N^(n2 P) -- two contiguous 16-byte look-ups per thread, the other rows by products
+		const long P = N1 / 16;
+		std::vector<double2> tc((size_t) (P + 1) * N2);
+		for (long jj = 0; jj <= P; ++jj)
+			for (long n2 = 0; n2 < N2; ++n2) {
+				const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double) ((n2 * jj) % N) / (long double) N;
+				tc[(size_t) jj * N2 + n2] = make_double2((double) cosl(a), (double) sinl(a));
+			}
+		if (!tw_col.upload(tc.data(), tc.size() * sizeof(double2))) return false;
+	}
 
 	// work buffer: streams are processed in chunks so that W (written by K1, rewritten by K2, read by K3)
 	// can stay in the 256 MiB Infinity Cache between the three launches

@@ -32,6 +32,7 @@ struct ConvParams {
 	                                    // queue up on the same memory channels (scripts/ubench/hbmprobe.hip: 4.7 -> 5.1 TB/s for its pattern)
 	const double2 *tw_n1, *tw_n2;       // exp(-2 pi i k / N1), exp(-2 pi i k / N2)
 	const double2 *tw_hi, *tw_lo;       // w_N^(hi << log2_lo), w_N^lo
+	const double2 *tw_col;              // [N1 / 16 + 1][N2]: w_N^(n2 j) for j < N1 / 16, then w_N^(n2 N1 / 16): the inter-pass twiddle as K1 / K3 read it
 	const double2 *H;                   // [n_filters][N] filter spectra in [k1][k2] order, pre-scaled by 1/N
 	double2 *Hout;                      // mode 1 of conv_row
 	double h_scale;

@@ -33,12 +33,6 @@
 #include "kparams.h"
 #include "fft_params.h"
 #include "pcm_device.h"
-#ifndef DUO_EXP
-#define DUO_EXP 0
-#endif
-#ifndef DUO_LDS_EXTRA
-#define DUO_LDS_EXTRA 0
-#endif
 
 namespace dspamd {
 
@@ -186,6 +180,31 @@ __device__ __forceinline__ cplx big_twiddle(const ConvParams &p, long m)
 	return cmul(a, b);
 }
 
+// The inter-pass twiddle of the four-step transform, w_N^(n2 k1), for the 16 rows k1 = j + P m a thread of a column kernel
+// holds of column n2: K1 applies it to its results, K3 its conjugate to what it loads (round 3: it used to sit in K2, where
+// 4 complex products per point and 32 LDS reads per thread were 7 % of the time of a kernel that is short of issue slots;
+// the column kernels are memory-bound with two thirds of their VALU idle).  Two contiguous table look-ups per thread
+// (w_N^(n2 j), w_N^(n2 P) from p.tw_col: the lanes of a column group read 256-byte runs), the rest by products four deep.
+template <bool INV, int P, int NV = 1>
+__device__ __forceinline__ void col_twiddle(const ConvParams &p, long n2, int j, cplx (&v)[16], cplx (*v2)[16] = nullptr)
+{
+	const cplx s1 = p.tw_col[(long) P * p.N2 + n2];
+	const cplx s2 = cmul(s1, s1), s3 = cmul(s2, s1), s4 = cmul(s2, s2);
+	cplx a = p.tw_col[(long) j * p.N2 + n2];
+	auto apply = [&](int m, cplx w) {
+		v[m] = INV ? cmulc(v[m], w) : cmul(v[m], w);
+		if constexpr (NV == 2) (*v2)[m] = INV ? cmulc((*v2)[m], w) : cmul((*v2)[m], w);
+	};
+#pragma unroll
+	for (int g = 0; g < 4; ++g) {
+		if (g) a = cmul(a, s4);
+		apply(4 * g, a);
+		apply(4 * g + 1, cmul(a, s1));
+		apply(4 * g + 2, cmul(a, s2));
+		apply(4 * g + 3, cmul(a, s3));
+	}
+}
+
 // ------------------------------------------------------------------ column kernels (K1, K3)
 //
 // A workgroup owns PPS pairs x TW adjacent columns; thread (q, t, j) owns the points n1 = j + P m of column t of
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(NT) void conv_col_fwd(ConvParams p)
 	}
 	lds_barrier();   // twiddle table visible (the data loads stay in flight)
 	col_fft<LOG2N1, 1, false>(v, 0, t, j, smem_raw, TwCol{ twt });
-	// the inter-pass twiddle w_N^(n2 k1) is applied by K2 when it reads the row (per row it is a geometric sequence in n2)
+	col_twiddle<false, P>(p, n2, j, v);
 	cplx *W = p.W + (pair - p.pair0) * p.w_stride;
 #pragma unroll
 	for (int m = 0; m < 16; ++m) st16(W + (long) (j + P * m) * p.N2 + n2, v[m], p.nt & 2);
@@ -362,6 +381,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 #pragma unroll
 			for (int m = 0; m < 16; ++m) v0[m] = v[m] = make_double2(0.0, 0.0);
 		}
+		col_twiddle<true, P, 2>(p, n2, j, v0, &v);
 		col_fft<LOG2N1, PPS, true>(v0, q, t, j, smem_raw, TwCol{ twt });
 		lds_barrier();
 		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
@@ -449,6 +469,7 @@ __global__ __launch_bounds__((ColCfg<LOG2N1, PPS>::THREADS)) void conv_col_inv(C
 			for (int m = 0; m < 16; ++m) v[m] = make_double2(0.0, 0.0);
 		}
 		if (ph > 0) lds_barrier();   // the previous phase's exchange has been read by everyone
+		col_twiddle<true, P>(p, n2, j, v);
 		col_fft<LOG2N1, PPS, true>(v, q, t, j, smem_raw, TwCol{ twt });
 		if (PLAIN && p.sink.on) {
 			// window sample of v[m]: f(m) = f0 + m P N2 -> output frame q_blk + f - k_origin; the valid m are a contiguous range
@@ -538,7 +559,7 @@ template <int LOG2N2> struct RowCfg {
 	static constexpr int N2 = 1 << LOG2N2, P = N2 / 16, RPW = NT / P, R3 = N2 / 256;
 	static constexpr int PITCH = N2 + N2 / 16;
 	static constexpr int T256 = 272, TLO = 68;            // padded table lengths (twpad)
-	static constexpr int NTW = T256 + TLO + 64 + RPW * 16;  // W_256, W_N2 lo / hi, per-row inter-pass twiddle steps
+	static constexpr int NTW = T256 + TLO + 64;             // W_256, W_N2 lo / hi
 	static constexpr size_t LDS = ((size_t) RPW * PITCH + NTW) * sizeof(cplx);
 	static constexpr bool WAVE_LOCAL = (P <= 64);
 };
@@ -582,19 +603,8 @@ __device__ __forceinline__ void row_fft(cplx (&v)[16], int j, cplx *lds, const R
 	pass16<LOG2N2, Cfg::R3, 256, INV, true>(v, j, lds, map, tw);
 }
 
-// The inter-pass twiddle of row k1 at position n2 = j0 + off_q:  w_N^(k1 n2) = w_N^(k1 j0) * w_N^(k1 off_q).
-// The second factor is the same for every thread of the row: lanes 0..15 of each wave fetch the 16 steps into LDS
-// once, so a thread pays one table lookup (two gathered loads) instead of sixteen.  The first 16 threads of a row
-// compute its steps
-// (the caller's next workgroup barrier publishes them)
-template <class OffFn>
-__device__ __forceinline__ void row_twiddle_steps(const ConvParams &p, long k1, int j, cplx *steps, OffFn off)
-{
-	if (j < 16) steps[j] = big_twiddle(p, (k1 * off(j)) & (p.N - 1));
-}
-
-// K2: per row k1: FFT over n2, multiply by the filter spectrum (already scaled by 1/N), IFFT over k2,
-// conjugate twiddle.  MODE 1: spectrum only (filter preparation): write scale * FFT to p.Hout.
+// K2: per row k1 (the inter-pass twiddle has been applied by K1): FFT over n2, multiply by the filter spectrum (already scaled
+// by 1/N), IFFT over k2 (K3 applies the conjugate twiddle).  MODE 1: spectrum only (filter preparation): write scale * FFT to p.Hout.
 template <int LOG2N2, int MODE>
 __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 {
@@ -615,12 +625,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
 	if (tid < 64) tlo[twpad(tid)] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
-	cplx *steps = thi + 64 + rw * 16;
-	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
-	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
 	lds_barrier();
-#pragma unroll
-	for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], cmul(twb, steps[m]));
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	row_fft<LOG2N2, false>(v, j, data, map, tw);
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 			row_fft<LOG2N2, true>(u, j, data, map, tw);
 			cplx *Wp = W + ph * p.phase_stride;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) Wp[P * m] = cmulc(u[m], cmul(twb, steps[m]));
+			for (int m = 0; m < 16; ++m) Wp[P * m] = u[m];
 		}
 		return;
 	}
@@ -657,12 +662,12 @@ __global__ __launch_bounds__(NT) void conv_row(ConvParams p)
 	row_sync<WL>();      // every forward gather has completed before the inverse passes overwrite the row
 	row_fft<LOG2N2, true>(v, j, data, map, tw);
 #pragma unroll
-	for (int m = 0; m < 16; ++m) st16(W + P * m, cmulc(v[m], cmul(twb, steps[m])), p.nt & 8);
+	for (int m = 0; m < 16; ++m) st16(W + P * m, v[m], p.nt & 8);
 }
 
 // K2, persistent form (plain convolution, one filter shared by every pair): a workgroup keeps ITS rows k1 and walks over the
 // pairs.  What the one-shot kernel above redoes per row and pair happens once per workgroup: the filter rows live in
-// registers, the pass twiddles and the 16 steps of each row's inter-pass twiddle in LDS.  The next pair's rows come in by LDS-DMA
+// registers, the pass twiddles in LDS.  The next pair's rows come in by LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, no ds_write pass) while the current ones are transformed, so the HBM
 // stream never waits for a compute phase -- at 244 VGPRs the one-shot kernel holds two workgroups per CU whose load, compute
 // and store phases overlap only by chance (2.0 ms for 8.6 GB where the bare access pattern moves them in 1.55,
@@ -713,9 +718,6 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
 	if (tid < 64) tlo[twpad(tid)] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
-	cplx *steps = thi + 64 + rw * 16;
-	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
-	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
 	cplx h[NPH][16];
 #pragma unroll
 	for (int ph = 0; ph < NPH; ++ph) {
@@ -725,10 +727,6 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the first fetch (the compiler does not know about it)
 	__syncthreads();                                                     // tables visible
-	// the inter-pass twiddles w_N^(k1 n2) are rebuilt from their 16 per-row steps in LDS at both uses instead of living in 64
-	// registers: with them resident the kernel needs ~110 AGPRs of spill space and as many copies per pair (9.0 -> 8.7 ms at
-	// 4096-point rows; the two-branch form would spill a hundred VGPRs to scratch)
-	auto twiddle = [&](int m) { return cmul(twb, steps[m]); };
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	for (long q = q0; q < q1; ++q) {
@@ -740,8 +738,6 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 		for (int m = 0; m < 16; ++m) v[m] = land[NT * m + tid];
 		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // own landing slots read: they may be overwritten
 		if (q + 1 < q1) fetch(q + 1);
-#pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], twiddle(m));
 		row_fft<LOG2N2, false>(v, j, data, map, tw);
 #pragma unroll
 		for (int ph = 0; ph < NPH; ++ph) {
@@ -752,7 +748,7 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 			row_fft<LOG2N2, true>(u, j, data, map, tw);
 			cplx *out = W + (long) ph * p.phase_stride + q * p.w_stride;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) out[P * m] = cmulc(u[m], twiddle(m));
+			for (int m = 0; m < 16; ++m) out[P * m] = u[m];
 		}
 		if (q + 1 == q1) break;
 		row_sync<WL>();      // the last gather of the inverse transform is done before the next forward pass writes the row
@@ -797,54 +793,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
 	if (tid < 64) tlo[twpad(tid)] = p.tw_n2[tid];
 	else if (tid < 64 + N2 / 64) thi[tid - 64] = p.tw_n2[(tid - 64) * 64];
-	cplx *steps = thi + 64 + rw * 16;
-	row_twiddle_steps(p, k1, j, steps, [](int q) { return (long) P * q; });
-	const cplx twb = big_twiddle(p, (k1 * j) & (p.N - 1));
 	cplx h[16];
 	{
 		const cplx *H = p.H + k1 * N2 + j;
 #pragma unroll
 		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
 	}
-	auto filter = [&](int m) { return h[m]; };
 	lds_barrier();                                                       // tables visible
-	auto twiddle = [&](int m) { return cmul(twb, steps[m]); };
 	const TwRow<N2> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
 	for (long q = q0; q < q1; ++q) {
-		// (the scheduling fences keep the unrolled element-wise loops from being turned into sixteen loads, then sixteen products ...:
-		// each of them would hold 64 more registers than the transforms need)
-#pragma unroll
-		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], twiddle(m)); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
-#if DUO_EXP != 1
 		row_fft<LOG2N2, false>(v, j, data, map, tw);
-#endif
+		// (the scheduling fences keep the unrolled element-wise loops from being turned into sixteen loads, then sixteen products ...)
 #pragma unroll
-		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], filter(m)); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
-#if DUO_EXP != 1
+		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], h[m]); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
 		row_sync<WL>();      // every gather of the forward transform has completed before the inverse passes overwrite the row
 		row_fft<LOG2N2, true>(v, j, data, map, tw);
-#endif
-#if DUO_EXP == 2
-		if (q + 1 == q1)
-#endif
 		{
 			// (the offset of a 128-bit buffer store rides in the per-lane register, soffset = 0: DESIGN.md section 4.1, the gfx950 hazard)
 			const __amdgpu_buffer_rsrc_t r = pair_rsrc(q);
 #pragma unroll
 			for (int m = 0; m < 16; ++m) {
-				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cmulc(v[m], twiddle(m))), r, vo + P * m * (int) sizeof(cplx), 0, 0);
+				__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[m]), r, vo + P * m * (int) sizeof(cplx), 0, 0);
 				if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
 			}
 		}
 		if (q + 1 == q1) break;
-#if DUO_EXP != 2
 		{
 			const __amdgpu_buffer_rsrc_t r = pair_rsrc(q + 1);
 #pragma unroll
 			for (int m = 0; m < 16; ++m) v[m] = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r, vo, P * m * (int) sizeof(cplx), 0));
 		}
-#endif
 		row_sync<WL>();      // the last gather of the inverse transform is done before the next forward pass writes the row
 	}
 }
@@ -883,12 +862,7 @@ __global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
 	if (tid < 64) { tlo[tid] = p.tw_n2[tid]; t1lo[twpad(tid)] = p.tw_n2[tid * WV]; }
 	else if (tid < 128) { thi[tid - 64] = (tid - 64 < N2 / 64) ? p.tw_n2[(tid - 64) * 64] : make_double2(0.0, 0.0); }
 	else if (tid < 144) t1hi[tid - 128] = p.tw_n2[(tid - 128) * 64 * WV];
-	cplx *steps = t1hi + 64 + rw * 16;
-	row_twiddle_steps(p, k1, tr, steps, [](int q) { return (long) TR * (q / WV) + 1024L * (q % WV); });
-	const cplx twb = big_twiddle(p, (k1 * tr) & (p.N - 1));
 	lds_barrier();
-#pragma unroll
-	for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], cmul(twb, steps[q]));
 	const TwRow<1024> tw1{ t256, t1lo, t1hi };
 	const int rbase = rw * WV * PITCH;
 	const RowMap mymap{ wq * PITCH };
@@ -941,7 +915,7 @@ __global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
 		for (int kb = 0; kb < WV; ++kb) RowMap{ rbase + kb * PITCH }.load(data, a, u[kb]);
 		dftR<WV, true>(u);
 #pragma unroll
-		for (int b = 0; b < WV; ++b) W[a + 1024 * b] = cmulc(u[b], cmul(twb, steps[i * WV + b]));
+		for (int b = 0; b < WV; ++b) W[a + 1024 * b] = u[b];
 	}
 }
 
@@ -1274,7 +1248,7 @@ template <int L2> static void launch_row(const ConvParams &p, int mode, int n_pa
 
 template <int WV> static void launch_row_big(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + RowCfg<10>::T256 + 3 * 64 + RowCfg<10>::TLO + 4 * 16) * sizeof(cplx);
+	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + RowCfg<10>::T256 + 3 * 64 + RowCfg<10>::TLO) * sizeof(cplx);
 	if (mode) grant_lds(conv_row_big<WV, 1>, LDS); else grant_lds(conv_row_big<WV, 0>, LDS);
 	dim3 grid((unsigned) (p.N1 / (4 / WV)), n_pairs), block(NT);
 	if (mode == 1) hipLaunchKernelGGL((conv_row_big<WV, 1>), grid, block, LDS, st, p);
@@ -1311,7 +1285,7 @@ template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, 
 template <int L2> static void launch_row_duo(const ConvParams &p, int n_pairs, hipStream_t st)
 {
 	using Cfg = RowCfg<L2>;
-	constexpr size_t LDS = ((size_t) Cfg::RPW * Cfg::PITCH + Cfg::NTW) * sizeof(cplx) + DUO_LDS_EXTRA;
+	constexpr size_t LDS = ((size_t) Cfg::RPW * Cfg::PITCH + Cfg::NTW) * sizeof(cplx);
 	const int groups = (int) (p.N1 / Cfg::RPW);
 	// two workgroups per CU: the row groups times as many pair ranges as it takes to fill 512 slots
 	int r = (512 + groups - 1) / groups;
@@ -1347,7 +1321,7 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 	// (the two-branch form holds both filter rows in registers: at 2048- / 4096-point rows it spills 100 VGPRs and is behind the
 	// one-shot kernel, 16.7 against 15.0 ms; at 1024-point rows ahead, 3.26 against 3.53)
 	static const int duo_env = [] { const char *e = getenv("DSP_AMD_ROW_DUO"); return e ? atoi(e) : 1; }();
-	if (duo_env && plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= (duo_env > 1 ? 11 : 12)) {
+	if (duo_env && plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= 11 && (duo_env == 1 || p.log2N2 == 10 + duo_env)) {
 		if (p.log2N2 == 11) launch_row_duo<11>(p, n_pairs, st); else launch_row_duo<12>(p, n_pairs, st);
 		return;
 	}
