@@ -141,19 +141,30 @@ def parity_of_first_step(chain, filt_dir, fs, picks):
             return {"checked": False, "why": "oracle/_ref not built"}
         t0 = time.time()
         worst, worst_rel, n = 0.0, 0.0, 0
+        against = "oracle/_ref: the reference's own sources, same input, whole first step"
         for s, c, xin, y in picks:
-            ref = RefChain(chain, fs, 1, directory=filt_dir)
-            parts = [ref.run(xin[p:p + 2048].reshape(-1, 1)) for p in range(0, xin.shape[0], 2048)]
-            r = np.concatenate([q for q in parts if q.shape[0]])[:, 0]
+            if "zita_convolver" in chain:
+                # the reference build here has no libzita-convolver (PARITY UNPINNED): the restated contract, hilbert in fp64 first
+                from oracle_api import Oracle, zita_contract
+                from scipy.signal import fftconvolve
+                pre = xin
+                if chain.startswith("hilbert -p 4095 "):
+                    pre = fftconvolve(xin, Oracle.hilbert_taps(4095))[:xin.shape[0]]
+                r = zita_contract(pre.reshape(-1, 1), np.fromfile(os.path.join(filt_dir, "filt.raw")))[:xin.shape[0], 0]
+                against = "the restated zita_convolver contract (float32 in / exact convolution / float32 out; parity unpinned: libzita-convolver absent), tolerance 1e-6 of the signal"
+            else:
+                ref = RefChain(chain, fs, 1, directory=filt_dir)
+                parts = [ref.run(xin[p:p + 2048].reshape(-1, 1)) for p in range(0, xin.shape[0], 2048)]
+                r = np.concatenate([q for q in parts if q.shape[0]])[:, 0]
+                ref.close()
             m = min(r.shape[0], y.shape[0])      # (a rate changer hands frames over in other portions than the reference: common prefix)
             d = r[:m] - y[:m]
             e = float(np.sqrt(np.mean(d * d)))
             worst = max(worst, e)
             worst_rel = max(worst_rel, e / max(float(np.sqrt(np.mean(r[:m] * r[:m]))), 1e-300))
             n = m
-            ref.close()
         return {"checked": True, "rms": worst, "rms_rel_to_signal": worst_rel, "frames_compared": n,
-                "picks": [[int(s), int(c)] for s, c, _, _ in picks], "against": "oracle/_ref: the reference's own sources, same input, whole first step",
+                "picks": [[int(s), int(c)] for s, c, _, _ in picks], "against": against,
                 "seconds": time.time() - t0}
     except Exception as e:  # pragma: no cover
         return {"checked": False, "why": str(e)[:300]}
@@ -164,7 +175,10 @@ CONFIGS = {
     "2": dict(streams=1, channels=8, block=1 << 20, chain=BIQUADS),                    # 1 stream x 8 ch, 10 biquads
     "3": dict(streams=256, channels=8, block=983040, taps=65536, chain="fir_p -t pcm -e double -c 1 {F}"),
     "4": dict(streams=256, channels=8, block=978944, taps=65536, chain=BIQUADS + " fir_p -t pcm -e double -c 1 {F} resample 96k"),
-    "5": dict(streams=1024, channels=2, block=917504, taps=131072, chain="hilbert -p 4095 fir_p -t pcm -e double -c 1 {F}"),
+    # config 5 as BASELINE.json states it: hilbert + a zita_convolver-contract convolution of 131072 taps (float32 in / transforms / out,
+    # zita_convolver.cpp:44,53,110; PARITY UNPINNED -- libzita-convolver is absent); "5f" = the same shape with the fp64 fir_p in its place
+    "5": dict(streams=1024, channels=2, block=917504, taps=131072, chain="hilbert -p 4095 zita_convolver -t pcm -e double -c 1 {F}"),
+    "5f": dict(streams=1024, channels=2, block=917504, taps=131072, chain="hilbert -p 4095 fir_p -t pcm -e double -c 1 {F}"),
 }
 
 
@@ -349,7 +363,7 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "inner_repeats": len(regions), "ms_per_step_of_each_region": [r / args.steps * 1e3 for r in regions],
             "ms_drain": ms_drain, "drain_frames": drained, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic (device sgen sine, 100+90*i Hz per stream; seeded random 65536-tap filter)",
+            "vs_baseline": None, "dtype": ("f32 (float32 transforms: the zita_convolver contract) + f64" if "f32-spectrum" in plan else "f64"), "data": "synthetic (device sgen sine, 100+90*i Hz per stream; seeded random 65536-tap filter)",
             "config": {"workload": (f"{S_total} streams x {C} ch @ {fs} Hz, chain = 10 biquads + fir_p({args.taps} taps), {args.block} frames/step/stream" if not (args.config or args.chain)
                                     else f"{S_total} streams x {C} ch @ {fs} Hz, chain = {chain_t}, {args.block} frames/step/stream"),
                        "streams": S_total, "channels": C, "block_frames": args.block, "taps": args.taps, "slab_pad_frames": args.slab_pad,
@@ -439,7 +453,11 @@ def main():
                 os.environ.pop("DSP_AMD_MERGE_IIR", None)
                 res["side_runs"]["merged_iir"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(chain, filt_dir, fs, C)
+            # (the reference build on this box has no libzita-convolver: its CPU baseline for a zita_convolver chain is the same chain with
+            # the reference's own fp64 fir_p in the convolver's place)
+            res["cpu_baseline"] = cpu_baseline(chain.replace("zita_convolver ", "fir_p "), filt_dir, fs, C)
+            if "zita_convolver " in chain and res["cpu_baseline"].get("sample"):
+                res["cpu_baseline"]["sample"] += "; zita_convolver replaced by the reference's fir_p (libzita-convolver is absent)"
             if res["cpu_baseline"].get("value"):
                 res["gpu_over_cpu"] = value / res["cpu_baseline"]["value"]
         else:

@@ -47,6 +47,15 @@ public:
 	ssize_t max_out_frames(ssize_t in_frames) const override { return ((long long) in_frames * up + down - 1) / down; }
 	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
+	// K3 simply starts writing d frames later (k_origin): the 64 frames of a zita_convolver's latency used to cost a whole pass
+	// over the output (9.8 of 43.5 ms on BASELINE config 5)
+	bool absorb_discard(long d) override
+	{
+		// (a channel that is not convolved passes through the de-interleaving pass, which knows nothing of frames to drop)
+		if (resampler || feeds || fdl || !all_selected || d <= 0) return false;
+		skip = skip_left = d;
+		return true;
+	}
 	// first stage of a pipeline fed in a wire format: the de-interleaving pass converts any format, K1 in direct mode the ones
 	// whose channel pairs are naturally aligned
 	bool wire_in_ok(int fmt, const void *in, long in_stride, ssize_t frames, bool also_out, int out_fmt) const override
@@ -118,6 +127,14 @@ private:
 	int feed_round = 0;
 	ConvStage *feeds = nullptr, *fed_by = nullptr;
 	DevBuf ring, W, H, tw_n1, tw_n2, tw_hi, tw_lo, tw_col, pair_h, pair_out_ch, slot_of_channel;
+	// float32 working precision (W, H, twiddle tables as float2; kernels_fft32.hip) -- the arithmetic of the reference's own
+	// zita_convolver path (float32 in, float32 transforms, float32 out: zita_convolver.cpp:44,53,110).  Filter spectra are
+	// still computed by the fp64 kernels (fp64 tables kept for that) and rounded once.
+	bool f32 = false;
+	DevBuf tw_n1f, tw_n2f, tw_colf;
+	long skip = 0, skip_left = 0;      // leading output frames of the stream that are dropped (absorb_discard)
+	size_t elem() const { return f32 ? sizeof(float2) : sizeof(double2); }
+	bool spectrum_f32(const std::vector<double> &taps_1ch, long n_taps, int stride, int offset, size_t index, int row_nph);
 	double2 *ring_dev = nullptr;         // ring.p, or the parent's rings (tail child)
 	// ---- small-call regime (calls much shorter than the filter; the reference's own block is 2048 frames, dsp.h:38) ----
 	// head: the first fD = fP1 x fB taps as a uniformly partitioned convolution with a frequency-domain delay line
@@ -142,7 +159,8 @@ std::string ConvStage::describe() const
 	if (resampler) o << " " << fs_in << "->" << fs_out << " " << up << "/" << down << " delay=" << out_delay;
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
-	  << (round_f32 ? " f32-io" : "") << ((direct && !fed) ? " slab-direct" : "");
+	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? " slab-direct" : "");
+	if (skip) o << " drops-first=" << skip;
 	if (fdl) {
 		o << " small-calls: head " << fP1 << "x" << fB << " taps delay line";
 		if (tail_conv) o << " + tail T=" << tail_conv->T << " N=" << tail_conv->N << " per " << fD << " frames";
@@ -162,8 +180,9 @@ ConvParams ConvStage::base_params() const
 	p.pair_h = pair_h.as<int>();
 	p.shared_h = (n_filters == 1) ? 1 : 0;
 	p.W = W.as<double2>();
-	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>();
-	p.tw_hi = tw_hi.as<double2>(); p.tw_lo = tw_lo.as<double2>(); p.tw_col = tw_col.as<double2>();
+	p.f32 = f32 ? 1 : 0;
+	p.tw_n1 = (f32 ? tw_n1f : tw_n1).as<double2>(); p.tw_n2 = (f32 ? tw_n2f : tw_n2).as<double2>();
+	p.tw_hi = tw_hi.as<double2>(); p.tw_lo = tw_lo.as<double2>(); p.tw_col = (f32 ? tw_colf : tw_col).as<double2>();
 	p.H = H.as<double2>();
 	p.h_scale = 1.0 / (double) N;
 	p.C = ch_in;
@@ -216,6 +235,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	T = sp.T;
 	lat = sp.latency;
 	round_f32 = (sp.conv_mode == CONV_ZITA_EQUIV);
+	f32 = round_f32 && !getenv("DSP_AMD_ZITA_F64");      // (the switch keeps fp64 transforms behind the float32 I/O: round 2's form)
 	nsel = num_set(sp.sel);
 	all_selected = (nsel == ch_in);
 	n_filters = (sp.fch == 1) ? 1 : nsel;
@@ -326,6 +346,15 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 				tc[(size_t) jj * N2 + n2] = make_double2((double) cosl(a), (double) sinl(a));
 			}
 		if (!tw_col.upload(tc.data(), tc.size() * sizeof(double2))) return false;
+		if (f32) {
+			auto as_f32 = [](const std::vector<double2> &d) { std::vector<float2> f(d.size()); for (size_t i = 0; i < d.size(); ++i) f[i] = make_float2((float) d[i].x, (float) d[i].y); return f; };
+			std::vector<double2> t1, t2;
+			make_twiddles(N1, N1, 1, t1);
+			make_twiddles(N2, N2, 1, t2);
+			const std::vector<float2> f1 = as_f32(t1), f2 = as_f32(t2), fc = as_f32(tc);
+			if (!tw_n1f.upload(f1.data(), f1.size() * sizeof(float2)) || !tw_n2f.upload(f2.data(), f2.size() * sizeof(float2)) ||
+			    !tw_colf.upload(fc.data(), fc.size() * sizeof(float2))) return false;
+		}
 	}
 
 	// work buffer: streams are processed in chunks so that W (written by K1, rewritten by K2, read by K3)
@@ -342,7 +371,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	n_sub = (senv && chunk_streams < S) ? std::max(1, std::min(8, atoi(senv))) : 1;
 	if (nph > 1) n_sub = 1;
 	{ static const long pad = [] { const char *e = getenv("DSP_AMD_CONV_WPAD"); return e ? atol(e) : 272L; }(); w_stride = N + pad; }
-	if (!W.alloc((size_t) n_sub * nph * pairs_per_chunk * w_stride * sizeof(double2), false)) return false;
+	// (at least one fp64 row set: the filter spectra of a float32 stage are computed by the fp64 kernels in this buffer)
+	if (!W.alloc(std::max((size_t) n_sub * nph * pairs_per_chunk * w_stride * elem(), (size_t) nph * w_stride * sizeof(double2)), false)) return false;
 	if (n_sub > 1) {
 		sub.resize(n_sub); sub_done.resize(n_sub);
 		for (int k = 0; k < n_sub; ++k) {
@@ -351,7 +381,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		}
 		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
 	}
-	if (!H.alloc((size_t) n_filters * nph * N * sizeof(double2), false)) return false;
+	if (!H.alloc((size_t) n_filters * nph * N * elem(), false)) return false;
 	if (!prepare_filters(sp)) return false;
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
@@ -496,6 +526,9 @@ bool ConvStage::spectrum_of(const std::vector<double> &src, long n_taps, int str
 	}
 	if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double2), hipMemcpyHostToDevice), "H2D taps")) return false;
 	ConvParams p = base_params();
+	p.no_split = f32 ? 1 : 0;
+	p.f32 = 0;                                   // always the fp64 kernels and tables (a float32 stage rounds the result: spectrum_f32)
+	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>(); p.tw_col = tw_col.as<double2>();
 	p.ring = tring.as<double2>();
 	p.ring_row_stride = N; p.ring_mask = N - 1;
 	p.win_base = 0; p.valid = n_taps;
@@ -508,11 +541,25 @@ bool ConvStage::spectrum_of(const std::vector<double> &src, long n_taps, int str
 	return hip_ok(hipDeviceSynchronize(), "filter spectrum");
 }
 
+// filter spectrum number `index` of a float32 stage: computed in fp64, rounded once to float2
+bool ConvStage::spectrum_f32(const std::vector<double> &src, long n_taps, int stride, int offset, size_t index, int row_nph)
+{
+	DevBuf hd;
+	if (!hd.alloc((size_t) N * sizeof(double2), false) || !spectrum_of(src, n_taps, stride, offset, hd.as<double2>(), row_nph)) return false;
+	std::vector<double2> h((size_t) N);
+	if (!hip_ok(hipMemcpy(h.data(), hd.p, (size_t) N * sizeof(double2), hipMemcpyDeviceToHost), "D2H spectrum")) return false;
+	std::vector<float2> hf((size_t) N);
+	for (long i = 0; i < N; ++i) hf[(size_t) i] = make_float2((float) h[(size_t) i].x, (float) h[(size_t) i].y);
+	return hip_ok(hipMemcpy(static_cast<char *>(H.p) + index * (size_t) N * sizeof(float2), hf.data(), (size_t) N * sizeof(float2), hipMemcpyHostToDevice), "H2D spectrum");
+}
+
 bool ConvStage::prepare_filters(const Spec &sp)
 {
 	for (int f = 0; f < n_filters * nph; ++f) {
-		const bool ok = resampler ? spectrum_of(rs_tab, T, up, f, H.as<double2>() + (size_t) f * N, nph)
-		                          : spectrum_of(sp.taps, T, sp.fch, f, H.as<double2>() + (size_t) f * N, nph);
+		bool ok;
+		if (f32) ok = resampler ? spectrum_f32(rs_tab, T, up, f, (size_t) f, nph) : spectrum_f32(sp.taps, T, sp.fch, f, (size_t) f, nph);
+		else ok = resampler ? spectrum_of(rs_tab, T, up, f, H.as<double2>() + (size_t) f * N, nph)
+		                    : spectrum_of(sp.taps, T, sp.fch, f, H.as<double2>() + (size_t) f * N, nph);
 		if (!ok) return false;
 	}
 	if (merged_pre) {
@@ -575,7 +622,7 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 				p.pair0 = s0 * pps;
 				p.stream0 = s0;
 				p.n_streams_launch = ns;
-				p.W = W.as<double2>() + (size_t) k * pairs_per_chunk * w_stride;
+				p.W = reinterpret_cast<double2 *>(static_cast<char *>(W.p) + (size_t) k * pairs_per_chunk * w_stride * elem());
 				launch_conv_col(p, false, (int) (ns * pps), sub[k]);
 				launch_conv_row(p, row_mode, (int) (ns * pps), sub[k]);
 				launch_conv_col(p, true, (int) (ns * pps), sub[k]);
@@ -649,11 +696,13 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 		return got;
 	}
 	// plain convolution: output frame m of this call = convolution at ring index pos + m
-	convolve(q_abs, q_abs + frames - 1, q_abs, frames, out, out_stride, st);
+	const long drop = std::min<long>(skip_left, frames);
+	if (drop < frames) convolve(q_abs + drop, q_abs + frames - 1, q_abs + drop, frames - drop, out, out_stride, st);
+	skip_left -= drop;
 	q_abs += frames;
-	feed_pos = (feed_pos + frames) & feed_mask;
+	feed_pos = (feed_pos + frames - drop) & feed_mask;     // (a consumer fed through its ring sees the frames that were written)
 	pos = (pos + frames) & (ring_len - 1);
-	return frames;
+	return frames - drop;
 }
 
 ssize_t ConvStage::drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st)
@@ -711,6 +760,7 @@ void ConvStage::reset(hipStream_t st)
 	if (ring.p) (void) hipMemsetAsync(ring.p, 0, ring.bytes, st);
 	pos = 0;
 	q_total = emitted = q_abs = 0;
+	skip_left = skip;
 	tail_frames = -1; tail_served = 0;
 	feed_pos = 0;
 	if (feeder_) feeder_->ring.pos = 0;

@@ -787,6 +787,11 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 		}
 		case Kind::Align: {
 			if (!flush()) return nullptr;
+			{
+				bool only_discard = sp->discard > 0 && !pl->stages.empty();
+				for (ssize_t len : sp->delay) if (len != 0) only_discard = false;
+				if (only_discard && !getenv("DSP_AMD_NO_DISCARD_FOLD") && pl->stages.back()->absorb_discard((long) sp->discard)) break;
+			}
 			DelayStage *d = new DelayStage;
 			base(d, *sp);
 			pl->stages.emplace_back(d);

@@ -82,6 +82,9 @@ public:
 	virtual ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) { (void) max_frames; (void) out; (void) out_stride; (void) st; return -1; }
 	virtual void reset(hipStream_t st) = 0;
 	virtual size_t device_bytes() const { return 0; }
+	// an end-of-chain alignment that only drops the first d frames of the stream (align.c:53-62 with no channel delayed: what is
+	// left of a `fir` / zita_convolver latency) can be taken over by the stage in front of it: true = done, no pass of its own
+	virtual bool absorb_discard(long d) { (void) d; return false; }
 	// Wire formats at the ends of a pipeline (Pipeline::run_wire): a first stage that answers wire_in_ok() reads samples of
 	// `wire_in_fmt` through its `in` pointer for this one call, a last stage that answers wire_out_ok() applies `wire_sink` (dither,
 	// clip, conversion: kparams.h) in its stores and writes samples of that format through `out`.  Both answers are pure

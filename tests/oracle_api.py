@@ -273,6 +273,18 @@ class RefChain:
         return out[:f].copy()
 
 
+def zita_contract(x, h):
+    """The zita_convolver contract restated with an fp64 FFT (parity unpinned: libzita-convolver is absent): float32 input,
+    float32 filter, exact convolution, float32 output (zita_convolver.cpp:44,53,110); the part_len frames of latency are
+    removed by the host's end-of-chain alignment (:93-102), so the visible stream is the plain convolution.  x: [frames, ch],
+    h: [taps].  Pinned against the oracle's direct-form zita_equiv at small sizes (tests/test_oracle_golden.py)."""
+    from scipy.signal import fftconvolve
+    xf = np.asarray(x, dtype=np.float64).astype(np.float32).astype(np.float64)
+    hf = np.asarray(h, dtype=np.float64).astype(np.float32).astype(np.float64)
+    y = np.stack([fftconvolve(xf[:, k], hf) for k in range(xf.shape[1])], axis=1)
+    return y.astype(np.float32).astype(np.float64)
+
+
 def rms(a):
     a = np.asarray(a, dtype=np.float64)
     return float(np.sqrt(np.mean(a * a))) if a.size else 0.0

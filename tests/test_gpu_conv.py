@@ -143,19 +143,62 @@ def test_hilbert_against_its_definition(amd):
     assert y.shape == ref.shape and rms(y - ref) < TOL
 
 
-def test_zita_equivalent_contract(amd, tmp_path):
-    # zita-convolver is absent (parity unpinned): check the restated contract -- float32 in/filter/out and
-    # min_part_len frames of latency removed by the host (zita_convolver.cpp:36-61, 93-113)
+@pytest.mark.parametrize("f64_transforms", [False, True])
+def test_zita_equivalent_contract(amd, tmp_path, monkeypatch, f64_transforms):
+    # zita-convolver is absent (PARITY UNPINNED): check the restated contract -- float32 in / filter / out and min_part_len
+    # frames of latency removed by the host (zita_convolver.cpp:36-61, 93-113).  The library's own arithmetic on this path is
+    # float32 (:44,53,110): the stage works on a float32 spectrum (kernels_fft32.hip) and is held to 1e-6 of the signal RMS
+    # (BASELINE.json's tolerance); with DSP_AMD_ZITA_F64=1 the transforms are fp64 and only the two roundings remain.
+    from oracle_api import zita_contract
+    if f64_transforms:
+        monkeypatch.setenv("DSP_AMD_ZITA_F64", "1")
     h = make_filter(2000, 5, 300.0)
     x = noise(5000, 2, 37)
     ec = amd.EffectsChain(f"zita_convolver -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, 2)
     y = ec.process(x, block=700)
-    ref = fftconv(x.astype(np.float32).astype(np.float64), h.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+    ref = zita_contract(x, h)
     assert y.shape == ref.shape
     assert np.array_equal(y, y.astype(np.float32).astype(np.float64))     # output is float32-representable
-    assert np.abs(y - ref).max() < 2e-7                                    # one float32 ulp at |y| < 1
     orc = Oracle.per_channel("zita_equiv", h, np.vstack([x, np.zeros((2063, 2))]), 64)[64:]
-    assert np.abs(y - orc).max() < 2e-7
+    if f64_transforms:
+        assert np.abs(y - ref).max() < 2e-7                                # one float32 ulp at |y| < 1
+        assert np.abs(y - orc).max() < 2e-7
+    else:
+        assert rms(y - ref) <= 1e-6 * rms(ref), rms(y - ref) / rms(ref)
+        assert rms(y - orc) <= 1e-6 * rms(orc)
+        assert np.abs(y - ref).max() < 5e-6
+
+
+def test_zita_float32_spectrum_geometries(amd, tmp_path, monkeypatch):
+    # the float32 instance of K1 / K2 / K3 at every row length (one-shot rows on one stream; the two-workgroup persistent kernel
+    # at 2048- / 4096-point rows on a batch), one filter per channel (no split-row kernels in this instance), odd channel counts
+    import torch
+    from oracle_api import zita_contract
+    h = make_filter(3001, 5, 300.0)
+    f = write(tmp_path, h)
+    for log2n in (13, 16, 18, 19, 20):
+        monkeypatch.setenv("DSP_AMD_CONV_LOG2N", str(log2n))
+        for channels in (1, 3):
+            x = noise(7000, channels, 70 + log2n)
+            y = amd.EffectsChain(f"zita_convolver -t pcm -e double -c 1 {f}", 48000, channels).process(x, block=2500)
+            ref = zita_contract(x, h)
+            assert y.shape == ref.shape and rms(y - ref) <= 1e-6 * rms(ref), (log2n, channels, rms(y - ref) / rms(ref))
+        if log2n >= 19:
+            S = 12
+            xs = np.stack([noise(6000, 2, 900 + s) for s in range(S)])
+            b = amd.BatchChain(f"zita_convolver -t pcm -e double -c 1 {f}", 48000, 2, S, 3000)
+            assert "f32-spectrum" in b.plan()
+            yb = b.process(torch.from_numpy(xs).cuda(), 3000).cpu().numpy()
+            for s in (0, 5, 11):
+                ref = zita_contract(xs[s], h)
+                assert yb[s].shape == ref.shape and rms(yb[s] - ref) <= 1e-6 * rms(ref), (log2n, s)
+    monkeypatch.delenv("DSP_AMD_CONV_LOG2N")
+    h2 = np.stack([make_filter(900, 6, 100.0), make_filter(900, 7, 150.0)], axis=1)          # one filter per channel
+    f2 = os.path.join(str(tmp_path), "h2.raw"); np.ascontiguousarray(h2, dtype="<f8").tofile(f2)
+    x = noise(5000, 2, 77)
+    y = amd.EffectsChain(f"zita_convolver -t pcm -e double -c 2 {f2}", 48000, 2).process(x, block=1024)
+    ref = np.concatenate([zita_contract(x[:, k:k + 1], h2[:, k]) for k in range(2)], axis=1)
+    assert y.shape == ref.shape and rms(y - ref) <= 1e-6 * rms(ref)
 
 
 @pytest.mark.parametrize("fs_in,fs_out,block", [(48000, 96000, 1), (48000, 96000, 4096), (96000, 48000, 333), (44100, 48000, 1000),
@@ -388,11 +431,37 @@ def test_slab_direct_history_over_ragged_calls(amd, tmp_path, taps, cap):
         assert rms(y[s] - ref) < TOL, (s, rms(y[s] - ref))
 
 
+def test_config5_full_size_zita_contract(amd, tmp_path):
+    """BASELINE config 5 as it is stated: 1024 streams x 2 ch, hilbert (fp64, zero latency) feeding a zita_convolver-contract
+    convolution of 131072 taps, complete streams (run + drain).  PARITY UNPINNED (libzita-convolver is absent): the checker is
+    the restated contract (oracle_api.zita_contract, pinned to the oracle's direct form at small sizes); tolerance 1e-6 of the
+    signal RMS -- the stage's transforms are float32 like the library's own (zita_convolver.cpp:44,53,110)."""
+    import torch
+    from oracle_api import zita_contract
+    taps, S, C, B = 131072, 1024, 2, 131072
+    h = make_filter(taps)
+    chain = f"hilbert -p 4095 zita_convolver -t pcm -e double -c 1 {write(tmp_path, h)}"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    assert "f32-spectrum" in b.plan() and "fed-by-conv" in b.plan(), b.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(14)
+    x = torch.rand((S, B + 30000, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = b.process(x, B)
+    hil = Oracle.hilbert_taps(4095)
+    for s in (1, S // 2, S - 1):
+        mid = fftconv(x[s].cpu().numpy(), hil)                 # hilbert -p: plain fp64 convolution, 4094 frames of tail
+        ref = zita_contract(mid, h)
+        got = y[s].cpu().numpy()
+        assert ref.shape == got.shape, (ref.shape, got.shape)
+        assert np.array_equal(got, got.astype(np.float32).astype(np.float64))
+        assert rms(ref - got) <= 1e-6 * rms(ref), (s, rms(ref - got) / rms(ref))
+
+
 @pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
 @pytest.mark.parametrize("cfg", ["config3", "config5"])
 def test_convolver_configs_full_size_vs_real_reference(amd, tmp_path, cfg):
-    """BASELINE config 3 (256 x 8 ch, fir_p 65536: the slab-direct K1 at N = 2^18) and the config-5 stand-in (1024 x 2 ch,
-    hilbert -p 4095 feeding fir_p 131072) at full size, complete streams (run + drain), against the real reference."""
+    """BASELINE config 3 (256 x 8 ch, fir_p 65536: the slab-direct K1 at N = 2^18) and config 5's shape with the fp64 `fir_p` in
+    the convolver's place (1024 x 2 ch, hilbert -p 4095 feeding fir_p 131072: what the real reference can check -- its build
+    here has no zita_convolver) at full size, complete streams (run + drain), against the real reference."""
     import torch
     if cfg == "config3":
         taps, S, C, B = 65536, 256, 8, 196608

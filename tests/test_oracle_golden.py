@@ -45,3 +45,22 @@ def test_case(case):
         assert np.array_equal(y, ref)
     else:
         assert rms(y - ref) < 1e-15, rms(y - ref)
+
+
+def test_zita_contract_restatements_agree():
+    # two restatements of the zita_convolver contract (PARITY UNPINNED: the library is absent): the oracle's direct form in
+    # extended precision (oracle/dsp_oracle.c, orc_zita_equiv_*) and the FFT form the full-size GPU test uses
+    # (oracle_api.zita_contract): the same float32 values but for a rounding tie in a handful of samples
+    import numpy as np
+    from oracle_api import Oracle, zita_contract
+    if not Oracle.available():
+        import pytest
+        pytest.skip("liboracle.so not built")
+    rng = np.random.Generator(np.random.PCG64(3))
+    h = rng.standard_normal(700) * np.exp(-np.arange(700) / 90.0) / 8
+    x = rng.uniform(-0.5, 0.5, size=(3000, 2))
+    a = Oracle.per_channel("zita_equiv", h, np.vstack([x, np.zeros((699 + 64, 2))]), 64)[64:]
+    b = zita_contract(x, h)
+    assert a.shape == b.shape
+    d = np.abs(a - b)
+    assert d.max() <= 1.2e-7 and np.count_nonzero(d) <= 0.01 * d.size, (d.max(), np.count_nonzero(d))
