@@ -452,6 +452,41 @@ def main():
             except Exception as e:  # pragma: no cover
                 os.environ.pop("DSP_AMD_MERGE_IIR", None)
                 res["side_runs"]["merged_iir"] = {"error": str(e)[:300]}
+            # SIDE FIGURES, never `value`: BASELINE.json's other configurations and the headline chain at the reference's own block
+            # (2048 frames, dsp.h:38) and at round 1's step (196608), a few steps each, so that these numbers too come from the
+            # driver's run of this file (parity of every one of them: tests/test_gpu_conv.py, test_gpu_parity.py, test_gpu_smallcalls.py)
+            res["side_runs"]["other_configs"] = {}
+            presets = [("headline_block_2048", dict(streams=S_total, channels=C, block=2048, taps=args.taps, chain=None, steps=200)),
+                       ("headline_block_196608", dict(streams=S_total, channels=C, block=196608, taps=args.taps, chain=None, steps=10))]
+            presets += [("config_" + k, dict(v, steps=6)) for k, v in sorted(CONFIGS.items()) if k in ("2", "3", "4", "5")]
+            for name, cfg in presets:
+                try:
+                    torch.cuda.empty_cache()
+                    ctext = (cfg["chain"] or (BIQUADS + " fir_p -t pcm -e double -c 1 {F}"))
+                    if cfg.get("taps") and cfg["taps"] != args.taps:
+                        np.asarray(make_filter(cfg["taps"]), dtype="<f8").tofile(os.path.join(filt_dir, f"filt{cfg['taps']}.raw"))
+                        ctext = ctext.replace("{F}", f"filt{cfg['taps']}.raw")
+                    ctext = ctext.replace("{F}", "filt.raw")
+                    Sx, Cx, Bx = cfg["streams"], cfg["channels"], cfg["block"]
+                    sb2 = dsp_amd.BatchChain(ctext, fs, Cx, Sx, Bx, directory=filt_dir)
+                    xs = torch.zeros((Sx, Bx + args.slab_pad, Cx), dtype=torch.float64, device="cuda")
+                    L.dspamd_sgen_sine(xs.data_ptr(), Sx, Bx + args.slab_pad, Cx, fs, 100.0, 90.0, 0, stream)
+                    os_ = torch.empty((Sx, sb2.max_out_frames(Bx) + args.slab_pad, sb2.ochannels), dtype=torch.float64, device="cuda")
+                    for _ in range(2):
+                        sb2.run(xs[:, :Bx, :], os_)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(cfg["steps"]):
+                        sb2.run(xs[:, :Bx, :], os_)
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / cfg["steps"]
+                    b_alg2 = 24.0 if name == "config_4" else B_ALG
+                    res["side_runs"]["other_configs"][name] = {
+                        "value": Sx * Cx * Bx / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3, "streams": Sx, "channels": Cx, "block_frames": Bx,
+                        "whole_chain_frac": Sx * Cx * Bx / dt * b_alg2 / HBM_PEAK, "finite": bool(torch.isfinite(os_[:, :min(Bx, os_.shape[1] - args.slab_pad), :]).all().item()), "plan": sb2.plan()}
+                    del sb2, xs, os_
+                except Exception as e:  # pragma: no cover
+                    res["side_runs"]["other_configs"][name] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             # (the reference build on this box has no libzita-convolver: its CPU baseline for a zita_convolver chain is the same chain with
             # the reference's own fp64 fir_p in the convolver's place)
