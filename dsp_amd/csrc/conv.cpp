@@ -608,6 +608,7 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 		p.q_blk = q_blk;
 		p.k_origin = k_origin;
 		p.out_count = out_count;
+		p.k3_pipe_ok = (all_selected && n_filters == 1 && pps == 4 && ch_in == 8 && !feeds && ((((size_t) out) & 15) == 0)) ? 1 : 0;
 		if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; p.slab_store = resampler ? 0 : 1; p.slab_fmt = wire_in_fmt; }
 		const int row_mode = (nph > 1) ? 2 : 0;
 		if (n_sub > 1) {

@@ -34,6 +34,8 @@ CASES = {
     "conv2048": dict(chain="fir_p -t pcm -e double -c 1 {F}", S=16, C=2, frames=9000, calls=(2500, 2500, 2500, 1500), pick=(0, 15), taps=(3001, 5, 300.0), log2n=19),
     "conv1024": dict(chain="fir_p -t pcm -e double -c 1 {F}", S=16, C=2, frames=9000, calls=(2500, 2500, 2500, 1500), pick=(3, 15), taps=(3001, 5, 300.0), log2n=18),
     "conv512":  dict(chain="fir_p -t pcm -e double -c 1 {F}", S=8, C=8, frames=9000, calls=(4500, 4500), pick=(0, 7), taps=(1500, 6, 200.0), log2n=13),
+    "conv_k3p": dict(chain="fir_p -t pcm -e double -c 1 {F}", S=8, C=8, frames=9000, calls=(4500, 4500), pick=(0, 7), taps=(3001, 13, 300.0), log2n=18),   # four pairs per stream, >= 1024 tiles: the persistent K3
+    "zita":     dict(chain="zita_convolver -t pcm -e double -c 1 {F}", S=12, C=2, frames=7000, calls=(3500, 3500), pick=(0, 11), taps=(3001, 14, 300.0), log2n=19),   # float32-spectrum instance (fp64 transforms with DSP_AMD_ZITA_F64=1)
     "headline": dict(chain=BIQ + " fir_p -t pcm -e double -c 1 {F}", S=8, C=8, frames=12000, calls=(4096, 4096, 3808), pick=(0, 7), taps=(5000, 7, 600.0)),
     "fir_lat":  dict(chain="fir -t pcm -e double -c 1 {F} :1 delay 7S", S=3, C=3, frames=6000, calls=(3000, 3000), pick=(0, 2), taps=(700, 8, 90.0)),
     "two_conv": dict(chain="fir_p -t pcm -e double -c 1 {F} hilbert -p 255", S=4, C=2, frames=7000, calls=(3500, 3500), pick=(0, 3), taps=(900, 9, 120.0)),

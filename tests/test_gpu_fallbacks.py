@@ -23,7 +23,7 @@ SWITCHES = [
     "DSP_AMD_ROW_DUO=0", "DSP_AMD_ROW_DUO=2", "DSP_AMD_ROW_DUO=0 DSP_AMD_ROW_PIPE=0", "DSP_AMD_ROW_DUO=0 DSP_AMD_ROW_PIPE=0 DSP_AMD_ROW_BIG=0", "DSP_AMD_ROW_DUO=0 DSP_AMD_ROW_PIPE=0 DSP_AMD_ROW_BIG=2",
     "DSP_AMD_CONV_WPAD=0 DSP_AMD_CONV_RPAD=0", "DSP_AMD_CONV_NT=0",
     "DSP_AMD_RESAMPLE_NO_GEMM=1", "DSP_AMD_RESAMPLE_DIRECT=1",
-    "DSP_AMD_NO_WIRE_FUSION=1", "DSP_AMD_PLUGIN_MAPPED_KB=0", "DSP_AMD_NO_DISCARD_FOLD=1",
+    "DSP_AMD_NO_WIRE_FUSION=1", "DSP_AMD_PLUGIN_MAPPED_KB=0", "DSP_AMD_NO_DISCARD_FOLD=1", "DSP_AMD_K3_PIPE=0", "DSP_AMD_ZITA_F64=1",
 ]
 
 
@@ -40,6 +40,12 @@ def reference(tmp_path_factory):
             np.asarray(h, dtype="<f8").tofile(f)
             chain = chain.replace("{F}", f)
         x = fp.inputs(name, c)
+        if "zita_convolver" in chain:
+            # not in the reference build here (libzita-convolver is absent; parity unpinned): the restated contract
+            from oracle_api import zita_contract
+            for s in c["pick"]:
+                ref[f"{name}/{s}"] = zita_contract(x[s], h)
+            continue
         if name in fp.HOST_CASES:
             ref[f"{name}/0"] = RefChain(chain, 48000, c["C"]).process(x, block=c["block"])
         else:
@@ -65,6 +71,9 @@ def test_every_switch_gives_the_reference_outputs(reference, tmp_path, switch):
     for key, want in reference.items():
         y = got[key]
         name = key.split("/")[0]
+        if name == "zita":
+            assert y.shape == want.shape and rms(y - want) <= 1e-6 * rms(want), (switch, key, rms(y - want) / rms(want))      # the contract's tolerance
+            continue
         if name.startswith("rs") or name == "host_conv":
             # a rate changer hands frames over in other portions than the reference mid-stream; after the drain the totals agree
             assert y.shape == want.shape, (switch, key, y.shape, want.shape)
