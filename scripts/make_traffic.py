@@ -36,7 +36,7 @@ spec = {   # bench name -> (rocprof substring, fetch factor, designed bytes)
     "cascade_fast": ("cascade_fast", 1.0, samples * 16),
     "cascade_wave": ("cascade_wave", 1.0, samples * 16),
     "conv_col_fwd": ("conv_col_fwd", fetch_factor, pairs * N * 32),
-    "conv_row": ("conv_row_pipe", fetch_factor, pairs * N * 32),        # (its loads are LDS-DMA, 16 B/lane: same under-count, MI355X_MICROARCH.md)
+    "conv_row": ("conv_row_duo" if find("conv_row_duo")[0] else "conv_row_pipe", fetch_factor, pairs * N * 32),        # (16 B/lane buffer loads / LDS-DMA: same under-count, MI355X_MICROARCH.md)
     "conv_col_inv": ("conv_col_inv", fetch_factor, pairs * N * 16 + samples * 8),
 }
 for name, (sub, ff, designed) in spec.items():
