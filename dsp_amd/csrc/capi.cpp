@@ -292,6 +292,19 @@ const char *dspamd_profile_collect(void)
 
 // ---------------------------------------------------------------- bench endpoints
 
+int dspamd_sgen_sweep(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double freq1, double dfreq, ssize_t total_frames, ssize_t pos0, void *stream)
+{
+	if (!(freq0 > 0.0) || !(freq1 > 0.0)) { set_error("sgen: frequencies must be > 0"); return -1; }
+	launch_sgen(static_cast<double *>(d_buf), n_streams, frames, channels, fs, 1, freq0, freq1, dfreq, total_frames, 0, 0, pos0, static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "sgen") ? 0 : -1;
+}
+
+int dspamd_sgen_delta(void *d_buf, int n_streams, ssize_t frames, int channels, ssize_t offset, ssize_t doffset, ssize_t pos0, void *stream)
+{
+	launch_sgen(static_cast<double *>(d_buf), n_streams, frames, channels, 48000, 2, 1.0, 1.0, 0.0, 0, offset, doffset, pos0, static_cast<hipStream_t>(stream));
+	return hip_ok(hipGetLastError(), "sgen") ? 0 : -1;
+}
+
 int dspamd_sgen_sine(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double dfreq, ssize_t pos0, void *stream)
 {
 	launch_sgen_sine(static_cast<double *>(d_buf), n_streams, frames, channels, fs, freq0, dfreq, pos0, static_cast<hipStream_t>(stream));

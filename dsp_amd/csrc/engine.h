@@ -139,6 +139,7 @@ void launch_remix(const RemixParams &p, int n_streams, hipStream_t stream);
 void launch_delay_ex(const DelayParams &p, long ring_alt_off, long skip, long max_len, int n_streams, hipStream_t stream);
 void launch_copy_slab(const double *in, long in_stride, double *out, long out_stride, long frames, long skip, int C, int n_streams, hipStream_t stream);
 void launch_sgen_sine(double *buf, int n_streams, long frames, int channels, int fs, double freq0, double dfreq, long pos0, hipStream_t stream);
+void launch_sgen(double *buf, int n_streams, long frames, int channels, int fs, int kind, double freq0, double freq1, double dfreq, long total_frames, long offset, long doffset, long pos0, hipStream_t stream);
 void launch_digest(const double *buf, int n_streams, long frames, long stride, int channels, double *out, hipStream_t stream);
 void launch_copy_probe(const void *src, void *dst, size_t bytes, hipStream_t stream);
 

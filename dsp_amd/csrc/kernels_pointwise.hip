@@ -166,6 +166,34 @@ __global__ __launch_bounds__(256) void sgen_kernel(double *buf, long frames, int
 	}
 }
 
+// the other two forms of sgen_run_generator: a sine sweep freq0 -> freq1 over total_frames (sgen.c:60-62 with v of :163:
+// sin(w0 / v (exp(t v) - 1)), v = log(w1 / w0) / (total_frames / fs)) and a unit impulse at frame `offset` (sgen.c:46-52).
+// kind 1 = sweep, 2 = delta; stream s uses freq0 + s dfreq (and the same ratio freq1 / freq0), offset + s doffset
+__global__ __launch_bounds__(256) void sgen_kernel2(double *buf, long frames, int C, int fs, int kind, double freq0, double freq1, double dfreq, long total_frames, long offset, long doffset, long pos0)
+{
+	const int s = blockIdx.y;
+	const double w0 = (freq0 + s * dfreq) * (2.0 * M_PI), w1 = (freq1 + s * dfreq * (freq1 / freq0)) * (2.0 * M_PI);
+	const double v = (kind == 1 && total_frames > 0 && w0 != w1) ? log(w1 / w0) / ((double) total_frames / fs) : 0.0;
+	const long off = offset + s * doffset;
+	double *dst = buf + (size_t) s * frames * C;
+	const long n = frames * C;
+	for (long e = (long) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long) gridDim.x * blockDim.x) {
+		const long fr = pos0 + e / C;
+		if (kind == 2) { dst[e] = (fr == off) ? 1.0 : 0.0; continue; }
+		const double t = (double) fr / fs;
+		dst[e] = (v != 0.0) ? sin(w0 / v * (exp(t * v) - 1.0)) : sin(w0 * t);
+	}
+}
+
+void launch_sgen(double *buf, int n_streams, long frames, int channels, int fs, int kind, double freq0, double freq1, double dfreq, long total_frames, long offset, long doffset, long pos0, hipStream_t stream)
+{
+	const long n = frames * channels;
+	if (n <= 0) return;
+	long blocks = (n + 255) / 256;
+	if (blocks > 2048) blocks = 2048;
+	hipLaunchKernelGGL(sgen_kernel2, dim3((unsigned) blocks, n_streams), dim3(256), 0, stream, buf, frames, channels, fs, kind, freq0, freq1, dfreq, total_frames, offset, doffset, pos0);
+}
+
 void launch_sgen_sine(double *buf, int n_streams, long frames, int channels, int fs, double freq0, double dfreq, long pos0, hipStream_t stream)
 {
 	const long n = frames * channels;

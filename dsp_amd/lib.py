@@ -55,7 +55,7 @@ API_SYMBOLS = [
     "dspamd_chain_n_effects", "dspamd_chain_effect_name", "dspamd_batch_create", "dspamd_batch_out_fs",
     "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run", "dspamd_batch_run_strided",
     "dspamd_batch_drain", "dspamd_batch_reset", "dspamd_batch_destroy", "dspamd_batch_plan", "dspamd_batch_n_stages",
-    "dspamd_sgen_sine", "dspamd_digest", "dspamd_copy_probe", "dspamd_pcm_sample_bytes", "dspamd_pcm_read", "dspamd_pcm_write", "dspamd_profile_enable", "dspamd_profile_collect",
+    "dspamd_sgen_sine", "dspamd_sgen_sweep", "dspamd_sgen_delta", "dspamd_digest", "dspamd_copy_probe", "dspamd_pcm_sample_bytes", "dspamd_pcm_read", "dspamd_pcm_write", "dspamd_profile_enable", "dspamd_profile_collect",
     "dspamd_batch_run_wire", "dspamd_batch_drain_wire", "dspamd_batch_wire_fused",
 ]
 
@@ -109,6 +109,8 @@ def load_library():
         "dspamd_batch_reset": (None, [vp, vp]), "dspamd_batch_destroy": (None, [vp]),
         "dspamd_batch_plan": (cp, [vp]), "dspamd_batch_n_stages": (i, [vp]),
         "dspamd_sgen_sine": (i, [vp, i, ssize_t, i, i, C.c_double, C.c_double, ssize_t, vp]),
+        "dspamd_sgen_sweep": (i, [vp, i, ssize_t, i, i, C.c_double, C.c_double, C.c_double, ssize_t, ssize_t, vp]),
+        "dspamd_sgen_delta": (i, [vp, i, ssize_t, i, ssize_t, ssize_t, ssize_t, vp]),
         "dspamd_digest": (i, [vp, i, ssize_t, ssize_t, i, vp, vp]),
         "dspamd_copy_probe": (i, [vp, vp, C.c_size_t, vp]),
         "dspamd_pcm_sample_bytes": (C.c_size_t, [i]),

@@ -110,6 +110,10 @@ const char *dspamd_profile_collect(void);
 /* ---- device-side bench endpoints (sgen.c:55-67 / null.c:31-34 equivalents) ---- */
 /* stream s, frame t (absolute position pos0+t), every channel: sin(2 pi (freq0 + s*dfreq) * (pos0+t)/fs) */
 int dspamd_sgen_sine(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double dfreq, ssize_t pos0, void *stream);
+/* the generator's other two forms: `sine:freq=f0-f1` on a source of total_frames (sgen.c:60-62, 163: exponential sweep) and `delta:offset=N`
+ * (sgen.c:46-52); stream s uses freq0 + s dfreq with the same ratio freq1 / freq0, resp. offset + s doffset; pos0 = frames already generated */
+int dspamd_sgen_sweep(void *d_buf, int n_streams, ssize_t frames, int channels, int fs, double freq0, double freq1, double dfreq, ssize_t total_frames, ssize_t pos0, void *stream);
+int dspamd_sgen_delta(void *d_buf, int n_streams, ssize_t frames, int channels, ssize_t offset, ssize_t doffset, ssize_t pos0, void *stream);
 /* per-stream digests like stats.c:47-76: sum, sum of squares, peak -> d_out[S][3] */
 int dspamd_digest(const void *d_buf, int n_streams, ssize_t frames, ssize_t stride_frames, int channels, void *d_out, void *stream);
 /* ---- wire formats on the device (sampleconv.c:25-149 with the BIT_PERFECT macros of sampleconv.h:35-56) ---- */

@@ -786,6 +786,27 @@ void orc_hilbert_taps(ssize_t taps, double angle_deg, double *h)
 	}
 }
 
+/* sgen.c:55-67 with v != 0 (sgen.c:163: v = log(freq1 / freq0) / (frames / fs), both frequencies stored as 2 pi f): exponential sweep */
+void orc_sgen_sweep(double *buf, ssize_t frames, int channels, int fs, double f0_hz, double f1_hz, ssize_t total_frames, ssize_t pos0)
+{
+	const double w0 = 2.0 * M_PI * f0_hz, w1 = 2.0 * M_PI * f1_hz;
+	const double v = (total_frames > 0 && w0 != w1) ? log(w1 / w0) / ((double) total_frames / fs) : 0.0;
+	for (ssize_t i = 0; i < frames; ++i) {
+		const double t = (double) (pos0 + i) / fs;
+		const double s = (v != 0) ? sin(w0 / v * (exp(t * v) - 1.0)) : sin(w0 * t);
+		for (int k = 0; k < channels; ++k)
+			buf[i*channels + k] = 0.0 + s;
+	}
+}
+
+/* sgen.c:46-52: a unit impulse at frame `offset` of the source */
+void orc_sgen_delta(double *buf, ssize_t frames, int channels, ssize_t offset, ssize_t pos0)
+{
+	for (ssize_t i = 0; i < frames * channels; ++i) buf[i] = 0.0;
+	if (pos0 <= offset && offset - pos0 < frames)
+		for (int k = 0; k < channels; ++k) buf[(offset - pos0) * channels + k] += 1.0;
+}
+
 /* sgen.c:55-67 (fixed-frequency branch, v == 0): freq0 is stored as 2 pi f (sgen.c:150-160) */
 void orc_sgen_sine(double *buf, ssize_t frames, int channels, int fs, double freq_hz, ssize_t pos0)
 {

@@ -63,6 +63,8 @@ void orc_resample_free(void *st);
 
 void orc_hilbert_taps(ssize_t taps, double angle_deg, double *h);
 void orc_sgen_sine(double *buf, ssize_t frames, int channels, int fs, double freq_hz, ssize_t pos0);
+void orc_sgen_sweep(double *buf, ssize_t frames, int channels, int fs, double f0_hz, double f1_hz, ssize_t total_frames, ssize_t pos0);
+void orc_sgen_delta(double *buf, ssize_t frames, int channels, ssize_t offset, ssize_t pos0);
 
 /* fp64 direct-form linear convolution, full length n_x + n_taps - 1 (second oracle for fir/fir_p) */
 void orc_conv_full(const double *x, ssize_t n_x, const double *taps, ssize_t n_taps, double *y);

@@ -71,6 +71,8 @@ class Oracle:
             L.orc_resample_free.argtypes = [C.c_void_p]
             L.orc_hilbert_taps.argtypes = [_ss, C.c_double, C.c_void_p]
             L.orc_sgen_sine.argtypes = [C.c_void_p, _ss, C.c_int, C.c_int, C.c_double, _ss]
+            L.orc_sgen_sweep.argtypes = [C.c_void_p, _ss, C.c_int, C.c_int, C.c_double, C.c_double, _ss, _ss]
+            L.orc_sgen_delta.argtypes = [C.c_void_p, _ss, C.c_int, _ss, _ss]
             L.orc_conv_full.argtypes = [C.c_void_p, _ss, C.c_void_p, _ss, C.c_void_p]
             L.orc_zita_equiv_new.restype = C.c_void_p
             L.orc_zita_equiv_new.argtypes = [C.c_void_p, _ss, C.c_int]
@@ -180,6 +182,22 @@ class Oracle:
         b = np.zeros((frames, channels))
         cls.lib().orc_sgen_sine(_ptr(b), frames, channels, fs, freq, pos0)
         return b
+
+
+def _sgen_sweep(frames, channels, fs, f0, f1, total, pos0=0):
+    b = np.zeros((frames, channels))
+    Oracle.lib().orc_sgen_sweep(_ptr(b), frames, channels, fs, f0, f1, total, pos0)
+    return b
+
+
+def _sgen_delta(frames, channels, offset, pos0=0):
+    b = np.zeros((frames, channels))
+    Oracle.lib().orc_sgen_delta(_ptr(b), frames, channels, offset, pos0)
+    return b
+
+
+Oracle.sgen_sweep = staticmethod(_sgen_sweep)
+Oracle.sgen_delta = staticmethod(_sgen_delta)
 
 
 class RefChain:

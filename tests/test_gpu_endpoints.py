@@ -60,6 +60,29 @@ def test_sgen_kernel_vs_oracle(amd, pos0):
         assert np.array_equal(y[s][:, 0], y[s][:, Cn - 1])
 
 
+def test_sgen_sweep_and_delta_vs_oracle(amd):
+    """the generator's other two forms (sgen.c:46-52 impulse, :60-62 / :163 exponential sweep) on the device against the oracle's
+    restatement, which is pinned bit for bit to the stock CLI (tests/test_oracle_vs_ref.py).  The sweep's phase reaches 1e4 rad:
+    an ulp of the device's exp() there is 2e-12 of phase; the impulse is exact."""
+    import torch
+    L = amd.load_library()
+    S, F, Cn, fs = 3, 24000, 2, 48000
+    buf = torch.empty((S, F, Cn), dtype=torch.float64, device="cuda")
+    for pos0 in (0, 24000):
+        assert L.dspamd_sgen_sweep(buf.data_ptr(), S, F, Cn, fs, C.c_double(100.0), C.c_double(8000.0), C.c_double(50.0), 48000, pos0, None) == 0
+        torch.cuda.synchronize()
+        y = buf.cpu().numpy()
+        for s in range(S):
+            f0 = 100.0 + 50.0 * s
+            ref = Oracle.sgen_sweep(F, Cn, fs, f0, f0 * 80.0, 48000, pos0)
+            assert np.abs(y[s] - ref).max() <= 1e-10, (s, pos0, np.abs(y[s] - ref).max())
+        assert L.dspamd_sgen_delta(buf.data_ptr(), S, F, Cn, 100 + 24000 * (pos0 > 0), 7, pos0, None) == 0
+        torch.cuda.synchronize()
+        y = buf.cpu().numpy()
+        for s in range(S):
+            assert np.array_equal(y[s], Oracle.sgen_delta(F, Cn, 100 + 24000 * (pos0 > 0) + 7 * s, pos0)), (s, pos0)
+
+
 def test_digest_kernel_vs_numpy(amd):
     """the per-stream (sum, sum of squares, peak) bench.py reports: sums in another order than numpy's, so relative
     1e-12 on the sums; the peak is exact."""

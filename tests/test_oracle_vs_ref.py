@@ -227,3 +227,24 @@ def test_delays_bitexact(chain, ch):
     ref = RefChain(chain, FS, ch).process(x, block=500)
     y, _ = oracle_chain.run(chain, x, FS)
     assert y.shape == ref.shape and np.array_equal(ref, y)
+
+
+def test_sgen_sweep_and_delta_vs_reference_cli(tmp_path):
+    """sgen.c:46-67, 163: the oracle's restatement of the swept sine and of the impulse against the stock CLI's own generator
+    (same libm: bit for bit)."""
+    import os
+    import subprocess
+    from oracle_api import REF_DIR
+    exe = os.path.join(REF_DIR, "dsp_ref")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/dsp_ref not built")
+    o = os.path.join(str(tmp_path), "o.raw")
+    for spec, ref in (("sine:freq=100-8000+1", lambda: Oracle.sgen_sweep(48000, 2, 48000, 100.0, 8000.0, 48000)),
+                      ("sine:freq=3k-50+0.5", lambda: Oracle.sgen_sweep(24000, 2, 48000, 3000.0, 50.0, 24000)),
+                      ("delta:offset=100S+0.25", lambda: Oracle.sgen_delta(12000, 2, 100))):
+        r = subprocess.run([exe, "-q", "-t", "sgen", "-r", "48k", "-c", "2", spec, "-o", "-t", "pcm", "-e", "double", o], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr[-500:]
+        y = np.fromfile(o).reshape(-1, 2)
+        want = ref()
+        assert y.shape == want.shape, (spec, y.shape, want.shape)
+        assert np.array_equal(y, want), spec
