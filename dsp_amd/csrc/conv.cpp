@@ -382,6 +382,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
 	}
 	if (!H.alloc((size_t) n_filters * nph * N * elem(), false)) return false;
+	log_msg(LL_VERBOSE, "%s: info: device buffers ring %p (%zu MB) W %p (%zu MB) H %p", name.c_str(), ring_dev, ring.bytes >> 20, W.p, W.bytes >> 20, H.p);
 	if (!prepare_filters(sp)) return false;
 
 	// a cascade directly in front may write the planar rings itself (saves one interleaved round trip)
