@@ -299,3 +299,22 @@ def test_file_to_file_against_the_reference_cli(gpu, tmp_path):
     assert got.shape == want.shape
     d = got.astype(np.int32) - want.astype(np.int32)
     assert np.abs(d).max() <= 1 and np.count_nonzero(d) <= 4, (np.abs(d).max(), np.count_nonzero(d))
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("double", "float", 0), ("s32", "s24", 24), ("float", "double", 0)])
+def test_persistent_k3_speaks_the_formats(gpu, tmp_path, monkeypatch, in_fmt, out_fmt, prec):
+    # a shape that reaches the persistent K3 (streams of four pairs, N = 2^18: 8 streams x 128 column blocks = 1024 tiles):
+    # the plain call and the call with the sink must run the SAME kernel instance -- two instances of one FFT source are not
+    # guaranteed the same bits -- so every byte and both statistics agree with the stand-alone passes
+    monkeypatch.setenv("DSP_AMD_CONV_LOG2N", "18")
+    path, _ = write_filter(tmp_path, 3000)
+    chain = f"fir_p -t pcm -e double -c 1 {path}"
+    S, Cn, fs = 8, 8, 48000
+    blocks = (5000, 4096, 777)
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 31)
+    a, sa, plan = separate_passes(gpu, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert "N=262144" in plan
+    f, sf, bits = fused(gpu, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert same(a, f)
+    assert np.array_equal(sa, sf)
+    check_bits(bits[:3], [3 if in_fmt in ("s16", "s32", "s24", "float") else 2] * 3)
