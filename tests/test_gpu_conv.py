@@ -282,6 +282,23 @@ def test_every_transform_geometry(amd, tmp_path, monkeypatch, log2n, channels):
     assert rms(y - ref) < TOL, rms(y - ref)
 
 
+@pytest.mark.parametrize("log2n,S", [(16, 32), (17, 16), (18, 8), (19, 8)])
+def test_persistent_kernels_on_batches(amd, tmp_path, monkeypatch, log2n, S):
+    # the persistent forms of K2 (conv_row_pipe up to 1024-point rows, conv_row_duo from 2048) and of K3 (conv_col_inv_pipe at 64-,
+    # 128- and 256-point columns: streams of four pairs, at least 1024 tiles) are only taken on batches; every geometry against scipy,
+    # calls that leave the last block ragged, the drain through the same kernels
+    import torch
+    monkeypatch.setenv("DSP_AMD_CONV_LOG2N", str(log2n))
+    h = make_filter(3001, 5, 300.0)
+    b = amd.BatchChain(f"fir_p -t pcm -e double -c 1 {write(tmp_path, h)}", 48000, 8, S, 6000)
+    assert f"N={1 << log2n}=" in b.plan(), b.plan()
+    x = np.stack([noise(11000, 8, 300 + s) for s in range(S)])
+    y = b.process(torch.from_numpy(x).cuda(), 6000).cpu().numpy()
+    for s in (0, S // 2, S - 1):
+        ref = fftconv(x[s], h)
+        assert y[s].shape == ref.shape and rms(y[s] - ref) < TOL, (log2n, s, rms(y[s] - ref))
+
+
 @pytest.mark.parametrize("merge", [False, True])
 @pytest.mark.parametrize("channels", [2, 3, 8])
 def test_chained_convolvers_feed_each_other(amd, tmp_path, monkeypatch, channels, merge):
