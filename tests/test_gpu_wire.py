@@ -214,6 +214,9 @@ def test_unfused_paths_inside_run_wire(gpu, chain, S, Cn, in_fmt, out_fmt, prec,
     ("resample 96k", 128, 8, "float", "s24", 24, 3),
     (f"{EQ10} fir_p -t pcm -e double -c 1 {{F}} resample 96k", 128, 8, "s16", "s16", 16, (3, 3, 2)),   # BASELINE config 4's chain: cascade in (calls of at least one 512-frame tile), merged fir_p + 2x upsampler out; its drain tail goes through the stand-alone sink
     ("resample 44.1k", 32, 2, "s16", "s16", 16, 0),             # the general resampler speaks neither
+    ("fir -t pcm -e double -c 1 {F}", 64, 8, "s16", "s16", 16, 3),        # `fir` on every channel: K3 drops the latency frames itself (no alignment pass) and applies the sink
+    ("zita_convolver -t pcm -e double -c 1 {F}", 16, 2, "float", "float", 0, 3),   # float32 in -> float32-spectrum stage -> float32 out: the zita contract from wire to wire
+    ("zita_convolver -t pcm -e double -c 1 {F}", 16, 2, "s16", "s24", 24, 3),
 ])
 def test_other_first_and_last_kernels(gpu, tmp_path, chain, S, Cn, in_fmt, out_fmt, prec, bits_want):
     path, _ = write_filter(tmp_path, 700)
