@@ -215,7 +215,7 @@ ssize_t dspamd_chain_run(dspamd_chain *c, const double *in, ssize_t frames, doub
 		// small block: no copy commands (engine.h, MappedPair)
 		memcpy(c->mapped.in, in, (size_t) frames * ci * sizeof(double));
 		const ssize_t f = dspamd_batch_run(c->b, c->mapped.in, frames, c->mapped.out, (ssize_t) (c->mapped.bytes / (co * sizeof(double))), nullptr);
-		if (!hip_ok(hipStreamSynchronize(nullptr), "sync") || f < 0) return -1;
+		if (!c->mapped.wait_block(nullptr) || f < 0) return -1;
 		if (f > out_capacity_frames) { set_error("chain_run: output capacity exceeded"); return -1; }
 		if (f > 0) memcpy(out, c->mapped.out, (size_t) f * co * sizeof(double));
 		return f;

@@ -95,6 +95,10 @@ void MappedPair::alloc()
 	void *a = nullptr, *b = nullptr;
 	if (hipHostMalloc(&a, (size_t) kb << 10, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&b, (size_t) kb << 10, hipHostMallocDefault) == hipSuccess) {
 		in = static_cast<double *>(a); out = static_cast<double *>(b); bytes = (size_t) kb << 10;
+		void *f = nullptr;
+		static const bool spin = !getenv("DSP_AMD_PLUGIN_NO_SPIN");
+		if (spin && hipHostMalloc(&f, 64, hipHostMallocDefault) == hipSuccess) { flag = static_cast<volatile unsigned *>(f); *flag = 0; }
+		else (void) hipGetLastError();
 		return;
 	}
 	(void) hipGetLastError();
@@ -105,6 +109,25 @@ MappedPair::~MappedPair()
 {
 	if (in) (void) hipHostFree(in);
 	if (out) (void) hipHostFree(out);
+	if (flag) (void) hipHostFree(const_cast<unsigned *>(flag));
+}
+
+bool MappedPair::wait_block(hipStream_t st)
+{
+	if (flag && !flag_off) {
+		const unsigned want = ++seq;
+		if (hipStreamWriteValue32(st, const_cast<unsigned *>(flag), want, 0) == hipSuccess) {
+			// a small block is through in tens of microseconds: spin for at most ~2 ms worth of polls, then let the runtime wait
+			for (long spins = 0; spins < 2000000; ++spins) {
+				if (*flag == want) return true;
+				__builtin_ia32_pause();
+			}
+			return hip_ok(hipStreamSynchronize(st), "sync");
+		}
+		(void) hipGetLastError();
+		flag_off = true;                         // (no stream memory operations on this runtime / device: the plain wait from now on)
+	}
+	return hip_ok(hipStreamSynchronize(st), "sync");
 }
 
 bool DevBuf::upload(const void *src, size_t n)

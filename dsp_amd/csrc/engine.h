@@ -39,6 +39,13 @@ struct MappedPair {
 	~MappedPair();
 	void alloc();                               // failure just leaves bytes == 0
 	bool fits(size_t in_bytes, size_t out_bytes) const { return bytes && in_bytes <= bytes && out_bytes <= bytes; }
+	// end of a small block without the runtime's stream wait: a stream memory operation writes the block's sequence number into a
+	// mapped word behind the kernels, the host thread spins on it (falls back to hipStreamSynchronize when the word does not
+	// arrive within a few milliseconds or the operation is not available)
+	volatile unsigned *flag = nullptr;
+	unsigned seq = 0;
+	bool flag_off = false;
+	bool wait_block(hipStream_t st);
 };
 
 // Optional per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on

@@ -165,7 +165,7 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 		// small block: the kernels work on the mapped staging buffers themselves
 		memcpy(sg.mapped.in, ibuf, in_bytes);
 		const ssize_t f = sg.pipe->run(sg.mapped.in, total, sg.mapped.out, (ssize_t) (sg.mapped.bytes / (sg.ch_out * sizeof(double))), nullptr);
-		(void) hip_ok(hipStreamSynchronize(nullptr), "sync");
+		(void) sg.mapped.wait_block(nullptr);
 		if (f > 0) memcpy(dst, sg.mapped.out, (size_t) f * sg.ch_out * sizeof(double));
 		*frames = f < 0 ? 0 : f;
 		return dst;
