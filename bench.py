@@ -292,11 +292,12 @@ def main():
 
     # EXACTLY --steps steps per timed region, barrier + synchronize on both sides, max over ranks.  A region of a few
     # hundred milliseconds sits inside the GPU's clock ramp: regions are repeated until a second of work has gone by (at
-    # most 12) and the LAST one is the measurement; all of them are reported.
+    # most 12); the measurement is the MEDIAN region once the first (the ramp) is set aside; all of them are reported.
     regions = [timed_region()]
     while sum(regions) < 1.0 and len(regions) < 12:
         regions.append(timed_region())
-    elapsed = regions[-1]
+    settled = sorted(regions[1:]) if len(regions) > 1 else regions
+    elapsed = settled[len(settled) // 2]
 
     # ---- per-kernel averages with HIP events on the launch stream (same K steps, second pass) ----
     L.dspamd_profile_enable(1)
