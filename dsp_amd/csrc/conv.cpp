@@ -39,8 +39,10 @@ static void make_twiddles(long n, long count, long stride, std::vector<double2> 
 
 class ConvStage : public Stage {
 public:
-	// ring_parent (tail child of a small-call stage): work on that stage's rings instead of own ones; force_N: transform size
-	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev, ConvStage *ring_parent = nullptr, long force_N = 0);
+	// ring_parent (tail child of a small-call stage): work on that stage's rings instead of own ones; force_N: transform size;
+	// upc_block > 0: the uniformly partitioned form -- blocks of upc_block frames, transforms of 2 upc_block points, the filter in
+	// partitions of upc_block taps with a frequency-domain delay line in the row kernel (conv_row mode 3)
+	bool init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev, ConvStage *ring_parent = nullptr, long force_N = 0, long upc_block = 0);
 	const char *type() const override { return "conv"; }
 	std::string describe() const override;
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
@@ -80,7 +82,7 @@ public:
 	size_t device_bytes() const override
 	{
 		return (is_tail_child ? 0 : ring.bytes) + W.bytes + H.bytes + H_plain.bytes + tail_z.bytes + tail_scratch.bytes + tail_out.bytes
-		       + fdl_buf.bytes + fdl_H.bytes + tail_buf.bytes + (tail_conv ? tail_conv->device_bytes() : 0);
+		       + fdl_buf.bytes + fdl_H.bytes + tail_buf.bytes + upc_buf.bytes + (tail_conv ? tail_conv->device_bytes() : 0);
 	}
 private:
 	bool prepare_filters(const Spec &sp);
@@ -133,6 +135,11 @@ private:
 	bool f32 = false;
 	DevBuf tw_n1f, tw_n2f, tw_colf;
 	long skip = 0, skip_left = 0;      // leading output frames of the stream that are dropped (absorb_discard)
+	// uniformly partitioned form (round 3): upc_P partitions of upc_B taps, spectra H[q][N], delay lines upc_buf[upc_P][S pps][N];
+	// every block of upc_B frames must come through convolve() exactly once and in order (upc_slot = the slot the next one writes)
+	int upc_P = 0, upc_slot = 0;
+	long upc_B = 0, T_taps = 0;
+	DevBuf upc_buf;
 	size_t elem() const { return f32 ? sizeof(float2) : sizeof(double2); }
 	bool spectrum_f32(const std::vector<double> &taps_1ch, long n_taps, int stride, int offset, size_t index, int row_nph);
 	double2 *ring_dev = nullptr;         // ring.p, or the parent's rings (tail child)
@@ -163,7 +170,8 @@ std::string ConvStage::describe() const
 	if (skip) o << " drops-first=" << skip;
 	if (fdl) {
 		o << " small-calls: head " << fP1 << "x" << fB << " taps delay line";
-		if (tail_conv) o << " + tail T=" << tail_conv->T << " N=" << tail_conv->N << " per " << fD << " frames";
+		if (tail_conv && tail_conv->upc_P) o << " + tail " << tail_conv->upc_P << "x" << tail_conv->upc_B << " taps delay line N=" << tail_conv->N << " per " << fD << " frames";
+		else if (tail_conv) o << " + tail T=" << tail_conv->T << " N=" << tail_conv->N << " per " << fD << " frames";
 	}
 	o << "]";
 	return o.str();
@@ -228,14 +236,22 @@ long conv_plan(long T, long max_frames, bool resampler, double *cost_out)
 	return N;
 }
 
-bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev, ConvStage *ring_parent, long force_N)
+bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, Stage *prev, ConvStage *ring_parent, long force_N, long upc_block)
 {
 	is_tail_child = ring_parent != nullptr;
 	name = sp.name;
-	T = sp.T;
+	T = T_taps = sp.T;
+	if (upc_block > 0) {
+		// the window of a block is [the block before | the block]: as an overlap-save plan that is a filter of upc_block + 1 taps
+		// (first valid output = upc_block, hop = upc_block) on a transform of 2 upc_block points
+		upc_B = upc_block;
+		upc_P = (int) ((sp.T + upc_B - 1) / upc_B);
+		T = upc_B + 1;
+		force_N = 2 * upc_B;
+	}
 	lat = sp.latency;
 	round_f32 = (sp.conv_mode == CONV_ZITA_EQUIV);
-	f32 = round_f32 && !getenv("DSP_AMD_ZITA_F64");      // (the switch keeps fp64 transforms behind the float32 I/O: round 2's form)
+	f32 = round_f32 && !getenv("DSP_AMD_ZITA_F64") && !upc_block;      // (the switch keeps fp64 transforms behind the float32 I/O: round 2's form)
 	nsel = num_set(sp.sel);
 	all_selected = (nsel == ch_in);
 	n_filters = (sp.fch == 1) ? 1 : nsel;
@@ -381,7 +397,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		}
 		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
 	}
-	if (!H.alloc((size_t) n_filters * nph * N * elem(), false)) return false;
+	if (!H.alloc((size_t) (upc_P ? upc_P : n_filters * nph) * N * elem(), false)) return false;
+	if (upc_P && !upc_buf.alloc((size_t) upc_P * S * pps * N * sizeof(double2))) return false;
 	log_msg(LL_VERBOSE, "%s: info: device buffers ring %p (%zu MB) W %p (%zu MB) H %p", name.c_str(), ring_dev, ring.bytes >> 20, W.p, W.bytes >> 20, H.p);
 	if (!prepare_filters(sp)) return false;
 
@@ -463,7 +480,11 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 		tail_conv.reset(new ConvStage);
 		tail_conv->S = S; tail_conv->ch_in = ch_in; tail_conv->ch_out = ch_out; tail_conv->fs_in = fs_in; tail_conv->fs_out = fs_out;
 		const long fn = (ts.T - 1 + 7) & ~7L;
-		if (!tail_conv->init(ts, fD, nullptr, nullptr, this, std::max<long>(next_pow2(fn + fD), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)))
+		// more than one block of taps left: partitions of fD taps with a delay line of their own (transforms of 2 fD points instead of
+		// one of >= T - fD + fD points per fD frames); else the plain overlap-save tail
+		static const bool upc_on = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return !e || atoi(e) != 0; }();
+		const bool upc_tail = upc_on && ts.T > fD && 2 * fD >= (1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)) && 2 * fD <= (1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1));
+		if (!tail_conv->init(ts, fD, nullptr, nullptr, this, upc_tail ? 0 : std::max<long>(next_pow2(fn + fD), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)), upc_tail ? fD : 0)
 		    || !tail_buf.alloc((size_t) S * fD * ch_in * sizeof(double))) {
 			// the regime is an optimisation: without it the stage runs one transform per call as before
 			log_msg(LL_VERBOSE, "%s: info: small-call regime not available (%s)", name.c_str(), last_error());
@@ -556,6 +577,16 @@ bool ConvStage::spectrum_f32(const std::vector<double> &src, long n_taps, int st
 
 bool ConvStage::prepare_filters(const Spec &sp)
 {
+	if (upc_P) {
+		// partition q = taps [q B, q B + B) of the (one, shared) filter, zero-padded to the transform
+		for (int q = 0; q < upc_P; ++q) {
+			const long lo = (long) q * upc_B, n = std::min<long>(upc_B, T_taps - lo);
+			std::vector<double> part((size_t) n);
+			for (long i = 0; i < n; ++i) part[(size_t) i] = sp.taps[(size_t) (lo + i) * sp.fch];
+			if (!spectrum_of(part, n, 1, 0, H.as<double2>() + (size_t) q * N, 1)) return false;
+		}
+		return true;
+	}
 	for (int f = 0; f < n_filters * nph; ++f) {
 		bool ok;
 		if (f32) ok = resampler ? spectrum_f32(rs_tab, T, up, f, (size_t) f, nph) : spectrum_f32(sp.taps, T, sp.fch, f, (size_t) f, nph);
@@ -611,7 +642,11 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 		p.out_count = out_count;
 		p.k3_pipe_ok = (all_selected && n_filters == 1 && pps == 4 && ch_in == 8 && !feeds && ((((size_t) out) & 15) == 0)) ? 1 : 0;
 		if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frame0 = q_blk - cur_q0; p.slab_store = resampler ? 0 : 1; p.slab_fmt = wire_in_fmt; }
-		const int row_mode = (nph > 1) ? 2 : 0;
+		const int row_mode = upc_P ? 3 : (nph > 1) ? 2 : 0;
+		if (upc_P) {
+			p.fdl = upc_buf.as<double2>(); p.fdl_slot_stride = (long) S * pps * N; p.fdl_P = upc_P; p.fdl_slot = upc_slot;
+			upc_slot = (upc_slot + 1) % upc_P;
+		}
 		if (n_sub > 1) {
 			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
 			// every chunk's W is small enough to live in the Infinity Cache between its three launches
@@ -763,12 +798,14 @@ void ConvStage::reset(hipStream_t st)
 	pos = 0;
 	q_total = emitted = q_abs = 0;
 	skip_left = skip;
+	if (upc_P) { (void) hipMemsetAsync(upc_buf.p, 0, upc_buf.bytes, st); upc_slot = 0; }
 	tail_frames = -1; tail_served = 0;
 	feed_pos = 0;
 	if (feeder_) feeder_->ring.pos = 0;
 	if (fdl) {
 		(void) hipMemsetAsync(fdl_buf.p, 0, fdl_buf.bytes, st);
 		if (tail_buf.p) (void) hipMemsetAsync(tail_buf.p, 0, tail_buf.bytes, st);
+		if (tail_conv) tail_conv->reset(st);            // (its delay lines; the rings it works on are this stage's)
 		f_slot = 0;
 		fdl_live = true;
 	}

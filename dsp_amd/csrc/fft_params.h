@@ -54,6 +54,11 @@ struct ConvParams {
 	const int *pair_out_ch;             // [pairs_per_stream][2] channel written by re / im (or -1)
 	int round_f32;
 	int k3_pipe_ok;                     // every stream is four pairs of adjacent channels of an 8-channel, 16-byte aligned slab: K3 may take its persistent form
+	// mode 3 of conv_row (uniformly partitioned convolution through the four-step transform): the pairs' delay lines
+	// fdl[slot][pair][N] (slot stride in elements), fdl_P partitions whose spectra are H + q N, fdl_slot = the slot this launch writes
+	double2 *fdl;
+	long fdl_slot_stride;
+	int fdl_P, fdl_slot;
 	int no_split;                       // filter preparation of a float32 stage: keep the generic row kernel's spectrum order (the split-row kernels are fp64 only)
 	int f32;                            // 1: W, H and the twiddle tables hold float2 (the float32 instance, kernels_fft32.hip); rings / slabs / outputs stay fp64
 	WireSink sink;                      // K3 of a plain convolution at the end of a pipeline: `out` holds samples of sink.fmt (kparams.h)

@@ -36,6 +36,7 @@ def filt(tmp_path, taps, seed=7, name="h.raw"):
 @pytest.mark.parametrize("taps,block,S,C,chain_head", [
     (65536, 2048, 3, 8, "lowpass 1k 0.707 eq 400 2.0 1.5 "),      # the headline chain's shape at the reference's block size: head 8 x 2048 + tail
     (65536, 2048, 2, 2, ""),                                       # convolver first in the chain (de-interleaving pass feeds the rings)
+    (100000, 2048, 2, 2, "gain -2 "),                              # six tail partitions of 16384 taps (the last one ragged): the tail's delay line wraps
     (20000, 1024, 2, 4, "gain -3 "),                               # 1024-frame partitions, tail of 11808 taps
     (9000, 512, 3, 2, ""),                                         # short enough for the delay line alone (18 partitions -> no: 9000/512 = 18 > 16, tail)
     (7000, 512, 2, 3, "highpass 50 0.707 "),                       # 14 partitions, no tail; odd channel count (a half-empty pair)
@@ -46,10 +47,14 @@ def test_small_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chain_h
     p, h = filt(tmp_path, taps)
     chain = f"{chain_head}fir_p -t pcm -e double -c 1 {p}"
     n_blocks = 2 * 8 + 3 if taps > 16 * min(block, 2048) else 12      # across two tail hand-overs
+    if taps >= 65536:
+        n_blocks = (5 if taps == 65536 else 8) * 8 + 3                # ... and once around the tail's own delay line (3 / 6 partitions)
     N = n_blocks * block
     x = np.stack([noise(N, C, 300 + s) for s in range(S)])
     b = amd.BatchChain(chain, 48000, C, S, block)
     assert "small-calls" in b.plan(), b.plan()
+    if taps >= 65536 and not os.environ.get("DSP_AMD_CONV_UPC"):
+        assert "taps delay line N=32768" in b.plan(), b.plan()        # the tail as partitions of 16384 taps through 32768-point transforms
     y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
     for s in range(S):
         ref = RefChain(chain, 48000, C).process(x[s], block=block)
@@ -83,19 +88,20 @@ def test_small_calls_equal_one_transform_per_call(amd, tmp_path):
 
 def test_small_calls_reset(amd, tmp_path):
     import torch
-    p, h = filt(tmp_path, 40000)
-    chain = f"fir_p -t pcm -e double -c 1 {p}"
-    S, C, block = 2, 2, 2048
-    x1 = torch.from_numpy(np.stack([noise(11 * block, C, 1 + s) for s in range(S)])).cuda()
-    x2 = torch.from_numpy(np.stack([noise(11 * block, C, 9 + s) for s in range(S)])).cuda()
-    b = amd.BatchChain(chain, 48000, C, S, block)
-    for q in range(0, 11 * block, block):
-        b.run(x1[:, q:q + block, :].contiguous())
-    b.reset()
-    y = torch.cat([b.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, 11 * block, block)], dim=1)
-    f = amd.BatchChain(chain, 48000, C, S, block)
-    yf = torch.cat([f.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, 11 * block, block)], dim=1)
-    assert torch.equal(y, yf)
+    for taps, nb in ((40000, 11), (70000, 27)):          # an overlap-save tail; a tail with a delay line of its own (state in three places)
+        p, h = filt(tmp_path, taps, name=f"h{taps}.raw")
+        chain = f"fir_p -t pcm -e double -c 1 {p}"
+        S, C, block = 2, 2, 2048
+        x1 = torch.from_numpy(np.stack([noise(nb * block, C, 1 + s) for s in range(S)])).cuda()
+        x2 = torch.from_numpy(np.stack([noise(nb * block, C, 9 + s) for s in range(S)])).cuda()
+        b = amd.BatchChain(chain, 48000, C, S, block)
+        for q in range(0, nb * block, block):
+            b.run(x1[:, q:q + block, :].contiguous())
+        b.reset()
+        y = torch.cat([b.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, nb * block, block)], dim=1)
+        f = amd.BatchChain(chain, 48000, C, S, block)
+        yf = torch.cat([f.run(x2[:, q:q + block, :].contiguous()).clone() for q in range(0, nb * block, block)], dim=1)
+        assert torch.equal(y, yf), taps
 
 
 @pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
