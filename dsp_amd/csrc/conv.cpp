@@ -54,7 +54,7 @@ public:
 	bool absorb_discard(long d) override
 	{
 		// (a channel that is not convolved passes through the de-interleaving pass, which knows nothing of frames to drop)
-		if (resampler || feeds || fdl || !all_selected || d <= 0) return false;
+		if (resampler || feeds || fdl || upc_conv || !all_selected || d <= 0) return false;
 		skip = skip_left = d;
 		return true;
 	}
@@ -82,7 +82,8 @@ public:
 	size_t device_bytes() const override
 	{
 		return (is_tail_child ? 0 : ring.bytes) + W.bytes + H.bytes + H_plain.bytes + tail_z.bytes + tail_scratch.bytes + tail_out.bytes
-		       + fdl_buf.bytes + fdl_H.bytes + tail_buf.bytes + upc_buf.bytes + (tail_conv ? tail_conv->device_bytes() : 0);
+		       + fdl_buf.bytes + fdl_H.bytes + tail_buf.bytes + upc_buf.bytes + (tail_conv ? tail_conv->device_bytes() : 0)
+		       + (upc_conv ? upc_conv->device_bytes() : 0);
 	}
 private:
 	bool prepare_filters(const Spec &sp);
@@ -156,6 +157,13 @@ private:
 	DevBuf fdl_buf, fdl_H, fdl_tw, tail_buf;
 	std::unique_ptr<ConvStage> tail_conv;
 	bool init_fdl(const Spec &sp, ssize_t max_frames);
+	// ---- mid-size calls (a multiple of a power of two F of at least 4096 frames, at most half the filter): the WHOLE filter in the
+	// uniformly partitioned form with blocks of F frames -- a child stage on the same rings, transforms of 2 F points with one delay-line
+	// slot per F taps, instead of one transform sized for the filter per call (whose hop the call fills to a fraction only).
+	// As in the small-call regime the rings stay the state of truth: a call off the grid carries on with one transform per call.
+	std::unique_ptr<ConvStage> upc_conv;
+	bool upc_live = false;
+	bool init_upc(const Spec &sp, ssize_t max_frames);
 	void run_fdl(ssize_t frames, double *out, long out_stride, hipStream_t st);
 };
 
@@ -168,6 +176,7 @@ std::string ConvStage::describe() const
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
 	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? " slab-direct" : "");
 	if (skip) o << " drops-first=" << skip;
+	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N;
 	if (fdl) {
 		o << " small-calls: head " << fP1 << "x" << fB << " taps delay line";
 		if (tail_conv && tail_conv->upc_P) o << " + tail " << tail_conv->upc_P << "x" << tail_conv->upc_B << " taps delay line N=" << tail_conv->N << " per " << fD << " frames";
@@ -429,7 +438,39 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		feeder_ = feeder;
 		fed = true;
 	}
-	if (!ring_parent && !init_fdl(sp, max_frames)) return false;
+	if (!ring_parent && !init_upc(sp, max_frames)) return false;
+	if (!ring_parent && !upc_conv && !init_fdl(sp, max_frames)) return false;
+	return true;
+}
+
+// ---- mid-size calls: see the member comment.  Traffic per pair and frame in units of 32 bytes: P + 5.5 (P delay-line slots read or
+// written by the row kernel, 5.5 trips of the block's transform through HBM) against 3.25 N / frames for one transform of N
+// points per call (less what K1 does not read and K3 does not write) and about 18.5 for the small-call regime's two levels (which
+// wins from 16 slots on: measured at 4096-frame calls on 65536 taps, scripts/exp_mid.sh): chosen when 2 <= P = ceil(T / F) <= 12
+// (16 where the calls are too long for the small-call regime) and it moves less than one transform per call.
+bool ConvStage::init_upc(const Spec &sp, ssize_t max_frames)
+{
+	static const int max_slots = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return (!e || atoi(e) == 1) ? 12 : atoi(e); }();   // 0 = never, n > 1 = up to n slots
+	if (max_slots < 2 || resampler || nph != 1 || lat != 0 || round_f32 || n_filters != 1 || merged_pre) return true;
+	// the block: the largest power of two that divides the call size (a call is then a whole number of blocks)
+	long F = 1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1 - 1);
+	while (F > 1 && (max_frames % F)) F >>= 1;
+	if (F < (1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1 - 1)) || 2 * F > T) return true;
+	const long slots = (T + F - 1) / F;
+	// one transform per call: K1 reads the window's T + frames samples and writes N points, K2 reads and writes them, K3 reads them
+	const double one = (4.0 * (double) N + (double) T + (double) max_frames) / (2.0 * (double) max_frames) + 0.5;
+	const bool small_calls_possible = (long) max_frames * 8 <= T;
+	if (slots > (small_calls_possible ? max_slots : std::max(max_slots, 16)) || (double) slots + 5.5 >= 0.95 * one) return true;
+	upc_conv.reset(new ConvStage);
+	upc_conv->S = S; upc_conv->ch_in = ch_in; upc_conv->ch_out = ch_out; upc_conv->fs_in = fs_in; upc_conv->fs_out = fs_out;
+	Spec us(sp);
+	us.name = sp.name + ":blocks";
+	if (!upc_conv->init(us, F, nullptr, nullptr, this, 0, F)) {
+		log_msg(LL_VERBOSE, "%s: info: mid-size-call regime not available (%s)", name.c_str(), last_error());
+		upc_conv.reset();
+		return true;
+	}
+	upc_live = true;
 	return true;
 }
 
@@ -444,8 +485,23 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 	if (b < 256) return true;
 	fB = b; fNF = 2 * b;
 	const long parts = (T + fB - 1) / fB;
-	fP1 = (int) std::min<long>(parts, (env > 0) ? env : 8);
-	if (parts <= 16 && env <= 0) fP1 = (int) parts;            // short enough: the whole filter in the delay line, no tail
+	static const bool upc_on = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return !e || atoi(e) != 0; }();
+	auto upc_tail_ok = [&](long D) { return upc_on && T - D > D && 2 * D >= (1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)) && 2 * D <= (1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1)); };
+	if (env > 0) fP1 = (int) std::min<long>(parts, env);
+	else if (parts <= 16) fP1 = (int) parts;                   // short enough: the whole filter in the delay line, no tail
+	else {
+		// head partitions against the tail's work, in units of 32 bytes per pair and frame: the head moves P1 + 2 of them (at about two
+		// thirds of the rate the four-step kernels reach: every workgroup of conv_fdl walks through the same phases at the same time),
+		// a delay-line tail on blocks of D = P1 B frames its slots + 5.5, a one-transform tail 3.25 N / D
+		double best = 0.0;
+		for (int c : { 4, 8, 16 }) {
+			const long D = (long) c * fB;
+			const double tail = upc_tail_ok(D) ? (double) ((T - D + D - 1) / D) + 5.5
+			                                   : 3.25 * (double) std::max<long>(next_pow2(T - D + D), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)) / (double) D;
+			const double cost = 1.5 * (c + 2) + tail;
+			if (best == 0.0 || cost < best) { best = cost; fP1 = c; }
+		}
+	}
 	fD = (long) fP1 * fB;
 	const long n_pairs = (long) S * pps;
 	// conv_fdl addresses a pair's delay-line slots and its ring row with 32-bit byte offsets (buffer descriptors)
@@ -482,8 +538,7 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 		const long fn = (ts.T - 1 + 7) & ~7L;
 		// more than one block of taps left: partitions of fD taps with a delay line of their own (transforms of 2 fD points instead of
 		// one of >= T - fD + fD points per fD frames); else the plain overlap-save tail
-		static const bool upc_on = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return !e || atoi(e) != 0; }();
-		const bool upc_tail = upc_on && ts.T > fD && 2 * fD >= (1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)) && 2 * fD <= (1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1));
+		const bool upc_tail = upc_tail_ok(fD);
 		if (!tail_conv->init(ts, fD, nullptr, nullptr, this, upc_tail ? 0 : std::max<long>(next_pow2(fn + fD), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1)), upc_tail ? fD : 0)
 		    || !tail_buf.alloc((size_t) S * fD * ch_in * sizeof(double))) {
 			// the regime is an optimisation: without it the stage runs one transform per call as before
@@ -693,6 +748,18 @@ ssize_t ConvStage::emit(long count, double *out, long out_stride, hipStream_t st
 
 ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
+	if (upc_conv && upc_live) {
+		if (!feeds && frames % upc_conv->upc_B == 0 && q_abs % upc_conv->upc_B == 0) {
+			cur_slab = nullptr;
+			if (!fed) push(in, in_stride, frames, out, out_stride, st);
+			upc_conv->wire_sink = wire_sink;                 // (a plain convolution of every channel or not: K3's stores are the same kernel's)
+			upc_conv->convolve(q_abs, q_abs + frames - 1, q_abs, frames, out, out_stride, st);
+			q_abs += frames;
+			pos = (pos + frames) & (ring_len - 1);
+			return frames;
+		}
+		upc_live = false;
+	}
 	if (fdl && fdl_live) {
 		if (!feeds && frames % fB == 0 && q_abs % fB == 0) {
 			cur_slab = nullptr;
@@ -802,6 +869,7 @@ void ConvStage::reset(hipStream_t st)
 	tail_frames = -1; tail_served = 0;
 	feed_pos = 0;
 	if (feeder_) feeder_->ring.pos = 0;
+	if (upc_conv) { upc_conv->reset(st); upc_live = true; }
 	if (fdl) {
 		(void) hipMemsetAsync(fdl_buf.p, 0, fdl_buf.bytes, st);
 		if (tail_buf.p) (void) hipMemsetAsync(tail_buf.p, 0, tail_buf.bytes, st);

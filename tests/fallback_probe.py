@@ -43,6 +43,7 @@ CASES = {
     "rs441":    dict(chain="resample 44.1k", S=2, C=2, frames=9000, calls=(4000, 5000), pick=(0, 1)),
     "rs32":     dict(chain="resample 32k", S=2, C=3, frames=6000, calls=(6000,), pick=(0, 1)),
     "small":    dict(chain="fir_p -t pcm -e double -c 1 {F}", S=4, C=2, frames=24576, calls=(2048,) * 12, pick=(0, 3), taps=(40000, 11, 6000.0)),
+    "mid":      dict(chain="fir_p -t pcm -e double -c 1 {F}", S=4, C=2, frames=57344, calls=(8192,) * 7, pick=(0, 3), taps=(40000, 12, 6000.0)),   # 5 slots of 8192 taps in the row kernel's delay line (mid-size calls)
     "remix":    dict(chain="remix 0,1 2 . 1,2,3 :0 delay 37S", S=5, C=4, frames=3000, calls=(1000, 2000), pick=(0, 4)),
 }
 HOST_CASES = {   # through dspamd_chain_run (host buffers: mapped staging / copy commands)

@@ -40,7 +40,7 @@ def filt(tmp_path, taps, seed=7, name="h.raw"):
     (20000, 1024, 2, 4, "gain -3 "),                               # 1024-frame partitions, tail of 11808 taps
     (9000, 512, 3, 2, ""),                                         # short enough for the delay line alone (18 partitions -> no: 9000/512 = 18 > 16, tail)
     (7000, 512, 2, 3, "highpass 50 0.707 "),                       # 14 partitions, no tail; odd channel count (a half-empty pair)
-    (40000, 4096, 2, 2, ""),                                       # calls of two partitions each
+    (60000, 4096, 2, 2, ""),                                       # calls of two partitions each
 ])
 def test_small_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chain_head):
     import torch
@@ -54,12 +54,76 @@ def test_small_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chain_h
     b = amd.BatchChain(chain, 48000, C, S, block)
     assert "small-calls" in b.plan(), b.plan()
     if taps >= 65536 and not os.environ.get("DSP_AMD_CONV_UPC"):
-        assert "taps delay line N=32768" in b.plan(), b.plan()        # the tail as partitions of 16384 taps through 32768-point transforms
+        assert "+ tail " in b.plan() and "taps delay line N=16384" in b.plan(), b.plan()   # the tail as slots of 8192 taps through 16384-point transforms
     y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
     for s in range(S):
         ref = RefChain(chain, 48000, C).process(x[s], block=block)
         assert y[s].shape == ref.shape, (y[s].shape, ref.shape)
         assert rms(y[s] - ref) < 1e-12, (s, rms(y[s] - ref))
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("taps,block,S,C,chain_head", [
+    (65536, 8192, 2, 8, "lowpass 1k 0.707 eq 400 2.0 1.5 "),      # the headline chain at 8192-frame calls: 8 slots, 16384-point transforms, rings fed by the cascade
+    (65536, 16384, 2, 2, ""),                                      # convolver first in the chain (de-interleaving pass feeds the rings), 4 slots
+    (40000, 4096, 2, 2, ""),                                       # 10 slots of 4096 taps, the last one ragged; the smallest transform (8192 points)
+    (100000, 32768, 1, 3, "gain -2 "),                             # 4 slots at 65536-point transforms; odd channel count (a half-empty pair)
+    (16384, 8192, 2, 4, ""),                                       # the shortest filter the regime takes: two whole slots
+    (40000, 12288, 2, 2, "gain -1 "),                              # calls of three blocks of 4096 frames
+    (20000, 8192, 3, 4, ":0,2 "),                                  # two of four channels selected: the others pass through the de-interleaving pass
+])
+def test_mid_size_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chain_head):
+    """calls of a power of two of frames between 4096 and half the filter: the whole filter as slots of `block` taps in the row
+    kernel's delay line (conv_row mode 3), twice around the delay line, against the real reference at the same block size"""
+    import torch
+    p, h = filt(tmp_path, taps)
+    chain = f"{chain_head}fir_p -t pcm -e double -c 1 {p}"
+    F = block & -block                                            # the regime's block: the largest power of two that divides the call size
+    P = -(-taps // F)
+    n_blocks = (2 * P + 2) * F // block + 1
+    N = n_blocks * block
+    x = np.stack([noise(N, C, 500 + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    if os.environ.get("DSP_AMD_CONV_UPC") == "0":
+        assert "mid-size-calls" not in b.plan(), b.plan()
+    else:
+        assert f"mid-size-calls: {P}x{F} taps delay line N={2 * F}" in b.plan(), b.plan()
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    for s in range(S):
+        ref = RefChain(chain, 48000, C).process(x[s], block=block)
+        assert y[s].shape == ref.shape, (y[s].shape, ref.shape)
+        assert rms(y[s] - ref) < 1e-12, (s, rms(y[s] - ref))
+
+
+def test_mid_size_calls_off_the_grid_and_reset(amd, tmp_path):
+    """a stream that leaves the grid (a short call) carries on from the rings with one transform per call; reset() returns it
+    to the delay-line path; both equal a batch created for long calls"""
+    import torch
+    p, h = filt(tmp_path, 30000)
+    chain = f"eq 300 1.0 3 fir_p -t pcm -e double -c 1 {p}"
+    S, C, block = 2, 4, 8192
+    x = torch.from_numpy(np.stack([noise(9 * block + 700, C, 40 + s) for s in range(S)])).cuda()
+    mid = amd.BatchChain(chain, 48000, C, S, block)
+    big = amd.BatchChain(chain, 48000, C, S, 1 << 17)
+    assert "mid-size-calls" in mid.plan() and "mid-size-calls" not in big.plan() and "small-calls" not in mid.plan()
+    y_big = big.run(x).clone()
+
+    def in_calls(sizes):
+        outs, pos = [], 0
+        for n in sizes:
+            outs.append(mid.run(x[:, pos:pos + n, :].contiguous()).clone())
+            pos += n
+        assert pos == x.shape[1]
+        return torch.cat(outs, dim=1)
+
+    y = in_calls([block] * 5 + [700] + [block] * 4)
+    assert float((y - y_big).abs().max()) < 1e-12
+    mid.reset()
+    y = in_calls([block] * 9 + [700])                       # on the grid all the way after the reset
+    assert float((y - y_big).abs().max()) < 1e-12
+    mid.reset()
+    y = in_calls([5000, 3192] + [block] * 8 + [700])        # never on the grid's block size at position 0 ... and a later start on the grid is not taken up
+    assert float((y - y_big).abs().max()) < 1e-12
 
 
 def test_small_calls_equal_one_transform_per_call(amd, tmp_path):

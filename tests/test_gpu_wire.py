@@ -321,3 +321,20 @@ def test_persistent_k3_speaks_the_formats(gpu, tmp_path, monkeypatch, in_fmt, ou
     assert same(a, f)
     assert np.array_equal(sa, sf)
     check_bits(bits[:3], [3 if in_fmt in ("s16", "s32", "s24", "float") else 2] * 3)
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("float", "s24", 24)])
+def test_mid_size_calls_speak_the_formats(gpu, tmp_path, in_fmt, out_fmt, prec):
+    # calls of 8192 frames on a 20000-tap filter: the delay-line form of the convolver (a child stage on the same rings) takes the
+    # sink in its K3 like the plain form; the last, short call leaves the grid and goes through the plain form
+    path, _ = write_filter(tmp_path, 20000)
+    chain = f"fir_p -t pcm -e double -c 1 {path}"
+    S, Cn, fs = 16, 8, 48000
+    blocks = (8192, 8192, 8192, 8192, 900)
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 77)
+    a, sa, plan = separate_passes(gpu, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert "mid-size-calls" in plan or os.environ.get("DSP_AMD_CONV_UPC") == "0"
+    f, sf, bits = fused(gpu, chain, fs, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert same(a, f)
+    assert np.array_equal(sa, sf)
+    check_bits(bits[:4], [3] * 4)          # (input converted by the de-interleaving pass that fills the rings; K3 applies the sink)
