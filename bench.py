@@ -458,6 +458,7 @@ def main():
             # driver's run of this file (parity of every one of them: tests/test_gpu_conv.py, test_gpu_parity.py, test_gpu_smallcalls.py)
             res["side_runs"]["other_configs"] = {}
             presets = [("headline_block_2048", dict(streams=S_total, channels=C, block=2048, taps=args.taps, chain=None, steps=200)),
+                       ("headline_block_16384", dict(streams=S_total, channels=C, block=16384, taps=args.taps, chain=None, steps=60)),
                        ("headline_block_196608", dict(streams=S_total, channels=C, block=196608, taps=args.taps, chain=None, steps=10))]
             presets += [("config_" + k, dict(v, steps=6)) for k, v in sorted(CONFIGS.items()) if k in ("2", "3", "4", "5")]
             for name, cfg in presets:
