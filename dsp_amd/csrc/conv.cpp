@@ -76,7 +76,7 @@ public:
 		// (the two-phase form writes whole pairs only: adjacent channels of an aligned slab)
 		const bool twice = resampler && nph == 2 && up == 2 && down == 1 && pps >= 3 && !round_f32 && n_filters == 1 && (ch_in % 2) == 0 && ((((size_t) out) & 15) == 0);
 		if (!plain && !twice) return false;
-		if (fdl && fdl_live && frames % fB == 0 && q_abs % fB == 0) return false;      // the small-call regime writes through conv_fdl
+		// (the small-call regime writes through conv_fdl, which applies the sink like K3 -- pairs of adjacent channels or single ones)
 		return true;
 	}
 	size_t device_bytes() const override
@@ -575,6 +575,12 @@ void ConvStage::run_fdl(ssize_t frames, double *out, long out_stride, hipStream_
 		fp.pair_out_ch = pair_out_ch.as<int>();
 		fp.out = out + (size_t) done * fB * ch_in;
 		fp.out_stride_frames = out_stride;
+		fp.sink = wire_sink;
+		if (wire_sink.on) {
+			// (`out` holds samples of the sink's format; the dither sequence goes on where the sub-blocks before this launch left it)
+			fp.out = reinterpret_cast<double *>(reinterpret_cast<char *>(out) + (size_t) done * fB * ch_in * pcm_sample_bytes(wire_sink.fmt));
+			fp.sink.samples_before += done * fB * ch_in;
+		}
 		if (tail_conv) { fp.tail = tail_buf.as<double>(); fp.tail_stride_frames = fD; fp.tail_off = q_now % fD; }
 		{ ProfScope ps("conv_fdl", st); launch_conv_fdl(fp, st); }
 		f_slot = (int) ((f_slot + seg) % fP1);

@@ -377,6 +377,52 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 		}
 		row_sync<WL>();
 		row_fft<LOG2NF, true>(v, j, data, map, tw);
+		if (p.sink.on) {
+			// the last kernel of a pipeline run in wire formats: dither, clip and convert in the stores (dsp.c:685-699).  A lane's
+			// outputs are P frames apart, within a sub-block and from one to the next (B = 8 P): the generator values of its first
+			// sample by modular exponentiation, the others by one multiplication with A^(P C)
+			const bool dither = p.sink.dither_mult != 0.0;
+			const int bs = (p.sink.fmt == PCM_DOUBLE) ? 8 : (p.sink.fmt == PCM_S16) ? 2 : 4;
+			const WordFormat wf_sink = word_format(p.sink.fmt);
+			char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * bs;
+			const bool wpair = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) wout) & 15) == 0);
+			const bool tpair = wpair && tail && ((((size_t) tail) & 15) == 0);
+			double peak = 0.0;
+			unsigned long long clipped = 0;
+			if (active) {
+				const long fr0 = (long) b * B + j;
+				uint32_t ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0, j0 = 1, j1 = 1;
+				if (dither) {
+					const uint64_t na = (uint64_t) (p.sink.samples_before + fr0 * p.C + (cha >= 0 ? cha : 0)) + 1;
+					ua0 = pm_pow<0>(na); ua1 = pm_pow<1>(na);
+					if (chb == cha + 1) { ub0 = pm_mul(ua0, PM_A0); ub1 = pm_mul(ua1, PM_A1); }
+					else { const uint64_t nb = (uint64_t) (p.sink.samples_before + fr0 * p.C + (chb >= 0 ? chb : 0)) + 1; ub0 = pm_pow<0>(nb); ub1 = pm_pow<1>(nb); }
+					j0 = pm_pow<0>((uint64_t) P * p.C); j1 = pm_pow<1>((uint64_t) P * p.C);
+				}
+#pragma unroll
+				for (int m = 8; m < 16; ++m) {
+					const long f = fr0 + (long) P * (m - 8);
+					double ya = v[m].x, yb = v[m].y;
+					if (tpair) { const cplx t = *reinterpret_cast<const cplx *>(tail + f * p.C + cha); ya += t.x; yb += t.y; }
+					else if (tail) { if (cha >= 0) ya += tail[f * p.C + cha]; if (chb >= 0) yb += tail[f * p.C + chb]; }
+					if (cha >= 0) ya = sink_sample(ya, dither, ua0, ua1, p.sink.dither_mult, peak, clipped);
+					if (chb >= 0) yb = sink_sample(yb, dither, ub0, ub1, p.sink.dither_mult, peak, clipped);
+					if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
+					if (wpair && bs != 1) {
+						char *dst = wout + (f * p.C + cha) * bs;
+						if (bs == 8) *reinterpret_cast<double2 *>(dst) = make_double2(ya, yb);
+						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, wf_sink), pcm_to_word(yb, wf_sink));
+						else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+					}
+					else {
+						if (cha >= 0) pcm_store(wout, p.sink.fmt, f * p.C + cha, ya);
+						if (chb >= 0) pcm_store(wout, p.sink.fmt, f * p.C + chb, yb);
+					}
+				}
+			}
+			if (p.sink.stats) sink_stats_wave(p.sink.stats, s, active, peak, clipped);
+			continue;
+		}
 		if (!active) continue;
 		// outputs: positions B .. NF - 1 of the row = frames b B .. b B + B - 1 of this launch
 #pragma unroll

@@ -245,4 +245,30 @@ __device__ __forceinline__ void sink_stats_block(double *stats, long s, double p
 	}
 }
 
+// the same for a kernel whose waves may work on different streams (rows shorter than a workgroup): one reduction per wave when all its
+// lanes share the stream, else each lane for itself; every lane of the wave gets here (`mine` = this lane has a stream at all)
+__device__ __forceinline__ void sink_stats_wave(double *stats, long s, bool mine, double peak, unsigned long long clipped)
+{
+	const int s_first = __builtin_amdgcn_readfirstlane((int) s);
+	const bool uniform = __builtin_amdgcn_ballot_w64(mine && (int) s != s_first) == 0;
+	unsigned long long pk = (unsigned long long) __double_as_longlong(mine ? peak : 0.0);
+	if (!mine) clipped = 0;
+	bool writer = mine;
+	if (uniform) {
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1) {
+			const unsigned long long o = (unsigned long long) __shfl_xor((long long) pk, d, 64);
+			pk = (o > pk) ? o : pk;
+			clipped += (unsigned long long) __shfl_xor((long long) clipped, d, 64);
+		}
+		writer = (threadIdx.x & 63) == 0;
+		s = s_first;
+	}
+	if (writer && (clipped || pk)) {
+		unsigned long long *g = reinterpret_cast<unsigned long long *>(stats) + 2 * s;
+		if (clipped) atomicAdd(g, clipped);
+		if (pk > __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g + 1, pk);
+	}
+}
+
 }  // namespace dspamd

@@ -338,3 +338,25 @@ def test_mid_size_calls_speak_the_formats(gpu, tmp_path, in_fmt, out_fmt, prec):
     assert same(a, f)
     assert np.array_equal(sa, sf)
     check_bits(bits[:4], [3] * 4)          # (input converted by the de-interleaving pass that fills the rings; K3 applies the sink)
+
+
+@pytest.mark.parametrize("S,Cn,head,taps,blocks", [
+    (16, 8, "", 40000, [2048] * 9 + [300]),                                   # head 4 x 2048 + delay-line tail
+    (6, 3, "gain -1 ", 20000, [1024] * 9 + [300]),                            # odd channel count: a single channel in the last pair
+    (8, 2, "", 9000, [512] * 9 + [300]),                                      # 1024-point rows: four pairs per workgroup, streams differ inside a workgroup
+    (128, 8, EQ10 + " ", 70000, [4096] * 3 + [2048] * 3 + [300]),             # two sub-blocks per launch and one; cascade_rows in front (reads the wire format)
+])
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("float", "s24", 24), ("s32", "double", 0)])
+def test_small_calls_speak_the_formats(gpu, tmp_path, S, Cn, head, taps, blocks, in_fmt, out_fmt, prec):
+    # calls much shorter than the filter: the delay-line kernel (conv_fdl) is the last kernel of the call and applies the sink itself --
+    # pairs of adjacent channels as 16- / 8- / 4-byte stores, the single channel of an odd count sample by sample; sub-blocks of one
+    # launch and the launches of one call continue the dither sequence; the last, ragged call goes through the plain form's K3
+    path, _ = write_filter(tmp_path, taps)
+    chain = f"{head}fir_p -t pcm -e double -c 1 {path}"
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 91)
+    a, sa, plan = separate_passes(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert "small-calls" in plan or any(k.startswith("DSP_AMD_") for k in os.environ), plan
+    f, sf, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert same(a, f)
+    assert np.array_equal(sa, sf)
+    check_bits([b & 2 for b in bits], [2] * len(bits))          # the sink is applied by the stage's own last kernel in every call, on the grid or off it
