@@ -768,7 +768,6 @@ template <int G, int WIRE = 0, int LL = RW_L, int WPE = 2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void cascade_rows(CascadeParams p, const double *__restrict__ frows, const double *__restrict__ frq, int P, int p2p)
 {
-	static_assert(!WIRE || G >= 2, "wire formats: channel pairs");
 	double sink_peak = 0.0;                                     // statistics of the sink (WIRE with p.sink.on)
 	unsigned long long sink_clipped = 0;
 	constexpr int L = LL, LPC = 64 / G, TILE = LPC * L, K = L / 2, KH = K / 2;   // K slots (16 B) per lane and tile (L = 32: 2048 samples)
@@ -870,7 +869,20 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 			}
 			auto load_raw = [&](long t) {
 				const int tbb = (int) t * tile_bytes;
-				if constexpr (WIN) {
+				if constexpr (WIN && G == 1) {
+					// one channel per wave: element k (frame lane + 64 k) as it comes -- 8 / 4 / 2 bytes -- in raw[k >> 1].x / .y
+					typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+					const int tbi = (int) t * tile_bytes_in;
+#pragma unroll
+					for (int k = 0; k < 2 * K; ++k) {
+						u32x2 v;
+						if (in_bs == 8) v = __builtin_amdgcn_raw_buffer_load_b64(r_in, vo_in, tbi + k * so_in, 0);
+						else if (in_bs == 4) v = u32x2{ __builtin_amdgcn_raw_buffer_load_b32(r_in, vo_in, tbi + k * so_in, 0), 0u };
+						else v = u32x2{ (unsigned int) __builtin_amdgcn_raw_buffer_load_b16(r_in, vo_in, tbi + k * so_in, 0), 0u };
+						if (k & 1) raw[k >> 1].y = __builtin_bit_cast(double, v); else raw[k >> 1].x = __builtin_bit_cast(double, v);
+					}
+				}
+				else if constexpr (WIN) {
 					// raw[k] holds the slot as it comes: 16 / 8 / 4 bytes of it
 					const int tbi = (int) t * tile_bytes_in;
 					if (in_bs == 8) {
@@ -905,7 +917,16 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto raw_to_tb = [&]() {
-				if constexpr (WIN) {
+				if constexpr (WIN && G == 1) {
+					typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+					for (int k = 0; k < 2 * K; ++k) {
+						const double r = (k & 1) ? raw[k >> 1].y : raw[k >> 1].x;
+						const u32x2 v = __builtin_bit_cast(u32x2, r);
+						tb_rows[(64 + 64 / L) * k] = (in_bs == 8) ? r : (in_bs == 4) ? pcm_from_word(v.x, wf_in) : pcm_from_s16(v.x & 0xffffu);
+					}
+				}
+				else if constexpr (WIN) {
 					// (one loop per sample size, the format of the 4-byte ones folded into constants: no branch per value)
 					if (in_bs == 8) {
 #pragma unroll
@@ -956,7 +977,24 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 				}
 			};
 			auto store_out = [&](const double2 (&y)[K], long t_out) {
-				if constexpr (WOUT) {
+				if constexpr (WOUT && G == 1) {
+					if (sink_on) {
+						// one channel per wave: element k = frame lane + 64 k of the tile, 64 C samples from slot to slot
+						typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+						const int tbo = (int) t_out * tile_bytes_out;
+#pragma unroll
+						for (int k = 0; k < 2 * K; ++k) {
+							const double a = sink_sample((k & 1) ? y[k >> 1].y : y[k >> 1].x, dither, u0, u1, p.sink.dither_mult, peak, clipped);
+							if (dither) { u0 = pm_mul(u0, js0); u1 = pm_mul(u1, js1); }
+							if (out_bs == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), r_out, vo_out + tbo + k * so_out, 0, 0);
+							else if (out_bs == 4) __builtin_amdgcn_raw_buffer_store_b32(pcm_to_word(a, wf_out), r_out, vo_out + tbo + k * so_out, 0, 0);
+							else __builtin_amdgcn_raw_buffer_store_b16((unsigned short) pcm_to_s16(a), r_out, vo_out + tbo + k * so_out, 0, 0);
+						}
+						if (dither) { u0 = pm_mul(u0, jt0); u1 = pm_mul(u1, jt1); }   // 32 slots = one tile on: the wave's next tile is P - 1 further
+						return;
+					}
+				}
+				else if constexpr (WOUT) {
 					if (sink_on) {
 						// the last kernel of the pipeline: dither, clip and convert on the way out (slab order; no ring behind a sink)
 						const int tbo = (int) t_out * tile_bytes_out;
@@ -1104,16 +1142,13 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	dim3 grid(n_streams, p.C / G), block(64 * P);
 	const int wire = (p.in_fmt != PCM_DOUBLE ? 1 : 0) | (p.sink.on ? 2 : 0);
 	if (wire) {
-		if constexpr (G >= 2) {
-			// (an instance per end: the one that only reads a wire format -- the headline's file -> file run -- does not carry the sink)
-			auto go = [&](auto kernel) {
-				grant_dynamic_lds(reinterpret_cast<const void *>(kernel), lds);
-				hipLaunchKernelGGL(kernel, grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
-			};
-			if (wire == 1) go(cascade_rows<G, 1>); else if (wire == 2) go(cascade_rows<G, 2>); else go(cascade_rows<G, 3>);
-			return n_full * TILE;
-		}
-		return 0;
+		// (an instance per end: the one that only reads a wire format -- the headline's file -> file run -- does not carry the sink)
+		auto go = [&](auto kernel) {
+			grant_dynamic_lds(reinterpret_cast<const void *>(kernel), lds);
+			hipLaunchKernelGGL(kernel, grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
+		};
+		if (wire == 1) go(cascade_rows<G, 1>); else if (wire == 2) go(cascade_rows<G, 2>); else go(cascade_rows<G, 3>);
+		return n_full * TILE;
 	}
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_rows<G, 0>), lds);
 	hipLaunchKernelGGL((cascade_rows<G, 0>), grid, block, lds, stream, p, p.frows, p.frq, P, p2p);
@@ -1150,7 +1185,7 @@ static bool rows_choice(const CascadeParams &p, int n_streams, int *Gout, int *P
 	if (((size_t) G * p.n_ops * 2 + ((G <= 2) ? (size_t) p.n_ops * FQ_DOUBLES : 0) + (size_t) Pe * RW_TB + 8) * sizeof(double) > 160 * 1024) return false;
 	// the wire formats are spoken by the instances that move channel pairs -- and only where the plain call would run the SAME
 	// instance shape: fused or not, a call gives the same samples bit for bit
-	if (wire && (G < 2 || !pcm_fusable(p.in_fmt) || (p.sink.on && (!pcm_fusable(p.sink.fmt) || p.ring.base || !p.write_interleaved)))) return false;
+	if (wire && (!pcm_fusable(p.in_fmt) || (p.sink.on && (!pcm_fusable(p.sink.fmt) || p.ring.base || !p.write_interleaved)))) return false;
 	*Gout = G; *Pout = P;
 	return true;
 }

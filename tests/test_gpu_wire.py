@@ -164,7 +164,7 @@ def test_cascade_in_k3_out(gpu, tmp_path, in_fmt, out_fmt, prec):
 
 
 # a chain that is ONE cascade stage: both conversions in the same kernel; padded input slabs; the drain
-@pytest.mark.parametrize("S,Cn,bits_want", [(128, 8, 3), (64, 8, 3), (3, 2, 0), (40, 4, 0)])   # cascade_rows<4>, <2>; fewer channels run kernels that do not speak the formats
+@pytest.mark.parametrize("S,Cn,bits_want", [(128, 8, 3), (64, 8, 3), (3, 2, 3), (40, 4, 3), (5, 3, 0)])   # cascade_rows<4>, <2>, and <1> (one channel per wave: 8- / 4- / 2-byte elements); an odd channel count runs kernels that do not speak the formats
 @pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("s32", "float", 0), ("float", "s24", 20)])
 def test_cascade_both_ends(gpu, S, Cn, bits_want, in_fmt, out_fmt, prec):
     chain = f"gain 8 {EQ10}"
@@ -183,7 +183,8 @@ def test_cascade_both_ends(gpu, S, Cn, bits_want, in_fmt, out_fmt, prec):
     (f"gain 8 {EQ10}", 64, 8, "s8", "s24_3", 24, 0),
     (f"gain 8 {EQ10}", 64, 8, "s16", "s24_3", 0, 1),            # input fusable, output not
     (f"gain 8 {EQ10}", 64, 8, "u8", "s16", 16, 2),              # and the other way round
-    (f"gain 8 {EQ10}", 16, 2, "s16", "s16", 16, 0),             # few channels: kernels that do not speak the formats
+    (f"gain 8 {EQ10}", 16, 2, "s16", "s16", 16, (3, 0, 3)),     # few channels: cascade_rows<1> speaks them since round 3 (calls of at least one 2048-frame tile)
+    (f"gain 8 {EQ10}", 16, 2, "s16", "s24_3", 24, (1, 0, 1)),
     ("gain 3 resample 44.1k", 16, 2, "s16", "s16", 16, 0),      # rate changer last: its drain goes through the sink too
     ("", 16, 2, "s16", "float", 0, 0),                          # no effects at all: conversion only
 ])
@@ -360,3 +361,19 @@ def test_small_calls_speak_the_formats(gpu, tmp_path, S, Cn, head, taps, blocks,
     assert same(a, f)
     assert np.array_equal(sa, sf)
     check_bits([b & 2 for b in bits], [2] * len(bits))          # the sink is applied by the stage's own last kernel in every call, on the grid or off it
+
+
+@pytest.mark.parametrize("S,Cn", [(32, 8), (12, 4)])
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("float", "s32", 0), ("double", "s24", 24)])
+def test_strong_scaling_cascade_speaks_the_formats(gpu, S, Cn, in_fmt, out_fmt, prec):
+    # fewer than 512 channels: cascade_rows<1>, one channel per workgroup of time-skewed waves -- 8- / 4- / 2-byte elements a frame apart.
+    # Long calls: every wave walks several tiles (its dither generators jump P - 1 tiles between them), point-to-point ordering on
+    chain = f"gain 8 {EQ10}"
+    blocks = [43000, 2048 * 9 + 77]
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 5)
+    want, wstats, plan = separate_passes(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec, pad=8)
+    assert same(got, want)
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    assert wstats[:, 1].max() > 1.0 and wstats.view(np.uint64)[:, 0].min() > 0     # the boost clips: the statistics are exercised
+    check_bits(bits, (0 if in_fmt == "double" else 1) | 2)
