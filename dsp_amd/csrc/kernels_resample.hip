@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include "resample_params.h"
 #include "kparams.h"
+#include "pcm_device.h"
 
 namespace dspamd {
 
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleParams p)
 	__syncthreads();
 	const int groups = (C + CPT - 1) / CPT;
 	double *out = p.out + (size_t) s * p.out_stride_frames * C;
+	double sink_peak = 0.0;
+	unsigned long long sink_clipped = 0;
 	for (int w = threadIdx.x; w < nk * groups; w += blockDim.x) {
 		const int kl = w / groups, cg = (w % groups) * CPT;
 		const long k = m0 + kl + p.out_delay;
@@ -59,10 +62,25 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleParams p)
 				if (cg + i < C) acc[i] = fma(t, x[i], acc[i]);
 			x -= C;
 		}
+		if (p.sink.on) {
+			// the last kernel of a pipeline run in wire formats (dsp.c:685-699): every sample finds its place in the dither sequences by
+			// itself (4 table look-ups and 3 modular multiplications per generator: nothing beside the J taps it took to compute)
+#pragma unroll
+			for (int i = 0; i < CPT; ++i) {
+				if (cg + i >= C) continue;
+				const long idx = (m0 - p.m_first + kl + p.out_frame0) * C + cg + i;
+				const bool dither = p.sink.dither_mult != 0.0;
+				const uint64_t nn = (uint64_t) (p.sink.samples_before + idx) + 1;
+				const double y = sink_sample(acc[i], dither, dither ? pm_pow<0>(nn) : 0u, dither ? pm_pow<1>(nn) : 0u, p.sink.dither_mult, sink_peak, sink_clipped);
+				pcm_store(reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * C * p.sink_bs, p.sink.fmt, idx, y);
+			}
+			continue;
+		}
 #pragma unroll
 		for (int i = 0; i < CPT; ++i)
 			if (cg + i < C) out[(m0 - p.m_first + kl + p.out_frame0) * C + cg + i] = acc[i];
 	}
+	if (p.sink.on && p.sink.stats) sink_stats_block(p.sink.stats, s, sink_peak, sink_clipped);
 }
 
 // append `frames` interleaved frames to the per-stream history ring
@@ -168,6 +186,10 @@ __global__ __launch_bounds__(256) void resample_gemm_kernel(ResampleGemmParams p
 	}
 	// ---- store: C[row = (lane >> 4) + 4 reg][col = lane & 15] ----
 	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
+	char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * p.sink_bs;     // (the sink's samples)
+	const bool dither = p.sink.on && p.sink.dither_mult != 0.0;
+	double sink_peak = 0.0;
+	unsigned long long sink_clipped = 0;
 #pragma unroll
 	for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -179,9 +201,19 @@ __global__ __launch_bounds__(256) void resample_gemm_kernel(ResampleGemmParams p
 				const int R = 16 * (2 * wr + a) + (lane >> 4) + 4 * reg;
 				const int il = R >> p.log2cp, c = R & (CP - 1);
 				const long m = (long) p.NB * (i0 + il) + r - p.out_delay - p.m_first;   // visible output frame of this call
-				if (c < p.C && m >= 0 && m < p.m_count) out[(p.out_frame0 + m) * p.C + c] = acc[a][b][reg];
+				if (c < p.C && m >= 0 && m < p.m_count) {
+					const long idx = (p.out_frame0 + m) * p.C + c;
+					if (p.sink.on) {
+						// (every sample finds its place in the dither sequences by itself: see resample_kernel)
+						const uint64_t nn = (uint64_t) (p.sink.samples_before + idx) + 1;
+						const double y = sink_sample(acc[a][b][reg], dither, dither ? pm_pow<0>(nn) : 0u, dither ? pm_pow<1>(nn) : 0u, p.sink.dither_mult, sink_peak, sink_clipped);
+						pcm_store(wout, p.sink.fmt, idx, y);
+					}
+					else out[idx] = acc[a][b][reg];
+				}
 			}
 		}
+	if (p.sink.on && p.sink.stats) sink_stats_block(p.sink.stats, s, sink_peak, sink_clipped);
 }
 
 void launch_resample_gemm(const ResampleGemmParams &p, int n_streams, hipStream_t st)

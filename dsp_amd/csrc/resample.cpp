@@ -22,6 +22,12 @@ public:
 	ssize_t drain2(ssize_t max_frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override;
 	size_t device_bytes() const override { return ring.bytes + tab.bytes + G.bytes; }
+	// last stage of a pipeline run in wire formats: both kernels apply the sink sample by sample (any format)
+	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override
+	{
+		(void) fmt; (void) out; (void) out_stride; (void) frames; (void) in_fmt;
+		return wire_fusion_on() && !also_in;
+	}
 private:
 	ssize_t emit(long count, double *out, long out_stride, hipStream_t st);
 	int n = 1, d = 1, J = 0, KT = 256;
@@ -126,6 +132,7 @@ ssize_t ResampleStage::emit(long count, double *out, long out_stride, hipStream_
 		g.out_delay = out_delay; g.m_first = emitted; g.m_count = count;
 		g.i_first = (emitted + out_delay) / NB;
 		g.out = out; g.out_stride_frames = out_stride; g.out_frame0 = 0;
+		g.sink = wire_sink; g.sink_bs = (int) pcm_sample_bytes(wire_sink.fmt);
 		{ ProfScope ps("resample_gemm_kernel", st); launch_resample_gemm(g, S, st); }
 		emitted += count;
 		return count;
@@ -139,6 +146,7 @@ ssize_t ResampleStage::emit(long count, double *out, long out_stride, hipStream_
 	p.out_delay = out_delay;
 	p.m_first = emitted; p.m_count = count;
 	p.out = out; p.out_stride_frames = out_stride; p.out_frame0 = 0;
+	p.sink = wire_sink; p.sink_bs = (int) pcm_sample_bytes(wire_sink.fmt);
 	{ ProfScope ps("resample_kernel", st); launch_resample(p, S, st); }
 	emitted += count;
 	return count;

@@ -1,6 +1,7 @@
 // resample_params.h -- launch parameters of the polyphase resampler
 #pragma once
 #include <hip/hip_runtime.h>
+#include "kparams.h"
 
 namespace dspamd {
 
@@ -14,6 +15,8 @@ struct ResampleParams {
 	long m_first, m_count;     // visible output frames [m_first, m_first + m_count) to produce
 	double *out;               // [S][out_stride][C]
 	long out_stride_frames, out_frame0;
+	WireSink sink;             // last stage of a pipeline run in wire formats: `out` holds samples of sink.fmt (sink_bs bytes each)
+	int sink_bs;
 };
 
 // rational n/d as a GEMM on the fp64 matrix cores (kernels_resample.hip, resample_gemm_kernel)
@@ -26,6 +29,8 @@ struct ResampleGemmParams {
 	long out_delay, m_first, m_count, i_first;   // visible frames [m_first, m_first + m_count); first block index
 	double *out;
 	long out_stride_frames, out_frame0;
+	WireSink sink;             // as in ResampleParams
+	int sink_bs;
 };
 
 size_t resample_gemm_lds_bytes(int DB, int J, int log2cp);

@@ -185,7 +185,9 @@ def test_cascade_both_ends(gpu, S, Cn, bits_want, in_fmt, out_fmt, prec):
     (f"gain 8 {EQ10}", 64, 8, "u8", "s16", 16, 2),              # and the other way round
     (f"gain 8 {EQ10}", 16, 2, "s16", "s16", 16, (3, 0, 3)),     # few channels: cascade_rows<1> speaks them since round 3 (calls of at least one 2048-frame tile)
     (f"gain 8 {EQ10}", 16, 2, "s16", "s24_3", 24, (1, 0, 1)),
-    ("gain 3 resample 44.1k", 16, 2, "s16", "s16", 16, 0),      # rate changer last: its drain goes through the sink too
+    ("gain 3 resample 44.1k", 16, 2, "s16", "s16", 16, 2),      # rate changer last: the GEMM resampler applies the sink sample by sample (round 3); its drain goes through the stand-alone sink
+    ("resample 44.1k", 4, 10, "s16", "s24_3", 24, 2),           # more than 8 channels: the dot-product resampler; element-wise stores take any format
+    ("resample 32k", 6, 3, "float", "u8", 8, 2),
     ("", 16, 2, "s16", "float", 0, 0),                          # no effects at all: conversion only
 ])
 def test_unfused_paths_inside_run_wire(gpu, chain, S, Cn, in_fmt, out_fmt, prec, bits_want):
@@ -214,7 +216,7 @@ def test_unfused_paths_inside_run_wire(gpu, chain, S, Cn, in_fmt, out_fmt, prec,
     ("resample 96k", 128, 8, "s16", "s16", 16, 3),              # ... four pairs per stream: the two-phase K3 applies the sink (frames 2q, 2q + 1 per thread)
     ("resample 96k", 128, 8, "float", "s24", 24, 3),
     (f"{EQ10} fir_p -t pcm -e double -c 1 {{F}} resample 96k", 128, 8, "s16", "s16", 16, (3, 3, 2)),   # BASELINE config 4's chain: cascade in (calls of at least one 512-frame tile), merged fir_p + 2x upsampler out; its drain tail goes through the stand-alone sink
-    ("resample 44.1k", 32, 2, "s16", "s16", 16, 0),             # the general resampler speaks neither
+    ("resample 44.1k", 32, 2, "s16", "s16", 16, 2),             # the general resampler: input through the read pass, the sink in the GEMM kernel's stores
     ("fir -t pcm -e double -c 1 {F}", 64, 8, "s16", "s16", 16, 3),        # `fir` on every channel: K3 drops the latency frames itself (no alignment pass) and applies the sink
     ("zita_convolver -t pcm -e double -c 1 {F}", 16, 2, "float", "float", 0, 3),   # float32 in -> float32-spectrum stage -> float32 out: the zita contract from wire to wire
     ("zita_convolver -t pcm -e double -c 1 {F}", 16, 2, "s16", "s24", 24, 3),
