@@ -75,7 +75,11 @@ public:
 		const bool plain = !resampler && nph == 1 && up == 1 && down == 1;
 		// (the two-phase form writes whole pairs only: adjacent channels of an aligned slab)
 		const bool twice = resampler && nph == 2 && up == 2 && down == 1 && pps >= 3 && !round_f32 && n_filters == 1 && (ch_in % 2) == 0 && ((((size_t) out) & 15) == 0);
-		if (!plain && !twice) return false;
+		// any other phase count / ratio runs the general K3, which applies the sink sample by sample (what launch_col_inv_pps picks the
+		// two-phase form for must match `twice`, whose sink writes whole pairs)
+		const bool two_phase_form = resampler && nph == 2 && up == 2 && down == 1 && pps >= 3 && !round_f32;
+		const bool general = resampler && !two_phase_form;
+		if (!plain && !twice && !general) return false;
 		// (the small-call regime writes through conv_fdl, which applies the sink like K3 -- pairs of adjacent channels or single ones)
 		return true;
 	}

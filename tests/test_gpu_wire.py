@@ -212,7 +212,11 @@ def test_unfused_paths_inside_run_wire(gpu, chain, S, Cn, in_fmt, out_fmt, prec,
     ("fir_p -t pcm -e double -c 1 {F}", 24, 3, "s8", "s32", 0, 3),        # odd channels: the de-interleaving pass in; K3 out (single channel of a pair)
     (f"{EQ10} fir -t pcm -e double -c 1 {{F}}", 24, 3, "s16", "s16", 16, 2),   # cascade (few channels) ... fir, alignment stage out
     ("gain 6 fir_p -t pcm -e double -c 1 {F}", 24, 5, "float", "float", 0, 2),
-    ("resample 96k", 32, 2, "s16", "s16", 16, 1),               # 2x upsampler first and last: K1 + its history pass in; one pair per stream: the general K3, not fused
+    ("resample 96k", 32, 2, "s16", "s16", 16, 3),               # 2x upsampler first and last: K1 + its history pass in; one pair per stream: the general K3 applies the sink sample by sample (round 3)
+    ("resample 24k", 16, 8, "s16", "s16", 16, 3),               # 2:1 decimator, four pairs per stream: every second frame of the general K3 is a sample
+    ("resample 144k", 8, 2, "float", "s24", 24, 3),             # three phases
+    ("resample 192k", 6, 4, "s32", "float", 0, 3),              # four phases, two pairs per stream
+    ("resample 16k", 5, 3, "s16", "s32", 0, 3),                 # 3:1 decimator, odd channel count
     ("resample 96k", 128, 8, "s16", "s16", 16, 3),              # ... four pairs per stream: the two-phase K3 applies the sink (frames 2q, 2q + 1 per thread)
     ("resample 96k", 128, 8, "float", "s24", 24, 3),
     (f"{EQ10} fir_p -t pcm -e double -c 1 {{F}} resample 96k", 128, 8, "s16", "s16", 16, (3, 3, 2)),   # BASELINE config 4's chain: cascade in (calls of at least one 512-frame tile), merged fir_p + 2x upsampler out; its drain tail goes through the stand-alone sink
