@@ -24,6 +24,7 @@ struct dspamd_chain {
 	dspamd_batch *b = nullptr;
 	DevBuf d_in, d_out;
 	MappedPair mapped;
+	PinnedStage staged;
 	ssize_t cap = 0, out_cap = 0;
 };
 
@@ -218,6 +219,13 @@ ssize_t dspamd_chain_run(dspamd_chain *c, const double *in, ssize_t frames, doub
 		if (!c->mapped.wait_block(nullptr) || f < 0) return -1;
 		if (f > out_capacity_frames) { set_error("chain_run: output capacity exceeded"); return -1; }
 		if (f > 0) memcpy(out, c->mapped.out, (size_t) f * co * sizeof(double));
+		return f;
+	}
+	if (frames > c->cap && c->staged.ensure((size_t) std::min(frames, c->cap) * ci * sizeof(double), (size_t) c->b->pipe->max_out_frames(std::min(frames, c->cap)) * co * sizeof(double))) {
+		// larger blocks: through page-locked staging buffers, the calling thread copying beside the GPU's work (engine.h, PinnedStage)
+		const ssize_t f = c->staged.run(in, frames, c->cap, ci, out, out_capacity_frames, co, c->d_in.p, c->d_out.p, nullptr,
+		                                [&](const double *di, ssize_t nb, double *dout) { return dspamd_batch_run(c->b, di, nb, dout, c->out_cap, nullptr); });
+		if (f == -2) { set_error("chain_run: output capacity exceeded"); return -1; }
 		return f;
 	}
 	while (done < frames) {

@@ -112,6 +112,45 @@ MappedPair::~MappedPair()
 	if (flag) (void) hipHostFree(const_cast<unsigned *>(flag));
 }
 
+bool PinnedStage::ensure(size_t in_bytes, size_t out_bytes)
+{
+	static const bool enabled = [] { const char *e = getenv("DSP_AMD_PLUGIN_STAGE"); return !e || atoi(e) != 0; }();
+	if (!enabled || off) return false;
+	if (in_bytes <= in_cap && out_bytes <= out_cap) return true;
+	if (std::max(in_bytes, out_bytes) > ((size_t) 64 << 20)) return false;
+	if (done[0]) (void) hipDeviceSynchronize();           // (buffers that may still be in flight are about to be replaced)
+	for (int i = 0; i < 2; ++i) {
+		if (in[i]) (void) hipHostFree(in[i]);
+		if (out[i]) (void) hipHostFree(out[i]);
+		in[i] = out[i] = nullptr;
+	}
+	in_cap = out_cap = 0;
+	bool ok = true;
+	for (int i = 0; i < 2 && ok; ++i) {
+		void *a = nullptr, *b = nullptr;
+		ok = hipHostMalloc(&a, std::max<size_t>(in_bytes, 4096), hipHostMallocDefault) == hipSuccess && hipHostMalloc(&b, std::max<size_t>(out_bytes, 4096), hipHostMallocDefault) == hipSuccess;
+		in[i] = static_cast<char *>(a); out[i] = static_cast<char *>(b);
+		if (ok && !done[i]) ok = hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+	}
+	if (!ok) {
+		(void) hipGetLastError();
+		for (int i = 0; i < 2; ++i) { if (in[i]) (void) hipHostFree(in[i]); if (out[i]) (void) hipHostFree(out[i]); in[i] = out[i] = nullptr; }
+		off = true;
+		return false;
+	}
+	in_cap = std::max<size_t>(in_bytes, 4096); out_cap = std::max<size_t>(out_bytes, 4096);
+	return true;
+}
+
+PinnedStage::~PinnedStage()
+{
+	for (int i = 0; i < 2; ++i) {
+		if (in[i]) (void) hipHostFree(in[i]);
+		if (out[i]) (void) hipHostFree(out[i]);
+		if (done[i]) (void) hipEventDestroy(done[i]);
+	}
+}
+
 bool MappedPair::wait_block(hipStream_t st)
 {
 	if (flag && !flag_off) {

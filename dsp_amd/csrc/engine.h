@@ -5,6 +5,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <cstring>
+#include <algorithm>
 #include "effects.h"
 #include "kparams.h"
 
@@ -47,6 +49,67 @@ struct MappedPair {
 	bool flag_off = false;
 	bool wait_block(hipStream_t st);
 };
+
+// Host blocks of MORE than one pipeline call (the stand-alone host API takes buffers of any length; a host that hands over more than
+// the segment was planned for): page-locked staging buffers of this library, two each way -- the calling thread fills chunk k + 1 and
+// empties chunk k - 1 while the GPU copies and works on chunk k (8 ch x 2^20 frames: 168 -> 469 Msamples/s; plain copy commands on
+// pageable memory serialise copy and work).  Chunks are the pipeline's own call size (the plans of the stages are made for it).
+// A block of one chunk keeps the copy commands: alone, the thread's two copies only add to the call.  DSP_AMD_PLUGIN_STAGE=0 or a
+// chunk beyond 64 MB: copy commands throughout.
+struct PinnedStage {
+	char *in[2] = { nullptr, nullptr }, *out[2] = { nullptr, nullptr };
+	size_t in_cap = 0, out_cap = 0;
+	hipEvent_t done[2] = { nullptr, nullptr };
+	bool off = false;
+	PinnedStage() = default;
+	PinnedStage(const PinnedStage &) = delete;
+	PinnedStage &operator=(const PinnedStage &) = delete;
+	~PinnedStage();
+	bool ensure(size_t in_bytes, size_t out_bytes);     // buffers for chunks of this size (false: not available, use copy commands)
+	// run `frames` frames of `in` through run_chunk(device in, frames, device out) -> frames produced (< 0: failed) in chunks of at most
+	// `chunk` frames; d_in / d_out are the caller's device buffers of a chunk.  Returns the frames produced or -1.
+	template <class F>
+	ssize_t run(const double *in, ssize_t frames, ssize_t chunk, int ch_in, double *out, ssize_t out_capacity_frames, int ch_out,
+	            void *d_in, void *d_out, hipStream_t st, F run_chunk);
+};
+
+template <class F>
+ssize_t PinnedStage::run(const double *in, ssize_t frames, ssize_t chunk, int ch_in, double *out, ssize_t out_capacity_frames, int ch_out,
+                         void *d_in, void *d_out, hipStream_t st, F run_chunk)
+{
+	const size_t fi = (size_t) ch_in * sizeof(double), fo = (size_t) ch_out * sizeof(double);
+	ssize_t produced = 0, prev_f = 0;
+	int prev = -1;
+	auto collect = [&]() -> bool {                  // the results of the chunk before: wait for its copy, hand them over
+		if (prev < 0) return true;
+		if (hipEventSynchronize(done[prev]) != hipSuccess) { (void) hipGetLastError(); return false; }
+		if (prev_f > 0) memcpy(out + (size_t) produced * ch_out, this->out[prev], (size_t) prev_f * fo);
+		produced += prev_f;
+		prev = -1;
+		return true;
+	};
+	ssize_t done_frames = 0;
+	int k = 0;
+	if (frames > 0) memcpy(this->in[0], in, (size_t) std::min(frames, chunk) * fi);
+	while (done_frames < frames) {
+		const ssize_t nb = std::min(frames - done_frames, chunk);
+		const int b = k & 1;
+		if (hipMemcpyAsync(d_in, this->in[b], (size_t) nb * fi, hipMemcpyHostToDevice, st) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		const ssize_t f = run_chunk(static_cast<const double *>(d_in), nb, static_cast<double *>(d_out));
+		if (f < 0) { (void) hipStreamSynchronize(st); return -1; }
+		if (produced + prev_f * (prev >= 0 ? 1 : 0) + f > out_capacity_frames) { (void) hipStreamSynchronize(st); return -2; }
+		if (f > 0 && hipMemcpyAsync(this->out[b], d_out, (size_t) f * fo, hipMemcpyDeviceToHost, st) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		if (hipEventRecord(done[b], st) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		done_frames += nb;
+		// while the GPU works on this chunk: the next one in (its buffer's last DMA was two chunks ago, long done: the wait for
+		// chunk k - 1 below has passed it), the one before out
+		if (done_frames < frames) memcpy(this->in[b ^ 1], in + (size_t) done_frames * ch_in, (size_t) std::min(frames - done_frames, chunk) * fi);
+		if (!collect()) return -1;
+		prev = b; prev_f = f;
+		++k;
+	}
+	return collect() ? produced : -1;
+}
 
 // Optional per-kernel timing with HIP events recorded on the SAME stream the kernels are launched on
 // (bench.py's roofline object).  Off by default; when on, every launch site brackets itself.

@@ -22,6 +22,7 @@ struct Segment {
 	bool touched = false;                    // frames have gone through since the last reset
 	DevBuf d_in, d_out;
 	MappedPair mapped;                       // staging for small blocks (engine.h)
+	PinnedStage staged;                      // page-locked staging for larger ones (engine.h)
 	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the
 	// HIP runtime after a few sightings: the copies then run as DMA instead of through the runtime's pageable-memory staging.
 	struct Pin { char *base; size_t bytes; };

@@ -48,6 +48,7 @@ CASES = {
 }
 HOST_CASES = {   # through dspamd_chain_run (host buffers: mapped staging / copy commands)
     "host_eq":   dict(chain="gain -3 " + BIQ, C=2, frames=9000, block=512),
+    "host_big":  dict(chain="gain -3 " + BIQ, C=8, frames=24000, block=8192),     # 512 KB per block: page-locked staging / copy commands
     "host_conv": dict(chain="fir_p -t pcm -e double -c 1 {F} resample 44.1k", C=2, frames=9000, block=2048, taps=(800, 12, 100.0)),
 }
 

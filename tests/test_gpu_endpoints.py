@@ -279,6 +279,29 @@ def test_standalone_chains_on_several_threads(amd):
             assert np.array_equal(y, alone[k])
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("chain,C,frames", [
+    ("gain -3 eq 300 1.0 4 highshelf 5k 0.7 -2", 8, 200000),          # four chunks of the host path's 65536-frame call size, the last one ragged
+    ("eq 1k 2.0 3 resample 44.1k", 2, 150000),                        # a rate changer: the chunks come back shorter than they went in
+    ("remix 0,1 1 . delay 11S", 3, 70000),                            # channel count changes (4 out of 3)
+])
+def test_host_blocks_larger_than_the_call_size_vs_real_reference(amd, chain, C, frames):
+    """dspamd_chain_run with host buffers of any length: chunks through the page-locked staging buffers (the calling thread fills the
+    next chunk and empties the previous one while the GPU works), and the same with plain copy commands"""
+    x = np.random.default_rng(12).uniform(-0.5, 0.5, size=(frames, C))
+    ref = RefChain(chain, 48000, C).process(x, block=2048)
+    ec = amd.EffectsChain(chain, 48000, C)
+    outs = [ec.run(x)]
+    while True:
+        y = ec.drain(4096)
+        if y is None:
+            break
+        outs.append(y)
+    got = np.concatenate(outs, axis=0)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert rms(got - ref) < 1e-12, rms(got - ref)
+
+
 # ------------------------------------------------------------------ direct FIR forms bit-exact (a8)
 
 @pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
