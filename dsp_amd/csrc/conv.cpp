@@ -54,7 +54,7 @@ public:
 	bool absorb_discard(long d) override
 	{
 		// (a channel that is not convolved passes through the de-interleaving pass, which knows nothing of frames to drop)
-		if (resampler || feeds || fdl || upc_conv || !all_selected || d <= 0) return false;
+		if (resampler || feeds || fdl || !all_selected || d <= 0) return false;
 		skip = skip_left = d;
 		return true;
 	}
@@ -455,7 +455,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 bool ConvStage::init_upc(const Spec &sp, ssize_t max_frames)
 {
 	static const int max_slots = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return (!e || atoi(e) == 1) ? 12 : atoi(e); }();   // 0 = never, n > 1 = up to n slots
-	if (max_slots < 2 || resampler || nph != 1 || lat != 0 || round_f32 || n_filters != 1 || merged_pre) return true;
+	if (max_slots < 2 || resampler || nph != 1 || round_f32 || n_filters != 1 || merged_pre) return true;      // (`fir`'s latency is the child's too: its windows start lat frames earlier)
 	// the block: the largest power of two that divides the call size (a call is then a whole number of blocks)
 	long F = 1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1 - 1);
 	while (F > 1 && (max_frames % F)) F >>= 1;
@@ -763,10 +763,13 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 			cur_slab = nullptr;
 			if (!fed) push(in, in_stride, frames, out, out_stride, st);
 			upc_conv->wire_sink = wire_sink;                 // (a plain convolution of every channel or not: K3's stores are the same kernel's)
-			upc_conv->convolve(q_abs, q_abs + frames - 1, q_abs, frames, out, out_stride, st);
+			// (leading frames to drop -- absorb_discard: `fir`'s latency -- still go through the delay line, block by block; K3 starts writing later)
+			const long drop = std::min<long>(skip_left, frames);
+			upc_conv->convolve(q_abs, q_abs + frames - 1, q_abs + drop, frames - drop, out, out_stride, st);
+			skip_left -= drop;
 			q_abs += frames;
 			pos = (pos + frames) & (ring_len - 1);
-			return frames;
+			return frames - drop;
 		}
 		upc_live = false;
 	}
