@@ -482,7 +482,7 @@ bool ConvStage::init_upc(const Spec &sp, ssize_t max_frames)
 bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 {
 	static const int env = [] { const char *e = getenv("DSP_AMD_CONV_FDL"); return e ? atoi(e) : -1; }();   // 0 = never, P1 = force that many head partitions
-	if (env == 0 || resampler || nph != 1 || lat != 0 || round_f32 || n_filters != 1 || merged_pre) return true;
+	if (env == 0 || resampler || nph != 1 || round_f32 || n_filters != 1 || merged_pre) return true;      // (`fir`: every window lat frames earlier, head and tail alike)
 	if (max_frames < 256 || (long) max_frames * 8 > T) return true;
 	long b = 2048;
 	while (b >= 256 && (max_frames % b)) b >>= 1;
@@ -568,7 +568,7 @@ void ConvStage::run_fdl(ssize_t frames, double *out, long out_stride, hipStream_
 		memset(&fp, 0, sizeof(fp));
 		fp.log2NF = ilog2(fNF); fp.P1 = fP1; fp.NF = fNF; fp.B = fB;
 		fp.ring = ring_dev; fp.ring_row_stride = ring_stride; fp.ring_mask = ring_len - 1;
-		fp.win_base = (pos + done * fB - fB) & (ring_len - 1);
+		fp.win_base = (pos + done * fB - fB - lat) & (ring_len - 1);
 		fp.n_sub = (int) seg;
 		fp.slot0 = f_slot;
 		fp.fdl = fdl_buf.as<double2>();

@@ -41,11 +41,13 @@ def filt(tmp_path, taps, seed=7, name="h.raw"):
     (9000, 512, 3, 2, ""),                                         # short enough for the delay line alone (18 partitions -> no: 9000/512 = 18 > 16, tail)
     (7000, 512, 2, 3, "highpass 50 0.707 "),                       # 14 partitions, no tail; odd channel count (a half-empty pair)
     (60000, 4096, 2, 2, ""),                                       # calls of two partitions each
+    (40000, 2048, 2, 4, "FIR"),                                    # `fir`: the same values its latency late -- the head's and the tail's windows start that much earlier
+    (5000, 512, 2, 2, "FIR"),                                      # ... the whole filter in the head's delay line
 ])
 def test_small_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chain_head):
     import torch
     p, h = filt(tmp_path, taps)
-    chain = f"{chain_head}fir_p -t pcm -e double -c 1 {p}"
+    chain = f"{chain_head}fir_p -t pcm -e double -c 1 {p}" if chain_head != "FIR" else f"fir -t pcm -e double -c 1 {p}"
     n_blocks = 2 * 8 + 3 if taps > 16 * min(block, 2048) else 12      # across two tail hand-overs
     if taps >= 65536:
         n_blocks = (5 if taps == 65536 else 8) * 8 + 3                # ... and once around the tail's own delay line (3 / 6 partitions)
