@@ -129,6 +129,47 @@ def test_mid_size_calls_off_the_grid_and_reset(amd, tmp_path):
     assert float((y - y_big).abs().max()) < 1e-12
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DSPAMD_FUZZ_CALL_SIZES", "16"))))     # (more seeds: DSPAMD_FUZZ_CALL_SIZES=400)
+def test_random_call_sizes_vs_real_reference(amd, tmp_path, seed):
+    """filters of 3000 ... 90000 taps at call sizes from 512 to 24576 frames, `fir` and `fir_p`, with effects in front of and behind the
+    convolver, a ragged call in mid-stream for every second seed: whichever regime the planner picks (delay-line head + tail, the
+    whole filter as delay-line slots, one transform per call) and wherever the stream leaves it, the samples are the reference's"""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    taps = int(rng.choice([3000, 9000, 20000, 33000, 50000, 70000, 90000]))
+    block = int(rng.choice([512, 1024, 2048, 4096, 6144, 8192, 12288, 16384, 24576]))
+    S, C = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+    eff = str(rng.choice(["fir_p", "fir"]))
+    head = str(rng.choice(["", "gain -2 ", "eq 500 1.0 3 lowpass 8k 0.7 "]))
+    tail = str(rng.choice(["", " gain 1.5", " eq 2k 1.0 -3"]))
+    p, h = filt(tmp_path, taps, seed=seed)
+    chain = f"{head}{eff} -t pcm -e double -c 1 {p}{tail}"
+    n_calls = min(max(3, (2 * taps) // block + 3), 40)
+    sizes = [block] * n_calls
+    if seed % 2:
+        sizes.insert(n_calls // 2, int(rng.integers(1, block)))
+    N = sum(sizes)
+    x = np.stack([noise(N, C, 7000 + 10 * seed + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    xt = torch.from_numpy(x).cuda()
+    outs, pos = [], 0
+    for n in sizes:
+        outs.append(b.run(xt[:, pos:pos + n, :].contiguous()).clone())
+        pos += n
+    while True:
+        y = b.drain(block)
+        if y is None:
+            break
+        outs.append(y.clone())
+    y = torch.cat(outs, dim=1).cpu().numpy()
+    for s in range(S):
+        # (the reference in calls of `block` frames throughout: the stream these effects make does not depend on how it is cut into calls)
+        ref = RefChain(chain, 48000, C).process(x[s], block=block)
+        assert y[s].shape == ref.shape, (b.plan(), y[s].shape, ref.shape)
+        assert rms(y[s] - ref) < 1e-12, (b.plan(), s, rms(y[s] - ref))
+
+
 def test_small_calls_equal_one_transform_per_call(amd, tmp_path):
     """the same stream through the small-call path and through the one-transform-per-call path (a batch created for large
     calls), and a stream that leaves the grid half way (an odd call size) and continues on the rings"""
