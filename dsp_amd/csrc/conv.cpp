@@ -264,7 +264,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	}
 	lat = sp.latency;
 	round_f32 = (sp.conv_mode == CONV_ZITA_EQUIV);
-	f32 = round_f32 && !getenv("DSP_AMD_ZITA_F64") && !upc_block;      // (the switch keeps fp64 transforms behind the float32 I/O: round 2's form)
+	f32 = round_f32 && !getenv("DSP_AMD_ZITA_F64");      // (the switch keeps fp64 transforms behind the float32 I/O: round 2's form)
 	nsel = num_set(sp.sel);
 	all_selected = (nsel == ch_in);
 	n_filters = (sp.fch == 1) ? 1 : nsel;
@@ -411,7 +411,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
 	}
 	if (!H.alloc((size_t) (upc_P ? upc_P : n_filters * nph) * N * elem(), false)) return false;
-	if (upc_P && !upc_buf.alloc((size_t) upc_P * S * pps * N * sizeof(double2))) return false;
+	if (upc_P && !upc_buf.alloc((size_t) upc_P * S * pps * N * elem())) return false;      // (a float32 stage's delay line holds float2: half the traffic)
 	log_msg(LL_VERBOSE, "%s: info: device buffers ring %p (%zu MB) W %p (%zu MB) H %p", name.c_str(), ring_dev, ring.bytes >> 20, W.p, W.bytes >> 20, H.p);
 	if (!prepare_filters(sp)) return false;
 
@@ -455,7 +455,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 bool ConvStage::init_upc(const Spec &sp, ssize_t max_frames)
 {
 	static const int max_slots = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return (!e || atoi(e) == 1) ? 12 : atoi(e); }();   // 0 = never, n > 1 = up to n slots
-	if (max_slots < 2 || resampler || nph != 1 || round_f32 || n_filters != 1 || merged_pre) return true;      // (`fir`'s latency is the child's too: its windows start lat frames earlier)
+	if (max_slots < 2 || resampler || nph != 1 || n_filters != 1 || merged_pre) return true;      // (`fir`'s / zita's latency is the child's too: its windows start lat frames earlier)
 	// the block: the largest power of two that divides the call size (a call is then a whole number of blocks)
 	long F = 1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1 - 1);
 	while (F > 1 && (max_frames % F)) F >>= 1;
@@ -613,7 +613,7 @@ bool ConvStage::spectrum_of(const std::vector<double> &src, long n_taps, int str
 	}
 	if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double2), hipMemcpyHostToDevice), "H2D taps")) return false;
 	ConvParams p = base_params();
-	p.no_split = f32 ? 1 : 0;
+	p.no_split = (f32 || upc_P) ? 1 : 0;       // (the delay-line form runs the generic row kernel: its spectrum order)
 	p.f32 = 0;                                   // always the fp64 kernels and tables (a float32 stage rounds the result: spectrum_f32)
 	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>(); p.tw_col = tw_col.as<double2>();
 	p.ring = tring.as<double2>();
@@ -648,7 +648,7 @@ bool ConvStage::prepare_filters(const Spec &sp)
 			const long lo = (long) q * upc_B, n = std::min<long>(upc_B, T_taps - lo);
 			std::vector<double> part((size_t) n);
 			for (long i = 0; i < n; ++i) part[(size_t) i] = sp.taps[(size_t) (lo + i) * sp.fch];
-			if (!spectrum_of(part, n, 1, 0, H.as<double2>() + (size_t) q * N, 1)) return false;
+			if (!(f32 ? spectrum_f32(part, n, 1, 0, (size_t) q, 1) : spectrum_of(part, n, 1, 0, H.as<double2>() + (size_t) q * N, 1))) return false;
 		}
 		return true;
 	}

@@ -595,7 +595,7 @@ static bool rows_are_split(const ConvParams &p)
 
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
-	if (mode == 3) { core_launch_row(p, 3, n_pairs, st); return; }     // delay-line form: the generic row kernel (fp64 stages only)
+	if (mode == 3) { if (p.f32) p32::core_launch_row(p, 3, n_pairs, st); else core_launch_row(p, 3, n_pairs, st); return; }     // delay-line form: the generic row kernel
 	if (p.f32) {
 		// the float32 instance: the persistent two-workgroup kernel for the long rows of a shared filter, else the one-shot kernel
 		if (plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= 11) p32::core_launch_row_duo(p, n_pairs, st);

@@ -169,6 +169,29 @@ def test_zita_equivalent_contract(amd, tmp_path, monkeypatch, f64_transforms):
         assert np.abs(y - ref).max() < 5e-6
 
 
+@pytest.mark.parametrize("taps,block,S,C,f64_transforms", [(20000, 8192, 3, 2, False), (70000, 16384, 2, 4, False), (20000, 4096, 2, 2, True)])
+def test_zita_mid_size_calls(amd, tmp_path, monkeypatch, taps, block, S, C, f64_transforms):
+    # the zita contract at calls of a few thousand frames (what a real-time convolver is called with): the whole filter as delay-line
+    # slots of the call's block on the float32 instance -- float2 delay lines; the 64 frames of latency move the windows, the host's
+    # discard of them is done by K3 -- against the restated contract (PARITY UNPINNED), 1e-6 of the signal
+    import torch
+    from oracle_api import zita_contract
+    if f64_transforms:
+        monkeypatch.setenv("DSP_AMD_ZITA_F64", "1")
+    h = make_filter(taps, 5, taps / 7.0)
+    chain = f"zita_convolver -t pcm -e double -c 1 {write(tmp_path, h)}"
+    n_calls = 2 * (-(-taps // block)) + 2
+    xs = np.stack([noise(n_calls * block, C, 430 + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    assert "mid-size-calls" in b.plan() and ("f32-spectrum" in b.plan()) == (not f64_transforms), b.plan()
+    y = b.process(torch.from_numpy(xs).cuda(), block).cpu().numpy()
+    for s in range(S):
+        ref = zita_contract(xs[s], h)
+        assert y[s].shape == ref.shape, (y[s].shape, ref.shape)
+        assert rms(y[s] - ref) <= 1e-6 * rms(ref), (s, rms(y[s] - ref) / rms(ref))
+        assert np.array_equal(y[s], y[s].astype(np.float32).astype(np.float64))
+
+
 def test_zita_float32_spectrum_geometries(amd, tmp_path, monkeypatch):
     # the float32 instance of K1 / K2 / K3 at every row length (one-shot rows on one stream; the two-workgroup persistent kernel
     # at 2048- / 4096-point rows on a batch), one filter per channel (no split-row kernels in this instance), odd channel counts
