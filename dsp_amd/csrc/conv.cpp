@@ -482,7 +482,9 @@ bool ConvStage::init_upc(const Spec &sp, ssize_t max_frames)
 bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 {
 	static const int env = [] { const char *e = getenv("DSP_AMD_CONV_FDL"); return e ? atoi(e) : -1; }();   // 0 = never, P1 = force that many head partitions
-	if (env == 0 || resampler || nph != 1 || round_f32 || n_filters != 1 || merged_pre) return true;      // (`fir`: every window lat frames earlier, head and tail alike)
+	// (`fir` / the zita contract: every window lat frames earlier, head and tail alike; the zita contract's float32 roundings are those of
+	// its inputs -- already in the rings --, of its taps and of the finished output: transforms and delay lines stay fp64 here)
+	if (env == 0 || resampler || nph != 1 || n_filters != 1 || merged_pre) return true;
 	if (max_frames < 256 || (long) max_frames * 8 > T) return true;
 	long b = 2048;
 	while (b >= 256 && (max_frames % b)) b >>= 1;
@@ -518,7 +520,10 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 		// head partition spectra: partition q = taps [q B, q B + B), zero-padded to 2 B, through the kernel's own forward transform
 		std::vector<double2> rows((size_t) fP1 * fNF, make_double2(0.0, 0.0));
 		for (int q = 0; q < fP1; ++q)
-			for (long i = 0; i < fB && q * fB + i < T; ++i) rows[(size_t) q * fNF + i].x = sp.taps[(size_t) (q * fB + i) * sp.fch];
+			for (long i = 0; i < fB && q * fB + i < T; ++i) {
+				const double t = sp.taps[(size_t) (q * fB + i) * sp.fch];
+				rows[(size_t) q * fNF + i].x = round_f32 ? (double) (float) t : t;
+			}
 		DevBuf d_rows;
 		if (!d_rows.upload(rows.data(), rows.size() * sizeof(double2))) return false;
 		FdlParams fp;
@@ -537,6 +542,11 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 		ts.T = T - fD;
 		ts.taps.assign(sp.taps.begin() + (size_t) fD * sp.fch, sp.taps.end());
 		ts.name = sp.name + ":tail";
+		if (round_f32) {
+			// the tail's share is added to the head's in fp64 and rounded once, by conv_fdl: the child is a plain fp64 stage on float32 taps
+			ts.conv_mode = CONV_LATENCY_LEN;
+			for (double &t : ts.taps) t = (double) (float) t;
+		}
 		tail_conv.reset(new ConvStage);
 		tail_conv->S = S; tail_conv->ch_in = ch_in; tail_conv->ch_out = ch_out; tail_conv->fs_in = fs_in; tail_conv->fs_out = fs_out;
 		const long fn = (ts.T - 1 + 7) & ~7L;
@@ -579,6 +589,7 @@ void ConvStage::run_fdl(ssize_t frames, double *out, long out_stride, hipStream_
 		fp.pair_out_ch = pair_out_ch.as<int>();
 		fp.out = out + (size_t) done * fB * ch_in;
 		fp.out_stride_frames = out_stride;
+		fp.round_f32 = round_f32;
 		fp.sink = wire_sink;
 		if (wire_sink.on) {
 			// (`out` holds samples of the sink's format; the dither sequence goes on where the sub-blocks before this launch left it)

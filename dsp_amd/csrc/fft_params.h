@@ -88,6 +88,7 @@ struct FdlParams {
 	const double *tail;                 // [S][tail_stride_frames][C]: contribution of the taps from P1 B on, or nullptr
 	long tail_stride_frames, tail_off;  // frame tail_off + f of `tail` belongs to output frame f of this launch
 	WireSink sink;                      // the stage is the last of a pipeline run in wire formats: `out` holds samples of sink.fmt (kparams.h)
+	int round_f32;                      // the zita contract: outputs (head + tail share) rounded to float32 (zita_convolver.cpp:110)
 };
 void launch_conv_fdl(const FdlParams &p, hipStream_t st);
 

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 					double ya = v[m].x, yb = v[m].y;
 					if (tpair) { const cplx t = *reinterpret_cast<const cplx *>(tail + f * p.C + cha); ya += t.x; yb += t.y; }
 					else if (tail) { if (cha >= 0) ya += tail[f * p.C + cha]; if (chb >= 0) yb += tail[f * p.C + chb]; }
+					if (p.round_f32) { ya = (double) (float) ya; yb = (double) (float) yb; }
 					if (cha >= 0) ya = sink_sample(ya, dither, ua0, ua1, p.sink.dither_mult, peak, clipped);
 					if (chb >= 0) yb = sink_sample(yb, dither, ub0, ub1, p.sink.dither_mult, peak, clipped);
 					if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
@@ -434,17 +435,21 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 					// frame f = (b - 1) B + j + P m: one per-lane offset (j, the pair's channels), the rest scalar
 					const int so = (int) ((((long) b - 1) * B + P * m) * p.C * 8);
 					if (tail) { const cplx t = __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(r_tail, vo_out, so, 0)); y.x += t.x; y.y += t.y; }
+					if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
 					__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), r_out, vo_out + so, 0, 0);
 					continue;
 				}
 			}
 			if (wide) {
 				if (tail) { const cplx t = *reinterpret_cast<const cplx *>(tail + f * p.C + cha); y.x += t.x; y.y += t.y; }
+				if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
 				*reinterpret_cast<cplx *>(out + f * p.C + cha) = y;
 			}
 			else {
-				if (cha >= 0) out[f * p.C + cha] = y.x + (tail ? tail[f * p.C + cha] : 0.0);
-				if (chb >= 0) out[f * p.C + chb] = y.y + (tail ? tail[f * p.C + chb] : 0.0);
+				double ya = y.x + ((tail && cha >= 0) ? tail[f * p.C + cha] : 0.0), yb = y.y + ((tail && chb >= 0) ? tail[f * p.C + chb] : 0.0);
+				if (p.round_f32) { ya = (double) (float) ya; yb = (double) (float) yb; }
+				if (cha >= 0) out[f * p.C + cha] = ya;
+				if (chb >= 0) out[f * p.C + chb] = yb;
 			}
 		}
 	}

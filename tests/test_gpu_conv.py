@@ -192,6 +192,27 @@ def test_zita_mid_size_calls(amd, tmp_path, monkeypatch, taps, block, S, C, f64_
         assert np.array_equal(y[s], y[s].astype(np.float32).astype(np.float64))
 
 
+@pytest.mark.parametrize("taps,block,S,C", [(40000, 2048, 3, 2), (9000, 512, 2, 3), (5000, 256, 2, 2)])
+def test_zita_small_calls(amd, tmp_path, taps, block, S, C):
+    # the zita contract at the reference's own block and below: delay-line head + tail with fp64 transforms between the contract's
+    # three float32 roundings (inputs -- as they enter the rings --, taps, finished outputs); PARITY UNPINNED, 1e-6 of the signal
+    import torch
+    from oracle_api import zita_contract
+    h = make_filter(taps, 5, taps / 7.0)
+    chain = f"zita_convolver -t pcm -e double -c 1 {write(tmp_path, h)}"
+    n_calls = 2 * (-(-taps // block)) + 3
+    xs = np.stack([noise(n_calls * block, C, 530 + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    assert "small-calls" in b.plan(), b.plan()
+    y = b.process(torch.from_numpy(xs).cuda(), block).cpu().numpy()
+    for s in range(S):
+        ref = zita_contract(xs[s], h)
+        assert y[s].shape == ref.shape, (y[s].shape, ref.shape)
+        assert rms(y[s] - ref) <= 1e-6 * rms(ref), (s, rms(y[s] - ref) / rms(ref))
+        assert np.abs(y[s] - ref).max() < 5e-7
+        assert np.array_equal(y[s], y[s].astype(np.float32).astype(np.float64))
+
+
 def test_zita_float32_spectrum_geometries(amd, tmp_path, monkeypatch):
     # the float32 instance of K1 / K2 / K3 at every row length (one-shot rows on one stream; the two-workgroup persistent kernel
     # at 2048- / 4096-point rows on a batch), one filter per channel (no split-row kernels in this instance), odd channel counts
