@@ -95,6 +95,77 @@ def test_plot_text_identical(channels, chain):
     compare_scripts(channels, chain, same_text=True)
 
 
+def random_section(rng):
+    """one effect of the biquad family with random arguments in the reference's own notations (README.md:169-236)"""
+    def f0(lo=20.0, hi=20000.0):
+        f = float(np.exp(rng.uniform(np.log(lo), np.log(hi))))
+        return f"{f / 1000.0:.4g}k" if rng.random() < 0.4 else f"{f:.5g}"
+    def width(shelf=False):
+        kinds = ["q", "", "o", "h", "k"] + (["s", "d"] if shelf else [])
+        k = kinds[int(rng.integers(len(kinds)))]
+        if k in ("q", ""):
+            return f"{rng.uniform(0.3, 6.0):.4g}{k}"
+        if k == "o":
+            return f"{rng.uniform(0.2, 3.0):.4g}o"
+        if k == "h":
+            return f"{rng.uniform(5.0, 400.0):.4g}h"
+        if k == "k":
+            return f"{rng.uniform(0.01, 0.8):.4g}k"
+        if k == "s":
+            return f"{rng.uniform(0.3, 1.0):.4g}s"
+        return f"{rng.uniform(3.0, 12.0):.4g}d"
+    gain = lambda: f"{rng.uniform(-12.0, 12.0):+.3g}"
+    name = ["lowpass_1", "highpass_1", "allpass_1", "lowshelf_1", "highshelf_1", "lowpass_1p", "lowpass", "highpass", "bandpass_skirt",
+            "bandpass_peak", "notch", "allpass", "eq", "lowshelf", "highshelf", "lowpass_transform", "highpass_transform",
+            "linkwitz_transform", "deemph", "biquad", "bw"][int(rng.integers(21))]
+    if name in ("lowpass_1", "highpass_1", "allpass_1", "lowpass_1p"):
+        return f"{name} {f0()}"
+    if name in ("lowshelf_1", "highshelf_1"):
+        return f"{name} {f0()} {gain()}"
+    if name in ("lowpass", "highpass", "bandpass_skirt", "bandpass_peak", "notch", "allpass"):
+        return f"{name} {f0()} {width()}"
+    if name == "eq":
+        return f"eq {f0()} {width()} {gain()}"
+    if name in ("lowshelf", "highshelf"):
+        return f"{name} {f0()} {width(True)} {gain()}"
+    if name in ("lowpass_transform", "highpass_transform", "linkwitz_transform"):
+        return f"{name} {f0(20, 200)} {rng.uniform(0.4, 1.5):.3g} {f0(15, 150)} {rng.uniform(0.4, 1.0):.3g}"
+    if name == "deemph":
+        return "deemph"
+    if name == "biquad":
+        c = rng.uniform(-0.9, 0.9, size=6)
+        return "biquad " + " ".join(f"{v:.6g}" for v in (c[0], c[1], c[2], 1.0 + 0.2 * c[3], 0.5 * c[4], 0.2 * c[5]))
+    order = int(rng.integers(2, 9))                                      # Butterworth / Linkwitz-Riley sections: bw<order>[.<index>]
+    return f"{['lowpass', 'highpass'][int(rng.integers(2))]} {f0(40, 8000)} bw{order}" + (f".{int(rng.integers(order // 2 + order % 2))}" if rng.random() < 0.7 else "")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_biquad_family_arguments_print_the_reference_text(seed):
+    """every effect of the biquad family with random arguments in every notation of the reference (frequencies with k, widths as
+    q / o / h / k / s / d, bw<n>.<k> sections, gains): `dsp -p` through this library prints the reference's coefficients digit for digit"""
+    rng = np.random.default_rng(4000 + seed)
+    channels = int(rng.integers(1, 4))
+    parts = []
+    for _ in range(int(rng.integers(3, 9))):
+        if channels > 1 and rng.random() < 0.3:
+            parts.append(":" + ",".join(str(c) for c in sorted(rng.choice(channels, size=int(rng.integers(1, channels + 1)), replace=False))))
+        if rng.random() < 0.2:
+            parts.append(f"gain {rng.uniform(-9, 3):.3g}")
+        parts.append(random_section(rng))
+    fs = ["44.1k", "48k", "96k"][int(rng.integers(3))]
+    chain = " ".join(parts)
+    rc_r, _, err_r = script(REF, channels, chain, fs)
+    if rc_r != 0:
+        # (an argument the reference refuses -- a bw<n>.<k> index beyond the order, a frequency beyond fs / 2: the same verdict in the same words)
+        rc_g, _, err_g = script(GPU, channels, chain, fs)
+        assert rc_g == rc_r, (chain, err_r[-300:], err_g[-300:])
+        # (the program name in front of a message is the host's argv[0] in the reference and DSP_AMD_PROG_NAME -- "dsp" -- in this library)
+        norm = lambda t: re.sub(r"(?m)^\S*dsp(_ref|_gpu)?:", "dsp:", t)
+        assert norm(err_g) == norm(err_r), (chain, err_r[-300:], err_g[-300:])
+        return
+    compare_scripts(channels, chain, fs=fs, same_text=True)
+
+
 @pytest.mark.parametrize("channels,chain,cin", [
     (2, f"fir {COEFS40}", None),                                                      # FFT form: next_fast_fftw_len(40) terms
     (2, f"fir_p {COEFS40} :0 fir_p -a {COEFS40}", None),                              # 32 direct + one 32-tap partition
