@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <dlfcn.h>
 
 namespace dspamd {
 
@@ -18,19 +19,35 @@ int g_loglevel = initial_loglevel();
 static std::mutex g_log_mutex;
 static thread_local char g_err[1024] = "";
 
+// Linked into the reference host, messages carry ITS program name and obey ITS -v / -q: the host's `dsp_globals` (dsp.h:44-47,53:
+// `struct dsp_globals { int loglevel; const char *prog_name; }`) is looked up in the process like `fir_read_filter` is (an executable
+// exports it when linked with -rdynamic: INTEGRATION.md); the library's own level (DSP_AMD_LOGLEVEL, dspamd_set_loglevel) and name
+// (DSP_AMD_PROG_NAME) serve a stand-alone host and override the host's when set.
+struct HostGlobals { int loglevel; const char *prog_name; };
+static const HostGlobals *host_globals()
+{
+	static const HostGlobals *g = static_cast<const HostGlobals *>(dlsym(RTLD_DEFAULT, "dsp_globals"));
+	return g;
+}
+
 static const char *prog_name()
 {
-	static const char *p = nullptr;
-	if (!p) {
-		p = getenv("DSP_AMD_PROG_NAME");
-		if (!p) p = "dsp";
-	}
-	return p;
+	static const char *env = getenv("DSP_AMD_PROG_NAME");
+	if (env) return env;
+	const HostGlobals *g = host_globals();
+	return (g && g->prog_name) ? g->prog_name : "dsp";
+}
+
+static int effective_loglevel()
+{
+	static const bool own = getenv("DSP_AMD_LOGLEVEL") != nullptr;
+	const HostGlobals *g = host_globals();
+	return (g && !own && g_loglevel == LL_ERROR) ? g->loglevel : g_loglevel;      // (dspamd_set_loglevel moves g_loglevel off its default: the library's own then)
 }
 
 void log_msg(int level, const char *fmt, ...)
 {
-	if (g_loglevel < level) return;
+	if (effective_loglevel() < level) return;
 	char buf[2048];
 	va_list ap;
 	va_start(ap, fmt);

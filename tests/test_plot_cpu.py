@@ -159,8 +159,8 @@ def test_random_biquad_family_arguments_print_the_reference_text(seed):
         # (an argument the reference refuses -- a bw<n>.<k> index beyond the order, a frequency beyond fs / 2: the same verdict in the same words)
         rc_g, _, err_g = script(GPU, channels, chain, fs)
         assert rc_g == rc_r, (chain, err_r[-300:], err_g[-300:])
-        # (the program name in front of a message is the host's argv[0] in the reference and DSP_AMD_PROG_NAME -- "dsp" -- in this library)
-        norm = lambda t: re.sub(r"(?m)^\S*dsp(_ref|_gpu)?:", "dsp:", t)
+        # (messages carry the host's program name -- the library reads the host's dsp_globals: only the two binaries' names differ)
+        norm = lambda t: t.replace("dsp_ref", "dsp_X").replace("dsp_gpu", "dsp_X")
         assert norm(err_g) == norm(err_r), (chain, err_r[-300:], err_g[-300:])
         return
     compare_scripts(channels, chain, fs=fs, same_text=True)
@@ -210,3 +210,17 @@ def test_effects_without_plot_are_refused_alike():
         assert rc_r == rc_g
         assert ("does not support plotting" in err_r) == ("does not support plotting" in err_g), (err_r, err_g)
         assert ref == gpu
+
+
+def test_messages_follow_the_hosts_program_name_and_verbosity():
+    """the library's log lines carry the HOST's program name (dsp_globals.prog_name, dsp.h:44-47) and obey its -v / -q: a refused
+    argument reads the same through both builds, -q silences the library too, -v lets its info lines through"""
+    bad = ["-p", "-r", "48k", "-c", "1", "-n", "lowpass", "1k", "bw5.7"]
+    r = subprocess.run([REF] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    g = subprocess.run([GPU] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == g.returncode != 0
+    assert g.stderr.replace("dsp_gpu", "dsp_X") == r.stderr.replace("dsp_ref", "dsp_X"), (r.stderr, g.stderr)
+    assert GPU in g.stderr                                                       # argv[0] as the reference prints it, not a fixed "dsp"
+    q = subprocess.run([GPU, "-q"] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    qr = subprocess.run([REF, "-q"] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert q.returncode != 0 and q.stderr.replace("dsp_gpu", "dsp_X") == qr.stderr.replace("dsp_ref", "dsp_X"), (q.stderr, qr.stderr)
