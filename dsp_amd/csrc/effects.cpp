@@ -3,6 +3,7 @@
 #include "effects.h"
 #include <dlfcn.h>
 #include <cfloat>
+#include <cerrno>
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -166,6 +167,7 @@ static double parse_width(const char *s, int *type, char **endptr)
 		case 'k': w *= 1000.0;  // fall through
 		case 'h': *type = W_BW_HZ; ++*endptr; break;
 		}
+		if (**endptr != '\0') log_msg(LL_ERROR, "parse_width(): trailing characters: %s", *endptr);     // biquad.c:82
 	}
 	return w;
 fail:
@@ -189,8 +191,8 @@ SpecPtr parse_biquad(int num, const stream_info *is, const char *sel, int argc, 
 			if (g.arg) {                                    // biquad.c:391-395
 				char *e2;
 				thresh = (double) strtol(g.arg, &e2, 10);
-				if (bad_endptr(name, g.arg, e2, "thresh")) return nullptr;
-				if (!(thresh >= 10.0 && thresh <= 200.0)) { set_error("%s: error: thresh out of range", name); return nullptr; }
+				if (bad_endptr(name, g.arg, e2, "thresh")) { usage(name); return nullptr; }
+				if (!(thresh >= 10.0 && thresh <= 200.0)) { set_error("%s: error: parameter out of range: thresh", name); usage(name); return nullptr; }   // (option errors print the usage: biquad.c:394, 461-464)
 			}
 		}
 		else { g.print_error(opt, name); usage(name); return nullptr; }
@@ -204,7 +206,7 @@ SpecPtr parse_biquad(int num, const stream_info *is, const char *sel, int argc, 
 	auto freq = [&](const char *s, const char *what, double &out) {
 		out = parse_freq(s, &end);
 		if (bad_endptr(name, s, end, what)) return false;
-		if (!(out >= 0.0 && out < is->fs / 2.0)) { set_error("%s: error: %s out of range", name, what); return false; }
+		if (!(out >= 0.0 && out < is->fs / 2.0)) { set_error("%s: error: parameter out of range: %s", name, what); return false; }
 		return true;
 	};
 	auto num_arg = [&](const char *s, const char *what, double &out) {
@@ -214,7 +216,7 @@ SpecPtr parse_biquad(int num, const stream_info *is, const char *sel, int argc, 
 	auto width = [&](const char *s, const char *what, double &out) {
 		out = parse_width(s, &wt, &end);
 		if (bad_endptr(name, s, end, what)) return false;
-		if (!(out > 0.0)) { set_error("%s: error: %s out of range", name, what); return false; }
+		if (!(out > 0.0)) { set_error("%s: error: parameter out of range: %s", name, what); return false; }
 		return true;
 	};
 	const bool slope = (wt == W_SLOPE || wt == W_SLOPE_DB);
@@ -341,7 +343,7 @@ static bool pair_of(const char *name, const stream_info *is, const char *sel, in
 	*c0 = *c1 = -1;
 	int n = 0;
 	for (int k = 0; k < is->channels; ++k) if (sel[k]) { if (*c0 < 0) *c0 = k; else *c1 = k; ++n; }
-	if (n != 2) { set_error("%s: error: input channels must be 2", name); return false; }   // st2ms.c:88-91, crossfeed.c:99-102
+	if (n != 2) { set_error("%s: error: parameter out of range: input channels must be 2", name); return false; }   // st2ms.c:88-91, crossfeed.c:99-102
 	return true;
 }
 
@@ -391,10 +393,10 @@ SpecPtr parse_crossfeed(const stream_info *is, const char *sel, int argc, const 
 	char *end;
 	const double freq = parse_freq(argv[1], &end);
 	if (bad_endptr(name, argv[1], end, "f0")) return nullptr;
-	if (!(freq >= 0.0 && freq < is->fs / 2.0)) { set_error("%s: error: f0 out of range", name); return nullptr; }
+	if (!(freq >= 0.0 && freq < is->fs / 2.0)) { set_error("%s: error: parameter out of range: f0", name); return nullptr; }
 	const double sep_db = strtod(argv[2], &end);
 	if (bad_endptr(name, argv[2], end, "separation")) return nullptr;
-	if (!(sep_db >= 0.0)) { set_error("%s: error: separation out of range", name); return nullptr; }
+	if (!(sep_db >= 0.0)) { set_error("%s: error: parameter out of range: separation", name); return nullptr; }
 	SpecPtr s = new_spec(Kind::Crossfeed, name, is, sel);
 	s->flags = EFFECT_FLAG_PLOT_MIX;
 	s->xf_c0 = c0; s->xf_c1 = c1;
@@ -602,7 +604,7 @@ SpecPtr parse_delay(const stream_info *is, const char *sel, int argc, const char
 				char *e2;
 				order = (int) strtol(g.arg, &e2, 10);
 				if (bad_endptr(name, g.arg, e2, "order")) return nullptr;
-				if (!(order > 0 && order <= 50)) { set_error("%s: error: order out of range", name); return nullptr; }
+				if (!(order > 0 && order <= 50)) { set_error("%s: error: parameter out of range: order", name); return nullptr; }
 			}
 			continue;
 		}
@@ -852,7 +854,7 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 			int ch = 0;
 			ssize_t fr = 0;
 			sample_t *d = host_read(&ei, is, selc.data(), dir, &cp, &ch, &fr);
-			if (!d) { set_error("%s: error: the host's fir_read_filter could not read: %s", name, spec); return false; }   // (the host has logged why)
+			if (!d) { set_error_quiet("%s: error: the host's fir_read_filter could not read: %s", name, spec); return false; }   // (the host has logged why: nothing more on stderr)
 			data.assign(d, d + (size_t) fr * ch);
 			free(d);
 			*fch = ch; *T = fr;
@@ -863,7 +865,12 @@ static bool read_filter(const char *name, const stream_info *is, const char *sel
 		return false;
 	}
 	FILE *f = fopen(path.c_str(), "rb");
-	if (!f) { set_error("%s: error: failed to open filter file: %s", name, path.c_str()); return false; }
+	if (!f) {
+		// (the reference's codec layer names the container and the reason first: pcm.c / sndfile.c "failed to open file", then fir_util.c:115)
+		log_msg(LL_ERROR, "%s: error: failed to open file: %s: %s", wav ? "sndfile" : "pcm", path.c_str(), strerror(errno));
+		set_error("%s: error: failed to open filter file: %s", name, path.c_str());
+		return false;
+	}
 	fseek(f, 0, SEEK_END);
 	const long sz = ftell(f);
 	fseek(f, 0, SEEK_SET);
@@ -920,6 +927,8 @@ static ssize_t filter_offset(const FirOpts &o, const std::vector<double> &d, ssi
 	return off;
 }
 
+static constexpr int FIR_P_DIRECT_LEN = 32;     // fir_p.c:34
+
 SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, const char *sel, const char *dir, int argc, const char *const *argv)
 {
 	GetOpt g;
@@ -933,12 +942,6 @@ SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, con
 			max_part_len = strtol(argv[g.ind], &end, 10);
 			if (bad_endptr(name, argv[g.ind], end, "max_part_len")) return nullptr;
 			++g.ind;
-			// fir_p.c:374-382: accepted values are powers of two in [32, INT_MAX]; it only shapes the reference's
-			// latency-driven partition plan, which the GPU engine does not need
-			if (max_part_len != 0 && ((max_part_len & (max_part_len - 1)) || max_part_len < 32)) {
-				set_error("%s: error: max_part_len must be a power of two >= 32 or 0 for default", name);
-				return nullptr;
-			}
 		}
 	}
 	else if (g.ind != argc - 1) { usage(name); return nullptr; }
@@ -948,6 +951,12 @@ SpecPtr parse_fir(const char *name, bool partitioned, const stream_info *is, con
 	if (!read_filter(name, is, sel, dir, o, argv[g.ind], data, &fch, &T)) return nullptr;
 	const ssize_t ref = filter_offset(o, data, T);
 	SpecPtr s = make_fir_spec(name, is, sel, data.data(), fch, T, ref, partitioned ? CONV_ZERO_LATENCY : CONV_LATENCY_LEN, 0, 0);
+	if (s && partitioned && T > FIR_P_DIRECT_LEN && max_part_len != 0) {
+		// fir_p.c:364-384: a filter of up to 32 taps takes the direct form before the value is looked at; otherwise powers of two in
+		// [32, INT_MAX] (it only shapes the reference's latency-driven partition plan, which this engine does not need)
+		if (max_part_len & (max_part_len - 1)) { set_error("%s: error: max_part_len must be a power of two", name); return nullptr; }
+		if (max_part_len < FIR_P_DIRECT_LEN || max_part_len > 2147483647L) { set_error("%s: error: max_part_len must be within [%d,%d] or 0 for default", name, FIR_P_DIRECT_LEN, 2147483647); return nullptr; }
+	}
 	if (s) s->max_part_len = max_part_len;
 	return s;
 }
@@ -1107,7 +1116,7 @@ SpecPtr parse_resample(const stream_info *is, const char *sel, int argc, const c
 	if (bw_arg) {
 		bw = strtod(bw_arg, &end);
 		if (bad_endptr(name, bw_arg, end, "bandwidth")) return nullptr;
-		if (!(bw >= 0.7 && bw <= 0.999)) { set_error("%s: error: bandwidth out of range", name); return nullptr; }
+		if (!(bw >= 0.7 && bw <= 0.999)) { set_error("%s: error: parameter out of range: bandwidth", name); return nullptr; }
 	}
 	long rate;
 	if (rate_arg[0] == 'x') {
@@ -1124,7 +1133,7 @@ SpecPtr parse_resample(const stream_info *is, const char *sel, int argc, const c
 		rate = lround(parse_freq(rate_arg, &end));
 		if (bad_endptr(name, rate_arg, end, "fs")) return nullptr;
 	}
-	if (rate <= 0) { set_error("%s: error: rate out of range", name); return nullptr; }
+	if (rate <= 0) { set_error("%s: error: parameter out of range: rate", name); return nullptr; }
 	SpecPtr s = new_spec(Kind::Resample, name, is, sel);
 	s->sel.assign(is->channels, 1);            // resample ignores the selector (README.md:389-391)
 	s->flags = EFFECT_FLAG_CH_DEPS_IDENTITY;

@@ -66,6 +66,14 @@ void set_error(const char *fmt, ...)
 	log_msg(LL_ERROR, "%s", g_err);
 }
 
+void set_error_quiet(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
 const char *last_error() { return g_err; }
 
 bool bad_endptr(const char *name, const char *str, const char *endptr, const char *what)
@@ -81,9 +89,12 @@ double parse_freq(const char *s, char **r_endptr)
 {
 	char *end;
 	double f = strtod(s, &end);
-	if (end != s && *end == 'k') {
-		f *= 1000.0;
-		++end;
+	if (end != s) {
+		if (*end == 'k') {
+			f *= 1000.0;
+			++end;
+		}
+		if (*end != '\0') log_msg(LL_ERROR, "parse_freq: error: trailing characters: %s", end);     // util.c:58-59
 	}
 	if (r_endptr) *r_endptr = end;
 	return f;
@@ -98,6 +109,7 @@ double parse_len_frac(const char *s, double fs, char **r_endptr)
 		if (*end == 'm') { samples = d / 1000.0 * fs; ++end; }
 		else if (*end == 's') { ++end; }
 		else if (*end == 'S') { samples = d; ++end; }
+		if (*end != '\0') log_msg(LL_ERROR, "parse_len_frac_2: error: trailing characters: %s", end);     // util.c:83-84
 	}
 	if (r_endptr) *r_endptr = end;
 	return samples;
@@ -151,7 +163,7 @@ bool parse_selector(const char *s, Selector &b, int n)
 		if (!read_sel_item(item, q, it)) return false;
 		for (long v : { it.lo, it.hi })
 			if (v > n - 1) { set_error("parse_selector: error: value out of range: %ld", v); return false; }
-		if (it.range && it.lo >= 0 && it.hi >= 0 && it.hi < it.lo) { set_error("parse_selector: error: malformed range"); return false; }
+		if (it.range && it.lo >= 0 && it.hi >= 0 && it.hi < it.lo) { set_error("parse_selector: error: malformed range: %ld-%ld", it.lo, it.hi); return false; }     // util.c:148
 		// open ends: "-M" starts at 0, "N-" runs to the last channel, a lone number selects itself
 		const long first = it.lo >= 0 ? it.lo : 0;
 		const long last = it.hi >= 0 ? it.hi : (it.range ? n - 1 : it.lo);

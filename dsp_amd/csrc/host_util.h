@@ -15,6 +15,7 @@ enum { LL_SILENT = 0, LL_ERROR, LL_OPEN_ERROR, LL_NORMAL, LL_VERBOSE };  // dsp.
 extern int g_loglevel;
 void log_msg(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void set_error_quiet(const char *fmt, ...) __attribute__((format(printf, 1, 2)));   // last_error() only: the host has already said it on stderr
 const char *last_error();
 
 // returns true (and logs "failed to parse <what>: <str>") when the whole string was not consumed

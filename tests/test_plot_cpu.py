@@ -224,3 +224,34 @@ def test_messages_follow_the_hosts_program_name_and_verbosity():
     q = subprocess.run([GPU, "-q"] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     qr = subprocess.run([REF, "-q"] + bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
     assert q.returncode != 0 and q.stderr.replace("dsp_gpu", "dsp_X") == qr.stderr.replace("dsp_ref", "dsp_X"), (q.stderr, qr.stderr)
+
+
+ODD_ARGUMENTS = [
+    (2, "lowpass 30k 0.7"), (2, "lowpass 1k 0"), (2, "lowpass -r5 1k 0.7"), (2, "lowpass -r300 1k 0.7"), (2, "lowpass -rx 1k 0.7"), (2, "lowpass 1kk 0.7"), (2, "lowpass 1k 0.7z"),
+    (2, "eq 1k 0q 3"), (2, "eq 1k 1q x"), (2, "lowshelf 1k -1s 3"), (2, "highshelf 1k 0d 3"), (2, "lowpass 1k bw0"), (2, "lowpass 1k bw3.5"), (2, "lowpass 1k bwx"),
+    (2, "lowpass_1 -1"), (2, "linkwitz_transform 80 0 40 0.5"), (2, "linkwitz_transform 80 0.9 40000 0.5"), (2, "biquad 1 2 3 x 1 1"), (2, "lowpass"), (2, "eq 1k 1q 3 4"),
+    (2, "crossfeed 30k 3"), (2, "crossfeed 700 -1"), (2, "crossfeed 700 x"), (3, "crossfeed 700 3"), (1, "crossfeed 700 3"), (2, "crossfeed"),
+    (1, "st2ms"), (3, "st2ms"), (3, "ms2st"), (2, "st2ms 1"),
+    (2, "delay -f0 1S"), (2, "delay -f51 1S"), (2, "delay 1x"), (2, "delay"), (2, "delay -fx 1S"), (2, "delay -z 1S"),
+    (2, "resample 0"), (2, "resample -b 0.5 44.1k"), (2, "resample -b 1 44.1k"), (2, "resample -bx 44.1k"), (2, "resample 44.1kk"), (2, "resample"), (2, "resample -1"), (2, "resample x"),
+    (2, "remix 5"), (2, "remix x"), (2, "remix"), (2, "remix 0-"), (2, "remix 1-0"), (2, "remix 0,,1"),
+    (2, "gain x"), (2, "gain"), (2, "mult"), (2, "add"), (2, "gain 1 2"), (2, "mult 1x"),
+    (2, "fir coefs:"), (2, "fir coefs:1,x"), (2, "fir coefs:1,2/3/4"), (2, "fir_p x coefs:1"), (2, "fir -ax coefs:1,2"), (2, "fir"), (2, "fir_p 1 2 coefs:1"),
+    (2, "fir -t pcm nofile"), (2, "fir_p -e s16 -t pcm nofile"), (2, "fir nofile"), (2, "fir -z coefs:1"),
+    (2, "fir_p 48 coefs:" + ",".join(["0.1"] * 40)), (2, "fir_p 16 coefs:" + ",".join(["0.1"] * 40)),        # max_part_len: not a power of two / below 32 (filters of more than 32 taps)
+    (2, "hilbert 0"), (2, "hilbert 10"), (2, "hilbert -a x 127"), (2, "hilbert"), (2, "hilbert 127 3"),
+    (2, ":5 gain 1"), (2, ":x gain 1"), (2, ":, gain 1"),
+]
+ACCEPTED_ALIKE = [(2, "fir_p 3 coefs:1,2"), (2, "fir_p 16 8 coefs:1,2"), (2, "fir_p 0 coefs:1"), (2, "remix 0,1 ."), (2, "biquad 1 2 3 0 1 1"), (2, "hilbert -p 127"), (2, "fir -a coefs:1,2")]
+
+
+@pytest.mark.parametrize("channels,chain", ODD_ARGUMENTS + ACCEPTED_ALIKE)
+def test_refusals_read_the_same_through_both_builds(channels, chain):
+    """arguments the reference refuses, most of them (and a few it accepts against expectation: a `max_part_len` in front of a filter of up to 32 taps is
+    never looked at, fir_p.c:364-384): same exit status, and on stderr the same lines -- the parsers' own notes ("parse_freq: error:
+    trailing characters"), `parameter out of range: <what>` (util.c:541-563), the usage line where the reference prints it"""
+    args = ["-p", "-r", "48k", "-c", str(channels), "-n"] + chain.split()
+    r = subprocess.run([REF] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    g = subprocess.run([GPU] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert r.returncode == g.returncode, (chain, r.stderr[-300:], g.stderr[-300:])
+    assert g.stderr.replace("dsp_gpu", "dsp_X") == r.stderr.replace("dsp_ref", "dsp_X"), (chain, r.stderr[-400:], g.stderr[-400:])
