@@ -166,6 +166,54 @@ def test_random_biquad_family_arguments_print_the_reference_text(seed):
     compare_scripts(channels, chain, fs=fs, same_text=True)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_chains_print_the_reference_text(seed):
+    """whole chains of the effects whose plots are stored numbers -- sections, gain / mult / add (merged by the host), remix (channel
+    counts change), integer delays, st2ms / ms2st, crossfeed -- under random selectors: the same gnuplot script, character for character"""
+    rng = np.random.default_rng(9000 + seed)
+    channels = int(rng.integers(1, 6))
+    ch, parts = channels, []
+
+    def selector():
+        k = int(rng.integers(1, ch + 1))
+        return ":" + ",".join(str(c) for c in sorted(rng.choice(ch, size=k, replace=False)))
+
+    for _ in range(int(rng.integers(3, 10))):
+        r = rng.random()
+        if ch > 1 and r < 0.25:
+            parts.append(selector())
+            continue
+        if r < 0.45:
+            parts.append(random_section(rng))
+        elif r < 0.6:
+            parts.append(str(rng.choice(["gain", "mult", "add"])) + f" {rng.uniform(-6, 6):.3g}")
+        elif r < 0.7:
+            parts.append(f"delay {int(rng.integers(0, 200))}S" if rng.random() < 0.5 else f"delay {rng.uniform(0, 3):.3g}m")
+        elif r < 0.8 and ch >= 2:
+            pair = sorted(rng.choice(ch, size=2, replace=False))
+            parts.append(f":{pair[0]},{pair[1]}")
+            parts.append(str(rng.choice(["st2ms", "ms2st"])) if rng.random() < 0.6 else f"crossfeed {rng.uniform(300, 1200):.4g} {rng.uniform(2, 9):.3g}")
+            parts.append(":")
+        elif r < 0.9:
+            parts.append(":")                                                           # remix acts on its own argument list, not the selector
+            new_ch = int(rng.integers(1, 5))
+            outs = []
+            for _o in range(new_ch):
+                k = int(rng.integers(0, min(ch, 3) + 1))
+                outs.append(",".join(str(c) for c in sorted(rng.choice(ch, size=k, replace=False))) if k else ".")
+            parts.append("remix " + " ".join(outs))
+            ch = new_ch
+        else:
+            parts.append(":")
+    chain = " ".join(parts)
+    rc_r, _, err_r = script(REF, channels, chain)
+    if rc_r != 0:
+        rc_g, _, err_g = script(GPU, channels, chain)
+        assert rc_g == rc_r and err_g.replace("dsp_gpu", "dsp_X") == err_r.replace("dsp_ref", "dsp_X"), (chain, err_r[-300:], err_g[-300:])
+        return
+    compare_scripts(ch, chain, channels_in=channels, same_text=True)
+
+
 @pytest.mark.parametrize("channels,chain,cin", [
     (2, f"fir {COEFS40}", None),                                                      # FFT form: next_fast_fftw_len(40) terms
     (2, f"fir_p {COEFS40} :0 fir_p -a {COEFS40}", None),                              # 32 direct + one 32-tap partition
