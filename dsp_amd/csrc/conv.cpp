@@ -169,6 +169,15 @@ private:
 	bool upc_live = false;
 	bool init_upc(const Spec &sp, ssize_t max_frames);
 	void run_fdl(ssize_t frames, double *out, long out_stride, hipStream_t st);
+	// ---- the cascade in front fused into this stage's first pass (kernels_fused.hip) ----
+	// A call of exactly one hop on a window whose history is whole rows: the feeding cascade is not launched; fused_prepass +
+	// cascade_chunk_carry find the section states at every row start, fused_col_fwd runs the sections from them in front of
+	// its column transforms and files the last first_n frames of cascade output in the rings.  Everything else about the call
+	// (K2, K3, the rings as state of truth, the cascade's carried state) is as on the separate path, which any other call takes.
+	bool fuse_static = false;            // the plan allows it (decided once, in init)
+	int fuse_seg = 1;
+	bool fuse_accepts(const double *in, long in_stride, ssize_t frames) const;
+	bool run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st);
 };
 
 std::string ConvStage::describe() const
@@ -179,6 +188,7 @@ std::string ConvStage::describe() const
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
 	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? " slab-direct" : "");
+	if (fuse_static) o << " cascade-fused(" << (N1 - first_n / N2) * fuse_seg << " chunks of " << N2 / fuse_seg << ")";
 	if (skip) o << " drops-first=" << skip;
 	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N;
 	if (fdl) {
@@ -444,6 +454,82 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	}
 	if (!ring_parent && !init_upc(sp, max_frames)) return false;
 	if (!ring_parent && !upc_conv && !init_fdl(sp, max_frames)) return false;
+	// the cascade fused into the first pass: a uniform chain of sections in front, 256 rows whose first first_n / N2 are history
+	{
+		const char *fe = getenv("DSP_AMD_FUSE");          // 0 = the separate kernels always (read per stage: the tests build both plans in one process)
+		const bool fuse_on = !fe || atoi(fe) != 0;
+		const long hist_rows = (N2 > 0 && first_n % N2 == 0) ? first_n / N2 : 0;
+		if (fuse_on && feeder_ && !ring_parent)
+			log_msg(LL_VERBOSE, "%s: info: fused first pass: regimes %d%d kind %d%d%d%d%d%d rows %d pairs %d%d hist %ld hop %d whole %d%d sizes %d%d sections %d", name.c_str(),
+			        !upc_conv, !fdl, !resampler, nph == 1, n_filters == 1, !f32, !round_f32, lat == 0, log2N1 == 8, (pps % 2) == 0, ch_in == 2 * pps, hist_rows, B == N - first_n,
+			        pairs_per_chunk == (long) S * pps, n_sub == 1, (double) B * ch_in * sizeof(double) < 2.0e9, (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9, (int) feeder_->fuse_tables().ok);
+		if (fuse_on && feeder_ && !ring_parent && !upc_conv && !fdl && !resampler && nph == 1 && n_filters == 1 && !f32 && !round_f32 && lat == 0
+		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && (hist_rows == 16 || hist_rows == 32) && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
+		    && (double) B * ch_in * sizeof(double) < 2.0e9 && (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9 && feeder_->fuse_tables().ok) {
+			// row segments: enough workgroups for the chip when the streams are few, as far as the scan over the chunks fits its workgroup
+			const int D = 2 * feeder_->n_ops;
+			const long groups = (long) S * (pps / 2);
+			fuse_seg = 1;
+			auto scan_fits = [&](long k) { long g = 1; while (g * g < k) ++g; return (double) (k * D + ((k + g - 1) / g) * D + D * D) * sizeof(double) <= 150.0 * 1024 && ((k + g - 1) / g) * D <= 1024; };
+			while (fuse_seg < 4 && groups * fuse_seg < 224 && (N2 / 8) % (2 * fuse_seg) == 0 && scan_fits((N1 - hist_rows) * 2 * fuse_seg)) fuse_seg *= 2;
+			if (scan_fits((N1 - hist_rows) * fuse_seg)) {
+				fuse_static = true;
+				feeder_->fuse_probe = [this](const double *in, long in_stride, ssize_t frames) { return fuse_accepts(in, in_stride, frames); };
+			}
+		}
+	}
+	return true;
+}
+
+bool ConvStage::fuse_accepts(const double *in, long in_stride, ssize_t frames) const
+{
+	(void) in_stride;
+	return fuse_static && frames == B && skip_left == 0 && !feeds && (q_abs & 7) == 0 && ((((size_t) in) & 15) == 0) && wire_in_fmt == PCM_DOUBLE;
+}
+
+bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	const CascadeStage::Pending pd = feeder_->pending;
+	feeder_->pending = CascadeStage::Pending();
+	const CascadeStage::FuseTables &ft = feeder_->fuse_tables();
+	const long hist_rows = first_n / N2, len = N2 / fuse_seg, K = (N1 - hist_rows) * fuse_seg;
+	CascadeStage::ChunkPlan *plan = feeder_->chunk_plan_for(frames, (int) K, len);
+	if (!plan) return false;
+	FuseParams f;
+	memset(&f, 0, sizeof(f));
+	f.in = pd.in; f.in_stride_frames = pd.in_stride;
+	f.C = ch_in; f.n_sec = ft.n_sec; f.n_ops = feeder_->n_ops;
+	f.sec_op = ft.sec_op.as<int>();
+	f.gain = ft.gain;
+	f.seg = fuse_seg; f.hist_rows = (int) hist_rows;
+	f.K = K; f.len = len;
+	f.cstate = plan->cstate.as<double>(); f.X = plan->X.as<double>();
+	f.n_streams = S;
+	{ ProfScope ps("fused_prepass", st); if (!launch_fused_prepass(f, ft.sec.as<double>(), N2, pps, st)) return false; }
+	ChunkParams cp;
+	memset(&cp, 0, sizeof(cp));
+	cp.len = len; cp.C = ch_in; cp.K = (int) K; cp.D = 2 * feeder_->n_ops; cp.n_pow = plan->n_pow; cp.n_cls = plan->n_cls;
+	cp.cls = plan->cls.as<int>(); cp.H = plan->H.as<double>(); cp.Mp = plan->Mp.as<double>();
+	cp.cstate = plan->cstate.as<double>(); cp.X = plan->X.as<double>(); cp.state = feeder_->state.as<double>();
+	{ ProfScope ps("cascade_chunk_carry", st); launch_chunk_carry(cp, S, st); }
+	ConvParams p = base_params();
+	p.win_base = (q_abs - first_n) & (ring_len - 1);
+	p.first_n = first_n;
+	p.valid = N;
+	p.out = out;
+	p.out_stride_frames = out_stride;
+	p.sink = wire_sink;
+	p.in_count = frames;
+	p.q_blk = q_abs;
+	p.k_origin = q_abs;
+	p.out_count = frames;
+	p.k3_pipe_ok = (all_selected && n_filters == 1 && pps == 4 && ch_in == 8 && !feeds && ((((size_t) out) & 15) == 0)) ? 1 : 0;
+	p.pair0 = 0; p.stream0 = 0; p.n_streams_launch = S;
+	{ ProfScope ps("fused_col_fwd", st); if (!launch_fused_col_fwd(p, f, ft.sec.as<double>(), st)) return false; }
+	{ ProfScope ps("conv_row", st); launch_conv_row(p, 0, (int) ((long) S * pps), st); }
+	{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) ((long) S * pps), st); }
+	if (plan->done) (void) hipEventRecord(plan->done, st);
+	feeder_->ring.pos = (feeder_->ring.pos + frames) & feeder_->ring.mask;
 	return true;
 }
 
@@ -822,6 +908,14 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 			cur_slab = nullptr;
 		}
 		return got;
+	}
+	if (feeder_ && feeder_->pending.in) {
+		// (the feeding cascade left this call to the fused kernels: fuse_accepts said yes to exactly this call)
+		if (!run_fused(frames, out, out_stride, st)) { set_error("%s: fused first pass could not be launched", name.c_str()); return PIPE_FAILED; }
+		q_abs += frames;
+		feed_pos = (feed_pos + frames) & feed_mask;
+		pos = (pos + frames) & (ring_len - 1);
+		return frames;
 	}
 	// plain convolution: output frame m of this call = convolution at ring index pos + m
 	const long drop = std::min<long>(skip_left, frames);

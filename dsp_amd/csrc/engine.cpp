@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include "stages.h"
+#include "fft_params.h"
 #include "pcm_params.h"
 #include <cmath>
 #include <cstdlib>
@@ -523,12 +524,49 @@ bool CascadeStage::wire_out_ok(int fmt, const void *out, long out_stride, ssize_
 	return wire_ok(also_in ? in_fmt : PCM_DOUBLE, true, fmt, nullptr, out_stride, out, out_stride, frames);
 }
 
+const CascadeStage::FuseTables &CascadeStage::fuse_tables()
+{
+	FuseTables &ft = fuse_tab;
+	if (ft.tried) return ft;
+	ft.tried = true;
+	if (ch_in < 1 || n_ops < 1) return ft;
+	std::vector<double> sec;
+	std::vector<int> sec_op;
+	double gain = 1.0;
+	for (int j = 0; j < n_ops; ++j) {
+		const OpDesc &od = host_ops[j];
+		for (int c = 1; c < ch_in; ++c) {
+			const OpDesc &o = host_ops[(size_t) c * n_ops + j];
+			if (o.kind != od.kind || o.g != od.g || memcmp(o.c, od.c, sizeof(od.c)) != 0) return ft;
+		}
+		if (od.kind == OP_MUL) { gain *= od.g; continue; }
+		if (od.kind != OP_BIQUAD) return ft;
+		sec.insert(sec.end(), { od.c[0] * gain, od.c[1] * gain, od.c[2] * gain, od.c[3], od.c[4], 0.0 });     // y = H(g x): the b coefficients scaled, states untouched
+		sec_op.push_back(j);
+		gain = 1.0;
+	}
+	const int slots = fused_section_slots((int) sec_op.size());
+	if (sec_op.empty() || !slots) return ft;
+	while ((int) sec_op.size() < slots) { sec.insert(sec.end(), { 1.0, 0.0, 0.0, 0.0, 0.0, 0.0 }); sec_op.push_back(-1); }   // pass-through
+	if (!ft.sec.upload(sec.data(), sec.size() * sizeof(double)) || !ft.sec_op.upload(sec_op.data(), sec_op.size() * sizeof(int))) return ft;
+	ft.n_sec = slots;
+	ft.gain = gain;
+	ft.ok = true;
+	return ft;
+}
+
 ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
 	CascadeParams p = params(in, in_stride, frames, out, out_stride);
 	int K = 0;
 	long len = 0;
 	const bool wire = wire_in_fmt != PCM_DOUBLE || wire_sink.on;
+	pending = Pending();
+	if (fuse_probe && !wire && ring.base && !write_interleaved && fuse_probe(in, in_stride, frames)) {
+		// the convolver behind takes the call whole (ConvStage::run_fused): nothing to launch here
+		pending.in = in; pending.in_stride = in_stride; pending.frames = frames;
+		return frames;
+	}
 	if (!wire && !ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) {
 		ChunkPlan *cpl = chunk_plan_for(frames, K, len);
 		if (!cpl) return -1;
@@ -557,6 +595,7 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 void CascadeStage::reset(hipStream_t st)
 {
 	(void) hipMemsetAsync(state.p, 0, state.bytes, st);
+	pending = Pending();
 }
 
 // -------------------------------------------------------------- RemixStage

@@ -116,6 +116,32 @@ struct FirDirectParams {
 	double *hist_wr;
 };
 
+// The cascade fused into the convolver's first pass (round 4, kernels_fused.hip): a call of exactly one hop whose window rows
+// are whole chunks of the recurrence.  The window of N = N1 x N2 points is [hist_rows rows of history | N1 - hist_rows rows of new
+// frames]; row r (N2 consecutive frames) of every channel is cut into `seg` chunks; chunk c = (r - hist_rows) seg + sg.
+//   fused_prepass    every chunk run from ZERO state, its end state -> cstate           (reads the slab once, writes K D per channel)
+//   cascade_chunk_carry (kernels_chunk.hip)   the scan over the chunks with M = A^len   -> X = true state at every chunk start
+//   fused_col_fwd    K1 with the recurrence in front of its column transforms: the slab's frames -> sections (from X) -> W;
+//                    the last hist_rows rows of cascade output go to the pair rings on the way (the next window's history)
+// so the ring round trip of the cascade's output (write + K1's read: a quarter of the step's HBM traffic) is gone.
+struct FuseParams {
+	const double *in;                   // [S][in_stride_frames][C] fp64 slab; frame 0 = window element first_n
+	long in_stride_frames;
+	int C, n_sec, n_ops;                // n_sec biquad sections (gains folded in), n_ops ops per channel in the state layout (D = 2 n_ops)
+	const int *sec_op;                  // [n_sec] op index whose (m0, m1) the section carries
+	double gain;                        // product of the gains behind the last section
+	int seg, hist_rows;
+	long K, len;                        // chunks per channel = (N1 - hist_rows) seg, frames per chunk = N2 / seg
+	double *cstate;                     // [S K][C][D]
+	const double *X;                    // [S K][C][D]
+	int n_streams;
+};
+constexpr int FUSE_MAX_SEC = 12;
+// sec: [n_sec][6] device table c0 c1 c2 c3 c4 pad (read with scalar loads); false: no instance for this section count
+bool launch_fused_prepass(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st);
+int fused_section_slots(int n_sec);   // section count of the instance that takes n_sec sections (the host pads with pass-through sections), 0 = none
+bool launch_fused_col_fwd(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st);
+
 void launch_conv_col(const ConvParams &p, bool inverse, int grid_y, hipStream_t st);
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st);
 void launch_deinterleave(const DeintParams &p, int n_streams, hipStream_t st);

@@ -2,6 +2,7 @@
 #pragma once
 #include "engine.h"
 #include <cstdlib>
+#include <functional>
 
 namespace dspamd {
 
@@ -25,7 +26,20 @@ public:
 	PlanarRing ring = { nullptr, 0, 0, 0, nullptr, 0, 0 };
 	int write_interleaved = 1;
 	int n_ops = 0, Cg = 1;
+	// ---- the cascade fused into the following convolver's first pass (kernels_fused.hip; ConvStage::run_fused) ----
+	// The convolver installs fuse_probe; a call it accepts is not run here at all: run() only notes where the call's frames lie
+	// (`pending`) and the convolver's run() does the whole of it -- end states of the window's rows from zero state, the scan over
+	// them (the chunk plan's tables), the recurrence from the true states in front of the column transforms.  State and rings
+	// are left exactly as the separate kernels leave them, so any later call may take the ordinary path again.
+	std::function<bool(const double *in, long in_stride, ssize_t frames)> fuse_probe;
+	struct Pending { const double *in = nullptr; long in_stride = 0; ssize_t frames = 0; } pending;
+	// sections of a chain whose channels all run the same sections and gains (gains folded into the next section's b coefficients,
+	// as cascade_rows has them), padded with pass-through sections to a count the fused kernels are instantiated for
+	struct FuseTables { bool tried = false, ok = false; int n_sec = 0; double gain = 1.0; DevBuf sec, sec_op; };
+	const FuseTables &fuse_tables();
+	friend class ConvStage;
 private:
+	FuseTables fuse_tab;
 	std::vector<std::vector<OpDesc>> cols;   // [op][channel]
 	std::vector<std::string> names;
 	DevBuf ops, state, fops, fq, frows, frq;
