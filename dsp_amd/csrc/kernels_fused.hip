@@ -48,12 +48,20 @@ __device__ __forceinline__ void run_sections(cplx (&x)[NF], double2 (&m0)[NSEC],
 		double a0x = m0[k].x, a0y = m0[k].y, a1x = m1[k].x, a1y = m1[k].y;
 #pragma unroll
 		for (int i = 0; i < NF; ++i) {
+			// (one sample of both channels at a time, in this order: left to itself the scheduler computes the input-only products of all
+			// NF samples of a section first -- two registers each -- and a ten-section instance no longer fits 256 registers)
 			const double sa = x[i].x, sb = x[i].y;
 			const double ra = fma(c0, sa, a0x), rb = fma(c0, sb, a0y);
-			a0x = fma(-c3, ra, fma(c1, sa, a1x)); a0y = fma(-c3, rb, fma(c1, sb, a1y));
-			a1x = fma(-c4, ra, c2 * sa); a1y = fma(-c4, rb, c2 * sb);
+			const double ta = fma(c1, sa, a1x), tb = fma(c1, sb, a1y);
+			const double ua = c2 * sa, ub = c2 * sb;
+			a0x = fma(-c3, ra, ta); a0y = fma(-c3, rb, tb);
+			a1x = fma(-c4, ra, ua); a1y = fma(-c4, rb, ub);
 			x[i].x = ra; x[i].y = rb;
+			__builtin_amdgcn_sched_barrier(0);
 		}
+		// (the new states are wanted HERE: left alone they are computed in the loop latch, from the section's last input and output kept
+		// alive until then -- eight more registers per section)
+		asm volatile("" : "+v"(a0x), "+v"(a0y), "+v"(a1x), "+v"(a1y));
 		m0[k].x = a0x; m0[k].y = a0y; m1[k].x = a1x; m1[k].y = a1y;
 	}
 }
@@ -79,18 +87,19 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 	double2 m0[NSEC], m1[NSEC];
 #pragma unroll
 	for (int k = 0; k < NSEC; ++k) { m0[k] = make_double2(0.0, 0.0); m1[k] = make_double2(0.0, 0.0); }
-	cplx x[16], nx[16];
+	constexpr int NF = (NSEC > 10) ? 8 : 16;           // frames per step (twelve sections with 16: spills)
+	cplx x[NF], nx[NF];
 #pragma unroll
-	for (int i = 0; i < 16; ++i) nx[i] = buf_ldc(rs, vo, i * fb);
-	for (long i0 = 0; i0 < f.len; i0 += 16) {
+	for (int i = 0; i < NF; ++i) nx[i] = buf_ldc(rs, vo, i * fb);
+	for (long i0 = 0; i0 < f.len; i0 += NF) {
 #pragma unroll
-		for (int i = 0; i < 16; ++i) x[i] = nx[i];
-		if (i0 + 16 < f.len) {
-			vo += 16 * fb;
+		for (int i = 0; i < NF; ++i) x[i] = nx[i];
+		if (i0 + NF < f.len) {
+			vo += NF * fb;
 #pragma unroll
-			for (int i = 0; i < 16; ++i) nx[i] = buf_ldc(rs, vo, i * fb);
+			for (int i = 0; i < NF; ++i) nx[i] = buf_ldc(rs, vo, i * fb);
 		}
-		run_sections<NSEC, 16>(x, m0, m1, sec);
+		run_sections<NSEC, NF>(x, m0, m1, sec);
 	}
 	if (!live) return;
 	const int D = 2 * f.n_ops;
@@ -105,15 +114,22 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 }
 
 // ---- pass 1: K1 with the cascade in front of its column transforms (see the head of the file).
-// grid: S x groups x seg workgroups in the order of fz_block (the groups of a stream on one XCD), 256 threads = 4 waves, one per SIMD.
-// MH = hist_rows / 16: the window rows j + 16 m with m < MH are history (the pair rings), the others new frames (the slab).
-// A tile = 8 columns of the group's two pairs.  Two LDS buffers [2 pairs][256 rows] of pitch 9: `raw` holds the frames of the tile
-// as loaded (written in the column layout (pair, column, j), read by rows), `yb` the cascade's output (written by rows, read in
-// the column layout) and then the exchange of the two radix-16 passes; the next tile's frames are loaded into registers under
-// the recurrence of this one and move to `raw` before its transform starts.
-constexpr int FZ_TW = 8, FZ_PITCH = 9, FZ_QS = 256 * FZ_PITCH + 4;     // (the two pairs' rows 4 slots apart mod 8: the 8 lanes of a write group are (pair, column 0..3))
-constexpr int FZ_XQS = 256 * FZ_TW + 8;                                 // the exchange layout: ColCfg<8, 2>::QS
-constexpr size_t FZ_LDS = ((size_t) 4 * FZ_QS + 256) * sizeof(cplx);
+// grid: S x groups x seg workgroups in the order of fz_block (the groups of a stream on one XCD), 512 threads = 8 waves, two per SIMD
+// (a first version with 256 threads -- a thread's row of BOTH pairs, 160 state registers, one wave per SIMD with the whole
+// register file -- spent 37 % of its cycles in issue stalls with nothing to fill them: 10.0 ms where this one ...).
+// HR = the window rows that are history (the pair rings: 16 or 32), the others are new frames (the slab).
+// A tile = 8 columns of the group's two pairs.  Thread roles:
+//   recurrence   (pair rq, row rr): 8 consecutive frames of its row through the sections, states in registers (80)
+//   transform    (pair q, column t, j): the 8 points n1 = j + 32 m of a column -- three passes of radix 8, 8, 4
+// Two LDS buffers [2 pairs][256 rows] of pitch 9: `raw` holds the frames of the tile as loaded (written in the transform layout,
+// read by rows), `yb` the cascade's output (written by rows, read in the transform layout) and then both exchanges of the
+// transform (the second one in place: a thread's outputs go to the slots it has just read, FzMap2); the next tile's frames are
+// loaded into registers under this tile's transform and the next one's recurrence.
+constexpr int FZ_TW = 8, FZ_PITCH = 9, FZ_PT = 8, FZ_P = 256 / FZ_PT;
+constexpr int FZ_QS_RAW = 256 * FZ_PITCH + 8;      // = 8 mod 16: the 16 lanes of a row-layout read group (8 rows x 2 pairs) land in 16 different bank quads
+constexpr int FZ_QS_Y = 256 * FZ_PITCH + 4;        // = 4 mod 8: the 8 lanes of a row-layout write group (4 rows x 2 pairs) likewise
+constexpr int FZ_XQS = 256 * FZ_TW;                // exchange layout [pair][position][column]
+constexpr size_t FZ_LDS = ((size_t) 2 * FZ_QS_RAW + 2 * FZ_QS_Y + 256) * sizeof(cplx);
 
 __device__ __forceinline__ void fz_block(int n_streams, int n_gs, int &s, int &gs)
 {
@@ -126,124 +142,194 @@ __device__ __forceinline__ void fz_block(int n_streams, int n_gs, int &s, int &g
 	else { s = id / n_gs; gs = id % n_gs; }
 }
 
-template <int NSEC, int MH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// One Stockham pass on the PT register-resident points of a thread (pass16 of fft_core.inc for another number of points):
+// v[m] <-> position j + P m, P = N / PT; PT / R butterflies b = j + P q of radix R whose inputs b + (N / R) r are v[q + (PT / R) r].
+template <int PT, int LOG2N, int R, int NS, bool LAST, class Map, class Tw>
+__device__ __forceinline__ void fz_pass(cplx (&v)[PT], int j, cplx *lds, const Map &map, const Tw &tw)
+{
+	constexpr int N = 1 << LOG2N, P = N / PT, Q = PT / R;
+#pragma unroll
+	for (int qq = 0; qq < Q; ++qq) {
+		const int b = j + P * qq;
+		const int k = b & (NS - 1);
+		cplx u[R];
+#pragma unroll
+		for (int r = 0; r < R; ++r) u[r] = v[qq + Q * r];
+		if constexpr (NS > 1) {
+#pragma unroll
+			for (int r = 1; r < R; ++r) u[r] = cmul(u[r], tw.template get<R * NS>(r * k));
+		}
+		dftR<R, false>(u);
+		if constexpr (LAST) {
+#pragma unroll
+			for (int r = 0; r < R; ++r) v[qq + Q * r] = u[r];
+		}
+		else {
+			const int j0 = (b - k) * R + k;
+#pragma unroll
+			for (int r = 0; r < R; ++r) map.store(lds, j0 + NS * r, u[r]);
+		}
+	}
+}
+template <int PT, class Map> __device__ __forceinline__ void gather_n(cplx (&v)[PT], int j, const cplx *lds, const Map &map)
+{
+#pragma unroll
+	for (int m = 0; m < PT; ++m) map.load(lds, j + (256 / PT) * m, v[m]);
+}
+struct FzTw { const cplx *t; template <int M> __device__ __forceinline__ cplx get(int e) const { return t[e * (256 / M)]; } };   // W_256 table
+struct FzMap1 {          // first exchange: position pos of the column at base + pos * TW
+	int base;
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + pos * FZ_TW] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + pos * FZ_TW]; }
+};
+struct FzMap2 {          // second exchange, in place: the radix-8 butterfly of thread j (k = j & 7) writes its output r -- position 64 (j >> 3) + 8 r + k --
+	int base;            // into the slot j + 32 r it read its input r from; so position pos lives at slot 8 pos[7:6] + pos[2:0] + 32 pos[5:3]
+	__device__ __forceinline__ static int slot(int pos) { return 8 * (pos >> 6) + (pos & 7) + 32 * ((pos >> 3) & 7); }
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + slot(pos) * FZ_TW] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + slot(pos) * FZ_TW]; }
+};
+
+// the inter-pass twiddle w_N^(n2 k1) for the rows k1 = j + 32 m of a thread, from s = w_N^(16 n2) and a = w_N^(n2 (j & 15)) (tw_col's rows)
+__device__ __forceinline__ void fz_twiddle(cplx s16, cplx a, int j, cplx (&v)[FZ_PT])
+{
+	if (j >= 16) a = cmul(a, s16);
+	const cplx s1 = cmul(s16, s16), s2 = cmul(s1, s1), s3 = cmul(s2, s1), s4 = cmul(s2, s2);      // w^(32 n2) and its powers
+	const cplx a4 = cmul(a, s4);
+	v[0] = cmul(v[0], a); v[1] = cmul(v[1], cmul(a, s1)); v[2] = cmul(v[2], cmul(a, s2)); v[3] = cmul(v[3], cmul(a, s3));
+	v[4] = cmul(v[4], a4); v[5] = cmul(v[5], cmul(a4, s1)); v[6] = cmul(v[6], cmul(a4, s2)); v[7] = cmul(v[7], cmul(a4, s3));
+}
+
+template <int NSEC, int HR, int DBG = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 {
-	constexpr int N1 = 256, P = 16, HR = 16 * MH, TW = FZ_TW;
+	constexpr int N1 = 256, TW = FZ_TW, PT = FZ_PT, P = FZ_P;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *raw = reinterpret_cast<cplx *>(smem_raw);
-	cplx *yb = raw + 2 * FZ_QS;
-	cplx *twt = yb + 2 * FZ_QS;
+	cplx *yb = raw + 2 * FZ_QS_RAW;
+	cplx *twt = yb + 2 * FZ_QS_Y;
 	const int tid = threadIdx.x;
-	const int q = tid & 1, t = (tid >> 1) & (TW - 1), j = tid >> 4;      // column transform: points n1 = j + 16 m of column t of pair q
-	const int rr = tid;                                                   // recurrence: row rr of the window, both pairs
+	const int t = tid & (TW - 1), q = (tid >> 3) & 1, j = tid >> 4;      // transform: points n1 = j + 32 m of column t of pair q
+	const int rq = tid & 1, rr = tid >> 1;                               // recurrence: row rr of pair rq
 	const int groups = p.pairs_per_stream >> 1;
 	int s, gs;
 	fz_block(f.n_streams, groups * f.seg, s, gs);
 	const int grp = gs % groups, sg = gs / groups;
-	twt[tid] = TAB(p.tw_n1)[tid];
+	if (tid < N1) twt[tid] = TAB(p.tw_n1)[tid];
 	const long N2 = p.N2;
 	const int tiles = (int) (N2 / TW / f.seg);
 	const long col0 = (long) sg * tiles * TW;        // first column of this workgroup's segment
 	const long pair0 = (long) s * p.pairs_per_stream + 2 * grp;     // the group's first pair
-	// the slab through a buffer descriptor: element (row j + 16 m >= HR, column t) of pair q at vs + ((m - MH) 16 N2 + column) frame bytes
+	// the slab through a buffer descriptor: element (row j + 32 m >= HR, column t) of pair q at vs + (column + (32 m - HR) N2) frame bytes
 	const int fb = f.C * (int) sizeof(double);
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(f.in) + (size_t) s * f.in_stride_frames * f.C, 0, 0x7fffffff, 0x00020000);
 	const int vs = (int) ((((long) j * N2 + t) * f.C + 4 * grp + 2 * q) * (long) sizeof(double));
-	const int row_step = (int) (16 * N2 * fb);       // 16 rows further
+	const int vs0 = vs - (int) (HR * N2 * fb);       // row j itself (only looked at when j >= HR)
+	const int row_step = (int) (32 * N2 * fb);       // 32 rows further
+	const bool hist_row = j < HR;                    // wave-uniform: row j (m = 0) is history
 	// W of the group's two pairs through one descriptor
 	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
 	const int vw = (int) (((long) q * p.w_stride + (long) j * N2 + t) * (long) sizeof(cplx));
-	const int w_step = (int) (16 * N2 * (long) sizeof(cplx));
+	const int w_step = (int) (32 * N2 * (long) sizeof(cplx));
 	const double2 *ring0 = p.ring + pair0 * p.ring_row_stride;
 	const double2 *ringq = ring0 + q * p.ring_row_stride;
-	auto fetch = [&](int it, cplx (&d)[16]) {
+	auto fetch = [&](int it, cplx (&d)[PT]) {
 		const long col = col0 + (long) it * TW;
 		const int so = (int) (col * fb);
+		if (hist_row) d[0] = ringq[(p.win_base + (long) j * N2 + col + t) & p.ring_mask];
+		else if constexpr (DBG & 8) d[0] = mkc((double) so, 1.0);
+		else d[0] = buf_ldc(rs, vs0, so);
 #pragma unroll
-		for (int m = 0; m < 16; ++m) {
-			if (m < MH) d[m] = ringq[(p.win_base + (long) (j + 16 * m) * N2 + col + t) & p.ring_mask];
-			else d[m] = buf_ldc(rs, vs, so + (m - MH) * row_step);
+		for (int m = 1; m < PT; ++m) {
+			if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
+			else d[m] = buf_ldc(rs, vs, so + (int) ((32 * m - HR) * N2 * fb));
 		}
 	};
-	// states of this thread's row: chunk (rr - HR) seg + sg of channels 4 grp .. 4 grp + 3
-	double2 m0[2][NSEC], m1[2][NSEC];
+	// a fetched tile into `raw`; the history element (row j < HR) stays in a register
+#define FZ_STAGE(d, h) do { \
+		if (hist_row) h = d[0]; else raw[q * FZ_QS_RAW + j * FZ_PITCH + t] = d[0]; \
+		_Pragma("unroll") for (int m = 1; m < PT; ++m) raw[q * FZ_QS_RAW + (j + P * m) * FZ_PITCH + t] = d[m]; \
+	} while (0)
+	// states of this thread's row: chunk (rr - HR) seg + sg of channels 4 grp + 2 rq, + 1
+	double2 m0[NSEC], m1[NSEC];
 	const bool rec = rr >= HR;
 	{
 		const int D = 2 * f.n_ops;
 		const long c = rec ? (long) (rr - HR) * f.seg + sg : 0;
-		const double *xs = f.X + (((size_t) s * f.K + c) * f.C + 4 * grp) * D;
+		const double *xs = f.X + (((size_t) s * f.K + c) * f.C + 4 * grp + 2 * rq) * D;
 #pragma unroll
-		for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-			for (int k = 0; k < NSEC; ++k) {
-				const int op = f.sec_op[k];
-				if (op >= 0 && rec) {
-					m0[qq][k] = make_double2(xs[(2 * qq) * D + 2 * op], xs[(2 * qq + 1) * D + 2 * op]);
-					m1[qq][k] = make_double2(xs[(2 * qq) * D + 2 * op + 1], xs[(2 * qq + 1) * D + 2 * op + 1]);
-				}
-				else { m0[qq][k] = make_double2(0.0, 0.0); m1[qq][k] = make_double2(0.0, 0.0); }
+		for (int k = 0; k < NSEC; ++k) {
+			const int op = f.sec_op[k];
+			if (op >= 0 && rec) {
+				m0[k] = make_double2(xs[2 * op], xs[D + 2 * op]);
+				m1[k] = make_double2(xs[2 * op + 1], xs[D + 2 * op + 1]);
 			}
+			else { m0[k] = make_double2(0.0, 0.0); m1[k] = make_double2(0.0, 0.0); }
+		}
 	}
 	const bool keeps = rr >= N1 - HR;                // this row is history of the next window
-	double2 *ringw = const_cast<double2 *>(ring0);
+	double2 *ringw = const_cast<double2 *>(ring0) + rq * p.ring_row_stride;
 	const long ring_e0 = p.win_base + (long) rr * N2 + col0;      // (win_base is a multiple of 8 here: a run of 8 never straddles the ring's end)
-	cplx nx[16], hist[MH], hist_next[MH];
+	cplx nx[PT], hist = mkc(0.0, 0.0);
 	fetch(0, nx);
-#pragma unroll
-	for (int m = 0; m < 16; ++m) { if (m < MH) hist[m] = nx[m]; else raw[q * FZ_QS + (j + 16 * m) * FZ_PITCH + t] = nx[m]; }
+	FZ_STAGE(nx, hist);
 	lds_barrier();                                   // twiddle table and tile 0 visible
-	const TwCol tw{ twt };
-	const ColMap<TW> xmap{ q * FZ_XQS + t };
+	const FzTw tw{ twt };
+	const FzMap1 map1{ q * FZ_XQS + t };
+	const FzMap2 map2{ q * FZ_XQS + t };
+	const long tw_row = (long) (j & 15) * p.N2;
 	for (int it = 0; it < tiles; ++it) {
+		// the next tile's frames and this tile's inter-pass twiddles (two table entries): on their way under the recurrence
 		fetch(it + 1 < tiles ? it + 1 : it, nx);         // (the last iteration re-reads its own tile: the loop body stays uniform)
-		// this thread's row: 8 consecutive frames of both pairs through the sections
+		const long col = col0 + (long) it * TW;
+		const cplx tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + col + t], tw_a = TAB(p.tw_col)[tw_row + col + t];
+		// this thread's row: 8 consecutive frames of its pair through the sections (history rows: whatever the buffer holds --
+		// their results are never looked at)
 		{
-			cplx x0[TW], x1[TW];
+			cplx x[TW];
 #pragma unroll
-			for (int i = 0; i < TW; ++i) {
-				x0[i] = rec ? raw[rr * FZ_PITCH + i] : mkc(0.0, 0.0);
-				x1[i] = rec ? raw[FZ_QS + rr * FZ_PITCH + i] : mkc(0.0, 0.0);
-			}
-			run_sections<NSEC, TW>(x0, m0[0], m1[0], sec);
-			run_sections<NSEC, TW>(x1, m0[1], m1[1], sec);
+			for (int i = 0; i < TW; ++i) x[i] = raw[rq * FZ_QS_RAW + rr * FZ_PITCH + i];
+			// (the coefficients are re-read with scalar loads in every tile: hoisted out of the loop, the 50 of them end up as VGPR copies --
+			// 100 registers beside the 80 of the states)
+			int zero;
+			asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+			if constexpr (!(DBG & 1)) run_sections<NSEC, TW>(x, m0, m1, sec + zero);
 			if (f.gain != 1.0) {
 #pragma unroll
-				for (int i = 0; i < TW; ++i) { x0[i].x *= f.gain; x0[i].y *= f.gain; x1[i].x *= f.gain; x1[i].y *= f.gain; }
+				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
 			}
 			// the cascade's output into the second buffer; the rows the next window looks back at also go to the rings
-			if (rec) {
 #pragma unroll
-				for (int i = 0; i < TW; ++i) { yb[rr * FZ_PITCH + i] = x0[i]; yb[FZ_QS + rr * FZ_PITCH + i] = x1[i]; }
-			}
+			for (int i = 0; i < TW; ++i) yb[rq * FZ_QS_Y + rr * FZ_PITCH + i] = x[i];
 			if (keeps) {
 				double2 *w0 = ringw + ((ring_e0 + (long) it * TW) & p.ring_mask);
 #pragma unroll
-				for (int i = 0; i < TW; ++i) { w0[i] = x0[i]; w0[p.ring_row_stride + i] = x1[i]; }
+				for (int i = 0; i < TW; ++i) w0[i] = x[i];
 			}
 		}
 		lds_barrier();                                   // output visible; every row of `raw` has been read
-		// the next tile's frames into `raw`
+		cplx v[PT];
+		if (hist_row) v[0] = hist; else v[0] = yb[q * FZ_QS_Y + j * FZ_PITCH + t];
 #pragma unroll
-		for (int m = 0; m < 16; ++m) { if (m < MH) hist_next[m] = nx[m]; else raw[q * FZ_QS + (j + 16 * m) * FZ_PITCH + t] = nx[m]; }
-		cplx v[16];
-#pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = (m < MH) ? hist[m] : yb[q * FZ_QS + (j + 16 * m) * FZ_PITCH + t];
-#pragma unroll
-		for (int m = 0; m < MH; ++m) hist[m] = hist_next[m];
+		for (int m = 1; m < PT; ++m) v[m] = yb[q * FZ_QS_Y + (j + P * m) * FZ_PITCH + t];
+		FZ_STAGE(nx, hist);                              // the next tile's frames into `raw`
 		lds_barrier();                                   // every thread has its points: `yb` becomes the exchange buffer
-		pass16<8, 16, 1, false, false>(v, j, yb, xmap, tw);
+		if constexpr (!(DBG & 2)) {
+		fz_pass<PT, 8, 8, 1, false>(v, j, yb, map1, tw);
 		lds_barrier();
-		gather16<8>(v, j, yb, xmap);
-		pass16<8, 16, 16, false, true>(v, j, yb, xmap, tw);
-		const long col = col0 + (long) it * TW;
-		col_twiddle<false, P>(p, col + t, j, v);
+		gather_n<PT>(v, j, yb, map1);
+		fz_pass<PT, 8, 8, 8, false>(v, j, yb, map2, tw);     // (in place: no barrier between these reads and writes)
+		lds_barrier();
+		gather_n<PT>(v, j, yb, map2);
+		fz_pass<PT, 8, 4, 64, true>(v, j, yb, map2, tw);
+		}
+		if constexpr (!(DBG & 16)) fz_twiddle(tw_s, tw_a, j, v);
 		const int wo = vw + (int) (col * (long) sizeof(cplx));
 #pragma unroll
-		for (int m = 0; m < 16; ++m) buf_stc<2>(v[m], rw, wo + m * w_step);
+		for (int m = 0; m < PT; ++m) { if constexpr (DBG & 4) { if (v[m].x == 1.2345e-300) buf_stc<2>(v[m], rw, wo + m * w_step); } else buf_stc<2>(v[m], rw, wo + m * w_step); }
 		lds_barrier();                                   // the exchange reads are done before the next output is written; `raw` visible
 	}
+#undef FZ_STAGE
 }
 
 template <int NSEC> static void launch_pre(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st)
@@ -252,18 +338,18 @@ template <int NSEC> static void launch_pre(const FuseParams &f, const double *se
 	hipLaunchKernelGGL((fused_prepass<NSEC>), dim3((unsigned) ((n + 255) / 256), (unsigned) f.n_streams), dim3(256), 0, st, f, sec, N2, pps);
 }
 
-template <int NSEC, int MH> static void launch_col(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
+template <int NSEC, int HR, int DBG = 0> static void launch_col(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
 {
-	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, MH>), FZ_LDS);
+	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, DBG>), FZ_LDS);
 	const unsigned wgs = (unsigned) ((long) f.n_streams * (p.pairs_per_stream / 2) * f.seg);
-	hipLaunchKernelGGL((fused_col_fwd<NSEC, MH>), dim3(wgs), dim3(256), FZ_LDS, st, p, f, sec);
+	hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, DBG>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
 }
 
 template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
 {
 	switch (f.hist_rows) {
-	case 16: launch_col<NSEC, 1>(p, f, sec, st); return true;
-	case 32: launch_col<NSEC, 2>(p, f, sec, st); return true;
+	case 16: launch_col<NSEC, 16>(p, f, sec, st); return true;
+	case 32: launch_col<NSEC, 32>(p, f, sec, st); return true;
 	default: return false;
 	}
 }
@@ -300,7 +386,24 @@ bool launch_fused_col_fwd(const ConvParams &p, const FuseParams &f, const double
 	case 4: return pfz::launch_col_mh<4>(p, f, sec, st);
 	case 6: return pfz::launch_col_mh<6>(p, f, sec, st);
 	case 8: return pfz::launch_col_mh<8>(p, f, sec, st);
-	case 10: return pfz::launch_col_mh<10>(p, f, sec, st);
+	case 10:
+#ifdef FUSE_EXPERIMENTS
+		{
+			const char *e = getenv("DSP_AMD_FUSE_DBG");
+			switch (e ? atoi(e) : 0) {
+			case 1: pfz::launch_col<10, 16, 1>(p, f, sec, st); return true;
+			case 2: pfz::launch_col<10, 16, 2>(p, f, sec, st); return true;
+			case 3: pfz::launch_col<10, 16, 3>(p, f, sec, st); return true;
+			case 4: pfz::launch_col<10, 16, 4>(p, f, sec, st); return true;
+			case 8: pfz::launch_col<10, 16, 8>(p, f, sec, st); return true;
+			case 12: pfz::launch_col<10, 16, 12>(p, f, sec, st); return true;
+			case 16: pfz::launch_col<10, 16, 16>(p, f, sec, st); return true;
+			case 15: pfz::launch_col<10, 16, 15>(p, f, sec, st); return true;
+			default: break;
+			}
+		}
+#endif
+		return pfz::launch_col_mh<10>(p, f, sec, st);
 	case 12: return pfz::launch_col_mh<12>(p, f, sec, st);
 	default: return false;
 	}

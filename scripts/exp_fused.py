@@ -69,7 +69,7 @@ def small(taps=16384, S=8, C=8, B=245760, biq=BIQ, tag="10 sections"):
     return ok
 
 
-def timed(S=256, C=8, B=983040, taps=65536, steps=6):
+def timed(S=256, C=8, B=983040, taps=65536, steps=6, modes=(True, False, True)):
     L = dsp_amd.load_library()
     p = f"/tmp/fz_{taps}.raw"
     np.asarray(make_filter(taps), dtype="<f8").tofile(p)
@@ -79,7 +79,11 @@ def timed(S=256, C=8, B=983040, taps=65536, steps=6):
     L.dspamd_sgen_sine(x.data_ptr(), S, B + 68, C, 48000, 100.0, 90.0, 0, torch.cuda.current_stream().cuda_stream)
     o = torch.empty((S, B + 68, C), dtype=torch.float64, device="cuda")
     outs = {}
-    for fuse in (True, False, True):
+    for fuse in modes:
+        if isinstance(fuse, str):
+            os.environ["DSP_AMD_FUSE_DBG"] = fuse; tagname = "dbg" + fuse; fuse = True
+        else:
+            os.environ.pop("DSP_AMD_FUSE_DBG", None); tagname = "fused" if fuse else "separate"
         b = build(chain, C, S, B, fuse)
         for _ in range(2): b.run(x[:, :B, :], o)
         torch.cuda.synchronize()
@@ -94,9 +98,10 @@ def timed(S=256, C=8, B=983040, taps=65536, steps=6):
             prof[name] = round(float(ms) / max(int(cnt), 1), 3)
         L.dspamd_profile_enable(0)
         outs[fuse] = o[:, :B, :].clone()
-        res["fused" if fuse else "separate"] = {"ms_per_step": round(dt * 1e3, 3), "Gsamples_s": round(S * C * B / dt / 1e9, 2), "kernels_ms": prof}
-        print("fused" if fuse else "separate", json.dumps(res["fused" if fuse else "separate"]), flush=True)
+        res[tagname] = {"ms_per_step": round(dt * 1e3, 3), "Gsamples_s": round(S * C * B / dt / 1e9, 2), "kernels_ms": prof}
+        print(tagname, json.dumps(res[tagname]), flush=True)
         del b
+    if False not in outs: return res
     d = outs[True] - outs[False]
     print("headline shape, third step: rms(fused - separate) =", float(d.pow(2).mean().sqrt()), "signal", float(outs[False].pow(2).mean().sqrt()), flush=True)
     return res
@@ -108,6 +113,8 @@ if __name__ == "__main__":
     if what in ("small", "all"):
         ok = small()
         ok2 = small(taps=32768, S=8, C=4, B=491520, biq="lowpass 1k 0.707 gain -3 eq 400 2.0 1.5 gain 2", tag="2 sections + gains, 4 ch, N = 2^19")
+    if what == "dbg":
+        timed(steps=3, modes=[True] + sys.argv[2:])
     if what in ("time", "all"):
         r = timed()
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
