@@ -470,8 +470,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 			const int D = 2 * feeder_->n_ops;
 			const long groups = (long) S * (pps / 2);
 			fuse_seg = 1;
-			auto scan_fits = [&](long k) { long g = 1; while (g * g < k) ++g; return (double) (k * D + ((k + g - 1) / g) * D + D * D) * sizeof(double) <= 150.0 * 1024 && ((k + g - 1) / g) * D <= 1024; };
-			while (fuse_seg < 4 && groups * fuse_seg < 224 && (N2 / 8) % (2 * fuse_seg) == 0 && scan_fits((N1 - hist_rows) * 2 * fuse_seg)) fuse_seg *= 2;
+			auto scan_fits = [&](long k) { long g = 1; while (g * g < k) ++g; return (double) (k * D + ((k + g - 1) / g) * D + D * D) * sizeof(double) <= 160.0 * 1024 - 256 && ((k + g - 1) / g) * D <= 1024; };
+			while (fuse_seg < 4 && groups * fuse_seg < 224 && (N2 / 8) % (4 * fuse_seg) == 0 && scan_fits((N1 - hist_rows) * 2 * fuse_seg)) fuse_seg *= 2;
 			if (scan_fits((N1 - hist_rows) * fuse_seg)) {
 				fuse_static = true;
 				feeder_->fuse_probe = [this](const double *in, long in_stride, ssize_t frames) { return fuse_accepts(in, in_stride, frames); };

@@ -39,12 +39,23 @@ typedef double real;
 
 // NSEC sections on NF consecutive frames of one channel pair (x[i].x / .y = the two channels), states carried in (m0, m1):
 // biquad.h:76-92 -- r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r.  Coefficients are wave-uniform (scalar loads).
-template <int NSEC, int NF>
-__device__ __forceinline__ void run_sections(cplx (&x)[NF], double2 (&m0)[NSEC], double2 (&m1)[NSEC], const double *__restrict__ sec)
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+struct SecCoef { double c0, c1, c2, c3, c4; };
+__device__ __forceinline__ SecCoef load_coef(const double *__restrict__ sec, int k) { return { sec[6 * k], sec[6 * k + 1], sec[6 * k + 2], sec[6 * k + 3], sec[6 * k + 4] }; }
+// `between(k)` is called in front of section k: a place to put one memory instruction each.
+// `cf` holds the coefficients of section 0 on entry and again on exit: every section asks for the next one's (scalar loads) before its
+// own samples, the last one for section 0's -- asked for where they are used, the scalar cache's latency stood in front of every
+// section (9 waits per 16-frame step of the prepass: a quarter of its time).
+template <int NSEC, int NF, class Hook = NoHook>
+__device__ __forceinline__ void run_sections(cplx (&x)[NF], double2 (&m0)[NSEC], double2 (&m1)[NSEC], const double *__restrict__ sec, SecCoef &cf, const Hook &between = Hook())
 {
 #pragma unroll
 	for (int k = 0; k < NSEC; ++k) {
-		const double c0 = sec[6 * k], c1 = sec[6 * k + 1], c2 = sec[6 * k + 2], c3 = sec[6 * k + 3], c4 = sec[6 * k + 4];
+		between(k);
+		const SecCoef cur = cf;
+		cf = load_coef(sec, k + 1 < NSEC ? k + 1 : 0);
+		__builtin_amdgcn_sched_barrier(0);
+		const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, c3 = cur.c3, c4 = cur.c4;
 		double a0x = m0[k].x, a0y = m0[k].y, a1x = m1[k].x, a1y = m1[k].y;
 #pragma unroll
 		for (int i = 0; i < NF; ++i) {
@@ -91,6 +102,7 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 	cplx x[NF], nx[NF];
 #pragma unroll
 	for (int i = 0; i < NF; ++i) nx[i] = buf_ldc(rs, vo, i * fb);
+	SecCoef cf = load_coef(sec, 0);
 	for (long i0 = 0; i0 < f.len; i0 += NF) {
 #pragma unroll
 		for (int i = 0; i < NF; ++i) x[i] = nx[i];
@@ -99,7 +111,7 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 #pragma unroll
 			for (int i = 0; i < NF; ++i) nx[i] = buf_ldc(rs, vo, i * fb);
 		}
-		run_sections<NSEC, NF>(x, m0, m1, sec);
+		run_sections<NSEC, NF>(x, m0, m1, sec, cf);
 	}
 	if (!live) return;
 	const int D = 2 * f.n_ops;
@@ -126,8 +138,8 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 // transform (the second one in place: a thread's outputs go to the slots it has just read, FzMap2); the next tile's frames are
 // loaded into registers under this tile's transform and the next one's recurrence.
 constexpr int FZ_TW = 8, FZ_PITCH = 9, FZ_PT = 8, FZ_P = 256 / FZ_PT;
-constexpr int FZ_QS_RAW = 256 * FZ_PITCH + 8;      // = 8 mod 16: the 16 lanes of a row-layout read group (8 rows x 2 pairs) land in 16 different bank quads
-constexpr int FZ_QS_Y = 256 * FZ_PITCH + 4;        // = 4 mod 8: the 8 lanes of a row-layout write group (4 rows x 2 pairs) likewise
+constexpr int FZ_QS_RAW = 256 * FZ_PITCH + 4;      // = 4 mod 8: the 8 lanes of a write group of the loading layout are (pair, column 0..3)
+constexpr int FZ_QS_Y = 256 * FZ_PITCH;            // = 0 mod 16: the 16 lanes of a read group of the transform layout (two pairs, two rows) collide once
 constexpr int FZ_XQS = 256 * FZ_TW;                // exchange layout [pair][position][column]
 constexpr size_t FZ_LDS = ((size_t) 2 * FZ_QS_RAW + 2 * FZ_QS_Y + 256) * sizeof(cplx);
 
@@ -209,8 +221,10 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	cplx *yb = raw + 2 * FZ_QS_RAW;
 	cplx *twt = yb + 2 * FZ_QS_Y;
 	const int tid = threadIdx.x;
-	const int t = tid & (TW - 1), q = (tid >> 3) & 1, j = tid >> 4;      // transform: points n1 = j + 32 m of column t of pair q
-	const int rq = tid & 1, rr = tid >> 1;                               // recurrence: row rr of pair rq
+	// three roles of a thread, three ways to number the tile's elements:
+	const int lq = tid & 1, lt = (tid >> 1) & (TW - 1), lj = tid >> 4;   // loading: rows lj + 32 m of column lt of pair lq -- the two pairs of a frame (32 contiguous bytes) in adjacent lanes
+	const int rr = tid & (N1 - 1), rq = tid >> 8;                        // recurrence: row rr of pair rq (a wave = 64 consecutive rows of one pair)
+	const int t = tid & (TW - 1), q = (tid >> 3) & 1, j = tid >> 4;      // transform: points n1 = j + 32 m of column t of pair q (128-byte runs of W per 8 lanes)
 	const int groups = p.pairs_per_stream >> 1;
 	int s, gs;
 	fz_block(f.n_streams, groups * f.seg, s, gs);
@@ -220,39 +234,40 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const int tiles = (int) (N2 / TW / f.seg);
 	const long col0 = (long) sg * tiles * TW;        // first column of this workgroup's segment
 	const long pair0 = (long) s * p.pairs_per_stream + 2 * grp;     // the group's first pair
-	// the slab through a buffer descriptor: element (row j + 32 m >= HR, column t) of pair q at vs + (column + (32 m - HR) N2) frame bytes
+	// the slab through a buffer descriptor: element (row lj + 32 m >= HR, column lt) of pair lq at vs + (column + (32 m - HR) N2) frame bytes
 	const int fb = f.C * (int) sizeof(double);
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(f.in) + (size_t) s * f.in_stride_frames * f.C, 0, 0x7fffffff, 0x00020000);
-	const int vs = (int) ((((long) j * N2 + t) * f.C + 4 * grp + 2 * q) * (long) sizeof(double));
-	const int vs0 = vs - (int) (HR * N2 * fb);       // row j itself (only looked at when j >= HR)
-	const int row_step = (int) (32 * N2 * fb);       // 32 rows further
-	const bool hist_row = j < HR;                    // wave-uniform: row j (m = 0) is history
+	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) sizeof(double));
+	const int vs0 = vs - (int) (HR * N2 * fb);       // row lj itself (only looked at when lj >= HR)
+	const bool hist_row = lj < HR;                   // wave-uniform: row lj (m = 0) is history: the pair rings
 	// W of the group's two pairs through one descriptor
 	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
 	const int vw = (int) (((long) q * p.w_stride + (long) j * N2 + t) * (long) sizeof(cplx));
 	const int w_step = (int) (32 * N2 * (long) sizeof(cplx));
 	const double2 *ring0 = p.ring + pair0 * p.ring_row_stride;
-	const double2 *ringq = ring0 + q * p.ring_row_stride;
-	auto fetch = [&](int it, cplx (&d)[PT]) {
+	const double2 *ringl = ring0 + lq * p.ring_row_stride;
+	auto fetch1 = [&](int it, int m, cplx (&d)[PT]) {    // (m is a compile-time constant at every call)
 		const long col = col0 + (long) it * TW;
 		const int so = (int) (col * fb);
-		if (hist_row) d[0] = ringq[(p.win_base + (long) j * N2 + col + t) & p.ring_mask];
-		else if constexpr (DBG & 8) d[0] = mkc((double) so, 1.0);
-		else d[0] = buf_ldc(rs, vs0, so);
-#pragma unroll
-		for (int m = 1; m < PT; ++m) {
-			if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
-			else d[m] = buf_ldc(rs, vs, so + (int) ((32 * m - HR) * N2 * fb));
+		if (m == 0) {
+			if (hist_row) d[0] = ringl[(p.win_base + (long) lj * N2 + col + lt) & p.ring_mask];
+			else if constexpr (DBG & 8) d[0] = mkc((double) so, 1.0);
+			else d[0] = buf_ldc(rs, vs0, so);
 		}
+		else if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
+		else d[m] = buf_ldc(rs, vs, so + (int) ((32 * m - HR) * N2 * fb));
 	};
-	// a fetched tile into `raw`; the history element (row j < HR) stays in a register
-#define FZ_STAGE(d, h) do { \
-		if (hist_row) h = d[0]; else raw[q * FZ_QS_RAW + j * FZ_PITCH + t] = d[0]; \
-		_Pragma("unroll") for (int m = 1; m < PT; ++m) raw[q * FZ_QS_RAW + (j + P * m) * FZ_PITCH + t] = d[m]; \
-	} while (0)
+	auto fetch = [&](int it, cplx (&d)[PT]) {
+#pragma unroll
+		for (int m = 0; m < PT; ++m) fetch1(it, m, d);
+	};
+	auto stage = [&](const cplx (&d)[PT]) {              // a fetched tile into `raw`
+#pragma unroll
+		for (int m = 0; m < PT; ++m) raw[lq * FZ_QS_RAW + (lj + P * m) * FZ_PITCH + lt] = d[m];
+	};
 	// states of this thread's row: chunk (rr - HR) seg + sg of channels 4 grp + 2 rq, + 1
 	double2 m0[NSEC], m1[NSEC];
-	const bool rec = rr >= HR;
+	const bool rec = rr >= HR;                       // (history rows pass through unchanged)
 	{
 		const int D = 2 * f.n_ops;
 		const long c = rec ? (long) (rr - HR) * f.seg + sg : 0;
@@ -270,33 +285,38 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const bool keeps = rr >= N1 - HR;                // this row is history of the next window
 	double2 *ringw = const_cast<double2 *>(ring0) + rq * p.ring_row_stride;
 	const long ring_e0 = p.win_base + (long) rr * N2 + col0;      // (win_base is a multiple of 8 here: a run of 8 never straddles the ring's end)
-	cplx nx[PT], hist = mkc(0.0, 0.0);
+	cplx nx[PT];
 	fetch(0, nx);
-	FZ_STAGE(nx, hist);
+	stage(nx);
+	SecCoef cf = load_coef(sec, 0);
 	lds_barrier();                                   // twiddle table and tile 0 visible
 	const FzTw tw{ twt };
 	const FzMap1 map1{ q * FZ_XQS + t };
 	const FzMap2 map2{ q * FZ_XQS + t };
 	const long tw_row = (long) (j & 15) * p.N2;
 	for (int it = 0; it < tiles; ++it) {
-		// the next tile's frames and this tile's inter-pass twiddles (two table entries): on their way under the recurrence
-		fetch(it + 1 < tiles ? it + 1 : it, nx);         // (the last iteration re-reads its own tile: the loop body stays uniform)
+		// the next tile's frames, asked for one row set per section of the recurrence (the last iteration re-reads its own tile: the loop
+		// body stays uniform), and this tile's inter-pass twiddles (two table entries)
+		const int nit = it + 1 < tiles ? it + 1 : it;
+		if constexpr (NSEC < PT) fetch(nit, nx);
 		const long col = col0 + (long) it * TW;
 		const cplx tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + col + t], tw_a = TAB(p.tw_col)[tw_row + col + t];
-		// this thread's row: 8 consecutive frames of its pair through the sections (history rows: whatever the buffer holds --
-		// their results are never looked at)
+		// this thread's row: 8 consecutive frames of its pair through the sections
 		{
 			cplx x[TW];
 #pragma unroll
 			for (int i = 0; i < TW; ++i) x[i] = raw[rq * FZ_QS_RAW + rr * FZ_PITCH + i];
-			// (the coefficients are re-read with scalar loads in every tile: hoisted out of the loop, the 50 of them end up as VGPR copies --
-			// 100 registers beside the 80 of the states)
-			int zero;
-			asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-			if constexpr (!(DBG & 1)) run_sections<NSEC, TW>(x, m0, m1, sec + zero);
-			if (f.gain != 1.0) {
+			{
+				if constexpr (DBG & 1) { if constexpr (NSEC >= PT) fetch(nit, nx); }
+				else run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, k, nx); } });
+				if (f.gain != 1.0) {
 #pragma unroll
-				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
+					for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
+				}
+			}
+			if (!rec) {                                  // history rows pass through unchanged (the first 16 or 32 lanes of the first wave of either pair)
+#pragma unroll
+				for (int i = 0; i < TW; ++i) x[i] = raw[rq * FZ_QS_RAW + rr * FZ_PITCH + i];
 			}
 			// the cascade's output into the second buffer; the rows the next window looks back at also go to the rings
 #pragma unroll
@@ -309,10 +329,9 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 		}
 		lds_barrier();                                   // output visible; every row of `raw` has been read
 		cplx v[PT];
-		if (hist_row) v[0] = hist; else v[0] = yb[q * FZ_QS_Y + j * FZ_PITCH + t];
 #pragma unroll
-		for (int m = 1; m < PT; ++m) v[m] = yb[q * FZ_QS_Y + (j + P * m) * FZ_PITCH + t];
-		FZ_STAGE(nx, hist);                              // the next tile's frames into `raw`
+		for (int m = 0; m < PT; ++m) v[m] = yb[q * FZ_QS_Y + (j + P * m) * FZ_PITCH + t];
+		stage(nx);                                       // the next tile's frames into `raw`
 		lds_barrier();                                   // every thread has its points: `yb` becomes the exchange buffer
 		if constexpr (!(DBG & 2)) {
 		fz_pass<PT, 8, 8, 1, false>(v, j, yb, map1, tw);
@@ -329,7 +348,6 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 		for (int m = 0; m < PT; ++m) { if constexpr (DBG & 4) { if (v[m].x == 1.2345e-300) buf_stc<2>(v[m], rw, wo + m * w_step); } else buf_stc<2>(v[m], rw, wo + m * w_step); }
 		lds_barrier();                                   // the exchange reads are done before the next output is written; `raw` visible
 	}
-#undef FZ_STAGE
 }
 
 template <int NSEC> static void launch_pre(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st)
