@@ -54,7 +54,9 @@ public:
 	bool absorb_discard(long d) override
 	{
 		// (a channel that is not convolved passes through the de-interleaving pass, which knows nothing of frames to drop)
-		if (resampler || feeds || fdl || !all_selected || d <= 0) return false;
+		// (nor for a stage that reads the slab itself: K1 files only what lies behind first_n there -- dropped frames of a short call would never
+		// reach the rings that later windows look back at)
+		if (resampler || feeds || fdl || !all_selected || direct || d <= 0) return false;
 		skip = skip_left = d;
 		return true;
 	}

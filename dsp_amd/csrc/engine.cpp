@@ -8,6 +8,7 @@
 #include "fft_params.h"
 #include "pcm_params.h"
 #include <cmath>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -132,6 +133,7 @@ bool PinnedStage::ensure(size_t in_bytes, size_t out_bytes)
 		ok = hipHostMalloc(&a, std::max<size_t>(in_bytes, 4096), hipHostMallocDefault) == hipSuccess && hipHostMalloc(&b, std::max<size_t>(out_bytes, 4096), hipHostMallocDefault) == hipSuccess;
 		in[i] = static_cast<char *>(a); out[i] = static_cast<char *>(b);
 		if (ok && !done[i]) ok = hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+		if (ok && !copied[i]) ok = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) == hipSuccess;
 	}
 	if (!ok) {
 		(void) hipGetLastError();
@@ -149,6 +151,7 @@ PinnedStage::~PinnedStage()
 		if (in[i]) (void) hipHostFree(in[i]);
 		if (out[i]) (void) hipHostFree(out[i]);
 		if (done[i]) (void) hipEventDestroy(done[i]);
+		if (copied[i]) (void) hipEventDestroy(copied[i]);
 	}
 }
 
@@ -157,10 +160,18 @@ bool MappedPair::wait_block(hipStream_t st)
 	if (flag && !flag_off) {
 		const unsigned want = ++seq;
 		if (hipStreamWriteValue32(st, const_cast<unsigned *>(flag), want, 0) == hipSuccess) {
-			// a small block is through in tens of microseconds: spin for at most ~2 ms worth of polls, then let the runtime wait
-			for (long spins = 0; spins < 2000000; ++spins) {
-				if (*flag == want) return true;
+			// a small block is through in tens of microseconds: poll for at most 2 ms by the clock (a pause is 40 ... 140 cycles: counting
+			// them bounds nothing), then let the runtime wait
+			timespec t0;
+			clock_gettime(CLOCK_MONOTONIC, &t0);
+			for (long spins = 0;; ++spins) {
+				if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) return true;       // (acquire: the block's output is read after this)
 				__builtin_ia32_pause();
+				if ((spins & 255) == 255) {
+					timespec t1;
+					clock_gettime(CLOCK_MONOTONIC, &t1);
+					if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L) break;
+				}
 			}
 			return hip_ok(hipStreamSynchronize(st), "sync");
 		}
@@ -392,9 +403,12 @@ CascadeStage::ChunkPlan *CascadeStage::chunk_plan_for(long frames, int K, long l
 {
 	// plans that fell out of the cache are released once the launches that used them have finished -- asked with an event
 	// query, never waited for: a new call size must not stall the device or break the caller's asynchronous stream
-	for (size_t i = 0; i < retired_plans.size();)
-		if (!retired_plans[i]->done || hipEventQuery(retired_plans[i]->done) == hipSuccess) retired_plans.erase(retired_plans.begin() + i);
+	for (size_t i = 0; i < retired_plans.size();) {
+		// (a plan whose event could not be created: nothing to ask -- wait for the device before its buffers go)
+		if (!retired_plans[i]->done) { (void) hipDeviceSynchronize(); retired_plans.erase(retired_plans.begin() + i); }
+		else if (hipEventQuery(retired_plans[i]->done) == hipSuccess) retired_plans.erase(retired_plans.begin() + i);
 		else { (void) hipGetLastError(); ++i; }
+	}
 	for (size_t i = 0; i < chunk_plans.size(); ++i)
 		if (chunk_plans[i]->frames == frames && chunk_plans[i]->K == K && chunk_plans[i]->len == len) {
 			std::rotate(chunk_plans.begin(), chunk_plans.begin() + i, chunk_plans.begin() + i + 1);

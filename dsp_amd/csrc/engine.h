@@ -60,6 +60,7 @@ struct PinnedStage {
 	char *in[2] = { nullptr, nullptr }, *out[2] = { nullptr, nullptr };
 	size_t in_cap = 0, out_cap = 0;
 	hipEvent_t done[2] = { nullptr, nullptr };
+	hipEvent_t copied[2] = { nullptr, nullptr };    // recorded right behind the host-to-device copy out of in[i]: the buffer may be refilled once it has passed
 	bool off = false;
 	PinnedStage() = default;
 	PinnedStage(const PinnedStage &) = delete;
@@ -82,7 +83,7 @@ ssize_t PinnedStage::run(const double *in, ssize_t frames, ssize_t chunk, int ch
 	int prev = -1;
 	auto collect = [&]() -> bool {                  // the results of the chunk before: wait for its copy, hand them over
 		if (prev < 0) return true;
-		if (hipEventSynchronize(done[prev]) != hipSuccess) { (void) hipGetLastError(); return false; }
+		if (!hip_ok(hipEventSynchronize(done[prev]), "staged D2H wait")) return false;
 		if (prev_f > 0) memcpy(out + (size_t) produced * ch_out, this->out[prev], (size_t) prev_f * fo);
 		produced += prev_f;
 		prev = -1;
@@ -90,20 +91,25 @@ ssize_t PinnedStage::run(const double *in, ssize_t frames, ssize_t chunk, int ch
 	};
 	ssize_t done_frames = 0;
 	int k = 0;
+	bool in_flight[2] = { false, false };               // in[i] has a copy command queued whose `copied` event has not been waited for
 	if (frames > 0) memcpy(this->in[0], in, (size_t) std::min(frames, chunk) * fi);
 	while (done_frames < frames) {
 		const ssize_t nb = std::min(frames - done_frames, chunk);
 		const int b = k & 1;
-		if (hipMemcpyAsync(d_in, this->in[b], (size_t) nb * fi, hipMemcpyHostToDevice, st) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		if (!hip_ok(hipMemcpyAsync(d_in, this->in[b], (size_t) nb * fi, hipMemcpyHostToDevice, st), "staged H2D") || !hip_ok(hipEventRecord(copied[b], st), "staged H2D event")) return -1;
+		in_flight[b] = true;
 		const ssize_t f = run_chunk(static_cast<const double *>(d_in), nb, static_cast<double *>(d_out));
 		if (f < 0) { (void) hipStreamSynchronize(st); return -1; }
 		if (produced + prev_f * (prev >= 0 ? 1 : 0) + f > out_capacity_frames) { (void) hipStreamSynchronize(st); return -2; }
-		if (f > 0 && hipMemcpyAsync(this->out[b], d_out, (size_t) f * fo, hipMemcpyDeviceToHost, st) != hipSuccess) { (void) hipGetLastError(); return -1; }
-		if (hipEventRecord(done[b], st) != hipSuccess) { (void) hipGetLastError(); return -1; }
+		if (f > 0 && !hip_ok(hipMemcpyAsync(this->out[b], d_out, (size_t) f * fo, hipMemcpyDeviceToHost, st), "staged D2H")) return -1;
+		if (!hip_ok(hipEventRecord(done[b], st), "staged D2H event")) return -1;
 		done_frames += nb;
-		// while the GPU works on this chunk: the next one in (its buffer's last DMA was two chunks ago, long done: the wait for
-		// chunk k - 1 below has passed it), the one before out
-		if (done_frames < frames) memcpy(this->in[b ^ 1], in + (size_t) done_frames * ch_in, (size_t) std::min(frames - done_frames, chunk) * fi);
+		// while the GPU works on this chunk: the next one in -- once the copy command that last read that buffer (chunk k - 1's) has
+		// passed: its own event, not an assumption about how far the stream has got -- and the one before out
+		if (done_frames < frames) {
+			if (in_flight[b ^ 1]) { if (!hip_ok(hipEventSynchronize(copied[b ^ 1]), "staged H2D wait")) return -1; in_flight[b ^ 1] = false; }
+			memcpy(this->in[b ^ 1], in + (size_t) done_frames * ch_in, (size_t) std::min(frames - done_frames, chunk) * fi);
+		}
 		if (!collect()) return -1;
 		prev = b; prev_f = f;
 		++k;

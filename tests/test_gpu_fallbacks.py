@@ -25,6 +25,7 @@ SWITCHES = [
     "DSP_AMD_RESAMPLE_NO_GEMM=1", "DSP_AMD_RESAMPLE_DIRECT=1",
     "DSP_AMD_NO_WIRE_FUSION=1", "DSP_AMD_PLUGIN_MAPPED_KB=0", "DSP_AMD_NO_DISCARD_FOLD=1", "DSP_AMD_K3_PIPE=0", "DSP_AMD_ZITA_F64=1", "DSP_AMD_CONV_UPC=0",
     "DSP_AMD_PLUGIN_STAGE=0", "DSP_AMD_PLUGIN_STAGE=0 DSP_AMD_PLUGIN_MAPPED_KB=0",
+    "DSP_AMD_FUSE=0",
 ]
 
 
@@ -108,5 +109,6 @@ def test_every_switch_gives_the_reference_outputs(reference, tmp_path, switch):
     plans = {k.split("/")[0]: str(got[k]) for k in got.files if k.endswith("/plan")}
     if "NO_LTI_MERGE" in switch:
         assert "+" not in plans["two_conv"].split("conv[")[1].split(" ")[0]
+    assert ("cascade-fused" in plans["fused"]) == ("DSP_AMD_FUSE=0" not in switch and "NO_FEED" not in switch), plans["fused"]
     if "CONV_NO_DIRECT" in switch:
         assert "slab-direct" not in plans["conv1024"]

@@ -1,0 +1,102 @@
+"""The cascade fused into the FFT convolver's first pass (kernels_fused.hip: fused_prepass, cascade_chunk_carry, fused_col_fwd) --
+the path the headline workload takes -- against the real reference and against the separate kernels (DSP_AMD_FUSE=0), at shapes the
+CPU finishes in seconds: every instance (section counts padded to 1 / 2 / 4 / 6 / 8 / 10 / 12, history of 16 and 32 rows, row
+segments of 1 / 2 / 4), gains folded in, calls that leave the grid and come back, reset, padded slabs.  The headline's own shape:
+tests/test_gpu_conv.py::test_bench_default_configuration_full_size_vs_real_reference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_api import RefChain, rms
+
+pytestmark = pytest.mark.gpu
+
+SECTIONS = ["lowpass 1k 0.707", "highshelf 8k 0.7 -3", "eq 100 1.0 3", "eq 200 1.0 -2", "eq 400 2.0 1.5", "eq 800 1.0 -1", "eq 1600 1.4 2",
+            "eq 3200 1.0 -2.5", "eq 6400 3.0 1", "highpass 20 0.707", "lowshelf 150 0.8 2", "eq 5000 2.0 -1.5"]
+
+
+def make_filter(n, seed=7, decay=8000.0):
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n) * np.exp(-np.arange(n) / decay)
+    return h / np.sqrt(np.sum(h * h)) / 4.0
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import dsp_amd
+    assert dsp_amd.load_library().dspamd_device_count() >= 1
+    return dsp_amd
+
+
+def build(amd, chain, C, S, B, fuse):
+    os.environ["DSP_AMD_FUSE"] = "1" if fuse else "0"
+    try:
+        return amd.BatchChain(chain, 48000, C, S, B)
+    finally:
+        os.environ.pop("DSP_AMD_FUSE")
+
+
+# (sections, gains, taps, hop, S, C, chunks in the plan): N = 2^18 = 256 x 1024 throughout (hop = N - taps)
+SHAPES = [
+    (10, False, 16384, 245760, 8, 8, "960 chunks of 256"),      # the headline's ten sections, 16 history rows, four segments per row
+    (1, True, 16384, 245760, 2, 4, "960 chunks of 256"),        # one section between gains, four segments
+    (3, True, 32768, 229376, 4, 8, "896 chunks of 256"),        # padded to four sections, 32 history rows
+    (5, False, 16384, 245760, 56, 8, "480 chunks of 512"),      # padded to six, two segments
+    (7, False, 32768, 229376, 112, 4, "448 chunks of 512"),     # padded to eight; two channel pairs per stream
+    (12, False, 16384, 245760, 120, 8, "240 chunks of 1024"),   # twelve sections, whole rows
+]
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("nsec,gains,taps,B,S,C,chunks", SHAPES)
+def test_fused_first_pass_vs_reference_and_separate_kernels(amd, tmp_path, nsec, gains, taps, B, S, C, chunks):
+    import torch
+    f = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(make_filter(taps, seed=taps + nsec), dtype="<f8").tofile(f)
+    secs = SECTIONS[:nsec]
+    if gains:
+        secs = ["gain -2.5"] + secs[:1] + ["gain 1.5"] + secs[1:] + ["gain -0.75"]
+    chain = " ".join(secs) + f" fir_p -t pcm -e double -c 1 {f}"
+    bf, bs = build(amd, chain, C, S, B, True), build(amd, chain, C, S, B, False)
+    assert f"cascade-fused({chunks})" in bf.plan(), bf.plan()
+    assert "cascade-fused" not in bs.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(1000 + nsec)
+    # hop, hop, a call off the grid (separate kernels, on the states and rings the fused ones left), hop again (q_abs a multiple of 8: fused)
+    sizes = [B, B, 5000, B]
+    pad = 68
+    xs = []
+    for n in sizes:
+        buf = torch.rand((S, n + pad, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+        xs.append(buf[:, :n, :])                       # padded slabs, as bench.py hands them over
+    yf = [bf.run(x).clone() for x in xs]
+    ys = [bs.run(x).clone() for x in xs]
+    for k, (a, b) in enumerate(zip(yf, ys)):
+        assert a.shape == b.shape == (S, sizes[k], C)
+        d = float((a - b).pow(2).mean().sqrt())
+        assert d < 1e-12, (k, d)
+    for s in sorted({0, S - 1, (7 * nsec) % S}):
+        x = torch.cat([t[s] for t in xs], dim=0).cpu().numpy()
+        ref = RefChain(chain, 48000, C).run(x)
+        got = torch.cat([t[s] for t in yf], dim=0).cpu().numpy()
+        assert ref.shape == got.shape
+        assert rms(ref - got) < 1e-12, (s, rms(ref - got))
+    # reset: the same call again gives the same bits
+    bf.reset()
+    assert torch.equal(bf.run(xs[0]), yf[0])
+    # every stream given the same input gives the same output
+    bf.reset()
+    y = bf.run(xs[0][0:1].expand(S, sizes[0], C).contiguous())
+    assert torch.equal(y[0], yf[0][0]) and bool((y == y[0:1]).all().item())
+
+
+def test_chains_the_fused_kernels_leave_alone(amd, tmp_path):
+    """per-channel sections, an `add` among the ops, a selector, a latency: the plan keeps the separate kernels"""
+    f = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(make_filter(16384), dtype="<f8").tofile(f)
+    for chain in (f"lowpass 1k 0.707 :0 eq 400 2.0 1.5 : fir_p -t pcm -e double -c 1 {f}",
+                  f"lowpass 1k 0.707 add 0.001 fir_p -t pcm -e double -c 1 {f}",
+                  f"gain -3 fir_p -t pcm -e double -c 1 {f}",
+                  f"lowpass 1k 0.707 fir -t pcm -e double -c 1 {f}"):
+        b = build(amd, chain, 8, 4, 245760, True)
+        assert "cascade-fused" not in b.plan(), b.plan()
