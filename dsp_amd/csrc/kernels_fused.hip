@@ -138,10 +138,10 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 // transform (the second one in place: a thread's outputs go to the slots it has just read, FzMap2); the next tile's frames are
 // loaded into registers under this tile's transform and the next one's recurrence.
 constexpr int FZ_TW = 8, FZ_PITCH = 9, FZ_PT = 8, FZ_P = 256 / FZ_PT;
-constexpr int FZ_QS_RAW = 256 * FZ_PITCH + 4;      // = 4 mod 8: the 8 lanes of a write group of the loading layout are (pair, column 0..3)
-constexpr int FZ_QS_Y = 256 * FZ_PITCH;            // = 0 mod 16: the 16 lanes of a read group of the transform layout (two pairs, two rows) collide once
-constexpr int FZ_XQS = 256 * FZ_TW;                // exchange layout [pair][position][column]
-constexpr size_t FZ_LDS = ((size_t) 2 * FZ_QS_RAW + 2 * FZ_QS_Y + 256) * sizeof(cplx);
+// one pair's rows in a buffer; = 8 mod 16: the 16 lanes of a read group of the two exchanges (two pairs x two rows 32 apart) land in 16 different
+// bank quads (the same group reading the cascade's output -- rows one apart -- collides in 7 of them, the staging writes two ways: the cheaper side)
+constexpr int FZ_QS = 256 * FZ_PITCH + 8;
+constexpr size_t FZ_LDS = ((size_t) 4 * FZ_QS + 256) * sizeof(cplx);
 
 __device__ __forceinline__ void fz_block(int n_streams, int n_gs, int &s, int &gs)
 {
@@ -189,16 +189,23 @@ template <int PT, class Map> __device__ __forceinline__ void gather_n(cplx (&v)[
 	for (int m = 0; m < PT; ++m) map.load(lds, j + (256 / PT) * m, v[m]);
 }
 struct FzTw { const cplx *t; template <int M> __device__ __forceinline__ cplx get(int e) const { return t[e * (256 / M)]; } };   // W_256 table
-struct FzMap1 {          // first exchange: position pos of the column at base + pos * TW
-	int base;
-	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + pos * FZ_TW] = v; }
-	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + pos * FZ_TW]; }
+// The column's 256 points live in the 256 slots (pair, row, column) of the tile buffer the whole time: a thread reads the rows j + 32 m
+// the cascade left there, and every pass writes its 8 outputs to the 8 slots the thread has just read (so only other threads'
+// READS need a barrier, never a free buffer).  Where a position of the Stockham sequence lives after that:
+//   after pass 1 (thread j wrote position 8 j + r to row j + 32 r):                  position p at row (p >> 3) + 32 (p & 7)
+//   after pass 2 (thread j, k = j & 7, wrote position 64 (j >> 3) + 8 r + k to the row it read its input r from,
+//                 (j >> 3) + 4 r + 32 k):                                            position p at row (p >> 6) + 4 ((p >> 3) & 7) + 32 (p & 7)
+struct FzMap1 {
+	int base;            // pair * FZ_QS + column
+	__device__ __forceinline__ static int row(int pos) { return (pos >> 3) + 32 * (pos & 7); }
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + row(pos) * FZ_PITCH] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + row(pos) * FZ_PITCH]; }
 };
-struct FzMap2 {          // second exchange, in place: the radix-8 butterfly of thread j (k = j & 7) writes its output r -- position 64 (j >> 3) + 8 r + k --
-	int base;            // into the slot j + 32 r it read its input r from; so position pos lives at slot 8 pos[7:6] + pos[2:0] + 32 pos[5:3]
-	__device__ __forceinline__ static int slot(int pos) { return 8 * (pos >> 6) + (pos & 7) + 32 * ((pos >> 3) & 7); }
-	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + slot(pos) * FZ_TW] = v; }
-	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + slot(pos) * FZ_TW]; }
+struct FzMap2 {
+	int base;
+	__device__ __forceinline__ static int row(int pos) { return (pos >> 6) + 4 * ((pos >> 3) & 7) + 32 * (pos & 7); }
+	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[base + row(pos) * FZ_PITCH] = v; }
+	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[base + row(pos) * FZ_PITCH]; }
 };
 
 // the inter-pass twiddle w_N^(n2 k1) for the rows k1 = j + 32 m of a thread, from s = w_N^(16 n2) and a = w_N^(n2 (j & 15)) (tw_col's rows)
@@ -217,9 +224,8 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 {
 	constexpr int N1 = 256, TW = FZ_TW, PT = FZ_PT, P = FZ_P;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *raw = reinterpret_cast<cplx *>(smem_raw);
-	cplx *yb = raw + 2 * FZ_QS_RAW;
-	cplx *twt = yb + 2 * FZ_QS_Y;
+	cplx *buf0 = reinterpret_cast<cplx *>(smem_raw);     // two tile buffers [2 pairs][256 rows] of pitch 9 that swap roles from tile to tile
+	cplx *twt = buf0 + 4 * FZ_QS;
 	const int tid = threadIdx.x;
 	// three roles of a thread, three ways to number the tile's elements:
 	const int lq = tid & 1, lt = (tid >> 1) & (TW - 1), lj = tid >> 4;   // loading: rows lj + 32 m of column lt of pair lq -- the two pairs of a frame (32 contiguous bytes) in adjacent lanes
@@ -261,9 +267,9 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 #pragma unroll
 		for (int m = 0; m < PT; ++m) fetch1(it, m, d);
 	};
-	auto stage = [&](const cplx (&d)[PT]) {              // a fetched tile into `raw`
+	auto stage = [&](const cplx (&d)[PT], cplx *dst) {   // a fetched tile into a tile buffer
 #pragma unroll
-		for (int m = 0; m < PT; ++m) raw[lq * FZ_QS_RAW + (lj + P * m) * FZ_PITCH + lt] = d[m];
+		for (int m = 0; m < PT; ++m) dst[lq * FZ_QS + (lj + P * m) * FZ_PITCH + lt] = d[m];
 	};
 	// states of this thread's row: chunk (rr - HR) seg + sg of channels 4 grp + 2 rq, + 1
 	double2 m0[NSEC], m1[NSEC];
@@ -287,66 +293,64 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const long ring_e0 = p.win_base + (long) rr * N2 + col0;      // (win_base is a multiple of 8 here: a run of 8 never straddles the ring's end)
 	cplx nx[PT];
 	fetch(0, nx);
-	stage(nx);
+	stage(nx, buf0);
 	SecCoef cf = load_coef(sec, 0);
 	lds_barrier();                                   // twiddle table and tile 0 visible
 	const FzTw tw{ twt };
-	const FzMap1 map1{ q * FZ_XQS + t };
-	const FzMap2 map2{ q * FZ_XQS + t };
 	const long tw_row = (long) (j & 15) * p.N2;
+	// Per tile (three barriers): the thread's row through the sections, in place in `cur` | the column's points out of `cur`, the next
+	// tile's frames into the other buffer, pass 1 in place | pass 2 in place | pass 3, twiddle, stores.  What orders the rest: a wave
+	// stages into the other buffer only behind this tile's first barrier, which every wave reaches after its last look at that buffer
+	// (the previous tile's third pass); the staged frames are read behind this tile's second barrier at the earliest.
 	for (int it = 0; it < tiles; ++it) {
+		cplx *cur = buf0 + (it & 1) * 2 * FZ_QS, *nxt = buf0 + ((it + 1) & 1) * 2 * FZ_QS;
+		const FzMap1 map1{ q * FZ_QS + t };
+		const FzMap2 map2{ q * FZ_QS + t };
 		// the next tile's frames, asked for one row set per section of the recurrence (the last iteration re-reads its own tile: the loop
 		// body stays uniform), and this tile's inter-pass twiddles (two table entries)
 		const int nit = it + 1 < tiles ? it + 1 : it;
 		if constexpr (NSEC < PT) fetch(nit, nx);
 		const long col = col0 + (long) it * TW;
 		const cplx tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + col + t], tw_a = TAB(p.tw_col)[tw_row + col + t];
-		// this thread's row: 8 consecutive frames of its pair through the sections
+		// this thread's row: 8 consecutive frames of its pair through the sections, back into the same slots (history rows stay as staged)
 		{
 			cplx x[TW];
 #pragma unroll
-			for (int i = 0; i < TW; ++i) x[i] = raw[rq * FZ_QS_RAW + rr * FZ_PITCH + i];
-			{
-				if constexpr (DBG & 1) { if constexpr (NSEC >= PT) fetch(nit, nx); }
-				else run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, k, nx); } });
-				if (f.gain != 1.0) {
+			for (int i = 0; i < TW; ++i) x[i] = cur[rq * FZ_QS + rr * FZ_PITCH + i];
+			if constexpr (DBG & 1) { if constexpr (NSEC >= PT) fetch(nit, nx); }
+			else run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, k, nx); } });
+			if (f.gain != 1.0) {
 #pragma unroll
-					for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
-				}
+				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
 			}
-			if (!rec) {                                  // history rows pass through unchanged (the first 16 or 32 lanes of the first wave of either pair)
+			if (rec) {                                   // (divergent in the first wave of either pair only)
 #pragma unroll
-				for (int i = 0; i < TW; ++i) x[i] = raw[rq * FZ_QS_RAW + rr * FZ_PITCH + i];
+				for (int i = 0; i < TW; ++i) cur[rq * FZ_QS + rr * FZ_PITCH + i] = x[i];
 			}
-			// the cascade's output into the second buffer; the rows the next window looks back at also go to the rings
-#pragma unroll
-			for (int i = 0; i < TW; ++i) yb[rq * FZ_QS_Y + rr * FZ_PITCH + i] = x[i];
-			if (keeps) {
+			if (keeps) {                                 // the rows the next window looks back at also go to the rings
 				double2 *w0 = ringw + ((ring_e0 + (long) it * TW) & p.ring_mask);
 #pragma unroll
 				for (int i = 0; i < TW; ++i) w0[i] = x[i];
 			}
 		}
-		lds_barrier();                                   // output visible; every row of `raw` has been read
+		lds_barrier();                                   // the cascade's output visible
 		cplx v[PT];
 #pragma unroll
-		for (int m = 0; m < PT; ++m) v[m] = yb[q * FZ_QS_Y + (j + P * m) * FZ_PITCH + t];
-		stage(nx);                                       // the next tile's frames into `raw`
-		lds_barrier();                                   // every thread has its points: `yb` becomes the exchange buffer
+		for (int m = 0; m < PT; ++m) v[m] = cur[q * FZ_QS + (j + P * m) * FZ_PITCH + t];
+		stage(nx, nxt);                                  // the next tile's frames into the other buffer
 		if constexpr (!(DBG & 2)) {
-		fz_pass<PT, 8, 8, 1, false>(v, j, yb, map1, tw);
+		fz_pass<PT, 8, 8, 1, false>(v, j, cur, map1, tw);    // (in place: a thread's outputs go where its inputs came from)
 		lds_barrier();
-		gather_n<PT>(v, j, yb, map1);
-		fz_pass<PT, 8, 8, 8, false>(v, j, yb, map2, tw);     // (in place: no barrier between these reads and writes)
+		gather_n<PT>(v, j, cur, map1);
+		fz_pass<PT, 8, 8, 8, false>(v, j, cur, map2, tw);
 		lds_barrier();
-		gather_n<PT>(v, j, yb, map2);
-		fz_pass<PT, 8, 4, 64, true>(v, j, yb, map2, tw);
+		gather_n<PT>(v, j, cur, map2);
+		fz_pass<PT, 8, 4, 64, true>(v, j, cur, map2, tw);
 		}
 		if constexpr (!(DBG & 16)) fz_twiddle(tw_s, tw_a, j, v);
 		const int wo = vw + (int) (col * (long) sizeof(cplx));
 #pragma unroll
 		for (int m = 0; m < PT; ++m) { if constexpr (DBG & 4) { if (v[m].x == 1.2345e-300) buf_stc<2>(v[m], rw, wo + m * w_step); } else buf_stc<2>(v[m], rw, wo + m * w_step); }
-		lds_barrier();                                   // the exchange reads are done before the next output is written; `raw` visible
 	}
 }
 
