@@ -80,8 +80,11 @@ __device__ __forceinline__ void run_sections(cplx (&x)[NF], double2 (&m0)[NSEC],
 // ---- pass 0: the end state of every chunk run from zero state.  grid (ceil(K pps / 256), S): thread = (chunk c, pair q) of
 // stream blockIdx.y, pair-fastest so that the lanes of one chunk read whole frames; every thread walks its len frames, 16 at a
 // time, the next 16 already on their way.
+#ifndef FZ_PRE_WAVES
+#define FZ_PRE_WAVES 2
+#endif
 template <int NSEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FZ_PRE_WAVES, FZ_PRE_WAVES)))
 void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pps)
 {
 	const long id = (long) blockIdx.x * 256 + threadIdx.x;
@@ -98,7 +101,11 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 	double2 m0[NSEC], m1[NSEC];
 #pragma unroll
 	for (int k = 0; k < NSEC; ++k) { m0[k] = make_double2(0.0, 0.0); m1[k] = make_double2(0.0, 0.0); }
+#ifdef FZ_PRE_NF
+	constexpr int NF = FZ_PRE_NF;
+#else
 	constexpr int NF = (NSEC > 10) ? 8 : 16;           // frames per step (twelve sections with 16: spills)
+#endif
 	cplx x[NF], nx[NF];
 #pragma unroll
 	for (int i = 0; i < NF; ++i) nx[i] = buf_ldc(rs, vo, i * fb);

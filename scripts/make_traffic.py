@@ -36,14 +36,21 @@ spec = {   # bench name -> (rocprof substring, fetch factor, designed bytes)
     "cascade_fast": ("cascade_fast", 1.0, samples * 16),
     "cascade_wave": ("cascade_wave", 1.0, samples * 16),
     "conv_col_fwd": ("conv_col_fwd", fetch_factor, pairs * N * 32),
+    # round 4, the cascade fused into the first pass: the prepass reads the call's frames once (its end states are a few MB); the fused
+    # first pass reads them again plus the history rows from the rings, writes W and the next window's history rows
+    "fused_prepass": ("fused_prepass", fetch_factor, samples * 8),
+    "fused_col_fwd": ("fused_col_fwd", fetch_factor, samples * 8 + pairs * (N - B) * 16 * 2 + pairs * N * 16),
+    "cascade_chunk_carry": ("cascade_chunk_carry", 1.0, 0),
     "conv_row": ("conv_row_duo" if find("conv_row_duo")[0] else "conv_row_pipe", fetch_factor, pairs * N * 32),        # (16 B/lane buffer loads / LDS-DMA: same under-count, MI355X_MICROARCH.md)
     "conv_col_inv": ("conv_col_inv", fetch_factor, pairs * N * 16 + samples * 8),
 }
+fused = find("fused_col_fwd")[0] is not None
 for name, (sub, ff, designed) in spec.items():
+    if fused and name in ("cascade_rows", "cascade_fast", "cascade_wave", "conv_col_fwd"): continue   # (the drain's and the filter preparation's launches, not the step's)
     k, v = find(sub)
     if not v or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v: continue
     dil = 1.0
-    if name == "conv_col_fwd":
+    if name == "conv_col_fwd" and not find("fused_col_fwd")[0]:
         n = v["FETCH_SIZE"]["launches"]
         dil = n / (n - 1.0) if n > 1 else 1.0
     fr = v["FETCH_SIZE"]["per_launch_raw"] * 1024 * dil
