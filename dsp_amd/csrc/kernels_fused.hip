@@ -251,7 +251,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const int fb = f.C * (int) sizeof(double);
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(f.in) + (size_t) s * f.in_stride_frames * f.C, 0, 0x7fffffff, 0x00020000);
 	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) sizeof(double));
-	const int vs0 = vs - (int) (HR * N2 * fb);       // row lj itself (only looked at when lj >= HR)
+	const int vs0 = vs - (int) (HR * N2 * fb);       // row lj itself (HR = 16 only, looked at when lj >= HR)
 	const bool hist_row = lj < HR;                   // wave-uniform: row lj (m = 0) is history: the pair rings
 	// W of the group's two pairs through one descriptor
 	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
@@ -262,12 +262,10 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	auto fetch1 = [&](int it, int m, cplx (&d)[PT]) {    // (m is a compile-time constant at every call)
 		const long col = col0 + (long) it * TW;
 		const int so = (int) (col * fb);
-		if (m == 0) {
-			if (hist_row) d[0] = ringl[(p.win_base + (long) lj * N2 + col + lt) & p.ring_mask];
-			else if constexpr (DBG & 8) d[0] = mkc((double) so, 1.0);
-			else d[0] = buf_ldc(rs, vs0, so);
-		}
+		const bool from_ring = (32 * m + 32 <= HR) || (32 * m < HR && hist_row);       // rows lj + 32 m below HR: history
+		if (from_ring) d[m] = ringl[(p.win_base + (long) (lj + 32 * m) * N2 + col + lt) & p.ring_mask];
 		else if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
+		else if (32 * m < HR) d[m] = buf_ldc(rs, vs0, so);                             // (HR = 16: the rows 16 .. 31 of m = 0)
 		else d[m] = buf_ldc(rs, vs, so + (int) ((32 * m - HR) * N2 * fb));
 	};
 	auto fetch = [&](int it, cplx (&d)[PT]) {

@@ -94,6 +94,10 @@ def test_chains_the_fused_kernels_leave_alone(amd, tmp_path):
     """per-channel sections, an `add` among the ops, a selector, a latency: the plan keeps the separate kernels"""
     f = os.path.join(str(tmp_path), "h.raw")
     np.asarray(make_filter(16384), dtype="<f8").tofile(f)
+    g = os.path.join(str(tmp_path), "h64.raw")
+    np.asarray(make_filter(65536), dtype="<f8").tofile(g)
+    b = build(amd, f"lowpass 1k 0.707 fir_p -t pcm -e double -c 1 {g}", 8, 4, 196608, True)      # 64 of the 256 rows are history: the separate kernels are faster
+    assert "cascade-fused" not in b.plan(), b.plan()
     for chain in (f"lowpass 1k 0.707 :0 eq 400 2.0 1.5 : fir_p -t pcm -e double -c 1 {f}",
                   f"lowpass 1k 0.707 add 0.001 fir_p -t pcm -e double -c 1 {f}",
                   f"gain -3 fir_p -t pcm -e double -c 1 {f}",
