@@ -5,22 +5,37 @@
 // trip of the samples through HBM instead of two (cascade_rows writing the pair rings + conv_col_fwd reading them back).
 //
 // The four-step transform's first pass is the STRIDED one (the column of a window holds samples N2 frames apart), and a
-// recurrence wants consecutive frames.  Both are served by giving a thread a whole ROW of the window: thread r of a workgroup
-// owns the N2 consecutive frames of row r and walks along them 16 at a time, its section states in registers; the 256 rows of
-// a tile of 16 columns are then exactly 16 complete columns, transformed on the spot (the two radix-16 passes of conv_col_fwd).
-// Rows are 4096 frames apart in time, so the state a row starts from is not known to the kernel that walks all rows at once:
+// recurrence wants consecutive frames.  Both are served by giving a thread a whole ROW of the window: a recurrence thread owns the
+// N2 consecutive frames of one row of one channel pair and walks along them 8 at a time, its section states in registers; the 256
+// rows of a tile of 8 columns are then exactly 8 complete columns per pair, transformed on the spot.
+// Rows are N2 frames apart in time, so the state a row starts from is not known to the kernel that walks all rows at once:
 // a first kernel (fused_prepass) runs every row from ZERO state and keeps only the END state, cascade_chunk_carry
 // (kernels_chunk.hip: x' = M x + e over the rows, M = A^N2 from the host in extended precision) turns those into the true state at
 // every row start, and fused_col_fwd runs the recurrence again from those states -- the reference's own recurrence, sample by
 // sample, no correction terms.  The recurrence costs its 5 fp64 operations per sample and section twice (cascade_rows spends
 // 12 once: zero-state pass, row scan, zero-input correction) and the input is read twice; the cascade's output never goes to
 // HBM except for the last `first_n` frames of the call, which are the next window's history (the pair rings, as before).
+// HBM bytes per input sample of a step: 8 (prepass) + 8 + 8.5 N / hop (first pass) against 16 + 16 N / hop for the separate kernels.
 //
-// Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 256 threads = one wave per SIMD with the
-// whole register file (state 4 channels x NSEC x 2, two register sets of 2 x 16 complex points: about 420 of the 512);
-// LDS = [2 pairs][256 rows][16 columns] complex, pitch 17 (a thread's own row: conflict-free both ways), reused as the
-// exchange buffer of the column transform.  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD, same L2):
-// each owns 32 of the 64 bytes of every frame.
+// What it took to make fused_col_fwd faster than the two kernels it replaces (256 x 8 ch, ten sections, 983040-frame steps; cascade_rows
+// + conv_col_fwd: 8.6 + 5.85 = 14.45 ms; fused_prepass + scan: 4.0 + 0.23):
+//   10.65 ms  256 threads, a thread = a row of BOTH pairs (160 state registers, one wave per SIMD with the whole register file, 16-column
+//             tiles needed 130 spilled registers, 8-column tiles none): 47 % VALU-busy, 37 % of the cycles in issue stalls nobody fills
+//    8.95     512 threads, a thread = a row of ONE pair (80 state registers, two waves per SIMD), 8 points per thread through radix 8 / 8 / 4
+//             passes; the section loop pinned sample by sample (the scheduler's own order kept 8 more registers per section alive twice
+//             over -- the input-only products of a whole section first, the new states computed in the loop latch -- : 46 spills at ten
+//             sections, none after)
+//    8.5      the two pairs of a frame in adjacent lanes of the loads; section coefficients asked for a section ahead (scalar loads)
+//    8.5      passes in place in the tile buffer, two buffers swapping roles: three barriers per tile instead of five (no change: the
+//             kernel does not wait at barriers)
+// What is left, by counter and by experiment (profiles/r04a_fzctr*_sq_counters.json, scripts/exp_fused.py dbg): without its loads and
+// stores the kernel takes 6.8 ms (60 % VALU-busy: recurrence 2.9 ms of issue, transform 1.2, LDS traffic + barriers 2.0); the memory
+// instructions add 1.7 ms whether their data comes from HBM or from the caches, whether they are issued in one burst or one per section,
+// one tile ahead or two -- it is the CU's own load / store path, not bandwidth (33 GB in 8.5 ms) and not latency.
+//
+// Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
+// LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
+// same L2): each owns 32 of the 64 bytes of every frame (PMC: the slab is fetched once, profiles/r04a_traffic.json).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstdint>
@@ -133,17 +148,12 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 }
 
 // ---- pass 1: K1 with the cascade in front of its column transforms (see the head of the file).
-// grid: S x groups x seg workgroups in the order of fz_block (the groups of a stream on one XCD), 512 threads = 8 waves, two per SIMD
-// (a first version with 256 threads -- a thread's row of BOTH pairs, 160 state registers, one wave per SIMD with the whole
-// register file -- spent 37 % of its cycles in issue stalls with nothing to fill them: 10.0 ms where this one ...).
+// grid: S x groups x seg workgroups in the order of fz_block (the groups of a stream on one XCD), 512 threads = 8 waves, two per SIMD.
 // HR = the window rows that are history (the pair rings: 16 or 32), the others are new frames (the slab).
 // A tile = 8 columns of the group's two pairs.  Thread roles:
+//   loading      (pair lq, column lt, lj): the rows lj + 32 m of a column, the two pairs of a frame (32 contiguous bytes) in adjacent lanes
 //   recurrence   (pair rq, row rr): 8 consecutive frames of its row through the sections, states in registers (80)
-//   transform    (pair q, column t, j): the 8 points n1 = j + 32 m of a column -- three passes of radix 8, 8, 4
-// Two LDS buffers [2 pairs][256 rows] of pitch 9: `raw` holds the frames of the tile as loaded (written in the transform layout,
-// read by rows), `yb` the cascade's output (written by rows, read in the transform layout) and then both exchanges of the
-// transform (the second one in place: a thread's outputs go to the slots it has just read, FzMap2); the next tile's frames are
-// loaded into registers under this tile's transform and the next one's recurrence.
+//   transform    (pair q, column t, j): the 8 points n1 = j + 32 m of a column -- three passes of radix 8, 8, 4, in place in the tile buffer
 constexpr int FZ_TW = 8, FZ_PITCH = 9, FZ_PT = 8, FZ_P = 256 / FZ_PT;
 // one pair's rows in a buffer; = 8 mod 16: the 16 lanes of a read group of the two exchanges (two pairs x two rows 32 apart) land in 16 different
 // bank quads (the same group reading the cascade's output -- rows one apart -- collides in 7 of them, the staging writes two ways: the cheaper side)
