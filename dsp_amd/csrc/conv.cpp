@@ -509,7 +509,15 @@ bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStrea
 	f.K = K; f.len = len;
 	f.cstate = plan->cstate.as<double>(); f.X = plan->X.as<double>();
 	f.n_streams = S;
-	{ ProfScope ps("fused_prepass", st); if (!launch_fused_prepass(f, ft.sec.as<double>(), N2, pps, st)) return false; }
+	{
+		// the chunks' end states from zero state: as a product on the matrix cores where the shape allows (8 channels), else by the recurrence
+		const char *me = getenv("DSP_AMD_FUSE_MM");
+		ProfScope ps("fused_prepass", st);
+		if ((me && atoi(me) == 0) || !feeder_->fuse_gtable(*plan) || !launch_fused_prepass_mm(f, plan->G.as<double>(), N2, plan->g_states, st)) {
+			if (!launch_fused_prepass(f, ft.sec.as<double>(), N2, pps, st)) return false;
+		}
+		else ps.rename("fused_prepass_mm");
+	}
 	ChunkParams cp;
 	memset(&cp, 0, sizeof(cp));
 	cp.len = len; cp.C = ch_in; cp.K = (int) K; cp.D = 2 * feeder_->n_ops; cp.n_pow = plan->n_pow; cp.n_cls = plan->n_cls;

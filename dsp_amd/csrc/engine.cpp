@@ -569,6 +569,37 @@ const CascadeStage::FuseTables &CascadeStage::fuse_tables()
 	return ft;
 }
 
+// Gt[t][d], d = 2 kk + b over the chain's sections kk (channel 0: the fused path is for chains whose channels agree): the state (m0, m1)[b]
+// of section kk that a unit sample at frame t of a zero-state chunk of plan.len frames leaves behind at the chunk's end -- the sections
+// themselves run on an impulse in extended precision, read backwards
+bool CascadeStage::fuse_gtable(ChunkPlan &plan)
+{
+	if (plan.G.p) return plan.g_states > 0;
+	std::vector<int> secs;
+	for (int j = 0; j < n_ops; ++j) if (host_ops[j].kind == OP_BIQUAD) secs.push_back(j);
+	if (secs.empty() || secs.size() > 16) return false;
+	const long len = plan.len;
+	std::vector<double> G((size_t) len * 32, 0.0);
+	std::vector<long double> st((size_t) 2 * n_ops, 0.0L);
+	for (long n = 0; n < len; ++n) {
+		long double v = (n == 0) ? 1.0L : 0.0L;
+		for (int j = 0; j < n_ops; ++j) {
+			const OpDesc &od = host_ops[j];
+			if (od.kind == OP_MUL) { v *= (long double) od.g; continue; }
+			if (od.kind != OP_BIQUAD) continue;
+			const long double y = (long double) od.c[0] * v + st[2 * j];                                  // biquad.h:76-92
+			st[2 * j] = (long double) od.c[1] * v - (long double) od.c[3] * y + st[2 * j + 1];
+			st[2 * j + 1] = (long double) od.c[2] * v - (long double) od.c[4] * y;
+			v = y;
+		}
+		double *row = &G[(size_t) (len - 1 - n) * 32];
+		for (size_t kk = 0; kk < secs.size(); ++kk) { row[2 * kk] = (double) st[2 * secs[kk]]; row[2 * kk + 1] = (double) st[2 * secs[kk] + 1]; }
+	}
+	if (!plan.G.upload(G.data(), G.size() * sizeof(double))) return false;
+	plan.g_states = (int) (2 * secs.size());
+	return true;
+}
+
 ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
 {
 	CascadeParams p = params(in, in_stride, frames, out, out_stride);

@@ -139,6 +139,7 @@ struct FuseParams {
 constexpr int FUSE_MAX_SEC = 12;
 // sec: [n_sec][6] device table c0 c1 c2 c3 c4 pad (read with scalar loads); false: no instance for this section count
 bool launch_fused_prepass(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st);
+bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int n_state, hipStream_t st);   // false: shape not served, take the other one
 int fused_section_slots(int n_sec);   // section count of the instance that takes n_sec sections (the host pads with pass-through sections), 0 = none
 bool launch_fused_col_fwd(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st);
 

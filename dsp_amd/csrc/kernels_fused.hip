@@ -147,6 +147,90 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 	}
 }
 
+// ---- pass 0 on the matrix cores.  The end state of a chunk run from zero state is LINEAR in its samples: e = sum_t A^(len-1-t) B x[t]
+// with (A, B) the state-space form of the whole cascade -- a product E[state][column] = G[state][t] X[t][column] over the chunk's frames
+// with the same G for every (chunk, channel) column: 2 n_sec multiply-adds per sample (padded to 32 rows) where the recurrence
+// itself costs 5 n_sec instructions.  G (host, extended precision: CascadeStage::fuse_gtable) is the state the cascade is left in
+// len - 1 - t samples after a unit impulse.  v_mfma_f64_16x16x4_f64: A = G^T rows from L2 ([t][32], 1 MB, the same for every wave),
+// B = four consecutive frames of 16 columns = (4 chunks) x (4 channel pairs), a lane's 16-byte load feeding two products (the pair's
+// two channels); a wave owns 8 chunks (two such column groups) of one stream: the fragments of G are used four times.
+// 8 channels per stream only (the launcher checks); anything else takes the recurrence above.
+typedef double fz_v4d __attribute__((ext_vector_type(4)));
+
+template <int DT>            // 16-row tiles of states: 1 (up to 8 sections) or 2
+__global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const double *__restrict__ Gt, long N2, int n_state)
+{
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const long s = blockIdx.y;
+	const long c0 = ((long) blockIdx.x * 4 + w) * 8;          // this wave's first chunk
+	if (c0 >= f.K) return;
+	const int k = lane >> 4, jc = lane & 15, cp = jc & 3;
+	const double2 *xb[2];
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		const long c = c0 + 4 * g + (jc >> 2);
+		const long row = c / f.seg, frame0 = row * N2 + (c - row * f.seg) * f.len;
+		xb[g] = reinterpret_cast<const double2 *>(f.in + ((size_t) s * f.in_stride_frames + frame0 + k) * 8 + 2 * cp);
+	}
+	const double *ga = Gt + (size_t) k * 32 + jc;
+	fz_v4d acc[2][2][DT];
+#pragma unroll
+	for (int g = 0; g < 2; ++g)
+#pragma unroll
+		for (int eo = 0; eo < 2; ++eo)
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) acc[g][eo][dt] = (fz_v4d) { 0.0, 0.0, 0.0, 0.0 };
+	double2 x0[2], x1[2];
+	double a0[DT], a1[DT];
+#pragma unroll
+	for (int g = 0; g < 2; ++g) x0[g] = xb[g][0];
+#pragma unroll
+	for (int dt = 0; dt < DT; ++dt) a0[dt] = ga[16 * dt];
+	// two steps of four frames per iteration, the next step's fragments asked for before this step's products (len is a multiple of 8)
+	for (long t0 = 0; t0 < f.len; t0 += 8) {
+#pragma unroll
+		for (int g = 0; g < 2; ++g) x1[g] = xb[g][(t0 + 4) * 4];                      // (a frame = 4 elements of 16 bytes)
+#pragma unroll
+		for (int dt = 0; dt < DT; ++dt) a1[dt] = ga[(size_t) (t0 + 4) * 32 + 16 * dt];
+#pragma unroll
+		for (int g = 0; g < 2; ++g)
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) {
+				acc[g][0][dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[dt], x0[g].x, acc[g][0][dt], 0, 0, 0);
+				acc[g][1][dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[dt], x0[g].y, acc[g][1][dt], 0, 0, 0);
+			}
+		const long tn = (t0 + 8 < f.len) ? t0 + 8 : t0;                               // (the last iteration re-reads: the body stays uniform)
+#pragma unroll
+		for (int g = 0; g < 2; ++g) x0[g] = xb[g][tn * 4];
+#pragma unroll
+		for (int dt = 0; dt < DT; ++dt) a0[dt] = ga[(size_t) tn * 32 + 16 * dt];
+#pragma unroll
+		for (int g = 0; g < 2; ++g)
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt) {
+				acc[g][0][dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[dt], x1[g].x, acc[g][0][dt], 0, 0, 0);
+				acc[g][1][dt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[dt], x1[g].y, acc[g][1][dt], 0, 0, 0);
+			}
+	}
+	// results: row (state) = (lane >> 4) + 4 reg + 16 dt, column = lane & 15 = (chunk, channel pair); state 2 kk + b -> (m0, m1)[b] of section kk
+	const int D = 2 * f.n_ops;
+#pragma unroll
+	for (int g = 0; g < 2; ++g) {
+		const long c = c0 + 4 * g + (jc >> 2);
+#pragma unroll
+		for (int eo = 0; eo < 2; ++eo) {
+			double *dst = f.cstate + (((size_t) s * f.K + c) * f.C + 2 * cp + eo) * D;
+#pragma unroll
+			for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const int d = k + 4 * r + 16 * dt;
+					if (d < n_state) dst[2 * f.sec_op[d >> 1] + (d & 1)] = acc[g][eo][dt][r];
+				}
+		}
+	}
+}
+
 // ---- pass 1: K1 with the cascade in front of its column transforms (see the head of the file).
 // grid: S x groups x seg workgroups in the order of fz_block (the groups of a stream on one XCD), 512 threads = 8 waves, two per SIMD.
 // HR = the window rows that are history (the pair rings: 16 or 32), the others are new frames (the slab).
@@ -392,6 +476,16 @@ template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FusePar
 }
 
 }  // namespace pfz
+
+// the matrix-core form of the prepass: 8 channels per stream, chunks in groups of 8, at most 16 sections' states; Gt: [len][32] (fuse_gtable)
+bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int n_state, hipStream_t st)
+{
+	if (f.C != 8 || (f.K % 8) != 0 || (f.len % 8) != 0 || n_state < 1 || n_state > 32) return false;
+	const dim3 grid((unsigned) ((f.K / 8 + 3) / 4), (unsigned) f.n_streams);
+	if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+	else hipLaunchKernelGGL((pfz::fused_prepass_mm<2>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+	return true;
+}
 
 // section counts with an instance (a chain with another count is padded with pass-through sections by the host: fuse_sections)
 int fused_section_slots(int n_sec)

@@ -37,6 +37,7 @@ public:
 	// as cascade_rows has them), padded with pass-through sections to a count the fused kernels are instantiated for
 	struct FuseTables { bool tried = false, ok = false; int n_sec = 0; double gain = 1.0; DevBuf sec, sec_op; };
 	const FuseTables &fuse_tables();
+
 	friend class ConvStage;
 private:
 	FuseTables fuse_tab;
@@ -52,6 +53,7 @@ private:
 	// only to rounding, ~1e-15).  Plans (tables + buffers, about a millisecond each) are kept for the last few call sizes.
 	struct ChunkPlan {
 		long frames = 0, len = 0; int K = 0, n_pow = 0, n_cls = 0; DevBuf cls, H, Mp, cstate, X;
+		DevBuf G; int g_states = 0;                            // fused path: [len][32] input-to-end-state table of the matrix-core prepass (fuse_gtable)
 		hipEvent_t done = nullptr;                             // recorded behind the plan's last launches
 		~ChunkPlan();
 	};
@@ -61,6 +63,7 @@ private:
 	CascadeParams params(const double *in, long in_stride, ssize_t frames, double *out, long out_stride) const;
 	bool wire_ok(int in_fmt, bool sink_on, int out_fmt, const void *in, long in_stride, const void *out, long out_stride, ssize_t frames) const;
 	ChunkPlan *chunk_plan_for(long frames, int K, long len);
+	bool fuse_gtable(ChunkPlan &plan);   // the plan's G table (matrix-core prepass of the fused path), made on first use; false: not available (more than 16 sections)
 	bool build_chunk_plan(ChunkPlan &chunk, long frames, int K, long len);
 };
 
