@@ -32,6 +32,9 @@
 // stores the kernel takes 6.8 ms (60 % VALU-busy: recurrence 2.9 ms of issue, transform 1.2, LDS traffic + barriers 2.0); the memory
 // instructions add 1.7 ms whether their data comes from HBM or from the caches, whether they are issued in one burst or one per section,
 // one tile ahead or two -- it is the CU's own load / store path, not bandwidth (33 GB in 8.5 ms) and not latency.
+// Tried and dropped (round 4): the workgroup as two halves that run on their own, one per pair, with counters in LDS for barriers (gfx950 has one
+// barrier per workgroup), so that one pair's transform would meet the other's recurrence on every SIMD -- each half must then load its own pair,
+// 16 of a frame's 64 bytes per lane, and that alone took the kernel from 8.4 to 10.4 ms (with real barriers; 11.4 with the polled ones).
 //
 // Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
 // LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
