@@ -335,6 +335,15 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	// (first_n) and the hop are multiples of 8: K3's runs of 8 frames then start on 512-byte boundaries of the slab.
 	first_n = (T - 1 + 7) & ~7L;
 	B = (N - first_n) & ~7L;
+	// behind a cascade, with 256-row windows: when the calls are exactly what is left of the window after 16 (or 32) WHOLE rows of history, take
+	// that much history -- more of it than overlap-save needs costs nothing (the hop is the call either way), and the cascade can then be fused
+	// into the first pass (below): a 50000-tap filter on 983040-frame calls is served like the 65536-tap one
+	if (feeder && !ring_parent && !upc_block && !force_N && log2N1 == 8 && sp.kind != Kind::Resample && lat == 0) {
+		for (long rows : { 16L, 32L }) {
+			const long fn = rows * N2;
+			if (fn >= first_n && N - fn == (long) max_frames) { first_n = fn; B = N - fn; break; }
+		}
+	}
 	ring_len = next_pow2(first_n + lat + std::max<long>(max_frames, B));
 	log2_lo = (ilog2(N) + 1) / 2;
 

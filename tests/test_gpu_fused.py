@@ -45,6 +45,8 @@ SHAPES = [
     (5, False, 16384, 245760, 56, 8, "480 chunks of 512"),      # padded to six, two segments
     (7, False, 32768, 229376, 112, 4, "448 chunks of 512"),     # padded to eight; two channel pairs per stream
     (12, False, 16384, 245760, 120, 8, "240 chunks of 1024"),   # twelve sections, whole rows
+    (4, False, 11111, 245760, 8, 8, "960 chunks of 256"),       # a filter shorter than 16 rows: the window takes 16 whole rows of history all the same
+    (2, False, 20000, 229376, 4, 4, "896 chunks of 256"),       # ... 32 rows
 ]
 
 
