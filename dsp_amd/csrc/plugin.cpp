@@ -110,9 +110,11 @@ void Segment::before_copy(const void *p, size_t n)
 
 bool Segment::pinned(int which, const void *p, size_t n)
 {
-	// opt-in (DSP_AMD_PLUGIN_PIN=1): registering takes milliseconds once -- not something to spring on a real-time host --
-	// and buys 10 % at the reference's 2048-frame blocks (scripts/exp_cli_rate.sh), where the host's own I/O dominates
-	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return e && atoi(e) != 0; }();
+	// on by default since round 4 (DSP_AMD_PLUGIN_PIN=0: off).  Registering takes milliseconds once -- only blocks that do not fit the
+	// mapped staging buffers get here, i.e. not the 64 ... 1024-frame blocks of a real-time host -- and turns the two copies of a block
+	// into DMA: 10 % at the reference's 2048-frame blocks (scripts/exp_cli_rate.sh, where the host's own I/O dominates), 3x on
+	// buffers of several chunks (dspamd_chain_run-sized blocks: one thread's memcpy into staging was the limit there)
+	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return !e || atoi(e) != 0; }();
 	if (!enabled || pin_off || !p || n == 0) return false;
 	char *lo = page_lo(p), *hi = page_hi(p, n);
 	for (const Pin &r : pins) if (lo >= r.base && hi <= r.base + r.bytes) return true;
@@ -161,6 +163,16 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	// for once; with registered host buffers the copies are asynchronous DMA, with pageable ones they simply block
 	const size_t in_bytes = (size_t) total * sg.ch_in * sizeof(double);
 	const size_t out_bytes = (size_t) sg.pipe->max_out_frames(total) * sg.ch_out * sizeof(double);
+	// The small-block rule (stated, not worked around: this library has no host path): a block costs a launch round trip of 23 ... 27 us whatever
+	// its size, which the reference's own loop undercuts below about 20000 channel-sample-sections per block (64 frames
+	// x 2 ch x 10 biquads: 3 us there).  A segment that keeps being driven below that says so once, at verbose level.
+	++sg.calls;
+	if ((double) total * sg.ch_in * std::max<size_t>(1, sg.members.size()) < 20000.0) ++sg.small_calls;
+	if (!sg.advised && sg.calls == 64 && sg.small_calls > 48) {
+		sg.advised = true;
+		log_msg(LL_VERBOSE, "%s: info: blocks of %zd frames x %d ch through %zu effects: below about 20000 channel-sample-effects per block a device round trip "
+		        "(about 25 us per block) is slower than the host's own loop; larger blocks (-b) or more channels per chain amortise it", e->name, total, sg.ch_in, sg.members.size());
+	}
 	if (total <= sg.pipe_frames && sg.mapped.fits(in_bytes, out_bytes)) {
 		// small block: the kernels work on the mapped staging buffers themselves
 		memcpy(sg.mapped.in, ibuf, in_bytes);
@@ -170,13 +182,15 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 		*frames = f < 0 ? 0 : f;
 		return dst;
 	}
-	{
-		// larger blocks: through this library's page-locked staging buffers (unless the host's own buffers are registered: opt-in below)
-		static const bool pin_user = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return e && atoi(e) != 0; }();
+	// larger blocks: the host's own buffers once they are registered for DMA (they are after coming back four times), until then -- and
+	// for buffers that never come back -- this library's page-locked staging buffers when the block is several pipeline calls long
+	const bool reg_in = sg.pinned(0, ibuf, in_bytes);
+	const bool reg_out = (dst == ibuf) ? reg_in : sg.pinned(1, dst, out_bytes);
+	if (!(reg_in && reg_out)) {
 		const ssize_t chunk = sg.pipe_frames;
 		// (one chunk alone gains nothing: the thread's two copies simply add to the call -- 1.45 against 1.24 ms at 4 MB -- so those keep the
 		// copy commands; from two chunks on the copies hide behind the GPU's work: 8 ch x 2^20 frames 168 -> 469 Msamples/s)
-		if (!pin_user && total > chunk && sg.staged.ensure((size_t) std::min(total, chunk) * sg.ch_in * sizeof(double), (size_t) sg.pipe->max_out_frames(std::min(total, chunk)) * sg.ch_out * sizeof(double))) {
+		if (total > chunk && sg.staged.ensure((size_t) std::min(total, chunk) * sg.ch_in * sizeof(double), (size_t) sg.pipe->max_out_frames(std::min(total, chunk)) * sg.ch_out * sizeof(double))) {
 			// (dst may be ibuf: every chunk's input has been copied to the staging buffer before its output comes back, and a chain that
 			// works in place does not make more frames than it takes)
 			const ssize_t f = sg.staged.run(ibuf, total, chunk, sg.ch_in, dst, (ssize_t) 1 << 40, sg.ch_out, sg.d_in.p, sg.d_out.p, nullptr,
@@ -185,8 +199,6 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 			return dst;
 		}
 	}
-	(void) sg.pinned(0, ibuf, in_bytes);
-	if (dst != ibuf) (void) sg.pinned(1, dst, out_bytes);
 	sg.before_copy(ibuf, in_bytes);
 	sg.before_copy(dst, out_bytes);
 	while (done < total) {

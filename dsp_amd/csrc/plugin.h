@@ -30,6 +30,8 @@ struct Segment {
 	const void *last_ptr[2] = { nullptr, nullptr };
 	int seen[2] = { 0, 0 };
 	bool pin_off = false;
+	long calls = 0, small_calls = 0;         // run() calls so far / of those, blocks that a host loop would have finished sooner (the advisory below)
+	bool advised = false;
 	bool pinned(int which, const void *p, size_t n);     // which: 0 = input, 1 = output buffer of run()
 	void before_copy(const void *p, size_t n);           // a range half inside a registration cannot be copied: drop all of them
 	void unpin_all();
