@@ -178,7 +178,7 @@ private:
 	// (K2, K3, the rings as state of truth, the cascade's carried state) is as on the separate path, which any other call takes.
 	bool fuse_static = false;            // the plan allows it (decided once, in init)
 	int fuse_seg = 1;
-	bool fuse_accepts(const double *in, long in_stride, ssize_t frames) const;
+	bool fuse_accepts(const void *in, long in_stride, ssize_t frames, int in_fmt) const;
 	bool run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st);
 };
 
@@ -487,17 +487,23 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 			while (fuse_seg < 4 && groups * fuse_seg < 224 && (N2 / 8) % (4 * fuse_seg) == 0 && scan_fits((N1 - hist_rows) * 2 * fuse_seg)) fuse_seg *= 2;
 			if (scan_fits((N1 - hist_rows) * fuse_seg)) {
 				fuse_static = true;
-				feeder_->fuse_probe = [this](const double *in, long in_stride, ssize_t frames) { return fuse_accepts(in, in_stride, frames); };
+				feeder_->fuse_probe = [this](const void *in, long in_stride, ssize_t frames, int in_fmt) { return fuse_accepts(in, in_stride, frames, in_fmt); };
 			}
 		}
 	}
 	return true;
 }
 
-bool ConvStage::fuse_accepts(const double *in, long in_stride, ssize_t frames) const
+bool ConvStage::fuse_accepts(const void *in, long in_stride, ssize_t frames, int in_fmt) const
 {
 	(void) in_stride;
-	return fuse_static && frames == B && skip_left == 0 && !feeds && (q_abs & 7) == 0 && ((((size_t) in) & 15) == 0) && wire_in_fmt == PCM_DOUBLE;
+	if (!(fuse_static && frames == B && skip_left == 0 && !feeds && (q_abs & 7) == 0)) return false;
+	if (in_fmt == PCM_DOUBLE) return (((size_t) in) & 15) == 0;
+	// a wire format (the cascade is the first stage of a pipeline run from format to format): read by the matrix-core prepass and by the first
+	// pass themselves -- 8 channels, naturally aligned pairs
+	const char *me = getenv("DSP_AMD_FUSE_MM");
+	if (me && atoi(me) == 0) return false;
+	return wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && (((size_t) in) & 7) == 0;
 }
 
 bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st)
@@ -510,7 +516,7 @@ bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStrea
 	if (!plan) return false;
 	FuseParams f;
 	memset(&f, 0, sizeof(f));
-	f.in = pd.in; f.in_stride_frames = pd.in_stride;
+	f.in = pd.in; f.in_stride_frames = pd.in_stride; f.in_fmt = pd.in_fmt;
 	f.C = ch_in; f.n_sec = ft.n_sec; f.n_ops = feeder_->n_ops;
 	f.sec_op = ft.sec_op.as<int>();
 	f.gain = ft.gain;
@@ -523,7 +529,7 @@ bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStrea
 		const char *me = getenv("DSP_AMD_FUSE_MM");
 		ProfScope ps("fused_prepass", st);
 		if ((me && atoi(me) == 0) || !feeder_->fuse_gtable(*plan) || !launch_fused_prepass_mm(f, plan->G.as<double>(), N2, plan->g_states, st)) {
-			if (!launch_fused_prepass(f, ft.sec.as<double>(), N2, pps, st)) return false;
+			if (f.in_fmt != PCM_DOUBLE || !launch_fused_prepass(f, ft.sec.as<double>(), N2, pps, st)) return false;       // (fuse_accepts lets a wire format through only where the matrix-core form serves it)
 		}
 		else ps.rename("fused_prepass_mm");
 	}

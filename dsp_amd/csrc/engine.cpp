@@ -529,6 +529,8 @@ bool CascadeStage::wire_ok(int in_fmt, bool sink_on, int out_fmt, const void *in
 
 bool CascadeStage::wire_in_ok(int fmt, const void *in, long in_stride, ssize_t frames, bool also_out, int out_fmt) const
 {
+	// (a call the fused first pass takes: its kernels read the format themselves -- what run() will decide by asking the same question)
+	if (wire_fusion_on() && !also_out && fuse_probe && ring.base && !write_interleaved && fuse_probe(in, in_stride, frames, fmt)) return true;
 	// (the destination of a first-but-not-last stage is one of the pipeline's own aligned buffers, or the ring)
 	return wire_ok(fmt, also_out, out_fmt, in, in_stride, nullptr, in_stride, frames);
 }
@@ -561,6 +563,7 @@ const CascadeStage::FuseTables &CascadeStage::fuse_tables()
 	}
 	const int slots = fused_section_slots((int) sec_op.size());
 	if (sec_op.empty() || !slots) return ft;
+	ft.n_real = (int) sec_op.size();
 	while ((int) sec_op.size() < slots) { sec.insert(sec.end(), { 1.0, 0.0, 0.0, 0.0, 0.0, 0.0 }); sec_op.push_back(-1); }   // pass-through
 	if (!ft.sec.upload(sec.data(), sec.size() * sizeof(double)) || !ft.sec_op.upload(sec_op.data(), sec_op.size() * sizeof(int))) return ft;
 	ft.n_sec = slots;
@@ -607,9 +610,9 @@ ssize_t CascadeStage::run(const double *in, long in_stride, ssize_t frames, doub
 	long len = 0;
 	const bool wire = wire_in_fmt != PCM_DOUBLE || wire_sink.on;
 	pending = Pending();
-	if (fuse_probe && !wire && ring.base && !write_interleaved && fuse_probe(in, in_stride, frames)) {
-		// the convolver behind takes the call whole (ConvStage::run_fused): nothing to launch here
-		pending.in = in; pending.in_stride = in_stride; pending.frames = frames;
+	if (fuse_probe && !wire_sink.on && ring.base && !write_interleaved && fuse_probe(in, in_stride, frames, wire_in_fmt)) {
+		// the convolver behind takes the call whole (ConvStage::run_fused; a wire format is read by its kernels' own loads): nothing to launch here
+		pending.in = in; pending.in_stride = in_stride; pending.frames = frames; pending.in_fmt = wire_in_fmt;
 		return frames;
 	}
 	if (!wire && !ring.base && write_interleaved && (S == 1 || (in_stride == frames && out_stride == frames)) && choose_chunks(frames, &K, &len)) {

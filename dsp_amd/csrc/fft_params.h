@@ -125,7 +125,9 @@ struct FirDirectParams {
 //                    the last hist_rows rows of cascade output go to the pair rings on the way (the next window's history)
 // so the ring round trip of the cascade's output (write + K1's read: a quarter of the step's HBM traffic) is gone.
 struct FuseParams {
-	const double *in;                   // [S][in_stride_frames][C] fp64 slab; frame 0 = window element first_n
+	const double *in;                   // [S][in_stride_frames][C] slab (fp64, or samples of in_fmt); frame 0 = window element first_n
+	int in_fmt;                         // PCM_DOUBLE, or the fusable wire format the slab holds (first stage of a pipeline run in wire formats: read_buf_<fmt>
+	                                    // in the loads of the matrix-core prepass and of the fused first pass)
 	long in_stride_frames;
 	int C, n_sec, n_ops;                // n_sec biquad sections (gains folded in), n_ops ops per channel in the state layout (D = 2 n_ops)
 	const int *sec_op;                  // [n_sec] op index whose (m0, m1) the section carries

@@ -160,7 +160,15 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 // 8 channels per stream only (the launcher checks); anything else takes the recurrence above.
 typedef double fz_v4d __attribute__((ext_vector_type(4)));
 
-template <int DT>            // 16-row tiles of states: 1 (up to 8 sections) or 2
+// one frame's channel pair (2 cp, 2 cp + 1) of a slab of samples of a wire format as fp64 (read_buf_<fmt>, pcm_device.h); bs = bytes per sample
+__device__ __forceinline__ double2 fz_wire_pair(const char *frame_pair, int bs, const WordFormat &wf)
+{
+	if (bs == 4) { const uint2 w = *reinterpret_cast<const uint2 *>(frame_pair); return make_double2(pcm_from_word(w.x, wf), pcm_from_word(w.y, wf)); }
+	const uint32_t w = *reinterpret_cast<const uint32_t *>(frame_pair);
+	return make_double2(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16));
+}
+
+template <int DT, bool WIRE = false>            // DT: 16-row tiles of states: 1 (up to 8 sections) or 2
 __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const double *__restrict__ Gt, long N2, int n_state)
 {
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -168,13 +176,21 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	const long c0 = ((long) blockIdx.x * 4 + w) * 8;          // this wave's first chunk
 	if (c0 >= f.K) return;
 	const int k = lane >> 4, jc = lane & 15, cp = jc & 3;
-	const double2 *xb[2];
+	// a lane's element of step t0: frame t0 + k of chunk (jc >> 2) of the column group, channel pair cp -- 16 bytes of an fp64 slab, 4 or 8 of a wire format
+	const int bs = !WIRE ? 8 : (f.in_fmt == PCM_S16) ? 2 : 4;
+	const WordFormat wf = word_format(f.in_fmt);
+	const char *xb[2];
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
 		const long c = c0 + 4 * g + (jc >> 2);
 		const long row = c / f.seg, frame0 = row * N2 + (c - row * f.seg) * f.len;
-		xb[g] = reinterpret_cast<const double2 *>(f.in + ((size_t) s * f.in_stride_frames + frame0 + k) * 8 + 2 * cp);
+		xb[g] = reinterpret_cast<const char *>(f.in) + (((size_t) s * f.in_stride_frames + frame0 + k) * 8 + 2 * cp) * bs;
 	}
+	const long fstep = 8L * bs;                                   // bytes per frame (8 channels)
+	auto xload = [&](int g, long t) -> double2 {
+		if constexpr (WIRE) return fz_wire_pair(xb[g] + t * fstep, bs, wf);
+		else return *reinterpret_cast<const double2 *>(xb[g] + t * fstep);
+	};
 	const double *ga = Gt + (size_t) k * 32 + jc;
 	fz_v4d acc[2][2][DT];
 #pragma unroll
@@ -186,13 +202,13 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	double2 x0[2], x1[2];
 	double a0[DT], a1[DT];
 #pragma unroll
-	for (int g = 0; g < 2; ++g) x0[g] = xb[g][0];
+	for (int g = 0; g < 2; ++g) x0[g] = xload(g, 0);
 #pragma unroll
 	for (int dt = 0; dt < DT; ++dt) a0[dt] = ga[16 * dt];
 	// two steps of four frames per iteration, the next step's fragments asked for before this step's products (len is a multiple of 8)
 	for (long t0 = 0; t0 < f.len; t0 += 8) {
 #pragma unroll
-		for (int g = 0; g < 2; ++g) x1[g] = xb[g][(t0 + 4) * 4];                      // (a frame = 4 elements of 16 bytes)
+		for (int g = 0; g < 2; ++g) x1[g] = xload(g, t0 + 4);
 #pragma unroll
 		for (int dt = 0; dt < DT; ++dt) a1[dt] = ga[(size_t) (t0 + 4) * 32 + 16 * dt];
 #pragma unroll
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 			}
 		const long tn = (t0 + 8 < f.len) ? t0 + 8 : t0;                               // (the last iteration re-reads: the body stays uniform)
 #pragma unroll
-		for (int g = 0; g < 2; ++g) x0[g] = xb[g][tn * 4];
+		for (int g = 0; g < 2; ++g) x0[g] = xload(g, tn);
 #pragma unroll
 		for (int dt = 0; dt < DT; ++dt) a0[dt] = ga[(size_t) tn * 32 + 16 * dt];
 #pragma unroll
@@ -322,7 +338,7 @@ __device__ __forceinline__ void fz_twiddle(cplx s16, cplx a, int j, cplx (&v)[FZ
 	v[4] = cmul(v[4], a4); v[5] = cmul(v[5], cmul(a4, s1)); v[6] = cmul(v[6], cmul(a4, s2)); v[7] = cmul(v[7], cmul(a4, s3));
 }
 
-template <int NSEC, int HR, int DBG = 0>
+template <int NSEC, int HR, int DBG = 0, bool WIRE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 {
@@ -345,10 +361,25 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const long col0 = (long) sg * tiles * TW;        // first column of this workgroup's segment
 	const long pair0 = (long) s * p.pairs_per_stream + 2 * grp;     // the group's first pair
 	// the slab through a buffer descriptor: element (row lj + 32 m >= HR, column lt) of pair lq at vs + (column + (32 m - HR) N2) frame bytes
-	const int fb = f.C * (int) sizeof(double);
-	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(f.in) + (size_t) s * f.in_stride_frames * f.C, 0, 0x7fffffff, 0x00020000);
-	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) sizeof(double));
+	// (WIRE: the slab holds samples of f.in_fmt -- s16 / s24 / s32 / float --, a pair of a frame is one 4- or 8-byte load, converted as it arrives)
+	const int bs = !WIRE ? (int) sizeof(double) : (f.in_fmt == PCM_S16) ? 2 : 4;
+	const WordFormat wf = word_format(f.in_fmt);
+	const int fb = f.C * bs;
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(f.in)) + (size_t) s * f.in_stride_frames * f.C * bs, 0, 0x7fffffff, 0x00020000);
+	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) bs);
 	const int vs0 = vs - (int) (HR * N2 * fb);       // row lj itself (HR = 16 only, looked at when lj >= HR)
+	auto slab_ld = [&](int vo, int so) -> cplx {
+		if constexpr (!WIRE) return buf_ldc(rs, vo, so);
+		else if (bs == 4) {
+			typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
+			const fz_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
+			return mkc(pcm_from_word(w.x, wf), pcm_from_word(w.y, wf));
+		}
+		else {
+			const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+			return mkc(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16));
+		}
+	};
 	const bool hist_row = lj < HR;                   // wave-uniform: row lj (m = 0) is history: the pair rings
 	// W of the group's two pairs through one descriptor
 	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
@@ -362,8 +393,8 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 		const bool from_ring = (32 * m + 32 <= HR) || (32 * m < HR && hist_row);       // rows lj + 32 m below HR: history
 		if (from_ring) d[m] = ringl[(p.win_base + (long) (lj + 32 * m) * N2 + col + lt) & p.ring_mask];
 		else if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
-		else if (32 * m < HR) d[m] = buf_ldc(rs, vs0, so);                             // (HR = 16: the rows 16 .. 31 of m = 0)
-		else d[m] = buf_ldc(rs, vs, so + (int) ((32 * m - HR) * N2 * fb));
+		else if (32 * m < HR) d[m] = slab_ld(vs0, so);                                 // (HR = 16: the rows 16 .. 31 of m = 0)
+		else d[m] = slab_ld(vs, so + (int) ((32 * m - HR) * N2 * fb));
 	};
 	auto fetch = [&](int it, cplx (&d)[PT]) {
 #pragma unroll
@@ -464,8 +495,15 @@ template <int NSEC> static void launch_pre(const FuseParams &f, const double *se
 
 template <int NSEC, int HR, int DBG = 0> static void launch_col(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
 {
-	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, DBG>), FZ_LDS);
 	const unsigned wgs = (unsigned) ((long) f.n_streams * (p.pairs_per_stream / 2) * f.seg);
+	if (f.in_fmt != PCM_DOUBLE) {
+		if constexpr (DBG == 0) {
+			grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 0, true>), FZ_LDS);
+			hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 0, true>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
+		}
+		return;
+	}
+	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, DBG>), FZ_LDS);
 	hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, DBG>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
 }
 
@@ -485,6 +523,12 @@ bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int
 {
 	if (f.C != 8 || (f.K % 8) != 0 || (f.len % 8) != 0 || n_state < 1 || n_state > 32) return false;
 	const dim3 grid((unsigned) ((f.K / 8 + 3) / 4), (unsigned) f.n_streams);
+	if (f.in_fmt != PCM_DOUBLE) {
+		if (!pcm_fusable(f.in_fmt)) return false;
+		if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1, true>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+		else hipLaunchKernelGGL((pfz::fused_prepass_mm<2, true>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+		return true;
+	}
 	if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
 	else hipLaunchKernelGGL((pfz::fused_prepass_mm<2>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
 	return true;

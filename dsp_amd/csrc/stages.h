@@ -31,11 +31,11 @@ public:
 	// (`pending`) and the convolver's run() does the whole of it -- end states of the window's rows from zero state, the scan over
 	// them (the chunk plan's tables), the recurrence from the true states in front of the column transforms.  State and rings
 	// are left exactly as the separate kernels leave them, so any later call may take the ordinary path again.
-	std::function<bool(const double *in, long in_stride, ssize_t frames)> fuse_probe;
-	struct Pending { const double *in = nullptr; long in_stride = 0; ssize_t frames = 0; } pending;
+	std::function<bool(const void *in, long in_stride, ssize_t frames, int in_fmt)> fuse_probe;     // in_fmt: PCM_DOUBLE or the wire format `in` holds
+	struct Pending { const double *in = nullptr; long in_stride = 0; ssize_t frames = 0; int in_fmt = PCM_DOUBLE; } pending;
 	// sections of a chain whose channels all run the same sections and gains (gains folded into the next section's b coefficients,
 	// as cascade_rows has them), padded with pass-through sections to a count the fused kernels are instantiated for
-	struct FuseTables { bool tried = false, ok = false; int n_sec = 0; double gain = 1.0; DevBuf sec, sec_op; };
+	struct FuseTables { bool tried = false, ok = false; int n_sec = 0, n_real = 0; double gain = 1.0; DevBuf sec, sec_op; };   // n_sec: with the padding, n_real: the chain's own
 	const FuseTables &fuse_tables();
 
 	friend class ConvStage;

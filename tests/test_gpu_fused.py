@@ -106,3 +106,26 @@ def test_chains_the_fused_kernels_leave_alone(amd, tmp_path):
                   f"lowpass 1k 0.707 fir -t pcm -e double -c 1 {f}"):
         b = build(amd, chain, 8, 4, 245760, True)
         assert "cascade-fused" not in b.plan(), b.plan()
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt,prec", [("s16", "s16", 16), ("s32", "s24", 24), ("float", "float", 0), ("s24", "double", 0)])
+def test_wire_formats_into_the_fused_first_pass(amd, tmp_path, in_fmt, out_fmt, prec):
+    """the headline chain's shape in small from wire format to wire format: the matrix-core prepass and the fused first pass read the
+    samples themselves (read_buf_<fmt> in their loads), K3 applies the sink -- every byte, clip count and peak equal to the same
+    conversions as passes of their own around the same (fused) fp64 step; hop, hop, a call off the grid, hop"""
+    import torch
+    import test_gpu_wire as tw
+    mods = (amd, amd.load_library(), torch)
+    f = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(make_filter(16384, seed=5), dtype="<f8").tofile(f)
+    chain = "gain 3 " + " ".join(SECTIONS[:10]) + f" fir_p -t pcm -e double -c 1 {f}"
+    S, C, B = 8, 8, 245760
+    blocks = [B, B, 5000, B]
+    x = tw.wire_input(torch, in_fmt, S, sum(blocks), C, 77)
+    got, gstats, bits = tw.fused(mods, chain, 48000, C, S, x, blocks, in_fmt, out_fmt, prec, pad=68)
+    want, wstats, plan = tw.separate_passes(mods, chain, 48000, C, S, x, blocks, in_fmt, out_fmt, prec)
+    assert "cascade-fused" in plan, plan
+    assert tw.same(got, want)
+    assert np.array_equal(gstats, wstats)
+    if in_fmt != "double":
+        tw.check_bits(bits, [3, 3, 3, 3])          # both ends converted inside kernels, in all four calls
