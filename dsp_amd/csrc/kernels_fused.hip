@@ -161,14 +161,14 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 typedef double fz_v4d __attribute__((ext_vector_type(4)));
 
 // one frame's channel pair (2 cp, 2 cp + 1) of a slab of samples of a wire format as fp64 (read_buf_<fmt>, pcm_device.h); bs = bytes per sample
-__device__ __forceinline__ double2 fz_wire_pair(const char *frame_pair, int bs, const WordFormat &wf)
+// (BS is a template parameter of the kernels: chosen at run time, the width of the load was a scalar branch in front of every load)
+template <int BS> __device__ __forceinline__ double2 fz_wire_pair(const char *frame_pair, const WordFormat &wf)
 {
-	if (bs == 4) { const uint2 w = *reinterpret_cast<const uint2 *>(frame_pair); return make_double2(pcm_from_word(w.x, wf), pcm_from_word(w.y, wf)); }
-	const uint32_t w = *reinterpret_cast<const uint32_t *>(frame_pair);
-	return make_double2(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16));
+	if constexpr (BS == 4) { const uint2 w = *reinterpret_cast<const uint2 *>(frame_pair); return make_double2(pcm_from_word(w.x, wf), pcm_from_word(w.y, wf)); }
+	else { const uint32_t w = *reinterpret_cast<const uint32_t *>(frame_pair); return make_double2(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16)); }
 }
 
-template <int DT, bool WIRE = false>            // DT: 16-row tiles of states: 1 (up to 8 sections) or 2
+template <int DT, int BS = 8>            // DT: 16-row tiles of states: 1 (up to 8 sections) or 2; BS: bytes per sample of the slab (8: fp64, 2: s16, 4: s24 / s32 / float)
 __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const double *__restrict__ Gt, long N2, int n_state)
 {
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	if (c0 >= f.K) return;
 	const int k = lane >> 4, jc = lane & 15, cp = jc & 3;
 	// a lane's element of step t0: frame t0 + k of chunk (jc >> 2) of the column group, channel pair cp -- 16 bytes of an fp64 slab, 4 or 8 of a wire format
-	const int bs = !WIRE ? 8 : (f.in_fmt == PCM_S16) ? 2 : 4;
+	constexpr int bs = BS;
 	const WordFormat wf = word_format(f.in_fmt);
 	const char *xb[2];
 #pragma unroll
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	}
 	const long fstep = 8L * bs;                                   // bytes per frame (8 channels)
 	auto xload = [&](int g, long t) -> double2 {
-		if constexpr (WIRE) return fz_wire_pair(xb[g] + t * fstep, bs, wf);
+		if constexpr (BS != 8) return fz_wire_pair<BS>(xb[g] + t * fstep, wf);
 		else return *reinterpret_cast<const double2 *>(xb[g] + t * fstep);
 	};
 	const double *ga = Gt + (size_t) k * 32 + jc;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void fz_twiddle(cplx s16, cplx a, int j, cplx (&v)[FZ
 	v[4] = cmul(v[4], a4); v[5] = cmul(v[5], cmul(a4, s1)); v[6] = cmul(v[6], cmul(a4, s2)); v[7] = cmul(v[7], cmul(a4, s3));
 }
 
-template <int NSEC, int HR, int DBG = 0, bool WIRE = false>
+template <int NSEC, int HR, int DBG = 0, int BS = 8>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 {
@@ -361,16 +361,16 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const long col0 = (long) sg * tiles * TW;        // first column of this workgroup's segment
 	const long pair0 = (long) s * p.pairs_per_stream + 2 * grp;     // the group's first pair
 	// the slab through a buffer descriptor: element (row lj + 32 m >= HR, column lt) of pair lq at vs + (column + (32 m - HR) N2) frame bytes
-	// (WIRE: the slab holds samples of f.in_fmt -- s16 / s24 / s32 / float --, a pair of a frame is one 4- or 8-byte load, converted as it arrives)
-	const int bs = !WIRE ? (int) sizeof(double) : (f.in_fmt == PCM_S16) ? 2 : 4;
+	// (BS != 8: the slab holds samples of f.in_fmt -- s16, or s24 / s32 / float --, a pair of a frame is one 4- or 8-byte load, converted as it arrives)
+	constexpr int bs = BS;
 	const WordFormat wf = word_format(f.in_fmt);
 	const int fb = f.C * bs;
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(f.in)) + (size_t) s * f.in_stride_frames * f.C * bs, 0, 0x7fffffff, 0x00020000);
 	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) bs);
 	const int vs0 = vs - (int) (HR * N2 * fb);       // row lj itself (HR = 16 only, looked at when lj >= HR)
 	auto slab_ld = [&](int vo, int so) -> cplx {
-		if constexpr (!WIRE) return buf_ldc(rs, vo, so);
-		else if (bs == 4) {
+		if constexpr (BS == 8) return buf_ldc(rs, vo, so);
+		else if constexpr (BS == 4) {
 			typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
 			const fz_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
 			return mkc(pcm_from_word(w.x, wf), pcm_from_word(w.y, wf));
@@ -498,8 +498,14 @@ template <int NSEC, int HR, int DBG = 0> static void launch_col(const ConvParams
 	const unsigned wgs = (unsigned) ((long) f.n_streams * (p.pairs_per_stream / 2) * f.seg);
 	if (f.in_fmt != PCM_DOUBLE) {
 		if constexpr (DBG == 0) {
-			grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 0, true>), FZ_LDS);
-			hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 0, true>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
+			if (f.in_fmt == PCM_S16) {
+				grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 0, 2>), FZ_LDS);
+				hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 0, 2>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
+			}
+			else {
+				grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 0, 4>), FZ_LDS);
+				hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 0, 4>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
+			}
 		}
 		return;
 	}
@@ -525,8 +531,12 @@ bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int
 	const dim3 grid((unsigned) ((f.K / 8 + 3) / 4), (unsigned) f.n_streams);
 	if (f.in_fmt != PCM_DOUBLE) {
 		if (!pcm_fusable(f.in_fmt)) return false;
-		if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1, true>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
-		else hipLaunchKernelGGL((pfz::fused_prepass_mm<2, true>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+		if (f.in_fmt == PCM_S16) {
+			if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1, 2>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+			else hipLaunchKernelGGL((pfz::fused_prepass_mm<2, 2>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+		}
+		else if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1, 4>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
+		else hipLaunchKernelGGL((pfz::fused_prepass_mm<2, 4>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
 		return true;
 	}
 	if (n_state <= 16) hipLaunchKernelGGL((pfz::fused_prepass_mm<1>), grid, dim3(256), 0, st, f, Gt, N2, n_state);
