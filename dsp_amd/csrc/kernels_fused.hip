@@ -387,18 +387,20 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const int w_step = (int) (32 * N2 * (long) sizeof(cplx));
 	const double2 *ring0 = p.ring + pair0 * p.ring_row_stride;
 	const double2 *ringl = ring0 + lq * p.ring_row_stride;
-	auto fetch1 = [&](int it, int m, cplx (&d)[PT]) {    // (m is a compile-time constant at every call)
-		const long col = col0 + (long) it * TW;
-		const int so = (int) (col * fb);
+	// so = the tile's first column in bytes of a slab row, wave-uniform BY CONSTRUCTION (readfirstlane): left to the compiler's own analysis it ended
+	// up in a VGPR -- a 32-bit VALU multiply per load and a waterfall loop around every buffer load to get the scalar offset back
+	auto tile_so = [&](int it) { return __builtin_amdgcn_readfirstlane((int) ((col0 + (long) it * TW) * fb)); };
+	auto fetch1 = [&](int it, int so, int m, cplx (&d)[PT]) {    // (m is a compile-time constant at every call)
 		const bool from_ring = (32 * m + 32 <= HR) || (32 * m < HR && hist_row);       // rows lj + 32 m below HR: history
-		if (from_ring) d[m] = ringl[(p.win_base + (long) (lj + 32 * m) * N2 + col + lt) & p.ring_mask];
+		if (from_ring) d[m] = ringl[(p.win_base + (long) (lj + 32 * m) * N2 + (col0 + (long) it * TW) + lt) & p.ring_mask];
 		else if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
 		else if (32 * m < HR) d[m] = slab_ld(vs0, so);                                 // (HR = 16: the rows 16 .. 31 of m = 0)
-		else d[m] = slab_ld(vs, so + (int) ((32 * m - HR) * N2 * fb));
+		else d[m] = slab_ld(vs, so + (int) __builtin_amdgcn_readfirstlane((int) ((32 * m - HR) * N2 * fb)));
 	};
 	auto fetch = [&](int it, cplx (&d)[PT]) {
+		const int so = tile_so(it);
 #pragma unroll
-		for (int m = 0; m < PT; ++m) fetch1(it, m, d);
+		for (int m = 0; m < PT; ++m) fetch1(it, so, m, d);
 	};
 	auto stage = [&](const cplx (&d)[PT], cplx *dst) {   // a fetched tile into a tile buffer
 #pragma unroll
@@ -442,6 +444,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 		// the next tile's frames, asked for one row set per section of the recurrence (the last iteration re-reads its own tile: the loop
 		// body stays uniform), and this tile's inter-pass twiddles (two table entries)
 		const int nit = it + 1 < tiles ? it + 1 : it;
+		const int nso = tile_so(nit);
 		if constexpr (NSEC < PT) fetch(nit, nx);
 		const long col = col0 + (long) it * TW;
 		const cplx tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + col + t], tw_a = TAB(p.tw_col)[tw_row + col + t];
@@ -451,7 +454,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 #pragma unroll
 			for (int i = 0; i < TW; ++i) x[i] = cur[rq * FZ_QS + rr * FZ_PITCH + i];
 			if constexpr (DBG & 1) { if constexpr (NSEC >= PT) fetch(nit, nx); }
-			else run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, k, nx); } });
+			else run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, nso, k, nx); } });
 			if (f.gain != 1.0) {
 #pragma unroll
 				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
