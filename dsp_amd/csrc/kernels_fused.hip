@@ -34,7 +34,9 @@
 // one tile ahead or two -- it is the CU's own load / store path, not bandwidth (33 GB in 8.5 ms) and not latency.
 // Tried and dropped (round 4): the workgroup as two halves that run on their own, one per pair, with counters in LDS for barriers (gfx950 has one
 // barrier per workgroup), so that one pair's transform would meet the other's recurrence on every SIMD -- each half must then load its own pair,
-// 16 of a frame's 64 bytes per lane, and that alone took the kernel from 8.4 to 10.4 ms (with real barriers; 11.4 with the polled ones).
+// 16 of a frame's 64 bytes per lane, and that alone took the kernel from 8.4 to 10.4 ms (with real barriers; 11.4 with the polled ones);
+// the tile loads by LDS-DMA (global_load_lds_dwordx4 into a buffer laid out in the loading lanes' order: no staging registers, no ds_write pass,
+// output bit-identical): 8.87 against 8.78 ms on the same box (commit 'experiment (kept in history)').
 //
 // Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
 // LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
@@ -490,146 +492,6 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	}
 }
 
-// ---- experiment (-DFUSE_EXPERIMENTS): the tile's frames by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).
-// A wave-instruction lands 64 lanes x 16 bytes contiguously, so the tile buffer is laid out in blocks of 4 rows in the loading layout's lane order:
-// slot(pair, row, column) = (row >> 2) 65 + (row & 3) 16 + column 2 + pair; the recurrence threads take rows 4 (l & 15) + (l >> 4) + 64 wave
-// (16 different blocks per read group: conflict-free), the transform threads as before.
-#ifdef FUSE_EXPERIMENTS
-constexpr int FZD_BP = 65, FZD_BUF = 64 * FZD_BP;
-constexpr size_t FZD_LDS = ((size_t) 2 * FZD_BUF + 256) * sizeof(cplx);
-__device__ __forceinline__ int fzd_slot(int pair, int row, int col) { return (row >> 2) * FZD_BP + (row & 3) * 16 + col * 2 + pair; }
-struct FzdMap1 {
-	int q, t;
-	__device__ __forceinline__ static int row(int pos) { return (pos >> 3) + 32 * (pos & 7); }
-	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[fzd_slot(q, row(pos), t)] = v; }
-	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[fzd_slot(q, row(pos), t)]; }
-};
-struct FzdMap2 {
-	int q, t;
-	__device__ __forceinline__ static int row(int pos) { return (pos >> 6) + 4 * ((pos >> 3) & 7) + 32 * (pos & 7); }
-	__device__ __forceinline__ void store(cplx *lds, int pos, cplx v) const { lds[fzd_slot(q, row(pos), t)] = v; }
-	__device__ __forceinline__ void load(const cplx *lds, int pos, cplx &v) const { v = lds[fzd_slot(q, row(pos), t)]; }
-};
-
-template <int NSEC, int HR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fused_col_fwd_dma(ConvParams p, FuseParams f, const double *__restrict__ sec)
-{
-	constexpr int N1 = 256, TW = FZ_TW, PT = FZ_PT, P = FZ_P;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *buf0 = reinterpret_cast<cplx *>(smem_raw);
-	cplx *twt = buf0 + 2 * FZD_BUF;
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int lq = tid & 1, lt = (tid >> 1) & (TW - 1), lj = tid >> 4;     // loading: rows lj + 32 m (lj = 4 wave + (lane >> 4)), lane order = slot order inside a block
-	const int rq = tid >> 8, rr = 64 * (wave & 3) + 4 * (lane & 15) + (lane >> 4);      // recurrence: row rr of pair rq
-	const int t = tid & (TW - 1), q = (tid >> 3) & 1, j = tid >> 4;        // transform
-	const int groups = p.pairs_per_stream >> 1;
-	int s, gs;
-	fz_block(f.n_streams, groups * f.seg, s, gs);
-	const int grp = gs % groups, sg = gs / groups;
-	if (tid < N1) twt[tid] = TAB(p.tw_n1)[tid];
-	const long N2 = p.N2;
-	const int tiles = (int) (N2 / TW / f.seg);
-	const long col0 = (long) sg * tiles * TW;
-	const long pair0 = (long) s * p.pairs_per_stream + 2 * grp;
-	const long fb = f.C * (long) sizeof(double);
-	// per-lane source of element (row lj + 32 m, column lt, pair lq) of tile 0: the slab for rows >= HR, the pair ring below
-	const char *slab = reinterpret_cast<const char *>(f.in) + ((size_t) s * f.in_stride_frames * f.C + 4 * grp + 2 * lq) * sizeof(double);
-	const double2 *ringl = p.ring + (pair0 + lq) * p.ring_row_stride;
-	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
-	const int vw = (int) (((long) q * p.w_stride + (long) j * N2 + t) * (long) sizeof(cplx));
-	const int w_step = (int) (32 * N2 * (long) sizeof(cplx));
-	const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned) (uintptr_t) buf0);
-	auto dma1 = [&](int it, int m, int which) {       // the wave's 4 rows x 8 columns x 2 pairs of row set m of tile it -> block wave + 8 m of buffer `which`
-		const long col = col0 + (long) it * TW + lt;
-		const int row = lj + 32 * m;
-		const void *src;
-		if (row < HR) src = ringl + ((p.win_base + (long) row * N2 + col) & p.ring_mask);
-		else src = slab + ((long) (row - HR) * N2 + col) * fb;
-		const unsigned dst = lds0 + (unsigned) ((which * FZD_BUF + (wave + 8 * m) * FZD_BP) * sizeof(cplx));
-		unsigned keep;
-		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-		             : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst)) : "memory");
-	};
-	double2 m0[NSEC], m1[NSEC];
-	const bool rec = rr >= HR;
-	{
-		const int D = 2 * f.n_ops;
-		const long c = rec ? (long) (rr - HR) * f.seg + sg : 0;
-		const double *xs = f.X + (((size_t) s * f.K + c) * f.C + 4 * grp + 2 * rq) * D;
-#pragma unroll
-		for (int k = 0; k < NSEC; ++k) {
-			const int op = f.sec_op[k];
-			if (op >= 0 && rec) {
-				m0[k] = make_double2(xs[2 * op], xs[D + 2 * op]);
-				m1[k] = make_double2(xs[2 * op + 1], xs[D + 2 * op + 1]);
-			}
-			else { m0[k] = make_double2(0.0, 0.0); m1[k] = make_double2(0.0, 0.0); }
-		}
-	}
-	const bool keeps = rr >= N1 - HR;
-	double2 *ringw = const_cast<double2 *>(p.ring) + (pair0 + rq) * p.ring_row_stride;
-	const long ring_e0 = p.win_base + (long) rr * N2 + col0;
-#pragma unroll
-	for (int m = 0; m < PT; ++m) dma1(0, m, 0);
-	SecCoef cf = load_coef(sec, 0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();                                 // tile 0 landed, tables visible
-	const FzTw tw{ twt };
-	const FzdMap1 map1{ q, t };
-	const FzdMap2 map2{ q, t };
-	const long tw_row = (long) (j & 15) * p.N2;
-	for (int it = 0; it < tiles; ++it) {
-		cplx *cur = buf0 + (it & 1) * FZD_BUF;
-		const int nit = it + 1 < tiles ? it + 1 : it, nwhich = (it + 1) & 1;
-		const long col = col0 + (long) it * TW;
-		const cplx tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + col + t], tw_a = TAB(p.tw_col)[tw_row + col + t];
-		{
-			cplx x[TW];
-#pragma unroll
-			for (int i = 0; i < TW; ++i) x[i] = cur[fzd_slot(rq, rr, i)];
-			// (the next tile's row sets, one per section: the other buffer is free -- every wave passed the barrier at the end of the tile before)
-			run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if (k < PT) dma1(nit, k, nwhich); });
-			if constexpr (NSEC < PT) {
-#pragma unroll
-				for (int m = NSEC; m < PT; ++m) dma1(nit, m, nwhich);
-			}
-			if (f.gain != 1.0) {
-#pragma unroll
-				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
-			}
-			if (rec) {
-#pragma unroll
-				for (int i = 0; i < TW; ++i) cur[fzd_slot(rq, rr, i)] = x[i];
-			}
-			if (keeps) {
-				double2 *w0 = ringw + ((ring_e0 + (long) it * TW) & p.ring_mask);
-#pragma unroll
-				for (int i = 0; i < TW; ++i) w0[i] = x[i];
-			}
-		}
-		lds_barrier();
-		cplx v[PT];
-#pragma unroll
-		for (int m = 0; m < PT; ++m) v[m] = cur[fzd_slot(q, j + P * m, t)];
-		fz_pass<PT, 8, 8, 1, false>(v, j, cur, map1, tw);
-		lds_barrier();
-		gather_n<PT>(v, j, cur, map1);
-		fz_pass<PT, 8, 8, 8, false>(v, j, cur, map2, tw);
-		lds_barrier();
-		gather_n<PT>(v, j, cur, map2);
-		fz_pass<PT, 8, 4, 64, true>(v, j, cur, map2, tw);
-		fz_twiddle(tw_s, tw_a, j, v);
-		const int wo = vw + (int) (col * (long) sizeof(cplx));
-#pragma unroll
-		for (int m = 0; m < PT; ++m) buf_stc<2>(v[m], rw, wo + m * w_step);
-		// the next tile has landed (this wave's part: its 8 row sets are older than the 8 stores just issued), then everybody's
-		asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-		lds_barrier();
-	}
-}
-#endif
-
 template <int NSEC> static void launch_pre(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st)
 {
 	const long n = f.K * pps;
@@ -719,12 +581,6 @@ bool launch_fused_col_fwd(const ConvParams &p, const FuseParams &f, const double
 	case 8: return pfz::launch_col_mh<8>(p, f, sec, st);
 	case 10:
 #ifdef FUSE_EXPERIMENTS
-		if (getenv("DSP_AMD_FUSE_DMA") && atoi(getenv("DSP_AMD_FUSE_DMA")) && f.hist_rows == 16 && f.in_fmt == PCM_DOUBLE) {
-			grant_dynamic_lds(reinterpret_cast<const void *>(pfz::fused_col_fwd_dma<10, 16>), pfz::FZD_LDS);
-			const unsigned wgs = (unsigned) ((long) f.n_streams * (p.pairs_per_stream / 2) * f.seg);
-			hipLaunchKernelGGL((pfz::fused_col_fwd_dma<10, 16>), dim3(wgs), dim3(512), pfz::FZD_LDS, st, p, f, sec);
-			return true;
-		}
 		{
 			const char *e = getenv("DSP_AMD_FUSE_DBG");
 			switch (e ? atoi(e) : 0) {

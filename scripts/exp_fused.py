@@ -80,10 +80,7 @@ def timed(S=256, C=8, B=983040, taps=65536, steps=6, modes=(True, False, True)):
     o = torch.empty((S, B + 68, C), dtype=torch.float64, device="cuda")
     outs = {}
     for fuse in modes:
-        os.environ.pop("DSP_AMD_FUSE_DMA", None)
-        if fuse == "dma":
-            os.environ["DSP_AMD_FUSE_DMA"] = "1"; os.environ.pop("DSP_AMD_FUSE_DBG", None); tagname = "dma"; fuse = True
-        elif isinstance(fuse, str):
+        if isinstance(fuse, str):
             os.environ["DSP_AMD_FUSE_DBG"] = fuse; tagname = "dbg" + fuse; fuse = True
         else:
             os.environ.pop("DSP_AMD_FUSE_DBG", None); tagname = "fused" if fuse else "separate"
@@ -100,13 +97,10 @@ def timed(S=256, C=8, B=983040, taps=65536, steps=6, modes=(True, False, True)):
             name, ms, cnt = line.split()
             prof[name] = round(float(ms) / max(int(cnt), 1), 3)
         L.dspamd_profile_enable(0)
-        outs[tagname if tagname == "dma" else fuse] = o[:, :B, :].clone()
+        outs[fuse] = o[:, :B, :].clone()
         res[tagname] = {"ms_per_step": round(dt * 1e3, 3), "Gsamples_s": round(S * C * B / dt / 1e9, 2), "kernels_ms": prof}
         print(tagname, json.dumps(res[tagname]), flush=True)
         del b
-    if "dma" in outs and True in outs:
-        dh = outs["dma"] - outs[True]
-        print("dma vs fused: rms", float(dh.pow(2).mean().sqrt()), "max", float(dh.abs().max()), flush=True)
     if False not in outs: return res
     d = outs[True] - outs[False]
     print("headline shape, third step: rms(fused - separate) =", float(d.pow(2).mean().sqrt()), "signal", float(outs[False].pow(2).mean().sqrt()), flush=True)
