@@ -113,6 +113,24 @@ def test_against_real_reference_chain(amd):
     assert rms(y - ref) < TOL
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_host_buffer_of_many_pipeline_calls(amd):
+    """dspamd_chain_run with a host buffer of several 65536-frame pipeline calls and a ragged rest: page-locked staging buffers
+    filled and emptied by the caller and three helper threads (engine.h: PinnedStage, crew_memcpy).  Same samples as the stream
+    fed in small blocks, and the real reference's (dsp.c:1295-1454 runs any block size through the same chain)."""
+    chain = "lowshelf 100 0.8s 6 eq 1k 1.2 -3 delay 7S gain -2"
+    frames, ch = 5 * 65536 + 12345, 8
+    x = noise(frames, ch, 21)
+    ec = amd.EffectsChain(chain, 48000, ch)
+    y = ec.run(x)
+    y2 = ec.run(x)                                           # (a second buffer continues the stream)
+    small = amd.EffectsChain(chain, 48000, ch)
+    z = np.concatenate([small.run(np.concatenate([x, x])[p:p + 50000]) for p in range(0, 2 * frames, 50000)])
+    assert y.shape == (frames, ch) and np.max(np.abs(np.concatenate([y, y2]) - z)) < 1e-13           # (other call sizes, other cascade kernels: not bit for bit)
+    ref = RefChain(chain, 48000, ch).run(np.concatenate([x, x]))
+    assert rms(np.concatenate([y, y2]) - ref) < TOL
+
+
 def test_plugin_abi_run(amd):
     """Drive one effect through the reference's plugin surface: init -> run -> destroy (effect.h:24-59)."""
     import ctypes as C
