@@ -37,6 +37,12 @@
 // 16 of a frame's 64 bytes per lane, and that alone took the kernel from 8.4 to 10.4 ms (with real barriers; 11.4 with the polled ones);
 // the tile loads by LDS-DMA (global_load_lds_dwordx4 into a buffer laid out in the loading lanes' order: no staging registers, no ds_write pass,
 // output bit-identical): 8.87 against 8.78 ms on the same box (commit 'experiment (kept in history)').
+// Measured again at the end of round 4, same box, a / b / a / b: without the recurrence the kernel still takes 8.2-8.4 ms (8.3-8.8 with it), without
+// the transform 6.8-7.1, without loads and stores 6.8-6.9 -- the sections' 2.7 ms of issue hide under the tile's chain of LDS and memory round
+// trips.  Three ways to break that chain, none faster: the second pair's waves one barrier behind the first pair's (all 512 threads still load and
+// stage; recurrence of one pair beside the passes of the other on every SIMD) 8.6-9.0 ms with the pairs in waves 0-3 / 4-7 and 10.1 with even / odd
+// waves -- a wave alone in the recurrence stalls on its own dependent chains, two of them fill each other's gaps; the next tile asked for right
+// behind the staging of this one (a whole tile's time in flight, loads issued before the stores they would otherwise wait behind) 8.7 against 8.4-8.6.
 //
 // Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
 // LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
