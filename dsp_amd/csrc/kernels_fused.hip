@@ -42,7 +42,8 @@
 // trips.  Three ways to break that chain, none faster: the second pair's waves one barrier behind the first pair's (all 512 threads still load and
 // stage; recurrence of one pair beside the passes of the other on every SIMD) 8.6-9.0 ms with the pairs in waves 0-3 / 4-7 and 10.1 with even / odd
 // waves -- a wave alone in the recurrence stalls on its own dependent chains, two of them fill each other's gaps; the next tile asked for right
-// behind the staging of this one (a whole tile's time in flight, loads issued before the stores they would otherwise wait behind) 8.7 against 8.4-8.6.
+// behind the staging of this one (a whole tile's time in flight, loads issued before the stores they would otherwise wait behind) 8.7 against 8.4-8.6;
+// the spectrum rows kept in registers and stored one per section of the NEXT tile's recurrence, beside its loads (239 registers) 8.43-8.50 against 8.35-8.59.
 //
 // Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
 // LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
