@@ -44,6 +44,12 @@
 // waves -- a wave alone in the recurrence stalls on its own dependent chains, two of them fill each other's gaps; the next tile asked for right
 // behind the staging of this one (a whole tile's time in flight, loads issued before the stores they would otherwise wait behind) 8.7 against 8.4-8.6;
 // the spectrum rows kept in registers and stored one per section of the NEXT tile's recurrence, beside its loads (239 registers) 8.43-8.50 against 8.35-8.59.
+// And the overlap moved INSIDE the waves (fused_col_fwd_x, in the history of this file): the passes of tile it - 1 in the gaps between the sections of
+// tile it -- LDS reads asked for in one gap, butterflies and writes in the next, behind the wait for the section's coefficients (scalar loads and LDS share
+// a counter) --, the next tile by LDS-DMA into a landing buffer of its own (no staging registers; 242 registers, no spills once the passes' LDS addresses
+// were base + constant instead of one register per slot), four barriers per tile, output bit-identical: 8.7-9.0 ms against 8.5-8.8, VALU-busy 50 % in
+// both (profiles/r04_fzx_sq_counters.json).  The clock is not the limit either: 2.04 GHz in this kernel, 2.04 in K2, 2.31 in K3, 1.79 in a pure fp64
+// VALU kernel, 2.40 idle-ish (profiles/r04_kernel_clocks.json, scripts/exp_clock_step.sh).
 //
 // Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
 // LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
