@@ -44,6 +44,12 @@
 // waves -- a wave alone in the recurrence stalls on its own dependent chains, two of them fill each other's gaps; the next tile asked for right
 // behind the staging of this one (a whole tile's time in flight, loads issued before the stores they would otherwise wait behind) 8.7 against 8.4-8.6;
 // the spectrum rows kept in registers and stored one per section of the NEXT tile's recurrence, beside its loads (239 registers) 8.43-8.50 against 8.35-8.59.
+// And the overlap moved INSIDE the waves (fused_col_fwd_x, in the history of this file): the passes of tile it - 1 in the gaps between the sections of
+// tile it -- LDS reads asked for in one gap, butterflies and writes in the next, behind the wait for the section's coefficients (scalar loads and LDS share
+// a counter) --, the next tile by LDS-DMA into a landing buffer of its own (no staging registers; 242 registers, no spills once the passes' LDS addresses
+// were base + constant instead of one register per slot), four barriers per tile, output bit-identical: 8.7-9.0 ms against 8.5-8.8, VALU-busy 50 % in
+// both (profiles/r04_fzx_sq_counters.json).  The clock is not the limit either: 2.04 GHz in this kernel, 2.04 in K2, 2.31 in K3, 1.79 in a pure fp64
+// VALU kernel, 2.40 idle-ish (profiles/r04_kernel_clocks.json, scripts/exp_clock_step.sh).
 //
 // Layout of fused_col_fwd: workgroup = (stream, group of 2 channel pairs, row segment), 512 threads, one workgroup per CU (152 KB of
 // LDS: two tile buffers [2 pairs][256 rows] of pitch 9).  The two groups of a stream are dispatched 8 workgroup ids apart (same XCD,
@@ -78,13 +84,9 @@ __device__ __forceinline__ void run_sections(cplx (&x)[NF], double2 (&m0)[NSEC],
 {
 #pragma unroll
 	for (int k = 0; k < NSEC; ++k) {
-		// (the gap's work goes BEHIND the wait for this section's coefficients: scalar loads and LDS share a counter, and a wait for the
-		// coefficients in front of the section would also wait for LDS reads the gap has just asked for)
-		const SecCoef cur = cf;
-		asm volatile("" :: "s"(cur.c0), "s"(cur.c1), "s"(cur.c2), "s"(cur.c3), "s"(cur.c4));
-		cf = load_coef(sec, k + 1 < NSEC ? k + 1 : 0);
-		__builtin_amdgcn_sched_barrier(0);
 		between(k);
+		const SecCoef cur = cf;
+		cf = load_coef(sec, k + 1 < NSEC ? k + 1 : 0);
 		__builtin_amdgcn_sched_barrier(0);
 		const double c0 = cur.c0, c1 = cur.c1, c2 = cur.c2, c3 = cur.c3, c4 = cur.c4;
 		double a0x = m0[k].x, a0y = m0[k].y, a1x = m1[k].x, a1y = m1[k].y;
@@ -503,231 +505,6 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	}
 }
 
-// ---- the same pass with the tile's three jobs overlapped INSIDE every wave (eight sections and more, fp64 slabs).
-// fused_col_fwd runs recurrence, transform and memory instructions as phases: all eight waves multiply, then all wait for LDS, then all store
-// (VALU 52 %, LDS 23 %, memory path 10 % busy -- one after the other; profiles/r04a_fzctr2_sq_counters.json).  Here the transform of tile it - 1
-// rides in the gaps between the sections of tile it, a pass spread over two gaps -- its LDS reads asked for in one gap, the butterflies and
-// the writes in the next, a section's multiplications in between -- and the next tile arrives by LDS-DMA (no staging registers: the 32 registers
-// hold the transform's points across the sections instead):
-//   A  landing buffer, in the loading lanes' order (blocks of 4 rows x 8 columns x 2 pairs = one wave-instruction, pitch 65): read once by the
-//      recurrence threads at the top of a tile, free from the first barrier on: tile it + 1 lands there during the sections of tile it
-//   B  work buffer [2 pairs][256 rows] of pitch 9: the cascade's output of tile it - 1, transformed in place during tile it, free behind the
-//      barrier in front of section 6: the cascade's output of tile it goes there at the end of the tile
-// gap 0: points out of B | 1: pass 1 | 2: barrier, points out of B | 3: pass 2 | 4: barrier, points | 5: pass 3, twiddle, W stores | 6: barrier;
-// row set k - 2 of the next tile is asked for in gap k = 2 .. 9.  Four barriers per tile.
-// The three passes with their LDS addresses spelled out (j < 32 is not something the compiler knows: through FzMap1 / FzMap2 every slot of a gather
-// gets an address register of its own -- about 25 of them; as base + compile-time offset there are three):
-//   rows read by pass 1: j + 32 m, written j + 32 r (the same);  read by pass 2: (j >> 3) + 32 (j & 7) + 4 m, written the same;
-//   read by pass 3: 4 (j >> 3) + 32 (j & 7) + (m >> 1) + 16 (m & 1)                                  (FzMap1::row / FzMap2::row of j + 32 m)
-struct FzRows {
-	cplx *b0, *b1, *b2;        // slot of the thread's first row in each pattern: buffer + pair + column included
-	__device__ __forceinline__ FzRows(cplx *buf, int q, int t, int j)
-	{
-		cplx *c = buf + q * FZ_QS + t;
-		b0 = c + j * FZ_PITCH;
-		b1 = c + ((j >> 3) + 32 * (j & 7)) * FZ_PITCH;
-		b2 = c + (4 * (j >> 3) + 32 * (j & 7)) * FZ_PITCH;
-	}
-	__device__ __forceinline__ void gather0(cplx (&v)[8]) const {
-#pragma unroll
-		for (int m = 0; m < 8; ++m) v[m] = b0[32 * m * FZ_PITCH];
-	}
-	__device__ __forceinline__ void pass1(cplx (&v)[8]) const {       // radix 8, no twiddles; outputs where the inputs came from
-		dftR<8, false>(v);
-#pragma unroll
-		for (int r = 0; r < 8; ++r) b0[32 * r * FZ_PITCH] = v[r];
-	}
-	__device__ __forceinline__ void gather1(cplx (&v)[8]) const {
-#pragma unroll
-		for (int m = 0; m < 8; ++m) v[m] = b1[4 * m * FZ_PITCH];
-	}
-	__device__ __forceinline__ void pass2(cplx (&v)[8], int j, const cplx *twt) const {     // radix 8 on W_64^(r k), k = j & 7
-		const int k = j & 7;
-#pragma unroll
-		for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twt[4 * r * k]);
-		dftR<8, false>(v);
-#pragma unroll
-		for (int r = 0; r < 8; ++r) b1[4 * r * FZ_PITCH] = v[r];
-	}
-	__device__ __forceinline__ void gather2(cplx (&v)[8]) const {
-#pragma unroll
-		for (int m = 0; m < 8; ++m) v[m] = b2[((m >> 1) + 16 * (m & 1)) * FZ_PITCH];
-	}
-	__device__ __forceinline__ void pass3(cplx (&v)[8], int j, const cplx *twt) const {     // two radix-4 butterflies b = j, j + 32 on W_256^(r b); results stay in v
-#pragma unroll
-		for (int qq = 0; qq < 2; ++qq) {
-			const int b = j + 32 * qq;
-			cplx u[4];
-#pragma unroll
-			for (int r = 0; r < 4; ++r) u[r] = v[qq + 2 * r];
-#pragma unroll
-			for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], twt[r * b]);
-			dftR<4, false>(u);
-#pragma unroll
-			for (int r = 0; r < 4; ++r) v[qq + 2 * r] = u[r];
-		}
-	}
-};
-
-constexpr int FZX_BP = 65, FZX_A = 64 * FZX_BP;
-constexpr size_t FZX_LDS = ((size_t) FZX_A + 2 * FZ_QS + 256 + 2 * 32 * FZ_TW) * sizeof(cplx);    // (+ the history rows of a tile, kept aside while their threads' registers run the sections on them)
-__device__ __forceinline__ int fzx_slot(int pair, int row, int col) { return (row >> 2) * FZX_BP + (row & 3) * 16 + col * 2 + pair; }
-
-template <int NSEC, int HR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fused_col_fwd_x(ConvParams p, FuseParams f, const double *__restrict__ sec)
-{
-	static_assert(NSEC >= 10, "gaps 0 .. 9 carry the transform and the loads");
-	constexpr int N1 = 256, TW = FZ_TW, PT = FZ_PT, P = FZ_P;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *bufA = reinterpret_cast<cplx *>(smem_raw);
-	cplx *bufB = bufA + FZX_A;
-	cplx *twt = bufB + 2 * FZ_QS;
-	cplx *hist = twt + 256;
-	const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const int lq = tid & 1, lt = (tid >> 1) & (TW - 1), lj = tid >> 4;               // loading: rows lj + 32 m (lj = 4 wave + (lane >> 4)): lane order = slot order inside a block
-	// recurrence: row rr of pair rq -- 16 different blocks of A per read group (row >> 2 = lane & 15), and row mod 16 different in 16 consecutive lanes
-	// (the pitch-9 rows of B they write: 9 row mod 16 bank quads) -- the row's low two bits rotate with lane >> 2
-	const int rq = tid >> 8, rr = 64 * (wave & 3) + 4 * (lane & 15) + (((lane >> 4) + ((lane >> 2) & 3)) & 3);
-	const int t = tid & (TW - 1), q = (tid >> 3) & 1, j = tid >> 4;                  // transform: points n1 = j + 32 m of column t of pair q
-	const int groups = p.pairs_per_stream >> 1;
-	int s, gs;
-	fz_block(f.n_streams, groups * f.seg, s, gs);
-	const int grp = gs % groups, sg = gs / groups;
-	if (tid < N1) twt[tid] = TAB(p.tw_n1)[tid];
-	const long N2 = p.N2;
-	const int tiles = (int) (N2 / TW / f.seg);
-	const long col0 = (long) sg * tiles * TW;
-	const long pair0 = (long) s * p.pairs_per_stream + 2 * grp;
-	const long fb = f.C * (long) sizeof(double);
-	// the slab as a scalar base per (tile, row set) + one per-lane offset: element (row lj + 32 m - HR, column lt, pair lq)
-	const char *slab = reinterpret_cast<const char *>(f.in) + ((size_t) s * f.in_stride_frames * f.C + 4 * grp) * sizeof(double);
-	const unsigned lane_off = (unsigned) (((long) lj * N2 + lt) * fb + 16 * lq);
-	const double2 *ringl = p.ring + (pair0 + lq) * p.ring_row_stride;
-	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
-	const int vw = (int) (((long) q * p.w_stride + (long) j * N2 + t) * (long) sizeof(cplx));
-	const int w_step = (int) (32 * N2 * (long) sizeof(cplx));
-	const unsigned ldsA = __builtin_amdgcn_readfirstlane((unsigned) (uintptr_t) bufA);
-	auto dma1 = [&](int it, int m) {       // the wave's 4 rows x 8 columns x 2 pairs of row set m of tile it -> block wave + 8 m of A
-		const unsigned dst = __builtin_amdgcn_readfirstlane(ldsA + (unsigned) ((wave + 8 * m) * FZX_BP * sizeof(cplx)));
-		const long tcol = col0 + (long) it * TW;
-		if (32 * m < HR) {                                            // (decided at compile time: m is a constant at every call)
-			// row set 0: history rows from the pair ring, with HR = 16 the rows 16 .. 31 (waves 4 .. 7) from the slab -- one instruction, a pointer per lane
-			const void *src = (lj + 32 * m < HR) ? static_cast<const void *>(ringl + ((p.win_base + (long) (lj + 32 * m) * N2 + tcol + lt) & p.ring_mask))
-			                                     : static_cast<const void *>(slab + ((long) (lj + 32 * m - HR) * N2 + tcol + lt) * fb + 16 * lq);
-			asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
-		}
-		else {
-			const char *base = slab + ((long) (32 * m - HR) * N2 + tcol) * fb;      // wave-uniform
-			const unsigned long long sb = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((unsigned) ((uintptr_t) base >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((unsigned) (uintptr_t) base);
-			asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(sb), "s"(dst) : "memory", "m0");
-		}
-	};
-	double2 m0[NSEC], m1[NSEC];
-	const bool rec = rr >= HR;
-	{
-		const int D = 2 * f.n_ops;
-		const long c = rec ? (long) (rr - HR) * f.seg + sg : 0;
-		const double *xs = f.X + (((size_t) s * f.K + c) * f.C + 4 * grp + 2 * rq) * D;
-#pragma unroll
-		for (int k = 0; k < NSEC; ++k) {
-			const int op = f.sec_op[k];
-			if (op >= 0 && rec) {
-				m0[k] = make_double2(xs[2 * op], xs[D + 2 * op]);
-				m1[k] = make_double2(xs[2 * op + 1], xs[D + 2 * op + 1]);
-			}
-			else { m0[k] = make_double2(0.0, 0.0); m1[k] = make_double2(0.0, 0.0); }
-		}
-	}
-	const bool keeps = rr >= N1 - HR;
-	double2 *ringw = const_cast<double2 *>(p.ring) + (pair0 + rq) * p.ring_row_stride;
-	const long ring_e0 = p.win_base + (long) rr * N2 + col0;
-#pragma unroll
-	for (int m = 0; m < PT; ++m) dma1(0, m);
-	SecCoef cf = load_coef(sec, 0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	__syncthreads();                                 // tile 0 landed, tables visible
-	const FzRows rows(bufB, q, t, j);
-	const long tw_row = (long) (j & 15) * p.N2;
-	auto store_w = [&](cplx (&v)[PT], long col) {
-		const int wo = vw + (int) (col * (long) sizeof(cplx));
-#pragma unroll
-		for (int m = 0; m < PT; ++m) buf_stc<2>(v[m], rw, wo + m * w_step);
-	};
-	for (int it = 0; it < tiles; ++it) {
-		const int nit = it + 1 < tiles ? it + 1 : it;
-		const bool has_prev = it > 0;
-		const long pcol = col0 + (long) (it - 1) * TW;
-		cplx tw_s = mkc(0.0, 0.0), tw_a = mkc(0.0, 0.0);
-		cplx v[PT];
-#pragma unroll
-		for (int m = 0; m < PT; ++m) v[m] = mkc(0.0, 0.0);
-		cplx x[TW];
-#pragma unroll
-		for (int i = 0; i < TW; ++i) x[i] = bufA[fzx_slot(rq, rr, i)];
-		if (!rec) {                                      // history rows pass through unchanged: set aside (a few lanes of two waves)
-#pragma unroll
-			for (int i = 0; i < TW; ++i) hist[(rq * HR + rr) * TW + i] = x[i];
-		}
-		run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) {
-			if (k == 2 || k == 4 || k == 6) lds_barrier();
-			if (k == 2) {                                // A is free (every wave has read its rows): the whole next tile, eight sections' time to land
-#pragma unroll
-				for (int m = 0; m < PT; ++m) dma1(nit, m);
-			}
-			if (has_prev) {
-				if (k == 0) rows.gather0(v);
-				if (k == 1) {
-					rows.pass1(v);
-					// (the inter-pass twiddles of tile it - 1, asked for in front of the tile loads: a wait for them does not wait for those)
-					tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + pcol + t]; tw_a = TAB(p.tw_col)[tw_row + pcol + t];
-				}
-				if (k == 2) rows.gather1(v);
-				if (k == 3) rows.pass2(v, j, twt);
-				if (k == 4) rows.gather2(v);
-				if (k == 5) {
-					rows.pass3(v, j, twt);
-					fz_twiddle(tw_s, tw_a, j, v);
-					store_w(v, pcol);
-				}
-			}
-		});
-		if (f.gain != 1.0) {
-#pragma unroll
-			for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
-		}
-		if (!rec) {
-#pragma unroll
-			for (int i = 0; i < TW; ++i) x[i] = hist[(rq * HR + rr) * TW + i];
-		}
-#pragma unroll
-		for (int i = 0; i < TW; ++i) bufB[rq * FZ_QS + rr * FZ_PITCH + i] = x[i];
-		if (keeps) {
-			double2 *w0 = ringw + ((ring_e0 + (long) it * TW) & p.ring_mask);
-#pragma unroll
-			for (int i = 0; i < TW; ++i) w0[i] = x[i];
-		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the next tile has landed ...
-		lds_barrier();                                         // ... and everybody's; the cascade's output visible
-	}
-	{
-		// the last tile's passes on their own
-		const long col = col0 + (long) (tiles - 1) * TW;
-		const cplx tw_s = TAB(p.tw_col)[(long) 16 * p.N2 + col + t], tw_a = TAB(p.tw_col)[tw_row + col + t];
-		cplx v[PT];
-		rows.gather0(v);
-		rows.pass1(v);
-		lds_barrier();
-		rows.gather1(v);
-		rows.pass2(v, j, twt);
-		lds_barrier();
-		rows.gather2(v);
-		rows.pass3(v, j, twt);
-		fz_twiddle(tw_s, tw_a, j, v);
-		store_w(v, col);
-	}
-}
-
 template <int NSEC> static void launch_pre(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st)
 {
 	const long n = f.K * pps;
@@ -749,14 +526,6 @@ template <int NSEC, int HR, int DBG = 0> static void launch_col(const ConvParams
 			}
 		}
 		return;
-	}
-	if constexpr (NSEC >= 10 && DBG == 0) {
-		static const bool overlapped = [] { const char *e = getenv("DSP_AMD_FUSE_X"); return !e || atoi(e) != 0; }();
-		if (overlapped) {
-			grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd_x<NSEC, HR>), FZX_LDS);
-			hipLaunchKernelGGL((fused_col_fwd_x<NSEC, HR>), dim3(wgs), dim3(512), FZX_LDS, st, p, f, sec);
-			return;
-		}
 	}
 	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, DBG>), FZ_LDS);
 	hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, DBG>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
