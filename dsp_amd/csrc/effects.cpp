@@ -453,74 +453,11 @@ SpecPtr make_delay_spec(const char *name, const stream_info *is, const char *sel
 }
 
 // Thiran all-pass of order n and delay D (> n - 1) as second-order sections.  The reference runs the ladder of Koshita et
-// al. (allpass.h:73-118, allpass.c:24-37); the transfer function is z^-n A(1/z) / A(z) with
-//     a_k = (-1)^k C(n, k) prod_{i=0..n} (D - n + i) / (D - n + k + i),
-// so its poles are the roots of sum a_k z^(n-k): found here in extended precision (Durand-Kerner + Newton polish), checked by
-// multiplying the factors back together, and paired into sections (c2 + c1 z^-1 + z^-2) / (1 + c1 z^-1 + c2 z^-2).  Orders
-// whose roots do not reproduce the polynomial to 1e-13 are refused (they cluster as n grows: from about n = 34; up to
-// n = 32 the outputs agree with the reference's ladder to 2e-14 RMS, scripts/exp_ap_orders.py).
-static bool thiran_sections(int n, double D, std::vector<std::array<double, 5>> &out)
-{
-	typedef std::complex<long double> cld;
-	std::vector<long double> a(n + 1);
-	for (int k = 0; k <= n; ++k) {
-		long double c = 1.0L;
-		for (int i = 1; i <= k; ++i) c = c * (long double) (n - k + i) / (long double) i;      // C(n, k)
-		long double pr = 1.0L;
-		for (int i = 0; i <= n; ++i) pr *= ((long double) D - n + i) / ((long double) D - n + k + i);
-		a[k] = ((k & 1) ? -1.0L : 1.0L) * c * pr;
-	}
-	auto P = [&](cld z) { cld v = a[0]; for (int k = 1; k <= n; ++k) v = v * z + a[k]; return v; };
-	auto dP = [&](cld z) { cld v = (long double) n * a[0]; for (int k = 1; k < n; ++k) v = v * z + (long double) (n - k) * a[k]; return v; };
-	std::vector<cld> r(n);
-	for (int i = 0; i < n; ++i) r[i] = std::pow(cld(0.4L, 0.9L), i) * 0.6L;
-	for (int it = 0; it < 2000; ++it) {
-		long double move = 0.0L;
-		for (int i = 0; i < n; ++i) {
-			cld den = a[0];
-			for (int j = 0; j < n; ++j) if (j != i) den *= (r[i] - r[j]);
-			const cld d = P(r[i]) / den;
-			r[i] -= d;
-			move = std::max(move, std::abs(d));
-		}
-		if (move < 1e-19L) break;
-	}
-	for (int i = 0; i < n; ++i) for (int it = 0; it < 4; ++it) r[i] -= P(r[i]) / dP(r[i]);
-	// pair the roots: complex ones with their conjugates, real ones two by two
-	std::vector<cld> cplx_up; std::vector<long double> real;
-	for (const cld &z : r) {
-		if (std::abs(z) >= 1.0L) return false;
-		if (fabsl(z.imag()) < 1e-12L) real.push_back(z.real());
-		else if (z.imag() > 0) cplx_up.push_back(z);
-	}
-	if ((int) (2 * cplx_up.size() + real.size()) != n) return false;
-	out.clear();
-	std::vector<long double> rec(1, 1.0L);                              // product of the factors, for the check
-	auto mul = [&](long double c1, long double c2, int deg) {
-		std::vector<long double> q(rec.size() + deg, 0.0L);
-		for (size_t i = 0; i < rec.size(); ++i) { q[i] += rec[i]; q[i + 1] += rec[i] * c1; if (deg == 2) q[i + 2] += rec[i] * c2; }
-		rec.swap(q);
-	};
-	for (const cld &z : cplx_up) {
-		const long double c1 = -2.0L * z.real(), c2 = std::norm(z);
-		out.push_back({ (double) c2, (double) c1, 1.0, (double) c1, (double) c2 });
-		mul(c1, c2, 2);
-	}
-	std::sort(real.begin(), real.end());
-	for (size_t i = 0; i + 1 < real.size(); i += 2) {
-		const long double c1 = -(real[i] + real[i + 1]), c2 = real[i] * real[i + 1];
-		out.push_back({ (double) c2, (double) c1, 1.0, (double) c1, (double) c2 });
-		mul(c1, c2, 2);
-	}
-	if (real.size() & 1) {
-		const long double c1 = -real.back();
-		out.push_back({ (double) c1, 1.0, 0.0, (double) c1, 0.0 });
-		mul(c1, 0.0L, 1);
-	}
-	long double err = 0.0L, big = 0.0L;
-	for (int k = 0; k <= n; ++k) { err = std::max(err, fabsl(rec[k] - a[k])); big = std::max(big, fabsl(a[k])); }
-	return err <= 1e-13L * big;
-}
+// al. (allpass.h:73-118, allpass.c:24-37); the transfer function is z^-n A(1/z) / A(z), so its poles are the roots of A: found in 113-bit
+// arithmetic (thiran_roots.cpp), checked by multiplying the double-rounded factors back together, and paired into sections
+// (c2 + c1 z^-1 + z^-2) / (1 + c1 z^-1 + c2 z^-2).  All of the reference's orders (1 .. 50, delay.c's option parser) pass the check; the outputs
+// agree with the reference's ladder to 2e-14 RMS at n = 32 (scripts/exp_ap_orders.py, tests/test_gpu_parity.py).
+static bool thiran_sections(int n, double D, std::vector<std::array<double, 5>> &out) { return thiran_pole_sections(n, D, out); }
 
 // delay_effect_prepare (delay.c:149-204): what is left of the summed fractional amounts becomes a first- or
 // second-order Thiran all-pass (allpass.h:46-71) -- the same transfer function as a biquad section
@@ -566,7 +503,7 @@ bool delay_prepare(Spec &sp, bool *noop)
 		else {
 			std::vector<std::array<double, 5>> secs;
 			if (!thiran_sections(sp.fd_ap_n[k], d, secs)) {
-				set_error("%s: error: all-pass order %d: the second-order factorisation of the Thiran filter is not accurate enough on this backend (orders up to about 33 are)", sp.name.c_str(), sp.fd_ap_n[k]);
+				set_error("%s: error: all-pass order %d: the second-order factorisation of the Thiran filter did not reproduce its polynomial", sp.name.c_str(), sp.fd_ap_n[k]);
 				return false;
 			}
 			sp.bq[k] = secs[0];

@@ -213,6 +213,10 @@ FRAC_DELAY_CHAINS = [
     ("delay -f10 12.5S", 2),
     ("delay -f24 0.3S", 2),
     (":1 delay -f32 7.77S", 2),
+    ("delay -f34 0.3S", 2),                                      # round 4: the poles in 113-bit arithmetic (thiran_roots.cpp): every order the reference's parser takes
+    ("delay -f41 12.77S", 2),
+    ("delay -f50 0.5S", 2),
+    (":0 delay -f50 30.05S : gain -1", 3),
 ]
 
 
@@ -232,10 +236,10 @@ def test_fractional_delay_vs_real_reference(amd, chain, ch):
     assert rms(y - ref) < 1e-13, rms(y - ref)
 
 
-def test_fractional_delay_very_high_order_refused(amd):
-    # the factorisation into second-order sections loses accuracy as the poles cluster: refused rather than wrong
-    with pytest.raises(ValueError, match="all-pass order 40"):
-        amd.EffectsChain("delay -f40 0.5S", 48000, 2)
+def test_fractional_delay_orders_beyond_the_parser_refused(amd):
+    # delay.c:700-701: fd_ap_n > 0 && fd_ap_n <= 50 -- the parser's refusal, in its words
+    with pytest.raises(ValueError, match="parameter out of range: order"):
+        amd.EffectsChain("delay -f51 0.5S", 48000, 2)
 
 
 PAIR_CHAINS = [
