@@ -431,7 +431,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		}
 		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
 	}
-	if (!H.alloc((size_t) (upc_P ? upc_P : n_filters * nph) * N * elem(), false)) return false;
+	if (!H.alloc((size_t) (upc_P ? (size_t) upc_P * n_filters : (size_t) n_filters * nph) * N * elem(), false)) return false;
 	if (upc_P && !upc_buf.alloc((size_t) upc_P * S * pps * N * elem())) return false;      // (a float32 stage's delay line holds float2: half the traffic)
 	log_msg(LL_VERBOSE, "%s: info: device buffers ring %p (%zu MB) W %p (%zu MB) H %p", name.c_str(), ring_dev, ring.bytes >> 20, W.p, W.bytes >> 20, H.p);
 	if (!prepare_filters(sp)) return false;
@@ -568,7 +568,7 @@ bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStrea
 bool ConvStage::init_upc(const Spec &sp, ssize_t max_frames)
 {
 	static const int max_slots = [] { const char *e = getenv("DSP_AMD_CONV_UPC"); return (!e || atoi(e) == 1) ? 12 : atoi(e); }();   // 0 = never, n > 1 = up to n slots
-	if (max_slots < 2 || resampler || nph != 1 || n_filters != 1 || merged_pre) return true;      // (`fir`'s / zita's latency is the child's too: its windows start lat frames earlier)
+	if (max_slots < 2 || resampler || nph != 1 || merged_pre) return true;      // (`fir`'s / zita's latency is the child's too: its windows start lat frames earlier)
 	// the block: the largest power of two that divides the call size (a call is then a whole number of blocks)
 	long F = 1L << (FFT_MAX_LOG2_N2 + FFT_MAX_LOG2_N1 - 1);
 	while (F > 1 && (max_frames % F)) F >>= 1;
@@ -597,7 +597,7 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 	static const int env = [] { const char *e = getenv("DSP_AMD_CONV_FDL"); return e ? atoi(e) : -1; }();   // 0 = never, P1 = force that many head partitions
 	// (`fir` / the zita contract: every window lat frames earlier, head and tail alike; the zita contract's float32 roundings are those of
 	// its inputs -- already in the rings --, of its taps and of the finished output: transforms and delay lines stay fp64 here)
-	if (env == 0 || resampler || nph != 1 || n_filters != 1 || merged_pre) return true;
+	if (env == 0 || resampler || nph != 1 || merged_pre) return true;
 	if (max_frames < 256 || (long) max_frames * 8 > T) return true;
 	long b = 2048;
 	while (b >= 256 && (max_frames % b)) b >>= 1;
@@ -625,18 +625,20 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 	const long n_pairs = (long) S * pps;
 	// conv_fdl addresses a pair's delay-line slots and its ring row with 32-bit byte offsets (buffer descriptors)
 	if ((double) fP1 * n_pairs * fNF * sizeof(double2) >= 2.0e9 || (double) ring_len * sizeof(double2) >= 2.0e9) return true;   // (regime off: one transform per call)
-	if (!fdl_buf.alloc((size_t) fP1 * n_pairs * fNF * sizeof(double2)) || !fdl_H.alloc((size_t) fP1 * fNF * sizeof(double2), false)) return false;
+	if (!fdl_buf.alloc((size_t) fP1 * n_pairs * fNF * sizeof(double2)) || !fdl_H.alloc((size_t) n_filters * fP1 * fNF * sizeof(double2), false)) return false;
 	std::vector<double2> t;
 	make_twiddles(fNF, fNF, 1, t);
 	if (!fdl_tw.upload(t.data(), t.size() * sizeof(double2))) return false;
 	{
 		// head partition spectra: partition q = taps [q B, q B + B), zero-padded to 2 B, through the kernel's own forward transform
-		std::vector<double2> rows((size_t) fP1 * fNF, make_double2(0.0, 0.0));
-		for (int q = 0; q < fP1; ++q)
-			for (long i = 0; i < fB && q * fB + i < T; ++i) {
-				const double t = sp.taps[(size_t) (q * fB + i) * sp.fch];
-				rows[(size_t) q * fNF + i].x = round_f32 ? (double) (float) t : t;
-			}
+		// (one set of rows per filter: a shared filter, or one per selected channel, fir_p.c:483-495)
+		std::vector<double2> rows((size_t) n_filters * fP1 * fNF, make_double2(0.0, 0.0));
+		for (int f = 0; f < n_filters; ++f)
+			for (int q = 0; q < fP1; ++q)
+				for (long i = 0; i < fB && q * fB + i < T; ++i) {
+					const double t = sp.taps[(size_t) (q * fB + i) * sp.fch + (sp.fch == 1 ? 0 : f)];
+					rows[((size_t) f * fP1 + q) * fNF + i].x = round_f32 ? (double) (float) t : t;
+				}
 		DevBuf d_rows;
 		if (!d_rows.upload(rows.data(), rows.size() * sizeof(double2))) return false;
 		FdlParams fp;
@@ -646,7 +648,7 @@ bool ConvStage::init_fdl(const Spec &sp, ssize_t max_frames)
 		fp.n_sub = 1;
 		fp.spec_out = fdl_H.as<double2>(); fp.h_scale = 1.0 / (double) fNF;
 		fp.tw_nf = fdl_tw.as<double2>();
-		fp.n_pairs = fP1; fp.C = ch_in; fp.pairs_per_stream = 1;
+		fp.n_pairs = (long) n_filters * fP1; fp.C = ch_in; fp.pairs_per_stream = 1;
 		launch_conv_fdl(fp, nullptr);
 		if (!hip_ok(hipDeviceSynchronize(), "head partition spectra")) return false;
 	}
@@ -696,6 +698,7 @@ void ConvStage::run_fdl(ssize_t frames, double *out, long out_stride, hipStream_
 		fp.slot0 = f_slot;
 		fp.fdl = fdl_buf.as<double2>();
 		fp.Hf = fdl_H.as<double2>();
+		fp.pair_h = (n_filters > 1) ? pair_h.as<int>() : nullptr;
 		fp.tw_nf = fdl_tw.as<double2>();
 		fp.n_pairs = (long) S * pps;
 		fp.C = ch_in; fp.pairs_per_stream = pps;
@@ -767,13 +770,15 @@ bool ConvStage::spectrum_f32(const std::vector<double> &src, long n_taps, int st
 bool ConvStage::prepare_filters(const Spec &sp)
 {
 	if (upc_P) {
-		// partition q = taps [q B, q B + B) of the (one, shared) filter, zero-padded to the transform
-		for (int q = 0; q < upc_P; ++q) {
-			const long lo = (long) q * upc_B, n = std::min<long>(upc_B, T_taps - lo);
-			std::vector<double> part((size_t) n);
-			for (long i = 0; i < n; ++i) part[(size_t) i] = sp.taps[(size_t) (lo + i) * sp.fch];
-			if (!(f32 ? spectrum_f32(part, n, 1, 0, (size_t) q, 1) : spectrum_of(part, n, 1, 0, H.as<double2>() + (size_t) q * N, 1))) return false;
-		}
+		// partition q = taps [q B, q B + B) of filter f (one shared filter, or one per selected channel: fir_p.c:483-495), zero-padded to the transform
+		for (int f = 0; f < n_filters; ++f)
+			for (int q = 0; q < upc_P; ++q) {
+				const long lo = (long) q * upc_B, n = std::min<long>(upc_B, T_taps - lo);
+				std::vector<double> part((size_t) n);
+				for (long i = 0; i < n; ++i) part[(size_t) i] = sp.taps[(size_t) (lo + i) * sp.fch + (sp.fch == 1 ? 0 : f)];
+				const size_t idx = (size_t) f * upc_P + q;
+				if (!(f32 ? spectrum_f32(part, n, 1, 0, idx, 1) : spectrum_of(part, n, 1, 0, H.as<double2>() + idx * N, 1))) return false;
+			}
 		return true;
 	}
 	for (int f = 0; f < n_filters * nph; ++f) {

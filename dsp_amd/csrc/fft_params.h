@@ -76,7 +76,8 @@ struct FdlParams {
 	int n_sub;                          // sub-blocks of B frames handled by this launch, one after the other
 	int slot0;                          // delay-line slot written by sub-block 0; sub-block b writes (slot0 + b) % P1
 	double2 *fdl;                       // [P1][n_pairs][NF] spectra of the last P1 windows, in the transform's own (natural) order
-	const double2 *Hf;                  // [P1][NF] spectra of the zero-padded head partitions, pre-scaled by 1 / NF
+	const double2 *Hf;                  // [n_filters][P1][NF] spectra of the zero-padded head partitions, pre-scaled by 1 / NF
+	const int *pair_h;                  // [n_pairs] filter of the pair (one filter per channel, fir_p.c:483-495), or nullptr: every pair uses filter 0
 	double2 *spec_out;                  // preparation mode: write h_scale x forward transform here ([n_pairs][NF]) and stop
 	double h_scale;
 	const double2 *tw_nf;               // exp(-2 pi i k / NF)

@@ -282,7 +282,10 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 	const long pair_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) ((active ? pair : 0) >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) (active ? pair : 0))) : 0;
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
 	const __amdgpu_buffer_rsrc_t r_fdl = __builtin_amdgcn_make_buffer_rsrc(p.fdl + (BUF ? pair_u * NF : 0), 0, 0x7fffffff, RSRC_FLAGS);
-	const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.Hf), 0, 0x7fffffff, RSRC_FLAGS);
+	// the pair's filter (wave-uniform where the descriptors are used: rows of whole waves)
+	const long h_off = (p.pair_h && active) ? (long) p.pair_h[pair] * p.P1 * NF : 0;
+	const long h_off_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) (h_off >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) h_off)) : 0;
+	const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.Hf) + h_off_u, 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.ring) + (BUF ? pair_u * p.ring_row_stride : 0), 0, 0x7fffffff, RSRC_FLAGS);
 	// (32-bit byte offsets: the host only enters this regime when the delay line of a pair's slots and a ring row stay below 2 GB)
 	const int jb = j * 16;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 				for (int m = 0; m < 16; ++m) line[(size_t) slot * slot_stride + P * m] = v[m];
 			}
 			{
-				const cplx *H = p.Hf + j;
+				const cplx *H = p.Hf + h_off + j;
 #pragma unroll
 				for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], H[P * m]);
 			}
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 				for (int q = 1; q < p.P1; ++q) {
 					const int sl = (slot + p.P1 - q) % p.P1;
 					const cplx *X = line + (size_t) sl * slot_stride;
-					const cplx *H = p.Hf + (size_t) q * NF + j;
+					const cplx *H = p.Hf + h_off + (size_t) q * NF + j;
 					// (eight bins at a time: two workgroups per CU need the kernel inside 256 registers)
 #pragma unroll
 					for (int half = 0; half < 2; ++half) {

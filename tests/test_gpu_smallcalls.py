@@ -98,6 +98,48 @@ def test_mid_size_calls_vs_real_reference(amd, tmp_path, taps, block, S, C, chai
         assert rms(y[s] - ref) < 1e-12, (s, rms(y[s] - ref))
 
 
+def filt_channels(tmp_path, taps, n, name="hn.raw"):
+    """a filter file of n channels: one filter per selected channel, in channel order (fir_p.c:483-495, fir.c:342-357)"""
+    hs = []
+    for c in range(n):
+        rng = np.random.default_rng(70 + c)
+        h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / (6.0 + c)))
+        hs.append(h / np.sqrt(np.sum(h * h)) / 4.0)
+    p = os.path.join(str(tmp_path), name)
+    np.asarray(np.stack(hs, axis=1), dtype="<f8").tofile(p)
+    return p
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("taps,block,S,C,sel,regime", [
+    (65536, 2048, 2, 4, "", "small-calls"),                       # four filters of the headline's length at the reference's block: head 4 x 2048 + delay-line tail, a filter per pair
+    (20000, 1024, 2, 3, "", "small-calls"),                       # odd channel count, plain tail
+    (7000, 512, 2, 4, ":1,3 ", "small-calls"),                    # two of four channels, two filters: the whole filter in the head's delay line
+    (65536, 8192, 2, 4, "", "mid-size-calls"),                    # the row kernel's delay line with a row of partition spectra per filter
+    (40000, 4096, 2, 2, "", "mid-size-calls"),
+    (30000, 8192, 2, 5, ":0,2,4 ", "mid-size-calls"),
+])
+def test_one_filter_per_channel_in_the_call_size_regimes(amd, tmp_path, taps, block, S, C, sel, regime):
+    """round 4: a filter file with one filter per selected channel (fir_p.c:483-495) in the small-call and mid-size-call regimes (round 3 sent it
+    down the one-transform-per-call plan): every pair carries one channel and reads its own filter's partition spectra"""
+    import torch
+    n_sel = C if not sel else len(sel.strip(": ").split(","))
+    p = filt_channels(tmp_path, taps, n_sel)
+    chain = f"{sel}fir_p -t pcm -e double -c {n_sel} {p}"
+    F = block & -block
+    n_blocks = (2 * (-(-taps // F)) + 2) * F // block + 1 if regime == "mid-size-calls" else 2 * 8 + 3
+    if taps >= 65536 and regime == "small-calls": n_blocks = 5 * 8 + 3
+    N = n_blocks * block
+    x = np.stack([noise(N, C, 700 + s) for s in range(S)])
+    b = amd.BatchChain(chain, 48000, C, S, block)
+    assert regime in b.plan() and "per-channel-filters" in b.plan(), b.plan()
+    y = b.process(torch.from_numpy(x).cuda(), block).cpu().numpy()
+    for s in range(S):
+        ref = RefChain(chain, 48000, C).process(x[s], block=block)
+        assert y[s].shape == ref.shape, (y[s].shape, ref.shape)
+        assert rms(y[s] - ref) < 1e-12, (s, rms(y[s] - ref))
+
+
 def test_mid_size_calls_off_the_grid_and_reset(amd, tmp_path):
     """a stream that leaves the grid (a short call) carries on from the rings with one transform per call; reset() returns it
     to the delay-line path; both equal a batch created for long calls"""
