@@ -180,6 +180,12 @@ private:
 	int fuse_seg = 1;
 	bool fuse_accepts(const void *in, long in_stride, ssize_t frames, int in_fmt) const;
 	bool run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st);
+	// ... and with NO cascade in front (fir_p first in the chain, 8 channels, calls of one whole hop): the same first pass with one pass-through section
+	// and all-zero states -- no prepass, no scan -- in place of K1's slab-direct form: two pairs of a frame per lane pair instead of one (K1 reads 16 of a
+	// frame's 64 bytes per workgroup: 8.9 ms at the headline shape against 6.9)
+	bool fuse_plain = false;
+	DevBuf plain_sec, plain_op, plain_X;
+	bool run_fused_plain(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st);
 };
 
 std::string ConvStage::describe() const
@@ -189,7 +195,7 @@ std::string ConvStage::describe() const
 	if (resampler) o << " " << fs_in << "->" << fs_out << " " << up << "/" << down << " delay=" << out_delay;
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
-	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? " slab-direct" : "");
+	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? (fuse_plain ? " slab-direct(two pairs per workgroup at whole hops)" : " slab-direct") : "");
 	if (fuse_static) o << " cascade-fused(" << (N1 - first_n / N2) * fuse_seg << " chunks of " << N2 / fuse_seg << ")";
 	if (skip) o << " drops-first=" << skip;
 	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N;
@@ -490,6 +496,18 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 				feeder_->fuse_probe = [this](const void *in, long in_stride, ssize_t frames, int in_fmt) { return fuse_accepts(in, in_stride, frames, in_fmt); };
 			}
 		}
+		if (fuse_on && !feeder_ && !fed && !ring_parent && direct && !upc_conv && !fdl && !resampler && nph == 1 && n_filters == 1 && !f32 && !round_f32 && lat == 0
+		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && (hist_rows == 16 || hist_rows == 32) && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
+		    && (double) B * ch_in * sizeof(double) < 2.0e9 && (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9 && fused_section_slots(1) == 1) {
+			const long groups = (long) S * (pps / 2);
+			fuse_seg = 1;
+			while (fuse_seg < 4 && groups * fuse_seg < 224 && (N2 / 8) % (4 * fuse_seg) == 0) fuse_seg *= 2;
+			const double one[6] = { 1.0, 0.0, 0.0, 0.0, 0.0, 0.0 };        // r = s + m0;  m0 = m1;  m1 = 0: the sample itself, bit for bit, from zero states
+			const int op0 = 0;
+			const long K = (N1 - hist_rows) * fuse_seg;
+			if (plain_sec.upload(one, sizeof(one)) && plain_op.upload(&op0, sizeof(op0)) && plain_X.alloc((size_t) S * K * ch_in * 2 * sizeof(double), true)) fuse_plain = true;
+			else { (void) hipGetLastError(); plain_sec.release(); plain_op.release(); plain_X.release(); }
+		}
 	}
 	return true;
 }
@@ -504,6 +522,38 @@ bool ConvStage::fuse_accepts(const void *in, long in_stride, ssize_t frames, int
 	const char *me = getenv("DSP_AMD_FUSE_MM");
 	if (me && atoi(me) == 0) return false;
 	return wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && (((size_t) in) & 7) == 0;
+}
+
+bool ConvStage::run_fused_plain(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
+	const long hist_rows = first_n / N2;
+	FuseParams f;
+	memset(&f, 0, sizeof(f));
+	f.in = in; f.in_stride_frames = in_stride; f.in_fmt = PCM_DOUBLE;
+	f.C = ch_in; f.n_sec = 1; f.n_ops = 1;
+	f.sec_op = plain_op.as<int>();
+	f.gain = 1.0;
+	f.seg = fuse_seg; f.hist_rows = (int) hist_rows;
+	f.K = (N1 - hist_rows) * fuse_seg; f.len = N2 / fuse_seg;
+	f.X = plain_X.as<double>();
+	f.n_streams = S;
+	ConvParams p = base_params();
+	p.win_base = (q_abs - first_n) & (ring_len - 1);
+	p.first_n = first_n;
+	p.valid = N;
+	p.out = out;
+	p.out_stride_frames = out_stride;
+	p.sink = wire_sink;
+	p.in_count = frames;
+	p.q_blk = q_abs;
+	p.k_origin = q_abs;
+	p.out_count = frames;
+	p.k3_pipe_ok = (all_selected && n_filters == 1 && pps == 4 && ch_in == 8 && !feeds && ((((size_t) out) & 15) == 0)) ? 1 : 0;
+	p.pair0 = 0; p.stream0 = 0; p.n_streams_launch = S;
+	{ ProfScope ps("fused_col_fwd", st); if (!launch_fused_col_fwd(p, f, plain_sec.as<double>(), st)) return false; }
+	{ ProfScope ps("conv_row", st); launch_conv_row(p, 0, (int) ((long) S * pps), st); }
+	{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) ((long) S * pps), st); }
+	return true;
 }
 
 bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st)
@@ -944,6 +994,15 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 	if (feeder_ && feeder_->pending.in) {
 		// (the feeding cascade left this call to the fused kernels: fuse_accepts said yes to exactly this call)
 		if (!run_fused(frames, out, out_stride, st)) { set_error("%s: fused first pass could not be launched", name.c_str()); return PIPE_FAILED; }
+		q_abs += frames;
+		feed_pos = (feed_pos + frames) & feed_mask;
+		pos = (pos + frames) & (ring_len - 1);
+		return frames;
+	}
+	if (fuse_plain && use_direct && wire_in_fmt == PCM_DOUBLE && frames == B && skip_left == 0 && !feeds && (q_abs & 7) == 0) {
+		// (one whole hop straight from the slab: the first pass in its two-pairs-per-workgroup form; it files the rows the next window looks back at)
+		if (!run_fused_plain(in, in_stride, frames, out, out_stride, st)) { set_error("%s: fused first pass could not be launched", name.c_str()); return PIPE_FAILED; }
+		cur_slab = nullptr;
 		q_abs += frames;
 		feed_pos = (feed_pos + frames) & feed_mask;
 		pos = (pos + frames) & (ring_len - 1);

@@ -157,3 +157,32 @@ def test_fused_path_with_poles_next_to_the_unit_circle(amd, tmp_path):
             # is stated against the level of the input, where both are 3e-13 .. 6e-13
             e = rms(ref - got) / rms(x)
             assert e < 3e-12, (name, s, e, rms(ref), rms(x))
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("taps,B,S,C", [(16384, 245760, 8, 8), (32768, 229376, 3, 8), (16384, 245760, 130, 4)])
+def test_fir_p_first_in_the_chain_takes_the_two_pair_first_pass(amd, tmp_path, taps, B, S, C):
+    """no cascade in front (BASELINE config 3's shape): calls of one whole hop go through the fused first pass with a pass-through section and zero
+    states instead of K1's slab-direct form -- the same samples into the same transform.  Against the separate kernels and the real reference,
+    across a call off the grid (K1 on the rings the fused pass filed) and back."""
+    import torch
+    f = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(make_filter(taps, seed=taps + 1), dtype="<f8").tofile(f)
+    chain = f"fir_p -t pcm -e double -c 1 {f}"
+    bf, bs = build(amd, chain, C, S, B, True), build(amd, chain, C, S, B, False)
+    assert "two pairs per workgroup" in bf.plan(), bf.plan()
+    assert "two pairs per workgroup" not in bs.plan(), bs.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    sizes = [B, B, 5000, B, 8 * 100, B]          # (the last hop starts at a multiple of 8 again: fused)
+    xs = [torch.rand((S, n, C), dtype=torch.float64, device="cuda", generator=g) - 0.5 for n in sizes]
+    yf = [bf.run(x).clone() for x in xs]
+    ys = [bs.run(x).clone() for x in xs]
+    for a, b_ in zip(yf, ys):
+        assert float((a - b_).abs().max()) < 1e-13
+    for s in sorted({0, S // 2, S - 1}):
+        x = torch.cat([t[s] for t in xs], dim=0).cpu().numpy()
+        ref = RefChain(chain, 48000, C).run(x)
+        got = torch.cat([t[s] for t in yf], dim=0).cpu().numpy()
+        assert rms(ref - got) < 1e-12, (s, rms(ref - got))
+    bf.reset()
+    assert torch.equal(bf.run(xs[0]), yf[0])
