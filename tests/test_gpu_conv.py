@@ -114,6 +114,20 @@ def test_fir_latency_semantics(amd, tmp_path, taps):
     assert r.drain_frames() == ec.drain_frames()
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("block", [2048, 700])
+def test_fir_then_a_mix_then_fir_p_at_small_calls(amd, tmp_path, block):
+    """a convolver that reads its slab directly must not swallow the discard of an upstream `fir`'s latency (the dropped frames would
+    never reach its rings): `fir A` + a mix stage + `fir_p B` at calls shorter than B's history, against the real reference"""
+    fa, fb = write(tmp_path, make_filter(300, 11, 40.0)), os.path.join(str(tmp_path), "b.raw")
+    np.asarray(make_filter(5000, 12, 900.0), dtype="<f8").tofile(fb)
+    chain = f"fir -t pcm -e double -c 1 {fa} st2ms gain -1 fir_p -t pcm -e double -c 1 {fb}"
+    x = noise(40000, 2, 36)
+    ref = RefChain(chain, 48000, 2).process(x, block=block)
+    y = amd.EffectsChain(chain, 48000, 2).process(x, block=block)
+    assert y.shape == ref.shape and rms(y - ref) < TOL, (y.shape, ref.shape, rms(y - ref))
+
+
 def test_fir_align_option(amd, tmp_path):
     # -a: the filter's peak becomes time zero (fir_util.c:187-205), reported as a negative requested delay.
     # On all channels that only moves the chain's zero reference; on a subset the OTHER channels get delayed
