@@ -131,6 +131,29 @@ def test_host_buffer_of_many_pipeline_calls(amd):
     assert rms(np.concatenate([y, y2]) - ref) < TOL
 
 
+def test_host_buffers_of_many_calls_from_two_threads(amd):
+    """two host threads, a chain each, buffers of several pipeline calls at the same time: the staging copies' helper threads serve one block at a
+    time (the other thread copies on its own, engine.cpp: CopyCrew::copy) -- same samples as each chain run alone"""
+    import threading
+    chain = "lowshelf 100 0.8s 6 eq 1k 1.2 -3 gain -2"
+    frames, ch = 6 * 65536 + 777, 8
+    xs = [noise(frames, ch, 50 + i) for i in range(2)]
+    alone = []
+    for x in xs:
+        ec = amd.EffectsChain(chain, 48000, ch)
+        alone.append([ec.run(x) for _ in range(3)])
+    got = [None, None]
+    def work(i):
+        ec = amd.EffectsChain(chain, 48000, ch)
+        got[i] = [ec.run(xs[i]) for _ in range(3)]
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for i in range(2):
+        for a, b in zip(alone[i], got[i]):
+            assert np.array_equal(a, b)
+
+
 def test_plugin_abi_run(amd):
     """Drive one effect through the reference's plugin surface: init -> run -> destroy (effect.h:24-59)."""
     import ctypes as C
