@@ -344,7 +344,9 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	// behind a cascade, with 256-row windows: when the calls are exactly what is left of the window after 16 (or 32) WHOLE rows of history, take
 	// that much history -- more of it than overlap-save needs costs nothing (the hop is the call either way), and the cascade can then be fused
 	// into the first pass (below): a 50000-tap filter on 983040-frame calls is served like the 65536-tap one
-	if (feeder && !ring_parent && !upc_block && !force_N && log2N1 == 8 && sp.kind != Kind::Resample && lat == 0) {
+	// (the same for a convolver that reads its slab directly -- fir_p first in the chain: its whole-hop calls take the fused first pass too)
+	const bool slab_direct_plan = !feeder && all_selected && n_filters == 1 && (ch_in % 2) == 0 && !round_f32 && !getenv("DSP_AMD_CONV_NO_DIRECT");
+	if ((feeder || slab_direct_plan) && !ring_parent && !upc_block && !force_N && log2N1 == 8 && sp.kind != Kind::Resample && lat == 0) {
 		for (long rows : { 16L, 32L }) {
 			const long fn = rows * N2;
 			if (fn >= first_n && N - fn == (long) max_frames) { first_n = fn; B = N - fn; break; }

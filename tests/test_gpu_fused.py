@@ -160,7 +160,7 @@ def test_fused_path_with_poles_next_to_the_unit_circle(amd, tmp_path):
 
 
 @pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
-@pytest.mark.parametrize("taps,B,S,C", [(16384, 245760, 8, 8), (32768, 229376, 3, 8), (16384, 245760, 130, 4)])
+@pytest.mark.parametrize("taps,B,S,C", [(16384, 245760, 8, 8), (32768, 229376, 3, 8), (16384, 245760, 130, 4), (11111, 245760, 4, 8)])      # (the last: a filter shorter than 16 rows takes 16 whole rows of history)
 def test_fir_p_first_in_the_chain_takes_the_two_pair_first_pass(amd, tmp_path, taps, B, S, C):
     """no cascade in front (BASELINE config 3's shape): calls of one whole hop go through the fused first pass with a pass-through section and zero
     states instead of K1's slab-direct form -- the same samples into the same transform.  Against the separate kernels and the real reference,
