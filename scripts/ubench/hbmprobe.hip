@@ -236,6 +236,17 @@ int main(int argc, char **argv)
 			const double t2 = time_ms([&] { k_col<256, 256><<<dim3((unsigned) (n2 / 16), np), 256>>>(a, b, pitch, pitch, pair, pair, 1, 0); }, reps);
 			printf("N2 %5ld pad %3ld : 128 B runs %6.2f   256 B runs %6.2f\n", n2, pad, (double) np * 256 * n2 * 16 / t / 1e9, (double) np * 256 * n2 * 16 / t2 / 1e9);
 		}
+	// K1's WRITE pattern (round 4: would 4-column tiles do?): 64- / 128- / 256-byte runs x 256 rows at the row pitch of the transform; store only
+	printf("# K1 write pattern: runs x 256 rows, pitch = N2 + 16 points; store-only TB/s\n");
+	for (long n2 : { 1024L, 4096L }) {
+		const long pitch = n2 + 16, pair = 256 * pitch + 272;
+		const int np = (int) (bytes / ((size_t) pair * 16));
+		const double t4 = time_ms([&] { k_col<64, 256><<<dim3((unsigned) (n2 / 4), np), 64>>>(a, b, pitch, pitch, pair, pair, 0, 1); }, reps);
+		const double t8 = time_ms([&] { k_col<128, 256><<<dim3((unsigned) (n2 / 8), np), 128>>>(a, b, pitch, pitch, pair, pair, 0, 1); }, reps);
+		const double t16 = time_ms([&] { k_col<256, 256><<<dim3((unsigned) (n2 / 16), np), 256>>>(a, b, pitch, pitch, pair, pair, 0, 1); }, reps);
+		const double by = (double) np * 256 * n2 * 16;
+		printf("N2 %5ld : 64 B runs %6.2f   128 B runs %6.2f   256 B runs %6.2f\n", n2, by / t4 / 1e9, by / t8 / 1e9, by / t16 / 1e9);
+	}
 	printf("# K3 as launched (512 threads, 4 pairs, 128 B read runs, 512 B write runs): TB/s of bytes moved\n");
 	for (long n2 : { 1024L, 2048L, 4096L })
 		for (long pad : { 0L, 16L })
