@@ -222,6 +222,8 @@ def test_random_chains_print_the_reference_text(seed):
     (3, f"gain -3 remix 0 1,2 0,2 fir {COEFS40} :1,2 st2ms", 3),
     (2, "delay -f 0.3S :1 delay -f1 2.7S", None),
     (2, "delay -f5 2.3S :0 delay -f3 0.4S", None),                                    # the reference prints the ladder, this library its sections
+    (2, "delay -f34 0.3S :1 delay -f41 12.77S", None),                                # round 4: the poles of orders above 33 in 113-bit arithmetic (thiran_roots.cpp)
+    (1, "delay -f50 0.5S", None),
     (2, "lowpass -r 1k 0.707", None),
     (2, "lowpass 2k 0.707 lowpass -r 2k 0.707 :0 highpass -r60 30 0.707", None),
     (1, "eq -r 400 2.0 1.5 highshelf -r 8k 0.7 -3 lowpass_1 -r 300", None),
