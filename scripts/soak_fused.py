@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Soak of the fused first pass (with and without a cascade in front): random sequences of call sizes -- whole hops, short calls, calls off the 8-frame
+grid, resets -- on random shapes, every output compared with the separate kernels' (DSP_AMD_FUSE=0) on the same inputs.  usage: soak_fused.py [seeds=24]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import dsp_amd
+SEC = ["lowpass 1k 0.707", "highshelf 8k 0.7 -3", "eq 100 1.0 3", "eq 200 1.0 -2", "eq 400 2.0 1.5", "eq 800 1.0 -1", "eq 1600 1.4 2", "eq 3200 1.0 -2.5",
+       "eq 6400 3.0 1", "highpass 20 0.707", "lowshelf 150 0.8 2", "eq 5000 2.0 -1.5"]
+
+
+def build(chain, C, S, B, fuse):
+    os.environ["DSP_AMD_FUSE"] = "1" if fuse else "0"
+    try: return dsp_amd.BatchChain(chain, 48000, C, S, B)
+    finally: os.environ.pop("DSP_AMD_FUSE")
+
+
+def main(n_seeds):
+    worst = 0.0
+    for seed in range(n_seeds):
+        rng = np.random.default_rng(1000 + seed)
+        rows = int(rng.choice([16, 32]))
+        N2 = 1024
+        taps = int(rng.integers(rows * N2 // 2, rows * N2 + 1))
+        B = 256 * N2 - rows * N2
+        C = int(rng.choice([4, 8])); S = int(rng.choice([1, 2, 5, 9, 40]))
+        nsec = int(rng.integers(0, 13))
+        h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / 4000.0); h = h / np.sqrt(np.sum(h * h)) / 4
+        f = f"/tmp/soak_{seed}.raw"; np.asarray(h, dtype="<f8").tofile(f)
+        secs = list(rng.choice(SEC, size=nsec, replace=False)) if nsec else []
+        if nsec and rng.random() < 0.4: secs.insert(int(rng.integers(0, len(secs) + 1)), "gain -1.5")
+        chain = " ".join(secs) + f" fir_p -t pcm -e double -c 1 {f}"
+        bf, bs = build(chain, C, S, B, True), build(chain, C, S, B, False)
+        fusedplan = ("cascade-fused" in bf.plan()) or ("two pairs per workgroup" in bf.plan())
+        g = torch.Generator(device="cuda"); g.manual_seed(seed)
+        err = 0.0
+        for step in range(7):
+            r = rng.random()
+            n = B if r < 0.55 else int(rng.choice([8 * int(rng.integers(1, 600)), int(rng.integers(1, 5000)), B // 2]))
+            if rng.random() < 0.1: bf.reset(); bs.reset()
+            x = torch.rand((S, n, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+            a, b = bf.run(x).clone(), bs.run(x).clone()
+            assert a.shape == b.shape and bool(torch.isfinite(a).all())
+            err = max(err, float((a - b).abs().max()))
+        print(f"seed {seed}: rows {rows} taps {taps} S {S} C {C} sections {len(secs)} fused-plan {fusedplan}  max |fused - separate| = {err:.2e}", flush=True)
+        worst = max(worst, err)
+        os.remove(f)
+        del bf, bs
+    print("worst", worst)
+    assert worst < 1e-12
+
+
+if __name__ == "__main__":
+    torch.cuda.set_device(0)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 24)
