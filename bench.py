@@ -203,6 +203,28 @@ def main():
         for k, v in CONFIGS[args.config].items():
             setattr(args, k, v)
 
+    # `python bench.py --gpus N` with no launcher around it starts its own N ranks: the same torch.distributed.run command the driver
+    # uses (one process per GPU, rendezvous on 127.0.0.1), with this process only waiting for them.  Under a launcher (WORLD_SIZE set)
+    # the world must be what --gpus says: a line that claims N GPUs is never printed by another number of ranks.
+    backend = os.environ.get("DSP_AMD_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        import torch
+        n_dev = torch.cuda.device_count()
+        if backend == "nccl" and n_dev < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but {n_dev} GPU(s) visible: refusing (one rank per GPU; DSP_AMD_BENCH_BACKEND=gloo is the test switch that lets ranks share a GPU)\n")
+            sys.exit(2)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: refusing to print a line for another number of ranks than it claims\n")
+        sys.exit(2)
+
     # every DSP_AMD_* switch that is set is printed with the result (they select between equivalent kernels / plans; the
     # library has no switch that skips work: round 1's DSP_AMD_CASCADE_DEBUG was removed from the kernels)
     env_set = {k: v for k, v in sorted(os.environ.items()) if k.startswith("DSP_AMD_")}
@@ -213,13 +235,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE\n")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     # one rank per GPU; DSP_AMD_BENCH_BACKEND=gloo (a test switch) lets several ranks share the GPUs there are -- the sharding, setup
     # broadcast, digest gathering and timing reductions run as they do over RCCL, on a box with one GPU
-    backend = os.environ.get("DSP_AMD_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible: one rank per GPU\n")
+        sys.exit(2)
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     L = dsp_amd.load_library()
@@ -375,7 +396,8 @@ def main():
             "config": {"workload": (f"{S_total} streams x {C} ch @ {fs} Hz, chain = 10 biquads + fir_p({args.taps} taps), {args.block} frames/step/stream" if not (args.config or args.chain)
                                     else f"{S_total} streams x {C} ch @ {fs} Hz, chain = {chain_t}, {args.block} frames/step/stream"),
                        "streams": S_total, "channels": C, "block_frames": args.block, "taps": args.taps, "slab_pad_frames": args.slab_pad,
-                       "parallelism": f"streams sharded {S_total // world}/GPU, no data-plane collective", "plan": plan},
+                       "parallelism": f"streams sharded {S_total // world}/GPU, no data-plane collective",
+                       "plan": plan},
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved * 1e9 / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": dom[1]["avg_ms"], "launches_per_step": launches_per_step,
@@ -386,6 +408,11 @@ def main():
             "digest": {"of": "step 0 of the stream (same for every --warmup / --steps)", "streams": int(dig.shape[0]), "frames": int(f0),
                        "sum_of_squares": float(dig[:, 1].sum().item()), "peak": float(dig[:, 2].max().item())},
         }
+        if world > 1:
+            # (N = 1 prints the line it always printed; a multi-rank line also says who ran what and over which communicator)
+            res["config"]["ranks"] = [{"rank": r, "streams": list(stream_range(S_total, r, world))} for r in range(world)]
+            res["config"]["communicator"] = {"backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend, "ranks": world, "communicators": 1,
+                                             "collectives": "setup broadcast, barriers around the timed region, digest all-gather, max / sum of timings and counts"}
         if picks:
             res["parity"] = parity_of_first_step(chain, filt_dir, fs, picks)
             res["parity"]["pick_seed"] = pick_seed

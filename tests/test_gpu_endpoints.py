@@ -401,3 +401,32 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert d["digest"]["streams"] == 24                       # every rank's streams are in the gathered digests
     assert d["config"]["streams"] == 24 and "12/GPU" in d["config"]["parallelism"]
     assert abs(d["value"] - 24 * 8 * 16384 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) < 1e-6 * d["value"]     # whole-job samples over the max-over-ranks time
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: it starts its own two ranks (the torch.distributed.run
+    command the driver uses), here sharing the one GPU over gloo; the one line says n_gpus == 2, who ran which streams and over what."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DSP_AMD_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "24", "--block", "16384", "--taps", "4096", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["output_finite"]
+    assert d["config"]["ranks"] == [{"rank": 0, "streams": [0, 12]}, {"rank": 1, "streams": [12, 24]}]
+    assert d["config"]["communicator"]["ranks"] == 2 and d["config"]["communicator"]["backend"] == "gloo"
+    assert d["digest"]["streams"] == 24
+    # without the test switch two ranks need two GPUs: on a one-GPU box the command refuses (non-zero exit, no line)
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("DSP_AMD_BENCH_BACKEND")
+        r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode != 0 and "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
