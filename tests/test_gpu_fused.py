@@ -37,7 +37,7 @@ def build(amd, chain, C, S, B, fuse):
         os.environ.pop("DSP_AMD_FUSE")
 
 
-# (sections, gains, taps, hop, S, C, chunks in the plan): N = 2^18 = 256 x 1024 throughout (hop = N - taps)
+# (sections, gains, taps, hop, S, C, chunks in the plan): N = 2^18 = 256 x 1024 (hop = N - taps) except the last shape, the headline's own N = 2^20 = 256 x 4096
 SHAPES = [
     (10, False, 16384, 245760, 8, 8, "960 chunks of 256"),      # the headline's ten sections, 16 history rows, four segments per row
     (1, True, 16384, 245760, 2, 4, "960 chunks of 256"),        # one section between gains, four segments
@@ -47,6 +47,7 @@ SHAPES = [
     (12, False, 16384, 245760, 120, 8, "240 chunks of 1024"),   # twelve sections, whole rows
     (4, False, 11111, 245760, 8, 8, "960 chunks of 256"),       # a filter shorter than 16 rows: the window takes 16 whole rows of history all the same
     (2, False, 20000, 229376, 4, 4, "896 chunks of 256"),       # ... 32 rows
+    (10, False, 65536, 983040, 112, 8, "240 chunks of 4096"),   # the headline's own instances: N = 2^20 (256 x 4096), whole rows as chunks (seg = 1), fused_prepass_mm<2>
 ]
 
 
@@ -100,6 +101,11 @@ def test_chains_the_fused_kernels_leave_alone(amd, tmp_path):
     np.asarray(make_filter(65536), dtype="<f8").tofile(g)
     b = build(amd, f"lowpass 1k 0.707 fir_p -t pcm -e double -c 1 {g}", 8, 4, 196608, True)      # 64 of the 256 rows are history: the separate kernels are faster
     assert "cascade-fused" not in b.plan(), b.plan()
+    # one filter per channel (fir_p.c:483-495): a pair then carries one channel, the fused first pass works on pairs of a shared filter
+    g8 = os.path.join(str(tmp_path), "h8.raw")
+    np.asarray(np.stack([make_filter(16384, seed=20 + c) for c in range(8)], axis=1), dtype="<f8").tofile(g8)
+    b = build(amd, f"lowpass 1k 0.707 fir_p -t pcm -e double -c 8 {g8}", 8, 4, 245760, True)
+    assert "per-channel-filters" in b.plan() and "cascade-fused" not in b.plan(), b.plan()
     for chain in (f"lowpass 1k 0.707 :0 eq 400 2.0 1.5 : fir_p -t pcm -e double -c 1 {f}",
                   f"lowpass 1k 0.707 add 0.001 fir_p -t pcm -e double -c 1 {f}",
                   f"gain -3 fir_p -t pcm -e double -c 1 {f}",
