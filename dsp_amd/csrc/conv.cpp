@@ -55,8 +55,9 @@ public:
 	{
 		// (a channel that is not convolved passes through the de-interleaving pass, which knows nothing of frames to drop)
 		// (nor for a stage that reads the slab itself: K1 files only what lies behind first_n there -- dropped frames of a short call would never
-		// reach the rings that later windows look back at)
-		if (resampler || feeds || fdl || !all_selected || direct || d <= 0) return false;
+		// reach the rings that later windows look back at.  A stage whose rings are written by the cascade or convolver in front never reads
+		// the slab, whatever `direct` says: the same predicate as run()'s use_direct)
+		if (resampler || feeds || fdl || !all_selected || (direct && !fed) || d <= 0) return false;
 		skip = skip_left = d;
 		return true;
 	}
@@ -518,12 +519,22 @@ bool ConvStage::fuse_accepts(const void *in, long in_stride, ssize_t frames, int
 {
 	(void) in_stride;
 	if (!(fuse_static && frames == B && skip_left == 0 && !feeds && (q_abs & 7) == 0)) return false;
-	if (in_fmt == PCM_DOUBLE) return (((size_t) in) & 15) == 0;
-	// a wire format (the cascade is the first stage of a pipeline run from format to format): read by the matrix-core prepass and by the first
-	// pass themselves -- 8 channels, naturally aligned pairs
-	const char *me = getenv("DSP_AMD_FUSE_MM");
-	if (me && atoi(me) == 0) return false;
-	return wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && (((size_t) in) & 7) == 0;
+	if (in_fmt == PCM_DOUBLE) { if ((((size_t) in) & 15) != 0) return false; }
+	else {
+		// a wire format (the cascade is the first stage of a pipeline run from format to format): read by the matrix-core prepass and by the first
+		// pass themselves -- 8 channels, naturally aligned pairs
+		const char *me = getenv("DSP_AMD_FUSE_MM");
+		if (me && atoi(me) == 0) return false;
+		if (!(wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && (((size_t) in) & 7) == 0)) return false;
+	}
+	// everything run_fused() will need exists before the answer is yes (the chunk plan's state buffers scale with S K C D; a plan is built
+	// once per call shape and kept): after a yes the cascade launches nothing, so a failure in there could no longer be served by the
+	// separate kernels -- a no here still can
+	const long hist_rows = first_n / N2;
+	CascadeStage::ChunkPlan *plan = feeder_->chunk_plan_for(frames, (int) ((N1 - hist_rows) * fuse_seg), N2 / fuse_seg);
+	if (!plan) { (void) hipGetLastError(); return false; }
+	if (in_fmt != PCM_DOUBLE && !feeder_->fuse_gtable(*plan)) { (void) hipGetLastError(); return false; }
+	return true;
 }
 
 bool ConvStage::run_fused_plain(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st)

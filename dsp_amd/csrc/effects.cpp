@@ -457,7 +457,15 @@ SpecPtr make_delay_spec(const char *name, const stream_info *is, const char *sel
 // arithmetic (thiran_roots.cpp), checked by multiplying the double-rounded factors back together, and paired into sections
 // (c2 + c1 z^-1 + z^-2) / (1 + c1 z^-1 + c2 z^-2).  All of the reference's orders (1 .. 50, delay.c's option parser) pass the check; the outputs
 // agree with the reference's ladder to 2e-14 RMS at n = 32 (scripts/exp_ap_orders.py, tests/test_gpu_parity.py).
-static bool thiran_sections(int n, double D, std::vector<std::array<double, 5>> &out) { return thiran_pole_sections(n, D, out); }
+static bool thiran_sections(int n, double D, std::vector<std::array<double, 5>> &out)
+{
+	double sec[33][5];
+	const int got = dspamd_thiran_pole_sections(n, D, &sec[0][0], 33);
+	if (got < 0) return false;
+	out.clear();
+	for (int i = 0; i < got; ++i) out.push_back({ sec[i][0], sec[i][1], sec[i][2], sec[i][3], sec[i][4] });
+	return true;
+}
 
 // delay_effect_prepare (delay.c:149-204): what is left of the summed fractional amounts becomes a first- or
 // second-order Thiran all-pass (allpass.h:46-71) -- the same transfer function as a biquad section

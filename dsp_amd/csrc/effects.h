@@ -112,7 +112,7 @@ void riir_sec_from_biquad(const std::array<double, 5> &c, double thresh, RiirSec
 bool riir_design(const char *name, int channel, std::vector<RiirSec> secs, std::vector<double> &taps, ssize_t *latency, std::string *plot = nullptr);
 bool riir_prepare(Spec &sp);   // the effect's prepare(): section lists -> per-channel FIRs
 SpecPtr make_frac_delay_spec(const char *name, const stream_info *is, const char *sel, double samples_frac, int fd_ap_n, bool *noop);
-bool thiran_pole_sections(int n, double D, std::vector<std::array<double, 5>> &out);   // thiran_roots.cpp (g++: 113-bit arithmetic)
+extern "C" __attribute__((visibility("hidden"))) int dspamd_thiran_pole_sections(int n, double D, double *out, int cap);   // thiran_roots.cpp (host compiler: 113-bit arithmetic); [cap][5] doubles out, sections written or -1
 bool delay_prepare(Spec &sp, bool *noop);   // delay.c:149-204: integer part + Thiran all-pass section per channel
 
 // number of filter terms the reference's fir_p prints in its plot (32 direct taps + the zero-padded partition groups, fir_p.c:242-289)

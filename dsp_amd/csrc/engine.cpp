@@ -120,20 +120,41 @@ MappedPair::~MappedPair()
 }
 
 namespace {
+// Large host-to-pinned copies spread over the caller and three helper threads.  The block is cut into slices that the participants
+// CLAIM one at a time (an atomic counter): a helper that does not get a core -- a cgroup quota, a SCHED_FIFO caller on its CPU --
+// simply claims nothing and the caller copies the whole block itself; the caller only ever waits for slices that are being copied,
+// first spinning, then sleeping so that a preempted helper can run.  The helpers are detached and live as long as the process:
+// the library is linked -z nodelete (Makefile), so a dlclose never unmaps the code under them.  DSP_AMD_COPY_CREW=0: caller alone.
 struct CopyCrew {
 	static constexpr int HELPERS = 3;
+	static constexpr unsigned NS = 16;       // slices per block, whatever its size (a constant: a late helper's claim is judged without reading anything of the block)
 	std::mutex use;                          // one block at a time
 	std::mutex m;
 	std::condition_variable cv;
-	std::atomic<unsigned> gen { 0 };         // one step per block handed out
-	std::atomic<int> pending { 0 };
+	std::atomic<unsigned> gen { 0 };         // one step per block handed out (what the helpers sleep on)
+	std::atomic<uint64_t> next { NS };       // (block number << 32) | the next unclaimed slice of that block
+	std::atomic<unsigned> done { 0 };        // slices of the current block copied
 	char *dst = nullptr;
 	const char *src = nullptr;
 	size_t slice = 0, bytes = 0;
 	int state = 0;                           // 0 not started, 1 running, -1 not available
 	pid_t pid = 0;                           // the process the helpers live in (a forked child has none)
 	static double now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
-	void helper(int i)
+	// claim and copy slices until none is left.  A claim with index < NS belongs to the block whose number came with it, and that
+	// block's fields stay as they are until the slice is counted done (the caller does not move on before); a helper that wakes
+	// up late either finds the counter past NS or claims a slice of a later block -- which is just as valid.
+	void work()
+	{
+		for (;;) {
+			const uint64_t v = next.fetch_add(1, std::memory_order_acq_rel);
+			const unsigned i = (unsigned) (v & 0xffffffffu);
+			if (i >= NS) return;
+			const size_t off = (size_t) i * slice;
+			if (off < bytes) memcpy(dst + off, src + off, std::min(slice, bytes - off));
+			done.fetch_add(1, std::memory_order_release);
+		}
+	}
+	void helper()
 	{
 		unsigned seen = 0;
 		for (;;) {
@@ -148,17 +169,16 @@ struct CopyCrew {
 				__builtin_ia32_pause();
 			}
 			seen = gen.load(std::memory_order_acquire);
-			const size_t off = (size_t) (i + 1) * slice;
-			if (off < bytes) memcpy(dst + off, src + off, std::min(slice, bytes - off));
-			pending.fetch_sub(1, std::memory_order_release);
+			work();
 		}
 	}
 	bool start()
 	{
+		static const bool enabled = [] { const char *e = getenv("DSP_AMD_COPY_CREW"); return !e || atoi(e) != 0; }();
 		cpu_set_t set;
-		if (sched_getaffinity(0, sizeof set, &set) != 0 || CPU_COUNT(&set) < HELPERS + 1) { state = -1; return false; }
+		if (!enabled || sched_getaffinity(0, sizeof set, &set) != 0 || CPU_COUNT(&set) < HELPERS + 1) { state = -1; return false; }
 		try {
-			for (int i = 0; i < HELPERS; ++i) std::thread([this, i] { helper(i); }).detach();
+			for (int i = 0; i < HELPERS; ++i) std::thread([this] { helper(); }).detach();
 		} catch (...) { state = -1; return false; }      // (helpers already started stay asleep: gen never moves)
 		state = 1;
 		pid = getpid();
@@ -170,13 +190,25 @@ struct CopyCrew {
 		if (state == 0) start();
 		if (state == 1 && pid != getpid()) state = -1;
 		if (state != 1) { use.unlock(); memcpy(d, s, n); return; }
+		// (no claim of the previous block is open: all its NS slices were counted done before copy() returned)
 		dst = static_cast<char *>(d); src = static_cast<const char *>(s); bytes = n;
-		slice = ((n + HELPERS) / (HELPERS + 1) + 4095) & ~(size_t) 4095;
-		pending.store(HELPERS, std::memory_order_relaxed);
-		{ std::lock_guard<std::mutex> lk(m); gen.fetch_add(1, std::memory_order_release); }
+		slice = ((n + NS - 1) / NS + 4095) & ~(size_t) 4095;
+		done.store(0, std::memory_order_relaxed);
+		unsigned g;
+		{
+			std::lock_guard<std::mutex> lk(m);
+			g = gen.load(std::memory_order_relaxed) + 1;
+			next.store((uint64_t) g << 32, std::memory_order_release);      // publishes the fields above with the first claimable index
+			gen.store(g, std::memory_order_release);
+		}
 		cv.notify_all();
-		memcpy(dst, src, std::min(slice, n));
-		while (pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
+		work();
+		// every slice is claimed by now; the ones still in a helper's hands take microseconds -- unless that helper lost its core
+		const double t0 = now_us();
+		while (done.load(std::memory_order_acquire) != NS) {
+			if (now_us() - t0 < 200.0) __builtin_ia32_pause();
+			else { timespec ts = { 0, 50000 }; nanosleep(&ts, nullptr); }       // (sleeping, not yielding: a real-time caller must leave the CPU for the helper to finish)
+		}
 		use.unlock();
 	}
 };

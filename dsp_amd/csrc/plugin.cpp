@@ -94,7 +94,11 @@ void Segment::unpin_all()
 {
 	if (pins.empty()) return;
 	(void) hipDeviceSynchronize();
-	for (const Pin &r : pins) if (hipHostUnregister(r.base) != hipSuccess) (void) hipGetLastError();
+	for (const Pin &r : pins)
+		if (hipHostUnregister(r.base) != hipSuccess) {
+			// (a range the host has unmapped in the meantime: nothing to undo, but worth a line -- see INTEGRATION.md, "host buffers")
+			log_msg(LL_VERBOSE, "info: host buffer %p could not be unregistered (%s)", (void *) r.base, hipGetErrorString(hipGetLastError()));
+		}
 	pins.clear();
 }
 
@@ -117,8 +121,15 @@ bool Segment::pinned(int which, const void *p, size_t n)
 	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return !e || atoi(e) != 0; }();
 	if (!enabled || pin_off || !p || n == 0) return false;
 	char *lo = page_lo(p), *hi = page_hi(p, n);
+	if (p != last_ptr[which]) {
+		// the host hands over another buffer in this role: the one before may be gone (the reference frees its block buffers on
+		// REALLOC_BUFS while a crossfading chain still holds this segment, effects_chain.c:1241-1274) -- a registration must not outlive
+		// the memory it pins, so every range is dropped and the count starts again
+		if (last_ptr[which]) unpin_all();
+		last_ptr[which] = p; seen[which] = 1;
+		return false;
+	}
 	for (const Pin &r : pins) if (lo >= r.base && hi <= r.base + r.bytes) return true;
-	if (p != last_ptr[which]) { last_ptr[which] = p; seen[which] = 1; return false; }
 	if (++seen[which] < 4) return false;
 	// grow over every registration this range touches
 	(void) hipDeviceSynchronize();
@@ -203,10 +214,11 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	sg.before_copy(dst, out_bytes);
 	while (done < total) {
 		const ssize_t nb = std::min<ssize_t>(total - done, sg.pipe_frames);
-		if (!hip_ok(hipMemcpyAsync(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice, nullptr), "H2D")) break;
+		// (a copy that fails on a registered buffer: the registration is suspect -- dropped for good, later blocks use pageable copies / staging)
+		if (!hip_ok(hipMemcpyAsync(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice, nullptr), "H2D")) { if (reg_in) { sg.unpin_all(); sg.pin_off = true; } break; }
 		const ssize_t f = sg.pipe->run(sg.d_in.as<double>(), nb, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 		if (f < 0) break;
-		if (f > 0 && !hip_ok(hipMemcpyAsync(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost, nullptr), "D2H")) break;
+		if (f > 0 && !hip_ok(hipMemcpyAsync(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost, nullptr), "D2H")) { if (reg_out) { sg.unpin_all(); sg.pin_off = true; } break; }
 		produced += f;
 		done += nb;
 	}
