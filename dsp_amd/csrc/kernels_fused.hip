@@ -353,7 +353,7 @@ __device__ __forceinline__ void fz_twiddle(cplx s16, cplx a, int j, cplx (&v)[FZ
 	v[4] = cmul(v[4], a4); v[5] = cmul(v[5], cmul(a4, s1)); v[6] = cmul(v[6], cmul(a4, s2)); v[7] = cmul(v[7], cmul(a4, s3));
 }
 
-template <int NSEC, int HR, int DBG = 0, int BS = 8>
+template <int NSEC, int HR, int BS = 8>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 {
@@ -408,7 +408,6 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	auto fetch1 = [&](int it, int so, int m, cplx (&d)[PT]) {    // (m is a compile-time constant at every call)
 		const bool from_ring = (32 * m + 32 <= HR) || (32 * m < HR && hist_row);       // rows lj + 32 m below HR: history
 		if (from_ring) d[m] = ringl[(p.win_base + (long) (lj + 32 * m) * N2 + (col0 + (long) it * TW) + lt) & p.ring_mask];
-		else if constexpr (DBG & 8) d[m] = mkc((double) so, 1.0);
 		else if (32 * m < HR) d[m] = slab_ld(vs0, so);                                 // (HR = 16: the rows 16 .. 31 of m = 0)
 		else d[m] = slab_ld(vs, so + (int) __builtin_amdgcn_readfirstlane((int) ((32 * m - HR) * N2 * fb)));
 	};
@@ -468,8 +467,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 			cplx x[TW];
 #pragma unroll
 			for (int i = 0; i < TW; ++i) x[i] = cur[rq * FZ_QS + rr * FZ_PITCH + i];
-			if constexpr (DBG & 1) { if constexpr (NSEC >= PT) fetch(nit, nx); }
-			else run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, nso, k, nx); } });
+			run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, nso, k, nx); } });
 			if (f.gain != 1.0) {
 #pragma unroll
 				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
@@ -489,7 +487,6 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 #pragma unroll
 		for (int m = 0; m < PT; ++m) v[m] = cur[q * FZ_QS + (j + P * m) * FZ_PITCH + t];
 		stage(nx, nxt);                                  // the next tile's frames into the other buffer
-		if constexpr (!(DBG & 2)) {
 		fz_pass<PT, 8, 8, 1, false>(v, j, cur, map1, tw);    // (in place: a thread's outputs go where its inputs came from)
 		lds_barrier();
 		gather_n<PT>(v, j, cur, map1);
@@ -497,11 +494,10 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 		lds_barrier();
 		gather_n<PT>(v, j, cur, map2);
 		fz_pass<PT, 8, 4, 64, true>(v, j, cur, map2, tw);
-		}
-		if constexpr (!(DBG & 16)) fz_twiddle(tw_s, tw_a, j, v);
+		fz_twiddle(tw_s, tw_a, j, v);
 		const int wo = vw + (int) (col * (long) sizeof(cplx));
 #pragma unroll
-		for (int m = 0; m < PT; ++m) { if constexpr (DBG & 4) { if (v[m].x == 1.2345e-300) buf_stc<2>(v[m], rw, wo + m * w_step); } else buf_stc<2>(v[m], rw, wo + m * w_step); }
+		for (int m = 0; m < PT; ++m) buf_stc<2>(v[m], rw, wo + m * w_step);
 	}
 }
 
@@ -511,24 +507,22 @@ template <int NSEC> static void launch_pre(const FuseParams &f, const double *se
 	hipLaunchKernelGGL((fused_prepass<NSEC>), dim3((unsigned) ((n + 255) / 256), (unsigned) f.n_streams), dim3(256), 0, st, f, sec, N2, pps);
 }
 
-template <int NSEC, int HR, int DBG = 0> static void launch_col(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
+template <int NSEC, int HR> static void launch_col(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
 {
 	const unsigned wgs = (unsigned) ((long) f.n_streams * (p.pairs_per_stream / 2) * f.seg);
 	if (f.in_fmt != PCM_DOUBLE) {
-		if constexpr (DBG == 0) {
-			if (f.in_fmt == PCM_S16) {
-				grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 0, 2>), FZ_LDS);
-				hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 0, 2>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
-			}
-			else {
-				grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 0, 4>), FZ_LDS);
-				hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 0, 4>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
-			}
+		if (f.in_fmt == PCM_S16) {
+			grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 2>), FZ_LDS);
+			hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 2>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
+		}
+		else {
+			grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, 4>), FZ_LDS);
+			hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, 4>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
 		}
 		return;
 	}
-	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR, DBG>), FZ_LDS);
-	hipLaunchKernelGGL((fused_col_fwd<NSEC, HR, DBG>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
+	grant_dynamic_lds(reinterpret_cast<const void *>(fused_col_fwd<NSEC, HR>), FZ_LDS);
+	hipLaunchKernelGGL((fused_col_fwd<NSEC, HR>), dim3(wgs), dim3(512), FZ_LDS, st, p, f, sec);
 }
 
 template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
@@ -592,24 +586,7 @@ bool launch_fused_col_fwd(const ConvParams &p, const FuseParams &f, const double
 	case 4: return pfz::launch_col_mh<4>(p, f, sec, st);
 	case 6: return pfz::launch_col_mh<6>(p, f, sec, st);
 	case 8: return pfz::launch_col_mh<8>(p, f, sec, st);
-	case 10:
-#ifdef FUSE_EXPERIMENTS
-		{
-			const char *e = getenv("DSP_AMD_FUSE_DBG");
-			switch (e ? atoi(e) : 0) {
-			case 1: pfz::launch_col<10, 16, 1>(p, f, sec, st); return true;
-			case 2: pfz::launch_col<10, 16, 2>(p, f, sec, st); return true;
-			case 3: pfz::launch_col<10, 16, 3>(p, f, sec, st); return true;
-			case 4: pfz::launch_col<10, 16, 4>(p, f, sec, st); return true;
-			case 8: pfz::launch_col<10, 16, 8>(p, f, sec, st); return true;
-			case 12: pfz::launch_col<10, 16, 12>(p, f, sec, st); return true;
-			case 16: pfz::launch_col<10, 16, 16>(p, f, sec, st); return true;
-			case 15: pfz::launch_col<10, 16, 15>(p, f, sec, st); return true;
-			default: break;
-			}
-		}
-#endif
-		return pfz::launch_col_mh<10>(p, f, sec, st);
+	case 10: return pfz::launch_col_mh<10>(p, f, sec, st);
 	case 12: return pfz::launch_col_mh<12>(p, f, sec, st);
 	default: return false;
 	}
