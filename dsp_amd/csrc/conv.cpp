@@ -180,7 +180,9 @@ private:
 	bool fuse_static = false;            // the plan allows it (decided once, in init)
 	int fuse_seg = 1;
 	bool fuse_accepts(const void *in, long in_stride, ssize_t frames, int in_fmt) const;
+	bool fused_first_pass(const ConvParams &p, ssize_t frames, hipStream_t st);
 	bool run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st);
+	bool fuse_this_call = false, fuse_failed = false;      // a resampler's call that convolve() starts with the fused first pass / that it could not
 	// ... and with NO cascade in front (fir_p first in the chain, 8 channels, calls of one whole hop): the same first pass with one pass-through section
 	// and all-zero states -- no prepass, no scan -- in place of K1's slab-direct form: two pairs of a frame per lane pair instead of one (K1 reads 16 of a
 	// frame's 64 bytes per workgroup: 8.9 ms at the headline shape against 6.9)
@@ -346,12 +348,12 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	// that much history -- more of it than overlap-save needs costs nothing (the hop is the call either way), and the cascade can then be fused
 	// into the first pass (below): a 50000-tap filter on 983040-frame calls is served like the 65536-tap one
 	// (the same for a convolver that reads its slab directly -- fir_p first in the chain: its whole-hop calls take the fused first pass too)
-	const bool slab_direct_plan = !feeder && all_selected && n_filters == 1 && (ch_in % 2) == 0 && !round_f32 && !getenv("DSP_AMD_CONV_NO_DIRECT");
-	if ((feeder || slab_direct_plan) && !ring_parent && !upc_block && !force_N && log2N1 == 8 && sp.kind != Kind::Resample && lat == 0) {
-		for (long rows : { 16L, 32L }) {
-			const long fn = rows * N2;
-			if (fn >= first_n && N - fn == (long) max_frames) { first_n = fn; B = N - fn; break; }
-		}
+	// (round 5: any whole number of history rows up to 32 -- 17 rows behind the 66119 taps of fir_p merged into a 2x resampler, BASELINE config 4 at
+	// 978944-frame calls: K3's output mapping counts from first_n whatever it is)
+	const bool slab_direct_plan = !feeder && all_selected && n_filters == 1 && (ch_in % 2) == 0 && !round_f32 && sp.kind != Kind::Resample && !getenv("DSP_AMD_CONV_NO_DIRECT");
+	if ((feeder || slab_direct_plan) && !ring_parent && !upc_block && !force_N && log2N1 == 8 && lat == 0 && (sp.kind != Kind::Resample || down == 1)) {
+		const long rows = (N - (long) max_frames) / N2;
+		if (rows >= 1 && rows <= 32 && rows * N2 >= first_n && N - rows * N2 == (long) max_frames) { first_n = rows * N2; B = N - first_n; }
 	}
 	ring_len = next_pow2(first_n + lat + std::max<long>(max_frames, B));
 	log2_lo = (ilog2(N) + 1) / 2;
@@ -485,8 +487,10 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 			log_msg(LL_VERBOSE, "%s: info: fused first pass: regimes %d%d kind %d%d%d%d%d%d rows %d pairs %d%d hist %ld hop %d whole %d%d sizes %d%d sections %d", name.c_str(),
 			        !upc_conv, !fdl, !resampler, nph == 1, n_filters == 1, !f32, !round_f32, lat == 0, log2N1 == 8, (pps % 2) == 0, ch_in == 2 * pps, hist_rows, B == N - first_n,
 			        pairs_per_chunk == (long) S * pps, n_sub == 1, (double) B * ch_in * sizeof(double) < 2.0e9, (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9, (int) feeder_->fuse_tables().ok);
-		if (fuse_on && feeder_ && !ring_parent && !upc_conv && !fdl && !resampler && nph == 1 && n_filters == 1 && !f32 && !round_f32 && lat == 0
-		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && (hist_rows == 16 || hist_rows == 32) && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
+		// (a resampler by an integer factor `up` -- nph = up branches on the same first pass, K2 / K3 in their multi-phase forms -- takes the same
+		// first pass: only the calls whose outputs start at phase 0 of the call's first frame are whole windows, fuse_accepts looks at that)
+		if (fuse_on && feeder_ && !ring_parent && !upc_conv && !fdl && (resampler ? (down == 1 && nph == up) : nph == 1) && n_filters == 1 && !f32 && !round_f32 && lat == 0
+		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && hist_rows >= 1 && hist_rows <= 32 && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
 		    && (double) B * ch_in * sizeof(double) < 2.0e9 && (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9 && feeder_->fuse_tables().ok) {
 			// row segments: enough workgroups for the chip when the streams are few, as far as the scan over the chunks fits its workgroup
 			const int D = 2 * feeder_->n_ops;
@@ -500,7 +504,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 			}
 		}
 		if (fuse_on && !feeder_ && !fed && !ring_parent && direct && !upc_conv && !fdl && !resampler && nph == 1 && n_filters == 1 && !f32 && !round_f32 && lat == 0
-		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && (hist_rows == 16 || hist_rows == 32) && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
+		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && hist_rows >= 1 && hist_rows <= 32 && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
 		    && (double) B * ch_in * sizeof(double) < 2.0e9 && (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9 && fused_section_slots(1) == 1) {
 			const long groups = (long) S * (pps / 2);
 			fuse_seg = 1;
@@ -518,7 +522,10 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 bool ConvStage::fuse_accepts(const void *in, long in_stride, ssize_t frames, int in_fmt) const
 {
 	(void) in_stride;
-	if (!(fuse_static && frames == B && skip_left == 0 && !feeds && (q_abs & 7) == 0)) return false;
+	if (!(fuse_static && frames == B && skip_left == 0 && !feeds && ((resampler ? q_total : q_abs) & 7) == 0)) return false;
+	// a resampler: the next output frame must be phase 0 of this call's first input frame (true from the second call on: the first one drops
+	// out_delay outputs and its windows start inside the history) -- then this call is one whole window and emits up x frames outputs
+	if (resampler && (emitted + out_delay) != q_total * up) return false;
 	if (in_fmt == PCM_DOUBLE) { if ((((size_t) in) & 15) != 0) return false; }
 	else {
 		// a wire format (the cascade is the first stage of a pipeline run from format to format): read by the matrix-core prepass and by the first
@@ -569,7 +576,9 @@ bool ConvStage::run_fused_plain(const double *in, long in_stride, ssize_t frames
 	return true;
 }
 
-bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st)
+// the first pass of a window whose new rows are the cascade's pending call (fuse_accepts said yes to exactly this call): the chunks' end states
+// from zero state, the scan, fused_col_fwd -- in K1's place; p describes the window as for K1
+bool ConvStage::fused_first_pass(const ConvParams &p, ssize_t frames, hipStream_t st)
 {
 	const CascadeStage::Pending pd = feeder_->pending;
 	feeder_->pending = CascadeStage::Pending();
@@ -602,6 +611,14 @@ bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStrea
 	cp.cls = plan->cls.as<int>(); cp.H = plan->H.as<double>(); cp.Mp = plan->Mp.as<double>();
 	cp.cstate = plan->cstate.as<double>(); cp.X = plan->X.as<double>(); cp.state = feeder_->state.as<double>();
 	{ ProfScope ps("cascade_chunk_carry", st); launch_chunk_carry(cp, S, st); }
+	{ ProfScope ps("fused_col_fwd", st); if (!launch_fused_col_fwd(p, f, ft.sec.as<double>(), st)) return false; }
+	if (plan->done) (void) hipEventRecord(plan->done, st);
+	feeder_->ring.pos = (feeder_->ring.pos + frames) & feeder_->ring.mask;
+	return true;
+}
+
+bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStream_t st)
+{
 	ConvParams p = base_params();
 	p.win_base = (q_abs - first_n) & (ring_len - 1);
 	p.first_n = first_n;
@@ -615,11 +632,9 @@ bool ConvStage::run_fused(ssize_t frames, double *out, long out_stride, hipStrea
 	p.out_count = frames;
 	p.k3_pipe_ok = (all_selected && n_filters == 1 && pps == 4 && ch_in == 8 && !feeds && ((((size_t) out) & 15) == 0)) ? 1 : 0;
 	p.pair0 = 0; p.stream0 = 0; p.n_streams_launch = S;
-	{ ProfScope ps("fused_col_fwd", st); if (!launch_fused_col_fwd(p, f, ft.sec.as<double>(), st)) return false; }
+	if (!fused_first_pass(p, frames, st)) return false;
 	{ ProfScope ps("conv_row", st); launch_conv_row(p, 0, (int) ((long) S * pps), st); }
 	{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) ((long) S * pps), st); }
-	if (plan->done) (void) hipEventRecord(plan->done, st);
-	feeder_->ring.pos = (feeder_->ring.pos + frames) & feeder_->ring.mask;
 	return true;
 }
 
@@ -929,7 +944,12 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 			p.pair0 = s0 * pps;
 			p.stream0 = s0;
 			p.n_streams_launch = ns;
-			{ ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, (int) (ns * pps), st); }
+			if (fuse_this_call) {
+				// (a resampler's whole-window call behind a cascade: the fused first pass in K1's place; one block, every stream in one launch)
+				fuse_this_call = false;
+				if (q_blk != q_lo || f != B || ns != S || p.valid != N || !fused_first_pass(p, f, st)) { fuse_failed = true; return; }
+			}
+			else { ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, (int) (ns * pps), st); }
 			{ ProfScope ps("conv_row", st); launch_conv_row(p, row_mode, (int) (ns * pps), st); }
 			{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) (ns * pps), st); }
 		}
@@ -987,7 +1007,11 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 		q_total += frames;
 		// full-rate outputs k with floor(k down / up) < q_total are computable: k < ceil(q_total up / down)
 		const long avail = std::max<long>(0, max_out_frames(q_total) - out_delay) - emitted;
+		// (the feeding cascade left this call to the fused kernels: fuse_accepts said yes to exactly this call -- one whole window)
+		fuse_this_call = feeder_ && feeder_->pending.in;
+		fuse_failed = false;
 		const ssize_t got = emit(std::min<long>(avail, max_out_frames(frames)), out, out_stride, st);
+		if (fuse_this_call || fuse_failed) { fuse_this_call = false; set_error("%s: fused first pass could not be launched", name.c_str()); return PIPE_FAILED; }
 		if (use_direct) {
 			// the windows of later calls (and of the drain) start at the next unemitted output's input index minus the history:
 			// only that tail of this call has to be in the ring

@@ -621,6 +621,12 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 		core_launch_row_duo(p, n_pairs, st);
 		return;
 	}
+	// (round 5) the 2x resampler's two branches at 2048- / 4096-point rows: the two-workgroup kernel with the filter rows from L2
+	static const int duo2_env = [] { const char *e = getenv("DSP_AMD_ROW_DUO2"); return e ? atoi(e) : 1; }();
+	if (duo2_env && plan_is_pipe(p) && mode == 2 && p.nph == 2 && n_pairs >= 8 && p.log2N2 >= 11) {
+		core_launch_row_duo(p, n_pairs, st);
+		return;
+	}
 	if (plan_is_pipe(p) && (mode == 0 || (mode == 2 && p.nph == 2)) && n_pairs >= 8) {
 		switch (p.log2N2) {
 		case 9: launch_row_pipe<9>(p, n_pairs, st); return;

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	const long s = blockIdx.y;
 	const long c0 = ((long) blockIdx.x * 4 + w) * 8;          // this wave's first chunk
 	if (c0 >= f.K) return;
+	// (K need not be a multiple of 8 -- 239 rows behind 17 rows of history: the columns past the last chunk read the last chunk again and store nothing)
 	const int k = lane >> 4, jc = lane & 15, cp = jc & 3;
 	// a lane's element of step t0: frame t0 + k of chunk (jc >> 2) of the column group, channel pair cp -- 16 bytes of an fp64 slab, 4 or 8 of a wire format
 	constexpr int bs = BS;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	const char *xb[2];
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
-		const long c = c0 + 4 * g + (jc >> 2);
+		const long c = (c0 + 4 * g + (jc >> 2) < f.K) ? c0 + 4 * g + (jc >> 2) : f.K - 1;
 		const long row = c / f.seg, frame0 = row * N2 + (c - row * f.seg) * f.len;
 		xb[g] = reinterpret_cast<const char *>(f.in) + (((size_t) s * f.in_stride_frames + frame0 + k) * 8 + 2 * cp) * bs;
 	}
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 #pragma unroll
 	for (int g = 0; g < 2; ++g) {
 		const long c = c0 + 4 * g + (jc >> 2);
+		if (c >= f.K) continue;
 #pragma unroll
 		for (int eo = 0; eo < 2; ++eo) {
 			double *dst = f.cstate + (((size_t) s * f.K + c) * f.C + 2 * cp + eo) * D;
@@ -267,7 +269,8 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 
 // ---- pass 1: K1 with the cascade in front of its column transforms (see the head of the file).
 // grid: S x groups x seg workgroups in the order of fz_block (the groups of a stream on one XCD), 512 threads = 8 waves, two per SIMD.
-// HR = the window rows that are history (the pair rings: 16 or 32), the others are new frames (the slab).
+// HR = the window rows that are history (the pair rings), the others are new frames (the slab): 16 or 32 as compile-time constants (the headline's
+// instances), or 0 = f.hist_rows at run time, any count from 1 to 32 (e.g. 17 rows behind the 66119 taps of fir_p merged into a 2x resampler).
 // A tile = 8 columns of the group's two pairs.  Thread roles:
 //   loading      (pair lq, column lt, lj): the rows lj + 32 m of a column, the two pairs of a frame (32 contiguous bytes) in adjacent lanes
 //   recurrence   (pair rq, row rr): 8 consecutive frames of its row through the sections, states in registers (80)
@@ -382,7 +385,8 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const int fb = f.C * bs;
 	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(f.in)) + (size_t) s * f.in_stride_frames * f.C * bs, 0, 0x7fffffff, 0x00020000);
 	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) bs);
-	const int vs0 = vs - (int) (HR * N2 * fb);       // row lj itself (HR = 16 only, looked at when lj >= HR)
+	const int hr = HR > 0 ? HR : f.hist_rows;        // (a constant in the HR > 0 instances)
+	const int vs0 = vs - (int) (hr * N2 * fb);       // row lj itself (looked at when hr <= lj: hr < 32)
 	auto slab_ld = [&](int vo, int so) -> cplx {
 		if constexpr (BS == 8) return buf_ldc(rs, vo, so);
 		else if constexpr (BS == 4) {
@@ -395,7 +399,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 			return mkc(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16));
 		}
 	};
-	const bool hist_row = lj < HR;                   // wave-uniform: row lj (m = 0) is history: the pair rings
+	const bool hist_row = lj < hr;                   // row lj (m = 0) is history: the pair rings (wave-uniform when hr is a multiple of 4)
 	// W of the group's two pairs through one descriptor
 	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
 	const int vw = (int) (((long) q * p.w_stride + (long) j * N2 + t) * (long) sizeof(cplx));
@@ -406,10 +410,10 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	// up in a VGPR -- a 32-bit VALU multiply per load and a waterfall loop around every buffer load to get the scalar offset back
 	auto tile_so = [&](int it) { return __builtin_amdgcn_readfirstlane((int) ((col0 + (long) it * TW) * fb)); };
 	auto fetch1 = [&](int it, int so, int m, cplx (&d)[PT]) {    // (m is a compile-time constant at every call)
-		const bool from_ring = (32 * m + 32 <= HR) || (32 * m < HR && hist_row);       // rows lj + 32 m below HR: history
+		const bool from_ring = (32 * m + 32 <= hr) || (32 * m < hr && hist_row);       // rows lj + 32 m below hr: history
 		if (from_ring) d[m] = ringl[(p.win_base + (long) (lj + 32 * m) * N2 + (col0 + (long) it * TW) + lt) & p.ring_mask];
-		else if (32 * m < HR) d[m] = slab_ld(vs0, so);                                 // (HR = 16: the rows 16 .. 31 of m = 0)
-		else d[m] = slab_ld(vs, so + (int) __builtin_amdgcn_readfirstlane((int) ((32 * m - HR) * N2 * fb)));
+		else if (32 * m < hr) d[m] = slab_ld(vs0, so);                                 // (hr < 32: the rows hr .. 31 of m = 0)
+		else d[m] = slab_ld(vs, so + (int) __builtin_amdgcn_readfirstlane((int) ((32 * m - hr) * N2 * fb)));
 	};
 	auto fetch = [&](int it, cplx (&d)[PT]) {
 		const int so = tile_so(it);
@@ -422,10 +426,10 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	};
 	// states of this thread's row: chunk (rr - HR) seg + sg of channels 4 grp + 2 rq, + 1
 	double2 m0[NSEC], m1[NSEC];
-	const bool rec = rr >= HR;                       // (history rows pass through unchanged)
+	const bool rec = rr >= hr;                       // (history rows pass through unchanged)
 	{
 		const int D = 2 * f.n_ops;
-		const long c = rec ? (long) (rr - HR) * f.seg + sg : 0;
+		const long c = rec ? (long) (rr - hr) * f.seg + sg : 0;
 		const double *xs = f.X + (((size_t) s * f.K + c) * f.C + 4 * grp + 2 * rq) * D;
 #pragma unroll
 		for (int k = 0; k < NSEC; ++k) {
@@ -437,7 +441,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 			else { m0[k] = make_double2(0.0, 0.0); m1[k] = make_double2(0.0, 0.0); }
 		}
 	}
-	const bool keeps = rr >= N1 - HR;                // this row is history of the next window
+	const bool keeps = rr >= N1 - hr;                // this row is history of the next window
 	double2 *ringw = const_cast<double2 *>(ring0) + rq * p.ring_row_stride;
 	const long ring_e0 = p.win_base + (long) rr * N2 + col0;      // (win_base is a multiple of 8 here: a run of 8 never straddles the ring's end)
 	cplx nx[PT];
@@ -530,7 +534,10 @@ template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FusePar
 	switch (f.hist_rows) {
 	case 16: launch_col<NSEC, 16>(p, f, sec, st); return true;
 	case 32: launch_col<NSEC, 32>(p, f, sec, st); return true;
-	default: return false;
+	default:
+		if (f.hist_rows < 1 || f.hist_rows > 32) return false;
+		launch_col<NSEC, 0>(p, f, sec, st);
+		return true;
 	}
 }
 
@@ -539,8 +546,8 @@ template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FusePar
 // the matrix-core form of the prepass: 8 channels per stream, chunks in groups of 8, at most 16 sections' states; Gt: [len][32] (fuse_gtable)
 bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int n_state, hipStream_t st)
 {
-	if (f.C != 8 || (f.K % 8) != 0 || (f.len % 8) != 0 || n_state < 1 || n_state > 32) return false;
-	const dim3 grid((unsigned) ((f.K / 8 + 3) / 4), (unsigned) f.n_streams);
+	if (f.C != 8 || f.K < 1 || (f.len % 8) != 0 || n_state < 1 || n_state > 32) return false;
+	const dim3 grid((unsigned) (((f.K + 7) / 8 + 3) / 4), (unsigned) f.n_streams);
 	if (f.in_fmt != PCM_DOUBLE) {
 		if (!pcm_fusable(f.in_fmt)) return false;
 		if (f.in_fmt == PCM_S16) {

@@ -526,6 +526,59 @@ def test_config4_full_size_vs_real_reference(amd, tmp_path):
         assert rms(ref - got) < 1e-11, (s, rms(ref - got))
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_config4_at_the_bench_block_takes_the_fused_first_pass(amd, tmp_path):
+    """BASELINE config 4 as bench.py runs it (`--config 4`: calls of 978944 frames = what is left of a 2^20-point window behind 17 whole rows of
+    history for the 66119 taps of fir_p merged into the 2x resampler): from the second call on a call is one whole window and the cascade runs
+    inside the convolver's first pass (round 5; hist_rows = 17 -> the run-time-history instance, 239 chunks: the matrix-core prepass past a
+    multiple of 8).  Whole streams -- a first call (separate kernels: its windows start inside the history), a fused one, a short one, the
+    drain with the merged stage's tail -- against the real reference; the fused call alone against the separate kernels."""
+    import torch
+    taps, S, C, B = 65536, 112, 8, 978944
+    h = make_filter(taps)
+    p = write(tmp_path, h)
+    biq = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 eq 800 1.0 -1 "
+           "eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    chain = f"{biq} fir_p -t pcm -e double -c 1 {p} resample 96k"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    assert "fft-resample[" in b.plan() and "hop=978944" in b.plan() and "cascade-fused(239 chunks of 4096)" in b.plan(), b.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(14)
+    x = torch.rand((S, 2 * B + 30000, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    L = amd.load_library()
+    outs, kernels = [], []
+    for lo, hi in ((0, B), (B, 2 * B), (2 * B, 2 * B + 30000)):
+        L.dspamd_profile_enable(1)
+        outs.append(b.run(x[:, lo:hi, :].contiguous()).clone())
+        kernels.append({ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()})
+        L.dspamd_profile_enable(0)
+    assert "cascade_rows" in kernels[0] and "fused_col_fwd" not in kernels[0], kernels[0]        # the first call drops out_delay outputs
+    assert "fused_col_fwd" in kernels[1] and not (kernels[1] & {"cascade_rows", "conv_col_fwd"}), kernels[1]
+    assert outs[0].shape[1] == 2 * B - 583 and outs[1].shape[1] == 2 * B, [o.shape for o in outs]
+    while True:
+        o = b.drain(B)
+        if o is None:
+            break
+        outs.append(o.clone())
+    y = torch.cat([o for o in outs if o.shape[1]], dim=1)
+    # the same calls on the separate kernels
+    os.environ["DSP_AMD_FUSE"] = "0"
+    try:
+        bs = amd.BatchChain(chain, 48000, C, S, B)
+    finally:
+        os.environ.pop("DSP_AMD_FUSE")
+    assert "cascade-fused" not in bs.plan()
+    ys = [bs.run(x[:, lo:hi, :].contiguous()).clone() for lo, hi in ((0, B), (B, 2 * B))]
+    assert torch.equal(ys[0], outs[0])
+    assert float((ys[1] - outs[1]).pow(2).mean().sqrt()) < 1e-12
+    del bs, ys
+    picks, seed = pick_streams(S)
+    for s in picks:
+        ref = RefChain(chain, 48000, C).process(x[s].cpu().numpy(), block=65536)
+        got = y[s].cpu().numpy()
+        assert ref.shape == got.shape, (ref.shape, got.shape)
+        assert rms(ref - got) < 1e-11, (s, rms(ref - got), "pick seed", seed)
+
+
 @pytest.mark.parametrize("taps,cap", [(5000, 4096), (5000, 65536), (40000, 16384)])
 def test_slab_direct_history_over_ragged_calls(amd, tmp_path, taps, cap):
     """A plain fir_p on all channels reads its new frames straight from the interleaved slab and files the history for later

@@ -93,6 +93,54 @@ def test_fused_first_pass_vs_reference_and_separate_kernels(amd, tmp_path, nsec,
     assert torch.equal(y[0], yf[0][0]) and bool((y == y[0:1]).all().item())
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("taps,S,C,chunks", [(16384, 8, 8, "956 chunks of 256"), (16384, 120, 8, "239 chunks of 1024"), (30000, 6, 4, "904 chunks of 256")])
+def test_fused_first_pass_in_front_of_the_2x_resampler(amd, tmp_path, taps, S, C, chunks):
+    """BASELINE config 4's shape in small (round 5): sections + fir_p + resample 48k -> 96k = ONE convolver stage with two polyphase branches (fir_p merged
+    into the resampler); its calls of one whole hop are whole windows from the second call on (the first drops out_delay outputs), and those take the
+    fused first pass -- history of 17 / 30 rows (the run-time-history instance), chunk counts that are no multiple of 8 in the matrix-core prepass.
+    Whole streams with the drain against the real reference, call by call against the separate kernels."""
+    import torch
+    f = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(make_filter(taps, seed=taps + 3), dtype="<f8").tofile(f)
+    chain = " ".join(SECTIONS[:10]) + f" fir_p -t pcm -e double -c 1 {f} resample 96k"
+    rows = -(-(taps + 583 + 7) // 1024)
+    B = (1 << 18) - rows * 1024
+    bf, bs = build(amd, chain, C, S, B, True), build(amd, chain, C, S, B, False)
+    assert f"cascade-fused({chunks})" in bf.plan() and f"hop={B}" in bf.plan(), bf.plan()
+    assert "cascade-fused" not in bs.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(31)
+    sizes = [B, B, B, 5000, B]
+    xs = [torch.rand((S, n, C), dtype=torch.float64, device="cuda", generator=g) - 0.5 for n in sizes]
+    L = amd.load_library()
+    yf, names = [], []
+    for x in xs:
+        L.dspamd_profile_enable(1)
+        yf.append(bf.run(x).clone())
+        names.append({ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()})
+        L.dspamd_profile_enable(0)
+    assert [("fused_col_fwd" in n) for n in names] == [False, True, True, False, True], names
+    ys = [bs.run(x).clone() for x in xs]
+    for k, (a, b) in enumerate(zip(yf, ys)):
+        assert a.shape == b.shape == (S, 2 * sizes[k] - (583 if k == 0 else 0), C), (k, a.shape, b.shape)
+        assert float((a - b).pow(2).mean().sqrt()) < 1e-12, k
+    tails = []
+    while True:
+        o = bf.drain(B)
+        if o is None:
+            break
+        tails.append(o.clone())
+    for s in sorted({0, S - 1, S // 2}):
+        x = torch.cat([t[s] for t in xs], dim=0).cpu().numpy()
+        ref = RefChain(chain, 48000, C).process(x, block=65536)
+        got = torch.cat([t[s] for t in yf + tails if t.shape[1]], dim=0).cpu().numpy()
+        assert ref.shape == got.shape, (ref.shape, got.shape)
+        assert rms(ref - got) < 1e-11, (s, rms(ref - got))
+    # reset: the stream starts over (a first call again: separate kernels), same bits
+    bf.reset()
+    assert torch.equal(bf.run(xs[0]), yf[0]) and torch.equal(bf.run(xs[1]), yf[1])
+
+
 def test_chains_the_fused_kernels_leave_alone(amd, tmp_path):
     """per-channel sections, an `add` among the ops, a selector, a latency: the plan keeps the separate kernels"""
     f = os.path.join(str(tmp_path), "h.raw")
