@@ -49,7 +49,6 @@ namespace p32 {
 void core_launch_conv_col(const ConvParams &p, bool inverse, int n_pairs, hipStream_t st);
 void core_launch_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st);
 void core_launch_row_duo(const ConvParams &p, int n_pairs, hipStream_t st);
-void core_launch_row_oct(const ConvParams &p, int n_pairs, hipStream_t st);
 }
 
 // K2, persistent form (plain convolution, one filter shared by every pair): a workgroup keeps ITS rows k1 and walks over the
@@ -618,8 +617,6 @@ void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 	// (the two-branch form holds both filter rows in registers: at 2048- / 4096-point rows it spills 100 VGPRs and is behind the
 	// one-shot kernel, 16.7 against 15.0 ms; at 1024-point rows ahead, 3.26 against 3.53)
 	static const int duo_env = [] { const char *e = getenv("DSP_AMD_ROW_DUO"); return e ? atoi(e) : 1; }();
-	static const int oct_env = [] { const char *e = getenv("DSP_AMD_ROW_OCT"); return e ? atoi(e) : 0; }();
-	if (oct_env && plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 == 12) { core_launch_row_oct(p, n_pairs, st); return; }
 	if (duo_env && plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= 11 && (duo_env == 1 || p.log2N2 == 10 + duo_env)) {
 		core_launch_row_duo(p, n_pairs, st);
 		return;

@@ -61,13 +61,6 @@
 #include "fft_params.h"
 #include "pcm_device.h"
 
-// (A/B builds: non-temporal hints on the slab loads of the matrix-core prepass / of the first pass)
-#ifndef FZ_PRE_NT
-#define FZ_PRE_NT 1        // (round 5, a / b / a on one box: the prepass 2.78 -> 2.59 ms -- its input is read once more, 16 GB later)
-#endif
-#ifndef FZ_SLAB_AUX
-#define FZ_SLAB_AUX 0
-#endif
 namespace dspamd {
 namespace pfz {
 typedef double real;
@@ -212,11 +205,9 @@ __global__ __launch_bounds__(256) void fused_prepass_mm(FuseParams f, const doub
 	const long fstep = 8L * bs;                                   // bytes per frame (8 channels)
 	auto xload = [&](int g, long t) -> double2 {
 		if constexpr (BS != 8) return fz_wire_pair<BS>(xb[g] + t * fstep, wf);
-#if FZ_PRE_NT
+		// (non-temporal: the slab is read once more, 16 GB later, by the first pass -- nothing of it survives in a cache anyway; round 5, a / b / a on one
+		// box: 2.78 -> 2.59 ms.  The same hint on the first pass's own slab loads and on K3's W loads / slab stores measures nothing: profiles/r05_*)
 		else { typedef double fz_d2 __attribute__((ext_vector_type(2))); const fz_d2 v = __builtin_nontemporal_load(reinterpret_cast<const fz_d2 *>(xb[g] + t * fstep)); return make_double2(v.x, v.y); }
-#else
-		else return *reinterpret_cast<const double2 *>(xb[g] + t * fstep);
-#endif
 	};
 	const double *ga = Gt + (size_t) k * 32 + jc;
 	fz_v4d acc[2][2][DT];
@@ -399,7 +390,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 	const int hr = HR > 0 ? HR : f.hist_rows;        // (a constant in the HR > 0 instances)
 	const int vs0 = vs - (int) (hr * N2 * fb);       // row lj itself (looked at when hr <= lj: hr < 32)
 	auto slab_ld = [&](int vo, int so) -> cplx {
-		if constexpr (BS == 8) return buf_ldc<FZ_SLAB_AUX>(rs, vo, so);
+		if constexpr (BS == 8) return buf_ldc(rs, vo, so);
 		else if constexpr (BS == 4) {
 			typedef unsigned int fz_u32x2 __attribute__((ext_vector_type(2)));
 			const fz_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
