@@ -468,7 +468,7 @@ def main():
                 del x, out
                 torch.cuda.empty_cache()
                 os.environ["DSP_AMD_MERGE_IIR"] = "1"
-                sb = 958208                                        # the hop of N = 2^20 for the merged filter (65536 + 24832 - 1 taps)
+                sb = 954368                                        # N = 2^20 less 23 whole rows of history for the merged filter (65536 + 24832 - 1 taps): whole-hop calls take the two-pair first pass
                 mb = dsp_amd.BatchChain(chain, fs, C, S, sb, directory=filt_dir)
                 os.environ.pop("DSP_AMD_MERGE_IIR")
                 mx = torch.zeros((S, sb + args.slab_pad, C), dtype=torch.float64, device="cuda")

@@ -199,7 +199,7 @@ std::string ConvStage::describe() const
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
 	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? (fuse_plain ? " slab-direct(two pairs per workgroup at whole hops)" : " slab-direct") : "");
-	if (fuse_static) o << " cascade-fused(" << (N1 - first_n / N2) * fuse_seg << " chunks of " << N2 / fuse_seg << ")";
+	if (fuse_static) o << " cascade-fused(" << (N1 - first_n / N2) * fuse_seg << " chunks of " << N2 / fuse_seg << (feeder_ && feeder_->fuse_tables().pairs > 1 ? ", sections per pair" : "") << ")";
 	if (skip) o << " drops-first=" << skip;
 	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N;
 	if (fdl) {
@@ -532,7 +532,7 @@ bool ConvStage::fuse_accepts(const void *in, long in_stride, ssize_t frames, int
 		// pass themselves -- 8 channels, naturally aligned pairs
 		const char *me = getenv("DSP_AMD_FUSE_MM");
 		if (me && atoi(me) == 0) return false;
-		if (!(wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && (((size_t) in) & 7) == 0)) return false;
+		if (!(wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && feeder_->fuse_tables().pairs == 1 && (((size_t) in) & 7) == 0)) return false;
 	}
 	// everything run_fused() will need exists before the answer is yes (the chunk plan's state buffers scale with S K C D; a plan is built
 	// once per call shape and kept): after a yes the cascade launches nothing, so a failure in there could no longer be served by the
@@ -592,6 +592,7 @@ bool ConvStage::fused_first_pass(const ConvParams &p, ssize_t frames, hipStream_
 	f.C = ch_in; f.n_sec = ft.n_sec; f.n_ops = feeder_->n_ops;
 	f.sec_op = ft.sec_op.as<int>();
 	f.gain = ft.gain;
+	if (ft.pairs > 1) { f.sec_stride = (long) ft.n_sec * 6; f.gain_tab = ft.gain_tab.as<double>(); }
 	f.seg = fuse_seg; f.hist_rows = (int) hist_rows;
 	f.K = K; f.len = len;
 	f.cstate = plan->cstate.as<double>(); f.X = plan->X.as<double>();

@@ -649,28 +649,53 @@ const CascadeStage::FuseTables &CascadeStage::fuse_tables()
 	if (ft.tried) return ft;
 	ft.tried = true;
 	if (ch_in < 1 || n_ops < 1) return ft;
-	std::vector<double> sec;
-	std::vector<int> sec_op;
-	double gain = 1.0;
-	for (int j = 0; j < n_ops; ++j) {
-		const OpDesc &od = host_ops[j];
+	auto same = [](const OpDesc &a, const OpDesc &b) { return a.kind == b.kind && a.g == b.g && memcmp(a.c, b.c, sizeof(a.c)) == 0; };
+	// every channel alike (one table), or at least the two channels of every pair (one table per pair)
+	bool uniform = true, pairwise = (ch_in % 2) == 0;
+	for (int j = 0; j < n_ops; ++j)
 		for (int c = 1; c < ch_in; ++c) {
-			const OpDesc &o = host_ops[(size_t) c * n_ops + j];
-			if (o.kind != od.kind || o.g != od.g || memcmp(o.c, od.c, sizeof(od.c)) != 0) return ft;
+			if (!same(host_ops[(size_t) c * n_ops + j], host_ops[j])) uniform = false;
+			if ((c & 1) && !same(host_ops[(size_t) c * n_ops + j], host_ops[(size_t) (c - 1) * n_ops + j])) pairwise = false;
 		}
-		if (od.kind == OP_MUL) { gain *= od.g; continue; }
-		if (od.kind != OP_BIQUAD) return ft;
-		sec.insert(sec.end(), { od.c[0] * gain, od.c[1] * gain, od.c[2] * gain, od.c[3], od.c[4], 0.0 });     // y = H(g x): the b coefficients scaled, states untouched
-		sec_op.push_back(j);
-		gain = 1.0;
+	if (!uniform && !pairwise) return ft;
+	// section slots: the ops that are a section in any channel (a selector makes them OP_SKIP in the others); gains have no slot
+	std::vector<int> sec_op;
+	for (int j = 0; j < n_ops; ++j) {
+		bool section = false;
+		for (int c = 0; c < ch_in; ++c) {
+			const int k = host_ops[(size_t) c * n_ops + j].kind;
+			if (k == OP_BIQUAD) section = true;
+			else if (k != OP_MUL && k != OP_SKIP) return ft;          // (`add` is not linear in the state)
+		}
+		if (section) sec_op.push_back(j);
 	}
 	const int slots = fused_section_slots((int) sec_op.size());
 	if (sec_op.empty() || !slots) return ft;
 	ft.n_real = (int) sec_op.size();
-	while ((int) sec_op.size() < slots) { sec.insert(sec.end(), { 1.0, 0.0, 0.0, 0.0, 0.0, 0.0 }); sec_op.push_back(-1); }   // pass-through
+	const int tables = uniform ? 1 : ch_in / 2;
+	std::vector<double> sec, gains;
+	for (int t = 0; t < tables; ++t) {
+		const OpDesc *od = &host_ops[(size_t) (2 * t) * n_ops];
+		double gain = 1.0;
+		size_t k = 0;
+		for (int j = 0; j < n_ops; ++j) {
+			if (od[j].kind == OP_MUL) { gain *= od[j].g; continue; }
+			if (k >= sec_op.size() || sec_op[k] != j) continue;      // (an op that is OP_SKIP in every channel)
+			// y = H(g x): the b coefficients scaled, states untouched; a pair the section is not for passes g x through (states stay zero)
+			if (od[j].kind == OP_BIQUAD) sec.insert(sec.end(), { od[j].c[0] * gain, od[j].c[1] * gain, od[j].c[2] * gain, od[j].c[3], od[j].c[4], 0.0 });
+			else sec.insert(sec.end(), { gain, 0.0, 0.0, 0.0, 0.0, 0.0 });
+			gain = 1.0;
+			++k;
+		}
+		for (int pad = (int) sec_op.size(); pad < slots; ++pad) sec.insert(sec.end(), { 1.0, 0.0, 0.0, 0.0, 0.0, 0.0 });   // pass-through
+		gains.push_back(gain);
+	}
+	while ((int) sec_op.size() < slots) sec_op.push_back(-1);
 	if (!ft.sec.upload(sec.data(), sec.size() * sizeof(double)) || !ft.sec_op.upload(sec_op.data(), sec_op.size() * sizeof(int))) return ft;
+	if (tables > 1 && !ft.gain_tab.upload(gains.data(), gains.size() * sizeof(double))) return ft;
 	ft.n_sec = slots;
-	ft.gain = gain;
+	ft.pairs = tables;
+	ft.gain = gains[0];
 	ft.ok = true;
 	return ft;
 }
@@ -681,6 +706,7 @@ const CascadeStage::FuseTables &CascadeStage::fuse_tables()
 bool CascadeStage::fuse_gtable(ChunkPlan &plan)
 {
 	if (plan.G.p) return plan.g_states > 0;
+	if (fuse_tables().pairs != 1) return false;          // (one table for every column of the product: chains whose channels all agree)
 	std::vector<int> secs;
 	for (int j = 0; j < n_ops; ++j) if (host_ops[j].kind == OP_BIQUAD) secs.push_back(j);
 	if (secs.empty() || secs.size() > 16) return false;

@@ -133,6 +133,8 @@ struct FuseParams {
 	int C, n_sec, n_ops;                // n_sec biquad sections (gains folded in), n_ops ops per channel in the state layout (D = 2 n_ops)
 	const int *sec_op;                  // [n_sec] op index whose (m0, m1) the section carries
 	double gain;                        // product of the gains behind the last section
+	long sec_stride;                    // 0: one section table for every pair; else doubles from one pair's table [n_sec][6] to the next pair's (pair = channels 2 q, 2 q + 1 of a stream)
+	const double *gain_tab;             // [pairs per stream] the gains behind the last section, per pair (sec_stride != 0), or nullptr
 	int seg, hist_rows;
 	long K, len;                        // chunks per channel = (N1 - hist_rows) seg, frames per chunk = N2 / seg
 	double *cstate;                     // [S K][C][D]

@@ -116,14 +116,17 @@ __device__ __forceinline__ void run_sections(cplx (&x)[NF], double2 (&m0)[NSEC],
 #ifndef FZ_PRE_WAVES
 #define FZ_PRE_WAVES 2
 #endif
-template <int NSEC>
+// PP: one section table per channel pair (f.sec_stride doubles apart): the lanes of a wave hold different pairs, so the coefficients are per-lane
+// loads (L1-resident tables) instead of scalar ones, and a step is 8 frames (their registers).
+template <int NSEC, bool PP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FZ_PRE_WAVES, FZ_PRE_WAVES)))
-void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pps)
+void fused_prepass(FuseParams f, const double *__restrict__ sec_all, long N2, int pps)
 {
 	const long id = (long) blockIdx.x * 256 + threadIdx.x;
 	const long s = blockIdx.y;
 	const bool live = id < f.K * pps;
 	const int q = (int) (id % pps);
+	const double *__restrict__ sec = PP ? sec_all + (size_t) q * f.sec_stride : sec_all;
 	const long c = live ? id / pps : 0;
 	const long row = c / f.seg;
 	const int sg = (int) (c - row * f.seg);
@@ -137,7 +140,7 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec, long N2, int pp
 #ifdef FZ_PRE_NF
 	constexpr int NF = FZ_PRE_NF;
 #else
-	constexpr int NF = (NSEC > 10) ? 8 : 16;           // frames per step (twelve sections with 16: spills)
+	constexpr int NF = (NSEC > 10 || PP) ? 8 : 16;     // frames per step (twelve sections with 16: spills)
 #endif
 	cplx x[NF], nx[NF];
 #pragma unroll
@@ -360,8 +363,9 @@ __device__ __forceinline__ void fz_twiddle(cplx s16, cplx a, int j, cplx (&v)[FZ
 
 template <int NSEC, int HR, int BS = 8>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
+void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec_all)
 {
+	const double *__restrict__ sec = sec_all;
 	constexpr int N1 = 256, TW = FZ_TW, PT = FZ_PT, P = FZ_P;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	cplx *buf0 = reinterpret_cast<cplx *>(smem_raw);     // two tile buffers [2 pairs][256 rows] of pitch 9 that swap roles from tile to tile
@@ -426,6 +430,9 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 #pragma unroll
 		for (int m = 0; m < PT; ++m) dst[lq * FZ_QS + (lj + P * m) * FZ_PITCH + lt] = d[m];
 	};
+	// one section table per pair (f.sec_stride != 0): a wave is 64 rows of ONE pair, so its table is still read with scalar loads
+	sec += (size_t) __builtin_amdgcn_readfirstlane((int) ((2 * grp + rq) * f.sec_stride));
+	const double gn = f.gain_tab ? f.gain_tab[__builtin_amdgcn_readfirstlane(2 * grp + rq)] : f.gain;
 	// states of this thread's row: chunk (rr - HR) seg + sg of channels 4 grp + 2 rq, + 1
 	double2 m0[NSEC], m1[NSEC];
 	const bool rec = rr >= hr;                       // (history rows pass through unchanged)
@@ -474,9 +481,9 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 #pragma unroll
 			for (int i = 0; i < TW; ++i) x[i] = cur[rq * FZ_QS + rr * FZ_PITCH + i];
 			run_sections<NSEC, TW>(x, m0, m1, sec, cf, [&](int k) { if constexpr (NSEC >= PT) { if (k < PT) fetch1(nit, nso, k, nx); } });
-			if (f.gain != 1.0) {
+			if (gn != 1.0) {
 #pragma unroll
-				for (int i = 0; i < TW; ++i) { x[i].x *= f.gain; x[i].y *= f.gain; }
+				for (int i = 0; i < TW; ++i) { x[i].x *= gn; x[i].y *= gn; }
 			}
 			if (rec) {                                   // (divergent in the first wave of either pair only)
 #pragma unroll
@@ -510,7 +517,9 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec)
 template <int NSEC> static void launch_pre(const FuseParams &f, const double *sec, long N2, int pps, hipStream_t st)
 {
 	const long n = f.K * pps;
-	hipLaunchKernelGGL((fused_prepass<NSEC>), dim3((unsigned) ((n + 255) / 256), (unsigned) f.n_streams), dim3(256), 0, st, f, sec, N2, pps);
+	const dim3 grid((unsigned) ((n + 255) / 256), (unsigned) f.n_streams);
+	if (f.sec_stride) hipLaunchKernelGGL((fused_prepass<NSEC, true>), grid, dim3(256), 0, st, f, sec, N2, pps);
+	else hipLaunchKernelGGL((fused_prepass<NSEC, false>), grid, dim3(256), 0, st, f, sec, N2, pps);
 }
 
 template <int NSEC, int HR> static void launch_col(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st)
@@ -548,7 +557,7 @@ template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FusePar
 // the matrix-core form of the prepass: 8 channels per stream, chunks in groups of 8, at most 16 sections' states; Gt: [len][32] (fuse_gtable)
 bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int n_state, hipStream_t st)
 {
-	if (f.C != 8 || f.K < 1 || (f.len % 8) != 0 || n_state < 1 || n_state > 32) return false;
+	if (f.C != 8 || f.K < 1 || (f.len % 8) != 0 || n_state < 1 || n_state > 32 || f.sec_stride != 0) return false;      // (one G for every column of the product)
 	const dim3 grid((unsigned) (((f.K + 7) / 8 + 3) / 4), (unsigned) f.n_streams);
 	if (f.in_fmt != PCM_DOUBLE) {
 		if (!pcm_fusable(f.in_fmt)) return false;

@@ -35,7 +35,9 @@ public:
 	struct Pending { const double *in = nullptr; long in_stride = 0; ssize_t frames = 0; int in_fmt = PCM_DOUBLE; } pending;
 	// sections of a chain whose channels all run the same sections and gains (gains folded into the next section's b coefficients,
 	// as cascade_rows has them), padded with pass-through sections to a count the fused kernels are instantiated for
-	struct FuseTables { bool tried = false, ok = false; int n_sec = 0, n_real = 0; double gain = 1.0; DevBuf sec, sec_op; };   // n_sec: with the padding, n_real: the chain's own
+	// (round 5: or whose channel PAIRS each run their own sections -- the two channels of a pair alike, `pairs` tables then: sections behind a
+	// pair-aligned selector are pass-through sections in the other pairs' tables, gains are per pair)
+	struct FuseTables { bool tried = false, ok = false; int n_sec = 0, n_real = 0, pairs = 1; double gain = 1.0; DevBuf sec, sec_op, gain_tab; };   // n_sec: with the padding, n_real: the chain's own; pairs: 1 = one table for every pair
 	const FuseTables &fuse_tables();
 
 	friend class ConvStage;

@@ -141,6 +141,48 @@ def test_fused_first_pass_in_front_of_the_2x_resampler(amd, tmp_path, taps, S, C
     assert torch.equal(bf.run(xs[0]), yf[0]) and torch.equal(bf.run(xs[1]), yf[1])
 
 
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("S,C,sel", [(8, 8, (":0,1", ":2,3", ":4-7")), (120, 8, (":0,1", ":2,3", ":4-7")), (6, 4, (":2,3", ":0,1", ":0-3"))])
+def test_sections_behind_pair_aligned_selectors_take_the_fused_path(amd, tmp_path, S, C, sel):
+    """the crossover shape (biquad.c:296-305: an effect acts on its selected channels): sections and gains behind selectors that keep the two channels
+    of every pair alike -- one section table per pair in the fused kernels (round 5: a wave of the first pass is 64 rows of one pair, its table
+    is still read with scalar loads; the prepass reads per-lane tables), pass-through sections where a pair is not selected, gains per pair.
+    Hop, hop, a call off the grid, hop: against the separate kernels and the real reference."""
+    import torch
+    f = os.path.join(str(tmp_path), "h.raw")
+    np.asarray(make_filter(16384, seed=41), dtype="<f8").tofile(f)
+    chain = (f"lowpass 6k 0.707 {sel[0]} eq 400 2.0 1.5 gain -2 lowshelf 150 0.8 2 {sel[1]} highpass 300 0.707 gain 1.5 {sel[2]} eq 3000 1.0 2 : "
+             f"highshelf 8k 0.7 -3 gain -1 fir_p -t pcm -e double -c 1 {f}")
+    B = 245760
+    bf, bs = build(amd, chain, C, S, B, True), build(amd, chain, C, S, B, False)
+    assert "cascade-fused(" in bf.plan() and "sections per pair" in bf.plan(), bf.plan()
+    assert "cascade-fused" not in bs.plan()
+    g = torch.Generator(device="cuda"); g.manual_seed(51)
+    sizes = [B, B, 5000, B]
+    xs = [torch.rand((S, n, C), dtype=torch.float64, device="cuda", generator=g) - 0.5 for n in sizes]
+    L = amd.load_library()
+    yf, names = [], []
+    for x in xs:
+        L.dspamd_profile_enable(1)
+        yf.append(bf.run(x).clone())
+        names.append({ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()})
+        L.dspamd_profile_enable(0)
+    assert [("fused_col_fwd" in n) for n in names] == [True, True, False, True], names
+    assert "fused_prepass" in names[0] and "fused_prepass_mm" not in names[0], names[0]        # (one G per product: the recurrence form serves per-pair tables)
+    ys = [bs.run(x).clone() for x in xs]
+    for k, (a, b) in enumerate(zip(yf, ys)):
+        assert a.shape == b.shape == (S, sizes[k], C)
+        assert float((a - b).pow(2).mean().sqrt()) < 1e-12, k
+    for s in sorted({0, S - 1, S // 2}):
+        x = torch.cat([t[s] for t in xs], dim=0).cpu().numpy()
+        ref = RefChain(chain, 48000, C).run(x)
+        got = torch.cat([t[s] for t in yf], dim=0).cpu().numpy()
+        assert ref.shape == got.shape
+        assert rms(ref - got) < 1e-12, (s, rms(ref - got))
+    bf.reset()
+    assert torch.equal(bf.run(xs[0]), yf[0])
+
+
 def test_chains_the_fused_kernels_leave_alone(amd, tmp_path):
     """per-channel sections, an `add` among the ops, a selector, a latency: the plan keeps the separate kernels"""
     f = os.path.join(str(tmp_path), "h.raw")
