@@ -40,6 +40,7 @@ CASES = {
     "fir_lat":  dict(chain="fir -t pcm -e double -c 1 {F} :1 delay 7S", S=3, C=3, frames=6000, calls=(3000, 3000), pick=(0, 2), taps=(700, 8, 90.0)),
     "two_conv": dict(chain="fir_p -t pcm -e double -c 1 {F} hilbert -p 255", S=4, C=2, frames=7000, calls=(3500, 3500), pick=(0, 3), taps=(900, 9, 120.0)),
     "rs96":     dict(chain=BIQ + " fir_p -t pcm -e double -c 1 {F} resample 96k", S=3, C=8, frames=9000, calls=(4096, 4904), pick=(0, 2), taps=(2000, 10, 300.0)),
+    "rs96_duo": dict(chain="fir_p -t pcm -e double -c 1 {F} resample 96k", S=8, C=2, frames=9000, calls=(4096, 4904), pick=(0, 7), taps=(2000, 10, 300.0), log2n=19),   # 2048-point rows, 8 pairs: the two-branch two-workgroup K2 (round 5; DSP_AMD_ROW_DUO2=0: the persistent three-pass kernel)
     "rs441":    dict(chain="resample 44.1k", S=2, C=2, frames=9000, calls=(4000, 5000), pick=(0, 1)),
     "rs32":     dict(chain="resample 32k", S=2, C=3, frames=6000, calls=(6000,), pick=(0, 1)),
     "small":    dict(chain="fir_p -t pcm -e double -c 1 {F}", S=4, C=2, frames=24576, calls=(2048,) * 12, pick=(0, 3), taps=(40000, 11, 6000.0)),
