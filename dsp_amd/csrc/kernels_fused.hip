@@ -544,6 +544,7 @@ template <int NSEC> static bool launch_col_mh(const ConvParams &p, const FusePar
 {
 	switch (f.hist_rows) {
 	case 16: launch_col<NSEC, 16>(p, f, sec, st); return true;
+	case 17: launch_col<NSEC, 17>(p, f, sec, st); return true;   // (BASELINE config 4: 66119 taps of fir_p merged into the 2x resampler; 8.54 against 8.92 ms for the run-time instance, profiles/r05_config4_hr17.txt)
 	case 32: launch_col<NSEC, 32>(p, f, sec, st); return true;
 	default:
 		if (f.hist_rows < 1 || f.hist_rows > 32) return false;
