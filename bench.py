@@ -418,7 +418,7 @@ def main():
             res["parity"]["pick_seed"] = pick_seed
         if world == 1 and not (args.config or args.chain) and not args.no_side_runs and not args.no_cpu_baseline:
             # SIDE FIGURE, never `value`: the same chain with the planner's opt-in LTI merge of the sections into the filter
-            # (DSP_AMD_MERGE_IIR=1): no cascade pass at all, exact to the decay criterion (2^-70).  The headline
+            # (DSP_AMD_MERGE_IIR=1, docs/history.md section 6): no cascade pass at all, exact to the decay criterion (2^-70).  The headline
             # above is measured with the cascade kernel in place, as the workload is defined.
             res["side_runs"] = {}
             try:

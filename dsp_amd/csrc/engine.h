@@ -30,7 +30,7 @@ struct DevBuf {
 
 // Small host blocks (LADSPA hosts: 64 ... 1024 frames): two page-locked, device-mapped staging buffers that the first kernel
 // reads and the last kernel writes over PCIe directly -- no copy commands, one launch sequence and one wait per call.  Measured
-// (DESIGN.md section 6): faster than H2D / D2H copy commands up to a few tens of KB per block, slower at 128 KB; the limit is
+// (docs/history.md section 6): faster than H2D / D2H copy commands up to a few tens of KB per block, slower at 128 KB; the limit is
 // DSP_AMD_PLUGIN_MAPPED_KB (default 32, 0 = off).
 struct MappedPair {
 	double *in = nullptr, *out = nullptr;

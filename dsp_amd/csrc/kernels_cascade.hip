@@ -43,7 +43,7 @@ namespace dspamd {
 
 constexpr int L16 = CASCADE_L;
 // per-channel LDS row: 64 lanes x (16 + 1 pad) doubles, + 2 so that rows of different channels land on
-// different bank pairs for the transposing store (see DESIGN.md "cascade kernel")
+// different bank pairs for the transposing store (see docs/history.md section 4.1)
 constexpr int CH_STRIDE = 64 * (L16 + 1) + 2;
 constexpr int NPOW_USED = 10;              // A^(2^k), k = 0..9
 constexpr int OPL_DOUBLES = 8 + 4 * NPOW_USED;   // compact LDS descriptor: kind, g, c0..c4, pad, P[10][4]
@@ -1166,7 +1166,7 @@ static bool rows_choice(const CascadeParams &p, int n_streams, int *Gout, int *P
 	if ((double) std::max(p.in_stride_frames, p.out_stride_frames) * p.C * 8 >= 2.0e9 || (double) p.ring.row_stride * 16 * (p.C / 2) >= 2.0e9) return false;
 	// Four channels per wave when that still gives 2048 waves of at most 8 per group (what the LDS transposers allow), i.e.
 	// from 1024 channels; two per wave from 512 channels; one per wave (all four DPP rows, three sequential row carries,
-	// 8-byte elements) below that.  Measured, 10 sections, ms per launch at 32 / 64 / 128 / 256 streams x 8 ch: see DESIGN.md.
+	// 8-byte elements) below that.  Measured, 10 sections, ms per launch at 32 / 64 / 128 / 256 streams x 8 ch: see docs/history.md section 4.1.
 	const long channels = (long) n_streams * p.C;
 	int G = (channels >= 1024 && p.rows4_ok) ? 4 : (channels >= 512) ? 2 : 1, P;
 	const bool wire = p.in_fmt != PCM_DOUBLE || p.sink.on;

@@ -5,7 +5,7 @@
 //   fir_p_effect_run + fft_part_group_compute   fir_p.c:64-181   (non-uniform partitions + frequency-domain delay line)
 // by their common mathematical content: y[n] = sum_k h[k] x[n-k] per channel, streamed.
 //
-// Design (DESIGN.md "FFT convolver"):
+// Design (docs/history.md section 4.2):
 //  * Two real channels that share one real filter ride one COMPLEX transform: z = x_a + i x_b,
 //    IFFT(FFT(z) H) = (x_a * h) + i (x_b * h) because h is real -- no real-FFT split step, no wasted half spectrum.
 //  * One big transform per block instead of the reference's many small partitions: the frequency-domain

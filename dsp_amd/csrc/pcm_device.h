@@ -32,7 +32,7 @@ __device__ __forceinline__ uint32_t pm_mul(uint32_t a, uint32_t b)
 // A^e for the two multipliers from byte tables: the generators have period 2^31 - 2 (A^(2^31 - 2) = 1 modulo the prime 2^31 - 1),
 // so e is first reduced modulo that, and A^e = T[0][e & 255] T[1][(e >> 8) & 255] T[2][...] T[3][...] with T[k][b] = A^(b 256^k):
 // four look-ups and three multiplications where square-and-multiply takes about sixty (measured on K3 with dither at the
-// headline shape: 13.7 -> see DESIGN.md section 4.5).  The tables are computed by the compiler.
+// headline shape: 13.7 -> see docs/history.md section 4.6).  The tables are computed by the compiler.
 struct PmTables { uint32_t t[2][4][256]; };
 constexpr uint32_t pm_mul_c(uint32_t a, uint32_t b)
 {

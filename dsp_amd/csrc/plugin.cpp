@@ -175,7 +175,7 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	const size_t in_bytes = (size_t) total * sg.ch_in * sizeof(double);
 	const size_t out_bytes = (size_t) sg.pipe->max_out_frames(total) * sg.ch_out * sizeof(double);
 	// The small-block rule (stated, not worked around: this library has no host path): a block costs a launch round trip of 23 ... 27 us whatever
-	// its size, which the reference's own loop undercuts below about 20000 channel-sample-sections per block (64 frames
+	// its size (docs/history.md section 6), which the reference's own loop undercuts below about 20000 channel-sample-sections per block (64 frames
 	// x 2 ch x 10 biquads: 3 us there).  A segment that keeps being driven below that says so once, at verbose level.
 	++sg.calls;
 	if ((double) total * sg.ch_in * std::max<size_t>(1, sg.members.size()) < 20000.0) ++sg.small_calls;

@@ -91,7 +91,7 @@ ssize_t dspamd_batch_drain_frames(dspamd_batch *);
 ssize_t dspamd_batch_run(dspamd_batch *, const void *d_in, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream);
 /* the same with the streams' input slabs in_stride_frames apart (>= frames): d_in is [S][in_stride_frames][C_in].  Slabs
  * whose distance is a large power of two (or a multiple of one: 196608 frames x 64 B = 3 x 4 MiB) put the same frame of every
- * stream on the same memory channels; a few hundred bytes of padding per stream avoid that (DESIGN.md section 4). */
+ * stream on the same memory channels; a few hundred bytes of padding per stream avoid that (DESIGN.md section 3). */
 ssize_t dspamd_batch_run_strided(dspamd_batch *, const void *d_in, ssize_t in_stride_frames, ssize_t frames, void *d_out, ssize_t out_stride_frames, void *stream);
 /* end of stream: push zeros / flush rate changers; returns frames produced, -1 when dry */
 ssize_t dspamd_batch_drain(dspamd_batch *, ssize_t block_frames, void *d_out, ssize_t out_stride_frames, void *stream);
@@ -138,7 +138,7 @@ int dspamd_pcm_write(int fmt, const void *d_in, ssize_t in_stride_frames, void *
  * identical sections on the channels of a group), a convolver's first kernel on the input side, the inverse column transform of
  * a plain convolution or of a 2x upsampler on the output side (s16 / s24 / s32 / float / double each), remix and the alignment
  * delay on either side (every format) -- otherwise the conversion kernels run before / after it on buffers of the batch
- * (DESIGN.md section 4.6 has the table).  The samples are the same either way, bit for bit; dspamd_batch_wire_fused() says
+ * (docs/history.md section 4.6 has the table).  The samples are the same either way, bit for bit; dspamd_batch_wire_fused() says
  * what the last call did.
  */
 ssize_t dspamd_batch_run_wire(dspamd_batch *, int in_fmt, const void *d_in, ssize_t in_stride_frames, ssize_t frames,

@@ -1,5 +1,5 @@
 // micro-benchmark: does v_mfma_f64_16x16x4 run beside fp64 VALU work of the same wave?  (the cascade's zero-input correction as
-// a rank-2 update on the matrix pipe: DESIGN.md section 8)   Build: hipcc -O3 --offload-arch=gfx950 mfmabench.hip -o mfmabench
+// a rank-2 update on the matrix pipe: docs/history.md section 8)   Build: hipcc -O3 --offload-arch=gfx950 mfmabench.hip -o mfmabench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)

@@ -235,7 +235,7 @@ def test_random_chain_ragged_calls(amd, seed):
 
 @pytest.mark.parametrize("seed", range(30))
 def test_random_chain_small_calls_vs_real_reference(amd, tmp_path, seed):
-    # the convolver's small-call regime (delay-line head + overlap-save tail) inside random chains: a long
+    # the convolver's small-call regime (delay-line head + overlap-save tail, DESIGN.md 4.3, docs/history.md 4.2b) inside random chains: a long
     # zero-latency filter on every channel between randomly drawn cascade effects, fed in calls of 256 ... 2048 frames that
     # cross several tail hand-overs, with a ragged last call (which takes the stream off the grid) and the drain
     import torch

@@ -315,7 +315,7 @@ def test_file_to_file_against_the_reference_cli(gpu, tmp_path):
 def test_persistent_k3_speaks_the_formats(gpu, tmp_path, monkeypatch, in_fmt, out_fmt, prec):
     # a shape that reaches the persistent K3 (streams of four pairs, N = 2^18: 8 streams x 128 column blocks = 1024 tiles):
     # the plain call and the call with the sink must run the SAME kernel instance -- two instances of one FFT source are not
-    # guaranteed the same bits -- so every byte and both statistics agree with the stand-alone passes
+    # guaranteed the same bits (docs/history.md section 4.6) -- so every byte and both statistics agree with the stand-alone passes
     monkeypatch.setenv("DSP_AMD_CONV_LOG2N", "18")
     path, _ = write_filter(tmp_path, 3000)
     chain = f"fir_p -t pcm -e double -c 1 {path}"
