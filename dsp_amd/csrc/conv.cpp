@@ -67,13 +67,14 @@ public:
 	{
 		(void) in; (void) in_stride; (void) frames; (void) out_fmt; (void) also_out;   // (K1 and K3 are different kernels: the ends are independent)
 		if (!wire_fusion_on() || fed) return false;
+		if (short_mode) return !direct;        // (the one-trip kernel reads fp64 slabs; the de-interleaving pass in front of it converts any format)
 		return !direct || (pcm_fusable(fmt) && fmt != PCM_DOUBLE);
 	}
 	// a plain convolution of every channel at the end of a pipeline: K3 applies the sink (dither, clip, wire format) in its stores
 	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override
 	{
 		(void) out_stride; (void) in_fmt; (void) also_in;
-		if (!wire_fusion_on() || !pcm_fusable(fmt) || !all_selected || feeds) return false;
+		if (!wire_fusion_on() || !pcm_fusable(fmt) || !all_selected || feeds || short_mode) return false;
 		// K3 speaks the formats in its plain form and in its two-phase form (the 2x upsampler, at least 3 pairs per stream)
 		const bool plain = !resampler && nph == 1 && up == 1 && down == 1;
 		// (the two-phase form writes whole pairs only: adjacent channels of an aligned slab)
@@ -188,6 +189,13 @@ private:
 	// frame's 64 bytes per workgroup: 8.9 ms at the headline shape against 6.9)
 	bool fuse_plain = false;
 	DevBuf plain_sec, plain_op, plain_X;
+	// ---- short filters behind long calls (round 5, kernels_short.hip): taps - 1 <= 4096 and calls of at least 1024 frames -- the whole transform of a pair
+	// (8192 points) in one workgroup's LDS: a block is one read of the window and one write of the outputs instead of three trips of W through HBM
+	bool short_mode = false;
+	long cur_frames = 0;
+	DevBuf tw_short;
+	bool prepare_short(const Spec &sp);
+	void convolve_short(long q_lo, long q_hi, long k_origin, long out_count, double *out, long out_stride, hipStream_t st);
 	bool run_fused_plain(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st);
 };
 
@@ -199,6 +207,7 @@ std::string ConvStage::describe() const
 	o << " T=" << T << " N=" << N << "=" << N1 << "x" << N2 << " hop=" << B << " pairs/stream=" << pps
 	  << (n_filters > 1 ? " per-channel-filters" : "") << (lat ? " latency=" + std::to_string(lat) : "") << (fed ? (fed_by ? " fed-by-conv" : " fed-by-cascade") : "")
 	  << (round_f32 ? " f32-io" : "") << (f32 ? " f32-spectrum" : "") << ((direct && !fed) ? (fuse_plain ? " slab-direct(two pairs per workgroup at whole hops)" : " slab-direct") : "");
+	if (short_mode) o << " one-trip";
 	if (fuse_static) o << " cascade-fused(" << (N1 - first_n / N2) * fuse_seg << " chunks of " << N2 / fuse_seg << (feeder_ && feeder_->fuse_tables().pairs > 1 ? ", sections per pair" : "") << ")";
 	if (skip) o << " drops-first=" << skip;
 	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N;
@@ -324,9 +333,16 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	// channel pairs share a transform only when they share the filter
 	pps = (n_filters == 1) ? (nsel + 1) / 2 : nsel;
 
-	N = conv_plan(T, max_frames, resampler, nullptr);
-	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
+	{
+		const char *se = getenv("DSP_AMD_CONV_SHORT");          // 0 = the four-step transforms whatever the filter's length (read per stage: the tests build both plans in one process)
+		const bool short_on = !se || atoi(se) != 0;
+		// (calls of at least 1024 frames: below that a launch is all latency; 32-bit byte offsets inside a stream's slab / a pair's ring)
+		short_mode = short_on && !env && !resampler && !round_f32 && !ring_parent && !upc_block && !force_N && ((T - 1 + 7) & ~7L) <= CONV_SHORT_N / 2
+		             && (long) max_frames >= 1024 && (long) max_frames <= (1L << 24) && (double) max_frames * sp.ch_in * sizeof(double) < 2.0e9;
+	}
+	N = short_mode ? CONV_SHORT_N : conv_plan(T, max_frames, resampler, nullptr);
+	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	if (env && !is_tail_child) N = std::max(lo, 1L << atoi(env));
 	if (force_N) N = force_N;
 	if (N > (1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2))) N = std::max(lo, 1L << (FFT_MAX_LOG2_N1 + FFT_MAX_LOG2_N2));
@@ -392,6 +408,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	if (!tw_n1.upload(t.data(), t.size() * sizeof(double2))) return false;
 	make_twiddles(N2, N2, 1, t);
 	if (!tw_n2.upload(t.data(), t.size() * sizeof(double2))) return false;
+	if (short_mode) { make_twiddles(N, N, 1, t); if (!tw_short.upload(t.data(), t.size() * sizeof(double2))) return false; }
 	make_twiddles(N, 1L << log2_lo, 1, t);
 	if (!tw_lo.upload(t.data(), t.size() * sizeof(double2))) return false;
 	make_twiddles(N, N >> log2_lo, 1L << log2_lo, t);
@@ -846,8 +863,55 @@ bool ConvStage::spectrum_f32(const std::vector<double> &src, long n_taps, int st
 	return hip_ok(hipMemcpy(static_cast<char *>(H.p) + index * (size_t) N * sizeof(float2), hf.data(), (size_t) N * sizeof(float2), hipMemcpyHostToDevice), "H2D spectrum");
 }
 
+// filter spectra of the one-trip form: the kernel's own forward transform of the taps as a window of N points (preparation mode), natural order
+bool ConvStage::prepare_short(const Spec &sp)
+{
+	std::vector<double2> rows((size_t) n_filters * N, make_double2(0.0, 0.0));
+	for (int f = 0; f < n_filters; ++f)
+		for (long i = 0; i < T; ++i) rows[(size_t) f * N + i].x = sp.taps[(size_t) i * sp.fch + (sp.fch == 1 ? 0 : f)];
+	DevBuf d_rows;
+	if (!d_rows.upload(rows.data(), rows.size() * sizeof(double2))) return false;
+	ShortParams p;
+	memset(&p, 0, sizeof(p));
+	p.N = N; p.first_n = 0; p.hop = N;
+	p.ring = d_rows.as<double2>(); p.ring_row_stride = N; p.ring_mask = N - 1;
+	p.q0 = 0; p.lat = 0; p.n_in = N;
+	p.C = 2; p.pairs_per_stream = 1;
+	p.pair_out_ch = pair_out_ch.as<int>(); p.pair_h = pair_h.as<int>();
+	p.Hout = H.as<double2>(); p.h_scale = 1.0 / (double) N;
+	p.tw = tw_short.as<double2>();
+	p.n_pairs = n_filters; p.blocks_per_wg = 1;
+	launch_conv_short(p, nullptr);
+	return hip_ok(hipDeviceSynchronize(), "filter spectrum");
+}
+
+void ConvStage::convolve_short(long q_lo, long q_hi, long k_origin, long out_count, double *out, long out_stride, hipStream_t st)
+{
+	ShortParams p;
+	memset(&p, 0, sizeof(p));
+	p.N = N; p.first_n = first_n; p.hop = B;
+	p.ring = ring_dev; p.ring_row_stride = ring_stride; p.ring_mask = ring_len - 1;
+	p.q0 = q_lo; p.lat = lat; p.n_in = q_hi - q_lo + 1;
+	if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_q0 = cur_q0; p.file_from = cur_q0 + cur_frames - first_n; }
+	p.C = ch_in; p.pairs_per_stream = pps;
+	p.pair_out_ch = pair_out_ch.as<int>(); p.pair_h = pair_h.as<int>();
+	p.H = H.as<double2>(); p.tw = tw_short.as<double2>();
+	p.out = out; p.out_stride_frames = out_stride; p.k_origin = k_origin; p.out_count = out_count;
+	p.ring_out = feed_ring; p.ring_out_stride = feed_stride; p.ring_out_mask = feed_mask; p.ring_out_pos = feed_pos; p.ring_out_round_f32 = feed_round;
+	p.round_f32 = round_f32;
+	p.n_pairs = (long) S * pps;
+	// a workgroup walks one pair's blocks with the filter row in registers; few pairs: the blocks of a pair are shared out until two workgroups per CU's worth exist
+	const long n_blocks = (p.n_in + B - 1) / B;
+	long ranges = (512 + p.n_pairs - 1) / p.n_pairs;
+	ranges = std::max<long>(1, std::min<long>(ranges, n_blocks));
+	p.blocks_per_wg = (int) ((n_blocks + ranges - 1) / ranges);
+	ProfScope ps("conv_short", st);
+	launch_conv_short(p, st);
+}
+
 bool ConvStage::prepare_filters(const Spec &sp)
 {
+	if (short_mode) return prepare_short(sp);
 	if (upc_P) {
 		// partition q = taps [q B, q B + B) of filter f (one shared filter, or one per selected channel: fir_p.c:483-495), zero-padded to the transform
 		for (int f = 0; f < n_filters; ++f)
@@ -898,6 +962,7 @@ void ConvStage::push(const double *in, long in_stride, ssize_t frames, double *o
 // at or beyond q_end read as zero: the drain), mapped to output frames by (up, down, k_origin): see fft_params.h.
 void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, double *out, long out_stride, hipStream_t st)
 {
+	if (short_mode) { convolve_short(q_lo, q_hi, k_origin, out_count, out, out_stride, st); return; }
 	const long chunk_streams = pairs_per_chunk / pps;
 	const long q_end = resampler ? q_total : q_hi + 1;
 	for (long q_blk = q_lo; q_blk <= q_hi; q_blk += B) {
@@ -1000,6 +1065,7 @@ ssize_t ConvStage::run(const double *in, long in_stride, ssize_t frames, double 
 	const bool use_direct = direct && !fed && ((((size_t) in) & 15) == 0) && (double) in_stride * ch_in * 8 < 1.0e18;
 	cur_slab = use_direct ? in : nullptr;
 	cur_slab_stride = in_stride;
+	cur_frames = frames;
 	cur_q0 = resampler ? q_total : q_abs;
 	if (!fed && !use_direct) push(in, in_stride, frames, out, out_stride, st);
 	if (resampler) {

@@ -148,6 +148,36 @@ bool launch_fused_prepass_mm(const FuseParams &f, const double *Gt, long N2, int
 int fused_section_slots(int n_sec);   // section count of the instance that takes n_sec sections (the host pads with pass-through sections), 0 = none
 bool launch_fused_col_fwd(const ConvParams &p, const FuseParams &f, const double *sec, hipStream_t st);
 
+// One-trip convolver for SHORT filters behind long calls (round 5, kernels_short.hip): taps - 1 <= N / 2, N = 8192: a pair's whole transform lives in one
+// workgroup's LDS, so a block of hop = N - first_n frames is one read of the window and one write of the outputs -- no W, no second and third trip.
+// Window element n of block b is input index q0 + b hop - lat - first_n + n (ring position = index & ring_mask; from the slab instead where the
+// index lies in the current call and the stage reads its slab directly); elements at or beyond first_n + in_count are zero; window sample
+// first_n + f is the convolution at input index q0 + b hop + f, written to output frame q0 + b hop + f - k_origin when inside [0, out_count).
+struct ShortParams {
+	long N, first_n, hop;
+	const double2 *ring;
+	long ring_row_stride, ring_mask;
+	long q0, lat, n_in;                 // first input index of block 0, the stage's latency, input indices covered (blocks of hop frames, the last one shorter)
+	const double *slab;                 // direct mode: [S][slab_stride_frames][C], frame 0 = input index slab_q0; nullptr = everything from the rings
+	long slab_stride_frames, slab_q0, file_from;   // slab frames with input index >= file_from are filed in the ring on the way (the history later calls look back at)
+	int C, pairs_per_stream;
+	const int *pair_out_ch;             // [pairs_per_stream][2]
+	const int *pair_h;                  // [n_pairs] filter of the pair
+	const double2 *H;                   // [n_filters][N], natural order, pre-scaled by 1 / N
+	double2 *Hout;                      // preparation mode: h_scale x forward transform of the window goes here ([n_pairs][N]) and the kernel stops
+	double h_scale;
+	const double2 *tw;                  // exp(-2 pi i k / N), k < N
+	double *out;
+	long out_stride_frames, k_origin, out_count;
+	double2 *ring_out;                  // the NEXT convolver's pair rings as destination (as in ConvParams), or nullptr
+	long ring_out_stride, ring_out_mask, ring_out_pos;
+	int ring_out_round_f32, round_f32;
+	long n_pairs;
+	int blocks_per_wg;
+};
+void launch_conv_short(const ShortParams &p, hipStream_t st);
+constexpr long CONV_SHORT_N = 8192;
+
 void launch_conv_col(const ConvParams &p, bool inverse, int grid_y, hipStream_t st);
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st);
 void launch_deinterleave(const DeintParams &p, int n_streams, hipStream_t st);

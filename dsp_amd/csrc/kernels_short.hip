@@ -1,0 +1,165 @@
+// kernels_short.hip -- one-trip FFT convolution for SHORT filters behind long calls (round 5).
+//
+// What it replaces, per block, in the reference: fir_p's / fir's block transform, spectrum product and inverse (fir_p.c:64-103, fir.c:109-149) for
+// filters of up to 4097 taps -- `hilbert -p 4095` (hilbert.c:28-92), crossover and correction FIRs, the FIRs `biquad -r` sections are designed into.
+// The four-step convolver (kernels_fft.hip) sends every window through HBM three times whatever the filter's length; a window of 8192 points of a
+// channel pair is 128 KB and fits one workgroup's LDS, so here a block is ONE read of the window (first_n frames of history + hop new ones) and ONE
+// write of hop outputs: (N + hop) / hop units of 16 bytes per pair and frame -- 3 at 4095 taps, 2.3 at 1000 -- against 6.4 for three trips of a
+// 65536-point transform.  BASELINE config 5's `hilbert -p 4095` stage was 22 of its 35 ms.
+//
+// Workgroup = one channel pair (z = x_a + i x_b, exact: h is real), 512 threads x 16 points, walking the pair's blocks with the filter row in registers;
+// radix 16 / 16 / 16 / 2 Stockham passes through the row buffer (the XOR-swizzled slots of conv_row: the same store and gather shapes).  One workgroup
+// per CU (139 KB of LDS).  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "kparams.h"
+#include "fft_params.h"
+#include "pcm_device.h"
+
+namespace dspamd {
+namespace psh {
+typedef double real;
+#define FFT_F32 0
+#define FFT_CORE_NO_LAUNCHERS 1
+#include "fft_core.inc"
+#undef FFT_CORE_NO_LAUNCHERS
+#undef FFT_F32
+
+constexpr int SH_LOG2N = 13, SH_N = 1 << SH_LOG2N, SH_P = SH_N / 16, SH_THREADS = SH_P;
+constexpr int SH_T256 = 272, SH_TLO = 68, SH_THI = SH_N / 64;
+constexpr size_t SH_LDS = ((size_t) SH_N + SH_T256 + SH_TLO + SH_THI) * sizeof(cplx);
+
+template <bool INV, class Tw>
+__device__ __forceinline__ void short_fft(cplx (&v)[16], int j, cplx *lds, const RowMap &map, const Tw &tw)
+{
+	// (j made opaque per pass: the thread's twiddle and exchange addresses depend on j alone and would all be computed once and kept)
+	asm volatile("" : "+v"(j));
+	pass16<SH_LOG2N, 16, 1, INV, false>(v, j, lds, map, tw);
+	lds_barrier();
+	gather16<SH_LOG2N>(v, j, lds, map);
+	lds_barrier();
+	asm volatile("" : "+v"(j));
+	pass16<SH_LOG2N, 16, 16, INV, false>(v, j, lds, map, tw);
+	lds_barrier();
+	gather16<SH_LOG2N>(v, j, lds, map);
+	lds_barrier();
+	asm volatile("" : "+v"(j));
+	pass16<SH_LOG2N, 16, 256, INV, false>(v, j, lds, map, tw);
+	lds_barrier();
+	gather16<SH_LOG2N>(v, j, lds, map);
+	asm volatile("" : "+v"(j));
+	pass16<SH_LOG2N, 2, 4096, INV, true>(v, j, lds, map, tw);
+}
+
+// (every address is a buffer descriptor + a 32-bit offset: the host checks that rings, slabs and outputs stay below 2 GB per stream / pair -- sixteen
+// 64-bit address pairs per direction do not fit beside the 64 registers of the window and the 64 of the filter row)
+typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
+{
+	constexpr int N = SH_N, P = SH_P;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+	cplx *data = reinterpret_cast<cplx *>(smem_raw);
+	cplx *t256 = data + N, *tlo = t256 + SH_T256, *thi = tlo + SH_TLO;
+	int j = threadIdx.x;
+	const long pair = blockIdx.x;
+	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
+	const long b0 = (long) blockIdx.y * p.blocks_per_wg, b1 = (b0 + p.blocks_per_wg < n_blocks) ? b0 + p.blocks_per_wg : n_blocks;
+	if (b0 >= b1) return;
+	if (j < 256) t256[twpad(j)] = TAB(p.tw)[j * (N / 256)];
+	else if (j < 256 + 64) tlo[twpad(j - 256)] = TAB(p.tw)[j - 256];
+	else if (j < 256 + 64 + SH_THI) thi[j - 320] = TAB(p.tw)[(j - 320) * 64];
+	cplx h[16];
+	if (!p.Hout) {
+		const cplx *H = TAB(p.H) + (long) p.pair_h[pair] * N + j;
+#pragma unroll
+		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
+	}
+	lds_barrier();                                                       // tables visible
+	const TwRow<N> tw{ t256, tlo, thi };
+	const RowMap map{ 0 };
+	const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
+	const int fb = p.C * (int) sizeof(double);                          // bytes per slab / output frame
+	const int mask = (int) p.ring_mask, omask = (int) p.ring_out_mask;
+	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(p.ring) + pair * p.ring_row_stride, 0, 0x7fffffff, 0x00020000);
+	// direct mode: the pair's two channels of a slab frame are 16 contiguous bytes (channels 2 qs, 2 qs + 1: the host checked)
+	const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.slab ? p.slab + ((size_t) s * p.slab_stride_frames * p.C + 2 * qs) : nullptr), 0, 0x7fffffff, 0x00020000);
+	const int cha = p.pair_out_ch[2 * qs], chb = p.pair_out_ch[2 * qs + 1];
+	double *out = p.out ? p.out + (size_t) s * p.out_stride_frames * p.C : nullptr;
+	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_rout = __builtin_amdgcn_make_buffer_rsrc(p.ring_out ? p.ring_out + pair * p.ring_out_stride : nullptr, 0, 0x7fffffff, 0x00020000);
+	const int first_n = (int) p.first_n;
+	for (long b = b0; b < b1; ++b) {
+		const long q_blk = p.q0 + b * p.hop;
+		const int in_count = (int) ((p.n_in - b * p.hop < p.hop) ? p.n_in - b * p.hop : p.hop);
+		const long a0 = q_blk - p.lat - p.first_n;                  // input index of window element 0
+		const int valid = first_n + in_count;
+		const int r0 = (int) (a0 & p.ring_mask);                    // its ring position
+		// window coordinates at which the slab starts / from which slab frames are filed in the ring (N: never)
+		const long d_slab = p.slab_q0 - a0, d_file = p.file_from - a0;
+		const int n_slab = !p.slab ? N : (d_slab <= 0 ? 0 : (d_slab < N ? (int) d_slab : N));
+		const int n_file = (d_file <= first_n) ? first_n : (d_file < N ? (int) d_file : N);
+		const int so = (int) (-d_slab * fb);                         // byte offset of element 0 in the stream's slab (negative while it lies in older calls)
+		cplx v[16];
+		asm volatile("" : "+v"(j));                                  // (addresses are recomputed per block: kept across blocks they are 40 registers nobody has)
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			const int n = j + P * m;
+			if (n >= valid) v[m] = mkc(0.0, 0.0);
+			else if (n >= n_slab) {
+				v[m] = buf_ldc(r_slab, so + n * fb, 0);
+				if (n >= n_file) buf_stc(v[m], r_ring, ((r0 + n) & mask) * 16);
+			}
+			else v[m] = buf_ldc(r_ring, ((r0 + n) & mask) * 16, 0);
+		}
+		if (b > b0) lds_barrier();                                   // the previous block's last gather is done
+		short_fft<false>(v, j, data, map, tw);
+		if (p.Hout) {
+			cplx *Ho = reinterpret_cast<cplx *>(p.Hout) + pair * N + j;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) Ho[P * m] = mkc(v[m].x * p.h_scale, v[m].y * p.h_scale);
+			return;
+		}
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], h[m]); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+		lds_barrier();                                               // every gather of the forward transform is done
+		short_fft<true>(v, j, data, map, tw);
+		// window sample first_n + f -> output frame mo0 + f, for f in [f_lo, f_hi)
+		const long mo0 = q_blk - p.k_origin;
+		const int f_lo = (mo0 >= 0) ? 0 : (-mo0 < in_count ? (int) -mo0 : in_count);
+		const int f_hi = (p.out_count - mo0 >= in_count) ? in_count : (p.out_count - mo0 > 0 ? (int) (p.out_count - mo0) : 0);
+		const int ob = (int) ((mo0 * p.C + (cha >= 0 ? cha : 0)) * (long) sizeof(double)), ob2 = (int) ((mo0 * p.C + (chb >= 0 ? chb : 0)) * (long) sizeof(double));
+		const int rp0 = (int) ((p.ring_out_pos + mo0) & p.ring_out_mask);
+		asm volatile("" : "+v"(j));
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			const int f = j + P * m - first_n;
+			if (f < f_lo || f >= f_hi) continue;
+			cplx y = v[m];
+			if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+			if (p.ring_out) {
+				if (p.ring_out_round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+				if (chb < 0) y.y = 0.0;
+				buf_stc(y, r_rout, ((rp0 + f) & omask) * 16);
+			}
+			else if (wide) buf_stc(y, r_out, ob + f * fb);
+			else {
+				if (cha >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.x), r_out, ob + f * fb, 0, 0);
+				if (chb >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.y), r_out, ob2 + f * fb, 0, 0);
+			}
+		}
+	}
+}
+
+}  // namespace psh
+
+void launch_conv_short(const ShortParams &p, hipStream_t st)
+{
+	if (p.N != psh::SH_N || p.n_pairs < 1 || p.n_in < 1) return;
+	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short), psh::SH_LDS);
+	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
+	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
+	hipLaunchKernelGGL(psh::conv_short, dim3((unsigned) p.n_pairs, (unsigned) ranges), dim3(psh::SH_THREADS), psh::SH_LDS, st, p);
+}
+
+}  // namespace dspamd
