@@ -67,14 +67,13 @@ public:
 	{
 		(void) in; (void) in_stride; (void) frames; (void) out_fmt; (void) also_out;   // (K1 and K3 are different kernels: the ends are independent)
 		if (!wire_fusion_on() || fed) return false;
-		if (short_mode) return !direct;        // (the one-trip kernel reads fp64 slabs; the de-interleaving pass in front of it converts any format)
 		return !direct || (pcm_fusable(fmt) && fmt != PCM_DOUBLE);
 	}
 	// a plain convolution of every channel at the end of a pipeline: K3 applies the sink (dither, clip, wire format) in its stores
 	bool wire_out_ok(int fmt, const void *out, long out_stride, ssize_t frames, bool also_in, int in_fmt) const override
 	{
 		(void) out_stride; (void) in_fmt; (void) also_in;
-		if (!wire_fusion_on() || !pcm_fusable(fmt) || !all_selected || feeds || short_mode) return false;
+		if (!wire_fusion_on() || !pcm_fusable(fmt) || !all_selected || feeds) return false;
 		// K3 speaks the formats in its plain form and in its two-phase form (the 2x upsampler, at least 3 pairs per stream)
 		const bool plain = !resampler && nph == 1 && up == 1 && down == 1;
 		// (the two-phase form writes whole pairs only: adjacent channels of an aligned slab)
@@ -880,6 +879,7 @@ bool ConvStage::prepare_short(const Spec &sp)
 	p.pair_out_ch = pair_out_ch.as<int>(); p.pair_h = pair_h.as<int>();
 	p.Hout = H.as<double2>(); p.h_scale = 1.0 / (double) N;
 	p.tw = tw_short.as<double2>();
+	p.slab_fmt = PCM_DOUBLE;
 	p.n_pairs = n_filters; p.blocks_per_wg = 1;
 	launch_conv_short(p, nullptr);
 	return hip_ok(hipDeviceSynchronize(), "filter spectrum");
@@ -892,7 +892,9 @@ void ConvStage::convolve_short(long q_lo, long q_hi, long k_origin, long out_cou
 	p.N = N; p.first_n = first_n; p.hop = B;
 	p.ring = ring_dev; p.ring_row_stride = ring_stride; p.ring_mask = ring_len - 1;
 	p.q0 = q_lo; p.lat = lat; p.n_in = q_hi - q_lo + 1;
-	if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_q0 = cur_q0; p.file_from = cur_q0 + cur_frames - first_n; }
+	p.slab_fmt = PCM_DOUBLE;
+	if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_q0 = cur_q0; p.file_from = cur_q0 + cur_frames - first_n; p.slab_fmt = wire_in_fmt; }
+	p.sink = wire_sink;
 	p.C = ch_in; p.pairs_per_stream = pps;
 	p.pair_out_ch = pair_out_ch.as<int>(); p.pair_h = pair_h.as<int>();
 	p.H = H.as<double2>(); p.tw = tw_short.as<double2>();

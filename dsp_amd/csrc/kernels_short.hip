@@ -54,6 +54,8 @@ __device__ __forceinline__ void short_fft(cplx (&v)[16], int j, cplx *lds, const
 // (every address is a buffer descriptor + a 32-bit offset: the host checks that rings, slabs and outputs stay below 2 GB per stream / pair -- sixteen
 // 64-bit address pairs per direction do not fit beside the 64 registers of the window and the 64 of the filter row)
 typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
+// BS: bytes per sample of the slab in direct mode (8: fp64; 4: s24 / s32 / float; 2: s16 -- read_buf_<fmt> of pcm_device.h in the loads)
+template <int BS>
 __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
 {
 	constexpr int N = SH_N, P = SH_P;
@@ -78,11 +80,18 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 	const TwRow<N> tw{ t256, tlo, thi };
 	const RowMap map{ 0 };
 	const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
-	const int fb = p.C * (int) sizeof(double);                          // bytes per slab / output frame
+	const int fb = p.C * (int) sizeof(double);                          // bytes per fp64 output frame
+	const int fbi = p.C * BS;                                           // bytes per slab frame
+	const WordFormat wf_slab = word_format(p.slab_fmt);
 	const int mask = (int) p.ring_mask, omask = (int) p.ring_out_mask;
 	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(p.ring) + pair * p.ring_row_stride, 0, 0x7fffffff, 0x00020000);
 	// direct mode: the pair's two channels of a slab frame are 16 contiguous bytes (channels 2 qs, 2 qs + 1: the host checked)
-	const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p.slab ? p.slab + ((size_t) s * p.slab_stride_frames * p.C + 2 * qs) : nullptr), 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.slab ? reinterpret_cast<const char *>(p.slab) + ((size_t) s * p.slab_stride_frames * p.C + 2 * qs) * BS : nullptr), 0, 0x7fffffff, 0x00020000);
+	auto slab_ld = [&](int vo) -> cplx {
+		if constexpr (BS == 8) return buf_ldc(r_slab, vo, 0);
+		else if constexpr (BS == 4) { const sh_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r_slab, vo, 0, 0); return mkc(pcm_from_word(w.x, wf_slab), pcm_from_word(w.y, wf_slab)); }
+		else { const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(r_slab, vo, 0, 0); return mkc(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16)); }
+	};
 	const int cha = p.pair_out_ch[2 * qs], chb = p.pair_out_ch[2 * qs + 1];
 	double *out = p.out ? p.out + (size_t) s * p.out_stride_frames * p.C : nullptr;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 		const long d_slab = p.slab_q0 - a0, d_file = p.file_from - a0;
 		const int n_slab = !p.slab ? N : (d_slab <= 0 ? 0 : (d_slab < N ? (int) d_slab : N));
 		const int n_file = (d_file <= first_n) ? first_n : (d_file < N ? (int) d_file : N);
-		const int so = (int) (-d_slab * fb);                         // byte offset of element 0 in the stream's slab (negative while it lies in older calls)
+		const int so = (int) (-d_slab * fbi);                        // byte offset of element 0 in the stream's slab (negative while it lies in older calls)
 		cplx v[16];
 		asm volatile("" : "+v"(j));                                  // (addresses are recomputed per block: kept across blocks they are 40 registers nobody has)
 #pragma unroll
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 			const int n = j + P * m;
 			if (n >= valid) v[m] = mkc(0.0, 0.0);
 			else if (n >= n_slab) {
-				v[m] = buf_ldc(r_slab, so + n * fb, 0);
+				v[m] = slab_ld(so + n * fbi);
 				if (n >= n_file) buf_stc(v[m], r_ring, ((r0 + n) & mask) * 16);
 			}
 			else v[m] = buf_ldc(r_ring, ((r0 + n) & mask) * 16, 0);
@@ -131,6 +140,54 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 		const int ob = (int) ((mo0 * p.C + (cha >= 0 ? cha : 0)) * (long) sizeof(double)), ob2 = (int) ((mo0 * p.C + (chb >= 0 ? chb : 0)) * (long) sizeof(double));
 		const int rp0 = (int) ((p.ring_out_pos + mo0) & p.ring_out_mask);
 		asm volatile("" : "+v"(j));
+		if (p.sink.on) {
+			// the END of a pipeline run from wire format to wire format: dither, clip() and the conversion in these stores (dsp.c:685-699), as K3 has
+			// them.  A thread's valid outputs are a contiguous range of m, P frames apart: from one to the next the position in the two dither
+			// sequences moves by P C samples.
+			const bool dither = p.sink.dither_mult != 0.0;
+			const int bs = (p.sink.fmt == PCM_DOUBLE) ? 8 : (p.sink.fmt == PCM_S16) ? 2 : 4;
+			const WordFormat wf_sink = word_format(p.sink.fmt);
+			char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * bs;
+			const bool wpair = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) wout) & 15) == 0);
+			int m_first = 16;
+#pragma unroll
+			for (int m = 15; m >= 0; --m) { const int f = j + P * m - first_n; if (f >= f_lo && f < f_hi) m_first = m; }
+			uint32_t ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0, j0 = 1, j1 = 1;
+			if (dither && m_first < 16) {
+				const long mo = mo0 + (j + P * m_first - first_n);
+				const uint64_t na = (uint64_t) (p.sink.samples_before + mo * p.C + (cha >= 0 ? cha : 0)) + 1;
+				const uint64_t nb = (uint64_t) (p.sink.samples_before + mo * p.C + (chb >= 0 ? chb : 0)) + 1;
+				ua0 = pm_pow<0>(na); ua1 = pm_pow<1>(na);
+				if (chb == cha + 1) { ub0 = pm_mul(ua0, PM_A0); ub1 = pm_mul(ua1, PM_A1); }
+				else { ub0 = pm_pow<0>(nb); ub1 = pm_pow<1>(nb); }
+				j0 = pm_pow<0>((uint64_t) P * p.C); j1 = pm_pow<1>((uint64_t) P * p.C);
+			}
+			double peak = 0.0;
+			unsigned long long clipped = 0;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) {
+				const int f = j + P * m - first_n;
+				if (f < f_lo || f >= f_hi) continue;
+				const long mo = mo0 + f;
+				double ya = v[m].x, yb = v[m].y;
+				if (p.round_f32) { ya = (double) (float) ya; yb = (double) (float) yb; }
+				if (cha >= 0) ya = sink_sample(ya, dither, ua0, ua1, p.sink.dither_mult, peak, clipped);
+				if (chb >= 0) yb = sink_sample(yb, dither, ub0, ub1, p.sink.dither_mult, peak, clipped);
+				if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
+				if (wpair) {
+					char *dst = wout + (mo * p.C + cha) * bs;
+					if (bs == 8) *reinterpret_cast<double2 *>(dst) = make_double2(ya, yb);
+					else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, wf_sink), pcm_to_word(yb, wf_sink));
+					else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+				}
+				else {
+					if (cha >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + cha, ya);
+					if (chb >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + chb, yb);
+				}
+			}
+			if (p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
+			continue;
+		}
 #pragma unroll
 		for (int m = 0; m < 16; ++m) {
 			const int f = j + P * m - first_n;
@@ -156,10 +213,13 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 void launch_conv_short(const ShortParams &p, hipStream_t st)
 {
 	if (p.N != psh::SH_N || p.n_pairs < 1 || p.n_in < 1) return;
-	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short), psh::SH_LDS);
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
-	hipLaunchKernelGGL(psh::conv_short, dim3((unsigned) p.n_pairs, (unsigned) ranges), dim3(psh::SH_THREADS), psh::SH_LDS, st, p);
+	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges), block(psh::SH_THREADS);
+	const int bs = (!p.slab || p.slab_fmt == PCM_DOUBLE) ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
+	if (bs == 8) { grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<8>), psh::SH_LDS); hipLaunchKernelGGL(psh::conv_short<8>, grid, block, psh::SH_LDS, st, p); }
+	else if (bs == 4) { grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<4>), psh::SH_LDS); hipLaunchKernelGGL(psh::conv_short<4>, grid, block, psh::SH_LDS, st, p); }
+	else { grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<2>), psh::SH_LDS); hipLaunchKernelGGL(psh::conv_short<2>, grid, block, psh::SH_LDS, st, p); }
 }
 
 }  // namespace dspamd
