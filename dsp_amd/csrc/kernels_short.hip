@@ -7,6 +7,12 @@
 // write of hop outputs: (N + hop) / hop units of 16 bytes per pair and frame -- 3 at 4095 taps, 2.3 at 1000 -- against 6.4 for three trips of a
 // 65536-point transform.  BASELINE config 5's `hilbert -p 4095` stage was 22 of its 35 ms.
 //
+// What bounds it (round 5, BASELINE config 5's hilbert stage: 1024 pairs x 224 blocks, 44 GB in 15.6 ms = 2.8 TB/s, where the four-step path took 22 ms for
+// 97 GB): not memory -- a block is two 8192-point transforms for 4096 outputs, about 7.5 us of fp64 issue and 6 us of LDS exchange traffic (six exchanges of
+// 128 KB each way) per CU against 9 us of HBM time, in one workgroup whose eight waves meet at a barrier between every two of those phases.  The next window
+// prefetched into a second register set (the filter row then read from L2 where it is used: 255 registers) measures 16.9 ms against 16.2 for the same
+// code without it (profiles/r05_conv_short_prefetch_ab.txt, scripts/conv_short_prefetch_r05.patch): there is no idle memory time to fill.
+//
 // Workgroup = one channel pair (z = x_a + i x_b, exact: h is real), 512 threads x 16 points, walking the pair's blocks with the filter row in registers;
 // radix 16 / 16 / 16 / 2 Stockham passes through the row buffer (the XOR-swizzled slots of conv_row: the same store and gather shapes).  One workgroup
 // per CU (139 KB of LDS).  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
