@@ -124,11 +124,8 @@ private:
 	bool direct = false;
 	const double *cur_slab = nullptr;
 	long cur_slab_stride = 0, cur_q0 = 0;
-	long pairs_per_chunk = 0;
-	int n_sub = 1;                       // chunks in flight on separate HIP streams (each with its own W)
-	std::vector<hipStream_t> sub;
-	std::vector<hipEvent_t> sub_done;
-	hipEvent_t ev_start = nullptr;
+	long pairs_per_chunk = 0;            // pairs whose W rows exist: every pair of the batch (launching a few streams at a time to keep W in the Infinity
+	                                     // Cache, with or without side streams, never paid -- docs/history.md section 4.2 -- and is gone)
 	std::string name;
 	CascadeStage *feeder_ = nullptr;
 	// this stage's K3 writes the next convolver's ring (set by the consumer's init)
@@ -434,30 +431,10 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		}
 	}
 
-	// work buffer: streams are processed in chunks so that W (written by K1, rewritten by K2, read by K3)
-	// can stay in the 256 MiB Infinity Cache between the three launches
-	long chunk_streams = S;
-	const char *cenv = getenv("DSP_AMD_CONV_CHUNK_MB");
-	const double chunk_mb = cenv ? atof(cenv) : 0.0;
-	if (chunk_mb > 0) {
-		const double per_stream_mb = (double) pps * N * 16.0 / (1024.0 * 1024.0);
-		chunk_streams = std::max<long>(1, std::min<long>(S, (long) (chunk_mb / per_stream_mb)));
-	}
-	pairs_per_chunk = chunk_streams * pps;
-	const char *senv = getenv("DSP_AMD_CONV_SUBSTREAMS");
-	n_sub = (senv && chunk_streams < S) ? std::max(1, std::min(8, atoi(senv))) : 1;
-	if (nph > 1) n_sub = 1;
+	pairs_per_chunk = (long) S * pps;
 	{ static const long pad = [] { const char *e = getenv("DSP_AMD_CONV_WPAD"); return e ? atol(e) : 272L; }(); w_stride = N + pad; }
 	// (at least one fp64 row set: the filter spectra of a float32 stage are computed by the fp64 kernels in this buffer)
-	if (!W.alloc(std::max((size_t) n_sub * nph * pairs_per_chunk * w_stride * elem(), (size_t) nph * w_stride * sizeof(double2)), false)) return false;
-	if (n_sub > 1) {
-		sub.resize(n_sub); sub_done.resize(n_sub);
-		for (int k = 0; k < n_sub; ++k) {
-			if (!hip_ok(hipStreamCreateWithFlags(&sub[k], hipStreamNonBlocking), "hipStreamCreate")) return false;
-			if (!hip_ok(hipEventCreateWithFlags(&sub_done[k], hipEventDisableTiming), "hipEventCreate")) return false;
-		}
-		if (!hip_ok(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming), "hipEventCreate")) return false;
-	}
+	if (!W.alloc(std::max((size_t) nph * pairs_per_chunk * w_stride * elem(), (size_t) nph * w_stride * sizeof(double2)), false)) return false;
 	if (!H.alloc((size_t) (upc_P ? (size_t) upc_P * n_filters : (size_t) n_filters * nph) * N * elem(), false)) return false;
 	if (upc_P && !upc_buf.alloc((size_t) upc_P * S * pps * N * elem())) return false;      // (a float32 stage's delay line holds float2: half the traffic)
 	log_msg(LL_VERBOSE, "%s: info: device buffers ring %p (%zu MB) W %p (%zu MB) H %p", name.c_str(), ring_dev, ring.bytes >> 20, W.p, W.bytes >> 20, H.p);
@@ -502,11 +479,11 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		if (fuse_on && feeder_ && !ring_parent)
 			log_msg(LL_VERBOSE, "%s: info: fused first pass: regimes %d%d kind %d%d%d%d%d%d rows %d pairs %d%d hist %ld hop %d whole %d%d sizes %d%d sections %d", name.c_str(),
 			        !upc_conv, !fdl, !resampler, nph == 1, n_filters == 1, !f32, !round_f32, lat == 0, log2N1 == 8, (pps % 2) == 0, ch_in == 2 * pps, hist_rows, B == N - first_n,
-			        pairs_per_chunk == (long) S * pps, n_sub == 1, (double) B * ch_in * sizeof(double) < 2.0e9, (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9, (int) feeder_->fuse_tables().ok);
+			        true, true, (double) B * ch_in * sizeof(double) < 2.0e9, (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9, (int) feeder_->fuse_tables().ok);
 		// (a resampler by an integer factor `up` -- nph = up branches on the same first pass, K2 / K3 in their multi-phase forms -- takes the same
 		// first pass: only the calls whose outputs start at phase 0 of the call's first frame are whole windows, fuse_accepts looks at that)
 		if (fuse_on && feeder_ && !ring_parent && !upc_conv && !fdl && (resampler ? (down == 1 && nph == up) : nph == 1) && n_filters == 1 && !f32 && !round_f32 && lat == 0
-		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && hist_rows >= 1 && hist_rows <= 32 && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
+		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && hist_rows >= 1 && hist_rows <= 32 && B == N - first_n
 		    && (double) B * ch_in * sizeof(double) < 2.0e9 && (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9 && feeder_->fuse_tables().ok) {
 			// row segments: enough workgroups for the chip when the streams are few, as far as the scan over the chunks fits its workgroup
 			const int D = 2 * feeder_->n_ops;
@@ -520,7 +497,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 			}
 		}
 		if (fuse_on && !feeder_ && !fed && !ring_parent && direct && !upc_conv && !fdl && !resampler && nph == 1 && n_filters == 1 && !f32 && !round_f32 && lat == 0
-		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && hist_rows >= 1 && hist_rows <= 32 && B == N - first_n && pairs_per_chunk == (long) S * pps && n_sub == 1
+		    && log2N1 == 8 && (pps % 2) == 0 && ch_in == 2 * pps && hist_rows >= 1 && hist_rows <= 32 && B == N - first_n
 		    && (double) B * ch_in * sizeof(double) < 2.0e9 && (double) (2 * w_stride + N) * sizeof(double2) < 2.0e9 && fused_section_slots(1) == 1) {
 			const long groups = (long) S * (pps / 2);
 			fuse_seg = 1;
@@ -965,7 +942,6 @@ void ConvStage::push(const double *in, long in_stride, ssize_t frames, double *o
 void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, double *out, long out_stride, hipStream_t st)
 {
 	if (short_mode) { convolve_short(q_lo, q_hi, k_origin, out_count, out, out_stride, st); return; }
-	const long chunk_streams = pairs_per_chunk / pps;
 	const long q_end = resampler ? q_total : q_hi + 1;
 	for (long q_blk = q_lo; q_blk <= q_hi; q_blk += B) {
 		const long f = std::min<long>(B, q_hi - q_blk + 1);
@@ -987,40 +963,19 @@ void ConvStage::convolve(long q_lo, long q_hi, long k_origin, long out_count, do
 			p.fdl = upc_buf.as<double2>(); p.fdl_slot_stride = (long) S * pps * N; p.fdl_P = upc_P; p.fdl_slot = upc_slot;
 			upc_slot = (upc_slot + 1) % upc_P;
 		}
-		if (n_sub > 1) {
-			// chunks round-robin over sub-streams: the launch tails of one chunk overlap the next chunk's kernels, and
-			// every chunk's W is small enough to live in the Infinity Cache between its three launches
-			(void) hipEventRecord(ev_start, st);
-			for (int k = 0; k < n_sub; ++k) (void) hipStreamWaitEvent(sub[k], ev_start, 0);
-			long c = 0;
-			for (long s0 = 0; s0 < S; s0 += chunk_streams, ++c) {
-				const long ns = std::min<long>(chunk_streams, S - s0);
-				const int k = (int) (c % n_sub);
-				p.pair0 = s0 * pps;
-				p.stream0 = s0;
-				p.n_streams_launch = ns;
-				p.W = reinterpret_cast<double2 *>(static_cast<char *>(W.p) + (size_t) k * pairs_per_chunk * w_stride * elem());
-				launch_conv_col(p, false, (int) (ns * pps), sub[k]);
-				launch_conv_row(p, row_mode, (int) (ns * pps), sub[k]);
-				launch_conv_col(p, true, (int) (ns * pps), sub[k]);
-			}
-			for (int k = 0; k < n_sub; ++k) { (void) hipEventRecord(sub_done[k], sub[k]); (void) hipStreamWaitEvent(st, sub_done[k], 0); }
-			continue;
+		// every stream in one launch of each kernel
+		const int n_pairs = (int) ((long) S * pps);
+		p.pair0 = 0;
+		p.stream0 = 0;
+		p.n_streams_launch = S;
+		if (fuse_this_call) {
+			// (a resampler's whole-window call behind a cascade: the fused first pass in K1's place; one block)
+			fuse_this_call = false;
+			if (q_blk != q_lo || f != B || p.valid != N || !fused_first_pass(p, f, st)) { fuse_failed = true; return; }
 		}
-		for (long s0 = 0; s0 < S; s0 += chunk_streams) {
-			const long ns = std::min<long>(chunk_streams, S - s0);
-			p.pair0 = s0 * pps;
-			p.stream0 = s0;
-			p.n_streams_launch = ns;
-			if (fuse_this_call) {
-				// (a resampler's whole-window call behind a cascade: the fused first pass in K1's place; one block, every stream in one launch)
-				fuse_this_call = false;
-				if (q_blk != q_lo || f != B || ns != S || p.valid != N || !fused_first_pass(p, f, st)) { fuse_failed = true; return; }
-			}
-			else { ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, (int) (ns * pps), st); }
-			{ ProfScope ps("conv_row", st); launch_conv_row(p, row_mode, (int) (ns * pps), st); }
-			{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, (int) (ns * pps), st); }
-		}
+		else { ProfScope ps("conv_col_fwd", st); launch_conv_col(p, false, n_pairs, st); }
+		{ ProfScope ps("conv_row", st); launch_conv_row(p, row_mode, n_pairs, st); }
+		{ ProfScope ps("conv_col_inv", st); launch_conv_col(p, true, n_pairs, st); }
 	}
 }
 

@@ -443,8 +443,6 @@ bool CascadeStage::finalize()
 	// channel group per workgroup: the whole stream when it fits in LDS (contiguous, vectorisable loads)
 	Cg = (ch_in <= 16) ? ch_in : 8;
 	while (Cg > 1 && cascade_lds_bytes(Cg, n_ops) > 150 * 1024) Cg = (Cg + 1) / 2;
-	const char *env = getenv("DSP_AMD_CASCADE_CG");
-	if (env && atoi(env) >= 1 && atoi(env) <= Cg) Cg = atoi(env);
 	return true;
 }
 

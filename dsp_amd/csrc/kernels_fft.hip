@@ -561,7 +561,7 @@ template <int WV> static void launch_row_big(const ConvParams &p, int mode, int 
 static void pipe_grid(int groups, int n_pairs, int *ranges, int *per)
 {
 	// one workgroup per CU (LDS): the row groups times as many pair ranges as it takes to give every CU two workgroups in turn
-	static const int wgs = [] { const char *e = getenv("DSP_AMD_ROW_PIPE_WGS"); return e ? atoi(e) : 512; }();
+	constexpr int wgs = 512;
 	int r = (wgs + groups - 1) / groups;
 	if (r > n_pairs) r = n_pairs;
 	if (r < 1) r = 1;
