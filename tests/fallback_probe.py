@@ -55,6 +55,7 @@ HOST_CASES = {   # through dspamd_chain_run (host buffers: mapped staging / copy
     "host_eq":   dict(chain="gain -3 " + BIQ, C=2, frames=9000, block=512),
     "host_big":  dict(chain="gain -3 " + BIQ, C=8, frames=24000, block=8192),     # 512 KB per block: page-locked staging / copy commands
     "host_conv": dict(chain="fir_p -t pcm -e double -c 1 {F} resample 44.1k", C=2, frames=9000, block=2048, taps=(800, 12, 100.0)),
+    "host_huge": dict(chain="gain -3 " + BIQ, C=2, frames=300000, block=131072),   # blocks of two pipeline calls: page-locked double buffers filled by the caller and its helper threads (DSP_AMD_COPY_CREW=0: the caller alone)
 }
 
 

@@ -25,7 +25,7 @@ SWITCHES = [
     "DSP_AMD_RESAMPLE_NO_GEMM=1", "DSP_AMD_RESAMPLE_DIRECT=1",
     "DSP_AMD_NO_WIRE_FUSION=1", "DSP_AMD_PLUGIN_MAPPED_KB=0", "DSP_AMD_NO_DISCARD_FOLD=1", "DSP_AMD_K3_PIPE=0", "DSP_AMD_ZITA_F64=1", "DSP_AMD_CONV_UPC=0",
     "DSP_AMD_PLUGIN_STAGE=0", "DSP_AMD_PLUGIN_STAGE=0 DSP_AMD_PLUGIN_MAPPED_KB=0",
-    "DSP_AMD_FUSE=0", "DSP_AMD_FUSE_MM=0", "DSP_AMD_ROW_DUO2=0", "DSP_AMD_CONV_SHORT=0",
+    "DSP_AMD_FUSE=0", "DSP_AMD_FUSE_MM=0", "DSP_AMD_ROW_DUO2=0", "DSP_AMD_CONV_SHORT=0", "DSP_AMD_COPY_CREW=0 DSP_AMD_PLUGIN_NO_SPIN=1",
 ]
 
 
