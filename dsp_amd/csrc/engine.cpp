@@ -100,7 +100,8 @@ void MappedPair::alloc()
 	static const long kb = [] { const char *v = getenv("DSP_AMD_PLUGIN_MAPPED_KB"); return v ? atol(v) : 32L; }();
 	if (kb <= 0 || bytes) return;
 	void *a = nullptr, *b = nullptr;
-	if (hipHostMalloc(&a, (size_t) kb << 10, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&b, (size_t) kb << 10, hipHostMallocDefault) == hipSuccess) {
+	// (coherent = fine-grained: a wave that stays on the device across blocks -- kernels_resident.hip -- must see what the host wrote a moment ago, not an L2 line)
+	if (hipHostMalloc(&a, (size_t) kb << 10, hipHostMallocCoherent) == hipSuccess && hipHostMalloc(&b, (size_t) kb << 10, hipHostMallocCoherent) == hipSuccess) {
 		in = static_cast<double *>(a); out = static_cast<double *>(b); bytes = (size_t) kb << 10;
 		void *f = nullptr;
 		static const bool spin = !getenv("DSP_AMD_PLUGIN_NO_SPIN");
@@ -1119,6 +1120,13 @@ ssize_t Pipeline::max_out_frames(ssize_t in_frames) const
 	ssize_t f = in_frames;
 	for (auto &s : stages) f = s->max_out_frames(f);
 	return f;
+}
+
+CascadeStage *Pipeline::sole_cascade() const
+{
+	if (stages.size() != 1 || S != 1) return nullptr;
+	CascadeStage *c = dynamic_cast<CascadeStage *>(stages[0].get());
+	return (c && !c->ring.base && c->write_interleaved) ? c : nullptr;
 }
 
 ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st, long in_stride)

@@ -199,6 +199,8 @@ public:
 	void reset(hipStream_t st);
 	std::string plan() const;
 	int n_stages() const { return (int) stages.size(); }
+	// the pipeline's only stage when that is a cascade writing interleaved frames (what the resident small-block path of plugin.cpp serves), or nullptr
+	class CascadeStage *sole_cascade() const;
 	size_t device_bytes() const;
 private:
 	Pipeline() {}
@@ -209,6 +211,28 @@ private:
 	int tmp_ch = 0;
 	int drain_stage = 0;
 };
+
+// ---- small plugin blocks through a wave that stays on the device for a bounded time (kernels_resident.hip, plugin.cpp) ----
+constexpr unsigned RESIDENT_STOP = 0xffffffffu;      // `frames` of a request that tells the wave to leave
+struct ResidentCtl {                                 // page-locked, device-mapped host memory: one 64-byte line per direction
+	unsigned long long req;                          // (sequence number << 32) | frames: written by the host once the block is in the staging buffer
+	unsigned long long pad0[7];
+	unsigned done;                                   // sequence number of the last block whose output is complete (the wave)
+	unsigned alive;                                  // set by the host before a launch, cleared by the wave as its last store
+	unsigned pad1[14];
+};
+struct ResidentParams {
+	ResidentCtl *ctl;
+	const double *in;                                // mapped staging buffers of the segment: [frames][C]
+	double *out;
+	int C, n_ops;
+	const OpDesc *ops;                               // [C][n_ops]
+	double *state;                                   // [C][n_ops][2]
+	unsigned long long lifetime_ticks;               // of the 100 MHz wall clock, without a block
+	unsigned max_polls, done0;                       // hard bound on the polling loop; the sequence number already served
+	int buf_doubles;                                 // doubles of the block buffer in LDS (a block is at most that many samples)
+};
+bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st);
 
 // kernel launchers (kernels_*.hip)
 size_t cascade_lds_bytes(int Cg, int n_ops);

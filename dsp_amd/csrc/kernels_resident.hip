@@ -1,0 +1,155 @@
+// kernels_resident.hip -- small plugin blocks without a launch per block (round 5).
+//
+// What it serves: the reference's LADSPA frontend and CLI drive a chain with run() calls of 64 ... 1024 frames (ladspa_dsp.c:316-355, dsp.h:38); a
+// kernel launch plus its completion costs 25 us on this platform whatever the block, the reference's own loop 3 us at 64 frames x 2 ch x 10 sections.
+// For a device segment that is ONE cascade of gains / adds / sections (the equaliser shape) a single wave stays on the device for a bounded time,
+// polls a doorbell in page-locked host memory, runs the block -- the reference's recurrence as written (biquad.h:76-92), sample by sample, one lane per op
+// per channel, states and coefficients in registers -- out of and into the mapped staging buffers, and says so in host memory.
+//
+// Bounded lifetime: the wave leaves after `lifetime` ticks of the 100 MHz clock without a block, when the host asks it to (frames = RESIDENT_STOP),
+// or after `max_polls` turns of its loop whatever the clock says -- so a hipDeviceSynchronize() anywhere in the process waits a few milliseconds at
+// most, and no failure of the host can leave a kernel behind.  Its last store is alive = 0; the host starts another one with the next block.
+// The states live in device memory between blocks (loaded and stored around every block, past the L1: the ordinary kernels may have run in between),
+// so a block of any other size simply takes the ordinary path on the same states.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "kparams.h"
+#include "engine.h"
+
+namespace dspamd {
+
+constexpr int RES_MAX_OPS = 16;
+
+__device__ __forceinline__ double ld_agent(const double *p)
+{
+	return __longlong_as_double((long long) __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the value of the lane below in the 16-lane row (lane 0 of a row keeps its own)
+__device__ __forceinline__ double row_shr1(double v)
+{
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+// Workgroup = ceil(C / 4) waves; a wave = 4 channels, one per 16-lane DPP row; lane j of a row = op j of its channel (n_ops <= 16).  A block runs as a
+// systolic array: at step t lane j works on frame t - j, its input the result lane j - 1 had a step earlier (one DPP move), lane 0 reads the frame from
+// the block buffer, the channel's last op writes it back -- frames + n_ops - 1 steps of one dependent fma each instead of frames x n_ops of them (the
+// first form of this kernel, one lane per channel: 116 us per 64-frame block of a stereo ten-section chain on a GPU that idles at a low clock).
+// Every lane runs the same instructions: r = fma(a, x, b) is the section's output (a = c0, b = m0), a gain (a = g, b = -0.0: the product keeps its
+// sign of zero), an add (a = 1, b = v) or a pass (a = 1, b = -0.0), bit for bit what __dmul_rn / __dadd_rn give; only sections update (m0, m1).
+__global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) double buf[];      // the block: [frames][C]; behind it one word for the request
+	const int tid = threadIdx.x, nth = blockDim.x, C = p.C, n_ops = p.n_ops;
+	const int j = tid & 15, ch = tid >> 4;                             // op and channel of this lane
+	const bool mine = ch < C && j < n_ops;
+	unsigned long long *req_w = reinterpret_cast<unsigned long long *>(buf + p.buf_doubles);
+	// this lane's op, in registers for the kernel's lifetime
+	double a = 1.0, b = -0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0;
+	bool biq = false;
+	if (mine) {
+		const OpDesc &od = p.ops[(size_t) ch * n_ops + j];
+		if (od.kind == OP_BIQUAD) { biq = true; a = od.c[0]; c1 = od.c[1]; c2 = od.c[2]; c3 = od.c[3]; c4 = od.c[4]; }
+		else if (od.kind == OP_MUL) a = od.g;
+		else if (od.kind == OP_ADD) b = od.g;
+	}
+	double *stp = p.state + ((size_t) ch * n_ops + j) * 2;
+	unsigned done = p.done0;
+	unsigned long long t_last = wall_clock64();
+	for (unsigned it = 0; it < p.max_polls; ++it) {
+		// thread 0 reads the doorbell and the clock and decides for everybody (the waves meet at barriers below: one decision, not one per wave)
+		if (tid == 0) {
+			unsigned long long rq0 = __hip_atomic_load(&p.ctl->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+			if ((unsigned) (rq0 >> 32) == done && (unsigned) (rq0 & 0xffffffffu) != RESIDENT_STOP && wall_clock64() - t_last > p.lifetime_ticks)
+				rq0 = ((unsigned long long) done << 32) | RESIDENT_STOP;            // nothing for a lifetime: leave
+			*req_w = rq0;
+		}
+		__syncthreads();
+		const unsigned long long rq = *req_w;
+		__syncthreads();
+		const unsigned seq = (unsigned) (rq >> 32), frames = (unsigned) (rq & 0xffffffffu);
+		if (frames == RESIDENT_STOP) break;
+		if (seq == done) { __builtin_amdgcn_s_sleep(8); continue; }
+		// ---- a block: in (mapped host memory, [frames][C]) -> LDS, the ops, LDS -> out
+		const int n = (int) frames * C;
+		// (host memory is a PCIe round trip away: sixteen bytes per lane and eight loads in flight before the first one is waited for -- one
+		// 8-byte load per turn, as this loop first read, was 80 of the 157 us of a 1024-frame block)
+		{
+			typedef double res_d2 __attribute__((ext_vector_type(2)));
+			const res_d2 *src = reinterpret_cast<const res_d2 *>(p.in);
+			res_d2 *dst = reinterpret_cast<res_d2 *>(buf);
+			const int n2 = n >> 1;
+			for (int base = 0; base < n2; base += 8 * nth) {
+				res_d2 v[8];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) { const int e = base + k * nth + tid; if (e < n2) v[k] = __builtin_nontemporal_load(src + e); }
+#pragma unroll
+				for (int k = 0; k < 8; ++k) { const int e = base + k * nth + tid; if (e < n2) dst[e] = v[k]; }
+			}
+			if ((n & 1) && tid == 0) buf[n - 1] = __builtin_nontemporal_load(p.in + n - 1);
+		}
+		double m0 = 0.0, m1 = 0.0;
+		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }
+		__syncthreads();
+		if (ch < C) {
+			const int nf = (int) frames, steps = nf + n_ops - 1;
+			const bool upd = mine && biq, wr = mine && j == n_ops - 1;
+			const double *rd = buf + ch;                                 // frame t of this row's channel at rd[t C]
+			double s0 = biq ? m0 : b;                                    // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
+			// frames are asked for two steps ahead of their use (by every lane of the row: one address, no branch): the wave is alone on its SIMD and
+			// would otherwise sit out an LDS round trip per step
+			double xa = rd[0], xb = rd[(nf > 1 ? 1 : 0) * C];
+			double prev = 0.0;
+			for (int t = 0; t < steps; ++t) {
+				const double below = row_shr1(prev);
+				const double x = (j == 0) ? xa : below;
+				xa = xb;
+				const int tn = (t + 2 < nf) ? t + 2 : nf - 1;
+				xb = rd[tn * C];
+				const bool active = t >= j && t < j + nf;
+				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
+				const double r = fma(a, x, s0);
+				const double tt = fma(c1, x, m1), u = c2 * x;
+				const double n0 = fma(-c3, r, tt), n1 = fma(-c4, r, u);
+				if (active && upd) { s0 = n0; m1 = n1; }
+				prev = r;
+				if (active && wr) buf[(t - j) * C + ch] = r;
+			}
+			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
+		}
+		__syncthreads();
+		{
+			typedef double res_d2 __attribute__((ext_vector_type(2)));
+			res_d2 *dst = reinterpret_cast<res_d2 *>(p.out);
+			const res_d2 *src = reinterpret_cast<const res_d2 *>(buf);
+			const int n2 = n >> 1;
+			for (int e = tid; e < n2; e += nth) __builtin_nontemporal_store(src[e], dst + e);
+			if ((n & 1) && tid == 0) __builtin_nontemporal_store(buf[n - 1], p.out + n - 1);
+		}
+		__threadfence_system();                                      // the block's output and states are out before the word that says so
+		__syncthreads();
+		done = seq;
+		if (tid == 0) __hip_atomic_store(&p.ctl->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		t_last = wall_clock64();
+	}
+	__threadfence_system();
+	__syncthreads();
+	if (tid == 0) __hip_atomic_store(&p.ctl->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st)
+{
+	if (p.C < 1 || p.C > 64 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) p.buf_doubles * sizeof(double) + 16 > lds_bytes) return false;
+	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident), lds_bytes);
+	const int waves = (p.C + 3) / 4;
+	hipLaunchKernelGGL(cascade_resident, dim3(1), dim3(64 * waves), lds_bytes, st, p);
+	return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace dspamd

@@ -5,6 +5,8 @@
 // drive HIP kernels.  run() works on the host's interleaved fp64 buffers (one PCIe round trip per call: this
 // is the compatibility path; throughput work goes through the device-resident batch API, capi.cpp).
 #include "plugin.h"
+#include "stages.h"
+#include <ctime>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +81,14 @@ static bool ensure_segment(struct effect *e, Node *n)
 	if (!seg->d_in.alloc((size_t) cap * seg->ch_in * sizeof(double), false) ||
 	    !seg->d_out.alloc((size_t) seg->out_cap_frames * seg->ch_out * sizeof(double), false)) { seg->pipe.reset(); return false; }
 	seg->mapped.alloc();
+	{
+		static const bool resident_on = [] { const char *v = getenv("DSP_AMD_PLUGIN_RESIDENT"); return !v || atoi(v) != 0; }();
+		CascadeStage *casc = resident_on ? seg->pipe->sole_cascade() : nullptr;
+		if (casc && seg->mapped.bytes) {
+			seg->resident.reset(new Resident);
+			if (!seg->resident->init(casc, seg->mapped)) seg->resident.reset();
+		}
+	}
 	if (seg->members.size() > 1) log_msg(LL_VERBOSE, "%s: info: %zu effects fused into one device segment: %s", e->name, seg->members.size(), seg->pipe->plan().c_str());
 	return true;
 }
@@ -153,7 +163,79 @@ bool Segment::pinned(int which, const void *p, size_t n)
 	return true;
 }
 
-Segment::~Segment() { unpin_all(); }
+Segment::~Segment() { resident.reset(); unpin_all(); }
+
+// ---- the resident small-block wave (see plugin.h) ----
+static inline double res_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
+
+bool Resident::init(CascadeStage *c, const MappedPair &mp)
+{
+	if (!c || c->n_ops < 1 || c->n_ops > 16 || c->ch_in < 1 || c->ch_in > 64 || !mp.bytes) return false;
+	void *m = nullptr;
+	if (hipHostMalloc(&m, sizeof(ResidentCtl), hipHostMallocCoherent) != hipSuccess) { (void) hipGetLastError(); return false; }
+	ctl = static_cast<ResidentCtl *>(m);
+	memset(ctl, 0, sizeof(*ctl));
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); (void) hipHostFree(ctl); ctl = nullptr; st = nullptr; return false; }
+	memset(&rp, 0, sizeof(rp));
+	rp.ctl = ctl; rp.in = mp.in; rp.out = mp.out;
+	rp.C = c->ch_in; rp.n_ops = c->n_ops;
+	rp.ops = c->device_ops(); rp.state = c->device_state();
+	rp.lifetime_ticks = 300000ull;           // 3 ms of the 100 MHz clock: more than two periods of a 64-frame block at 48 kHz
+	rp.max_polls = 1u << 18;                 // (a turn of the loop is a round trip to host memory: about a second at the very most)
+	const size_t block_bytes = std::min<size_t>(mp.bytes, (size_t) 64 << 10);
+	rp.buf_doubles = (int) (block_bytes / sizeof(double));
+	lds = block_bytes + 16;
+	sections = 1;
+	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel, 0.11 us per step on a GPU that idles at a low clock, on top of
+	// 5 us for the doorbell and the two trips of the block over PCIe (profiles/r05_ladspa_rate.txt: 12.4 us at 64 frames, 33 at 256); a launch of the
+	// ordinary, time-parallel kernels costs 24 ... 26 us whatever the block: the wave takes blocks of up to 160 frames
+	max_work = 160;
+	return true;
+}
+
+bool Resident::launch()
+{
+	__atomic_store_n(&ctl->alive, 1u, __ATOMIC_RELEASE);
+	rp.done0 = __atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE);
+	if (!launch_cascade_resident(rp, lds, st)) { (void) hipGetLastError(); __atomic_store_n(&ctl->alive, 0u, __ATOMIC_RELEASE); return false; }
+	return true;
+}
+
+bool Resident::serve(ssize_t frames)
+{
+	++seq;
+	__atomic_store_n(&ctl->req, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames, __ATOMIC_RELEASE);
+	const double t0 = res_now_us();
+	for (long spins = 0;; ++spins) {
+		if (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) == seq) return true;
+		if (__atomic_load_n(&ctl->alive, __ATOMIC_ACQUIRE) == 0 && !launch()) break;       // no wave (the first block, or the last one left): start one -- it finds the request
+		__builtin_ia32_pause();
+		if ((spins & 255) == 255 && res_now_us() - t0 > 20000.0) break;                   // 20 ms: something is wrong
+	}
+	// not served in time: ask the wave to leave, wait for it (bounded by its own loop), and see whether it got the block done after all
+	stop();
+	if (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) == seq) return true;
+	off = true;
+	log_msg(LL_VERBOSE, "info: resident small-block path switched off for this segment (a block was not served in time)");
+	return false;
+}
+
+void Resident::stop()
+{
+	if (!ctl) return;
+	if (__atomic_load_n(&ctl->alive, __ATOMIC_ACQUIRE)) {
+		__atomic_store_n(&ctl->req, ((unsigned long long) seq << 32) | (unsigned long long) RESIDENT_STOP, __ATOMIC_RELEASE);
+		(void) hipStreamSynchronize(st);
+		(void) hipGetLastError();
+	}
+}
+
+Resident::~Resident()
+{
+	stop();
+	if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+	if (ctl) (void) hipHostFree(ctl);
+}
 
 static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, sample_t *obuf)
 {
@@ -187,6 +269,11 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 	if (total <= sg.pipe_frames && sg.mapped.fits(in_bytes, out_bytes)) {
 		// small block: the kernels work on the mapped staging buffers themselves
 		memcpy(sg.mapped.in, ibuf, in_bytes);
+		if (sg.resident && sg.resident->takes(total) && sg.resident->serve(total)) {
+			// (one cascade, a block the resident wave finishes sooner than a launch: no launch at all)
+			memcpy(dst, sg.mapped.out, (size_t) total * sg.ch_out * sizeof(double));
+			return dst;
+		}
 		const ssize_t f = sg.pipe->run(sg.mapped.in, total, sg.mapped.out, (ssize_t) (sg.mapped.bytes / (sg.ch_out * sizeof(double))), nullptr);
 		(void) sg.mapped.wait_block(nullptr);
 		if (f > 0) memcpy(dst, sg.mapped.out, (size_t) f * sg.ch_out * sizeof(double));
@@ -267,6 +354,7 @@ static void plugin_destroy(struct effect *e)
 {
 	Node *n = node_of(e);
 	if (n) {
+		if (n->seg && n->seg->resident) n->seg->resident->stop();      // (the device-wide wait below would otherwise sit out the wave's lifetime)
 		(void) hipDeviceSynchronize();
 		if (n->seg) {
 			// the other members keep the segment alive but must not touch this effect any more

@@ -13,6 +13,27 @@ constexpr unsigned NODE_MAGIC = 0x44535041u;   // "DSPA"
 // e->next when the first of them runs) compiled into ONE fused pipeline -- one H2D copy at the head, the whole
 // segment on the device (cascade fusion, LTI merges, convolvers feeding each other, exactly as in the batch API),
 // one D2H copy; the other members' run() hand the result through.  SURVEY.md section 7 step 4 / section 8(f).
+// Small blocks of a segment that is one cascade (the equaliser shape) through a wave that stays on the device for a few milliseconds and polls a
+// doorbell in host memory -- no launch per block (kernels_resident.hip).  The wave leaves by itself (clock, loop bound) or when asked
+// to; the next block starts another one.  Any failure switches the mechanism off for the segment: the ordinary path works on the same states.
+struct Resident {
+	ResidentCtl *ctl = nullptr;
+	hipStream_t st = nullptr;
+	ResidentParams rp;
+	size_t lds = 0;
+	unsigned seq = 0;
+	long max_work = 0;                       // frames x sections a block may have (beyond it the ordinary, parallel kernels are faster)
+	int sections = 1;
+	bool off = false;
+	bool init(class CascadeStage *c, const MappedPair &mp);
+	bool takes(ssize_t frames) const { return !off && ctl && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * rp.C <= (size_t) rp.buf_doubles; }
+	bool serve(ssize_t frames);              // the block is in the mapped input buffer; true: its output is in the mapped output buffer
+	void stop();
+	~Resident();
+private:
+	bool launch();
+};
+
 struct Segment {
 	std::vector<struct effect *> members;    // chain order; members.front() is the head
 	std::unique_ptr<Pipeline> pipe;          // single-stream pipeline for run() on host buffers
@@ -22,6 +43,7 @@ struct Segment {
 	bool touched = false;                    // frames have gone through since the last reset
 	DevBuf d_in, d_out;
 	MappedPair mapped;                       // staging for small blocks (engine.h)
+	std::unique_ptr<Resident> resident;      // ... and, for a segment that is one cascade, the wave that serves them without a launch
 	PinnedStage staged;                      // page-locked staging for larger ones (engine.h)
 	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the
 	// HIP runtime after a few sightings: the copies then run as DMA instead of through the runtime's pageable-memory staging.

@@ -1,0 +1,59 @@
+"""Small plugin blocks through the resident wave (kernels_resident.hip, round 5): a device segment that is one cascade serves blocks of up to 1024 frames
+without a launch per block.  Through the plugin vtable as a host drives it (the reference's chain runtime linked over this library: oracle/_ref/
+libdspref_gpu.so), against the all-reference runtime on the same input: mixed block sizes (resident and ordinary paths alternate on the same states),
+gains and adds among the sections, selectors (ops that skip channels), eight channels (two waves), a pause longer than the wave's lifetime."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle_api import RefChain, rms
+
+pytestmark = pytest.mark.gpu
+
+BIQ = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 "
+       "eq 800 1.0 -1 eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_runtime():
+    # libdspref_gpu.so pulls in libdsp_amd.so, which leaves the choice of the HIP runtime to its host: loaded here
+    import dsp_amd
+    assert dsp_amd.load_library().dspamd_device_count() >= 1
+
+
+def stream(chain, C, x, blocks, variant, pause_at=None):
+    """the chain built and run by the reference's own effects_chain runtime; variant "_gpu": its effects come from libdsp_amd.so"""
+    r = RefChain(chain, 48000, C, variant=variant)
+    outs, pos, k = [], 0, 0
+    while pos < x.shape[0]:
+        n = blocks[k % len(blocks)]
+        if pause_at is not None and k in pause_at:
+            time.sleep(0.02)             # (the wave has left by now: the next block starts another one, which finds the request waiting)
+        outs.append(r.run(x[pos:pos + n]))
+        pos += n
+        k += 1
+    r.close()
+    return np.concatenate([o for o in outs if o.shape[0]])
+
+
+@pytest.mark.skipif(not RefChain.available("_gpu"), reason="oracle/_ref/libdspref_gpu.so not present")
+@pytest.mark.parametrize("chain,C,blocks,pause", [
+    ("gain -3 " + BIQ, 2, (64,), (5, 300)),                              # the LADSPA shape: every block through the resident wave; two pauses
+    ("gain -3 " + BIQ, 2, (64, 1, 1024, 17, 4096, 256, 3), None),        # resident and ordinary kernels in turn, on the same states
+    ("lowpass 2k 0.707 :0 eq 300 1.5 4 gain -2 : add 0.001 highshelf 6k 0.7 2 mult 0.5", 3, (128, 64, 500), None),   # gains, an add, an op that skips channels
+    (BIQ, 8, (256, 64), (3,)),                                           # eight channels: two waves
+    ("gain -6 mult 1.5 add 0.25", 2, (64, 200), None),                   # no section at all: bit-exact ops only
+])
+def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
+    rng = np.random.Generator(np.random.PCG64(99))
+    x = rng.uniform(-0.5, 0.5, size=(40000, C))
+    x[100:110] = 0.0                                                     # (and some exact zeros of both signs: gains keep the sign of zero)
+    x[105] = -0.0
+    got = stream(chain, C, x, blocks, "_gpu", pause)
+    ref = stream(chain, C, x, blocks, "")
+    assert got.shape == ref.shape
+    if "eq" not in chain and "pass" not in chain:
+        assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
+    else:
+        assert rms(got - ref) < 1e-12, rms(got - ref)
