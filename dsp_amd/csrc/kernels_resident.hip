@@ -78,6 +78,8 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		if (seq == done) { __builtin_amdgcn_s_sleep(8); continue; }
 		// ---- a block: in (mapped host memory, [frames][C]) -> LDS, the ops, LDS -> out
 		const int n = (int) frames * C;
+		double m0 = 0.0, m1 = 0.0;
+		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }      // (asked for in front of the block's trip over PCIe, not behind it)
 		// (host memory is a PCIe round trip away: sixteen bytes per lane and eight loads in flight before the first one is waited for -- one
 		// 8-byte load per turn, as this loop first read, was 80 of the 157 us of a 1024-frame block)
 		{
@@ -94,24 +96,22 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			}
 			if ((n & 1) && tid == 0) buf[n - 1] = __builtin_nontemporal_load(p.in + n - 1);
 		}
-		double m0 = 0.0, m1 = 0.0;
-		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }
 		__syncthreads();
 		if (ch < C) {
 			const int nf = (int) frames, steps = nf + n_ops - 1;
 			const bool upd = mine && biq, wr = mine && j == n_ops - 1;
 			const double *rd = buf + ch;                                 // frame t of this row's channel at rd[t C]
 			double s0 = biq ? m0 : b;                                    // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
-			// frames are asked for two steps ahead of their use (by every lane of the row: one address, no branch): the wave is alone on its SIMD and
-			// would otherwise sit out an LDS round trip per step
-			double xa = rd[0], xb = rd[(nf > 1 ? 1 : 0) * C];
+			// frames are asked for FOUR steps ahead of their use, by every lane of the row (one address, no branch), in a loop unrolled four times so that a
+			// loaded frame is used from the register it landed in: the wave is alone on its SIMD and would otherwise sit out an LDS round trip per step
+			// (with a rotating pair of registers the load was needed half a step after it had been asked for: 0.11 us per step)
+			double xq[4];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) xq[k] = rd[(k < nf ? k : nf - 1) * C];
 			double prev = 0.0;
-			for (int t = 0; t < steps; ++t) {
+			auto step = [&](int t, double xin) {
 				const double below = row_shr1(prev);
-				const double x = (j == 0) ? xa : below;
-				xa = xb;
-				const int tn = (t + 2 < nf) ? t + 2 : nf - 1;
-				xb = rd[tn * C];
+				const double x = (j == 0) ? xin : below;
 				const bool active = t >= j && t < j + nf;
 				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
 				const double r = fma(a, x, s0);
@@ -120,6 +120,14 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 				if (active && upd) { s0 = n0; m1 = n1; }
 				prev = r;
 				if (active && wr) buf[(t - j) * C + ch] = r;
+			};
+			for (int t = 0; t < steps; t += 4) {
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					if (t + k < steps) step(t + k, xq[k]);
+					const int tn = (t + k + 4 < nf) ? t + k + 4 : nf - 1;
+					xq[k] = rd[tn * C];
+				}
 			}
 			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
 		}

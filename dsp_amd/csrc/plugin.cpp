@@ -186,9 +186,9 @@ bool Resident::init(CascadeStage *c, const MappedPair &mp)
 	rp.buf_doubles = (int) (block_bytes / sizeof(double));
 	lds = block_bytes + 16;
 	sections = 1;
-	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel, 0.11 us per step on a GPU that idles at a low clock, on top of
-	// 5 us for the doorbell and the two trips of the block over PCIe (profiles/r05_ladspa_rate.txt: 12.4 us at 64 frames, 33 at 256); a launch of the
-	// ordinary, time-parallel kernels costs 24 ... 26 us whatever the block: the wave takes blocks of up to 160 frames
+	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of three dependent trips over PCIe (doorbell, block,
+	// completion): profiles/r05_ladspa_rate.txt -- 12.1 us at 64 frames, about 30 at 256; a launch of the ordinary, time-parallel kernels costs 24 ... 26 us
+	// whatever the block: the wave takes blocks of up to 160 frames
 	max_work = 160;
 	return true;
 }
