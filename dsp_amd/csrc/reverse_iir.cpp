@@ -30,44 +30,39 @@ static const double RES_LIM = 1e-8 / DBL_EPSILON;        // reverse_iir.c:37
 static inline int pq_n(int t) { return t == RIIR_CC ? 2 : t; }           // reverse_iir.c:47
 static inline int pq_n_eval(int t) { return t == RIIR_CC ? 1 : t; }      // reverse_iir.c:48
 
-// roots of z^2 + b z + c (reverse_iir.c:672-686): a conjugate pair unless the imaginary part is negligible
-static bool calc_qroots(double b, double c, double r[2], cd *rc)
+// The roots of 1 + p1 z^-1 + p2 z^-2 as the reference classifies them (reverse_iir.c:672-723: poles from (c3, c4), zeros from (c1, c2) / c0):
+// none / one real root (p2 == 0), else a conjugate pair -- unless its imaginary part is below 1e-6, which counts as two real roots of a
+// discriminant clamped at zero.  The arithmetic (which quotient is formed first, where the clamp sits) decides which sections a chain splits
+// into, so it is the reference's; the shape of the code is not.
+struct QuadRoots { int type = RIIR_NONE; double re[2] = { 0.0, 0.0 }; cd pair = cd(0.0, 0.0); };
+static QuadRoots quad_roots(double p1, double p2)
 {
-	const double d = b * b - 4.0 * c;
-	if (d < 0.0) {
-		const cd root = (std::sqrt(cd(d, 0.0)) - b) / 2.0;
-		if (std::fabs(root.imag()) >= 1e-6) { *rc = root; return true; }
+	QuadRoots q;
+	if (p2 == 0.0) {
+		if (p1 != 0.0) { q.type = RIIR_1R; q.re[0] = -p1; }
+		return q;
 	}
-	const double sq = std::sqrt(d > 0.0 ? d : 0.0);
-	r[0] = (sq - b) / 2.0;
-	r[1] = (-sq - b) / 2.0;
-	return false;
+	const double disc = p1 * p1 - 4.0 * p2;
+	if (disc < 0.0) {
+		const cd root = (std::sqrt(cd(disc, 0.0)) - p1) / 2.0;
+		if (std::fabs(root.imag()) >= 1e-6) { q.type = RIIR_CC; q.pair = root; return q; }
+	}
+	const double sq = std::sqrt(disc > 0.0 ? disc : 0.0);
+	q.type = RIIR_2R;
+	q.re[0] = (sq - p1) / 2.0;
+	q.re[1] = (-sq - p1) / 2.0;
+	return q;
 }
 
-// reverse_iir.c:688-723
 void riir_sec_from_biquad(const std::array<double, 5> &c, double thresh, RiirSec *s)
 {
 	*s = RiirSec();
 	s->thresh = thresh;
 	s->g = c[0];
-	if (c[4] == 0.0) {
-		if (c[3] == 0.0) s->pt = RIIR_NONE;
-		else { s->pt = RIIR_1R; s->pr[0] = -c[3]; }
-	}
-	else {
-		cd z;
-		if (calc_qroots(c[3], c[4], s->pr, &z)) { s->pt = RIIR_CC; s->pc_re = z.real(); s->pc_im = z.imag(); }
-		else s->pt = RIIR_2R;
-	}
-	if (c[2] == 0.0) {
-		if (c[1] == 0.0) s->qt = RIIR_NONE;
-		else { s->qt = RIIR_1R; s->qr[0] = -c[1] / c[0]; }
-	}
-	else {
-		cd z;
-		if (calc_qroots(c[1] / c[0], c[2] / c[0], s->qr, &z)) { s->qt = RIIR_CC; s->qc_re = z.real(); s->qc_im = z.imag(); }
-		else s->qt = RIIR_2R;
-	}
+	const QuadRoots poles = quad_roots(c[3], c[4]);
+	const QuadRoots zeros = (c[2] == 0.0 && c[1] == 0.0) ? QuadRoots() : quad_roots(c[1] / c[0], c[2] / c[0]);
+	s->pt = poles.type; s->pr[0] = poles.re[0]; s->pr[1] = poles.re[1]; s->pc_re = poles.pair.real(); s->pc_im = poles.pair.imag();
+	s->qt = zeros.type; s->qr[0] = zeros.re[0]; s->qr[1] = zeros.re[1]; s->qc_re = zeros.pair.real(); s->qc_im = zeros.pair.imag();
 }
 
 // one factor (z - root_i) / z of a section's numerator or denominator at z (reverse_iir.c:342-355)
