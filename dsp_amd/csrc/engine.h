@@ -229,6 +229,7 @@ struct ResidentParams {
 	const OpDesc *ops;                               // [C][n_ops]
 	double *state;                                   // [C][n_ops][2]
 	unsigned long long lifetime_ticks;               // of the 100 MHz wall clock, without a block
+	unsigned long long max_life_ticks;               // ... since the launch, blocks or not (the wave leaves between two blocks; the host starts another)
 	unsigned max_polls, done0;                       // hard bound on the polling loop; the sequence number already served
 	int buf_doubles;                                 // doubles of the block buffer in LDS (a block is at most that many samples)
 };

@@ -6,8 +6,8 @@
 // polls a doorbell in page-locked host memory, runs the block -- the reference's recurrence as written (biquad.h:76-92), sample by sample, one lane per op
 // per channel, states and coefficients in registers -- out of and into the mapped staging buffers, and says so in host memory.
 //
-// Bounded lifetime: the wave leaves after `lifetime` ticks of the 100 MHz clock without a block, when the host asks it to (frames = RESIDENT_STOP),
-// or after `max_polls` turns of its loop whatever the clock says -- so a hipDeviceSynchronize() anywhere in the process waits a few milliseconds at
+// Bounded lifetime: the wave leaves after `lifetime` ticks of the 100 MHz clock without a block, `max_life` ticks after its launch however busy it is kept
+// (between two blocks), when the host asks it to (frames = RESIDENT_STOP), or after `max_polls` turns of its loop whatever the clock says -- so a hipDeviceSynchronize() anywhere in the process waits a few milliseconds at
 // most, and no failure of the host can leave a kernel behind.  Its last store is alive = 0; the host starts another one with the next block.
 // The states live in device memory between blocks (loaded and stored around every block, past the L1: the ordinary kernels may have run in between),
 // so a block of any other size simply takes the ordinary path on the same states.
@@ -62,12 +62,16 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 	double *stp = p.state + ((size_t) ch * n_ops + j) * 2;
 	unsigned done = p.done0;
 	unsigned long long t_last = wall_clock64();
+	const unsigned long long t_start = t_last;
 	for (unsigned it = 0; it < p.max_polls; ++it) {
 		// thread 0 reads the doorbell and the clock and decides for everybody (the waves meet at barriers below: one decision, not one per wave)
 		if (tid == 0) {
 			unsigned long long rq0 = __hip_atomic_load(&p.ctl->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-			if ((unsigned) (rq0 >> 32) == done && (unsigned) (rq0 & 0xffffffffu) != RESIDENT_STOP && wall_clock64() - t_last > p.lifetime_ticks)
-				rq0 = ((unsigned long long) done << 32) | RESIDENT_STOP;            // nothing for a lifetime: leave
+			// nothing for a lifetime: leave.  And leave between two blocks once max_life_ticks have gone by however busy the host keeps the wave: another
+			// thread's hipDeviceSynchronize() (a second chain being built while this one plays) must not wait for the audio to stop
+			const unsigned long long now = wall_clock64();
+			if ((unsigned) (rq0 >> 32) == done && (unsigned) (rq0 & 0xffffffffu) != RESIDENT_STOP && (now - t_last > p.lifetime_ticks || now - t_start > p.max_life_ticks))
+				rq0 = ((unsigned long long) done << 32) | RESIDENT_STOP;
 			*req_w = rq0;
 		}
 		__syncthreads();

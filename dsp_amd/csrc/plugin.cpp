@@ -181,6 +181,7 @@ bool Resident::init(CascadeStage *c, const MappedPair &mp)
 	rp.C = c->ch_in; rp.n_ops = c->n_ops;
 	rp.ops = c->device_ops(); rp.state = c->device_state();
 	rp.lifetime_ticks = 300000ull;           // 3 ms of the 100 MHz clock: more than two periods of a 64-frame block at 48 kHz
+	rp.max_life_ticks = 2000000ull;          // 20 ms in all: what a hipDeviceSynchronize() on another thread waits at the very most while this segment plays
 	rp.max_polls = 1u << 18;                 // (a turn of the loop is a round trip to host memory: about a second at the very most)
 	const size_t block_bytes = std::min<size_t>(mp.bytes, (size_t) 64 << 10);
 	rp.buf_doubles = (int) (block_bytes / sizeof(double));

@@ -39,7 +39,7 @@ def stream(chain, C, x, blocks, variant, pause_at=None):
 
 @pytest.mark.skipif(not RefChain.available("_gpu"), reason="oracle/_ref/libdspref_gpu.so not present")
 @pytest.mark.parametrize("chain,C,blocks,pause", [
-    ("gain -3 " + BIQ, 2, (64,), (5, 300)),                              # the LADSPA shape: every block through the resident wave; two pauses
+    ("gain -3 " + BIQ, 2, (64,), (5, 300)),                              # the LADSPA shape: every block through the resident wave; two pauses; 3000 blocks back to back outlast a wave's 20 ms
     ("gain -3 " + BIQ, 2, (64, 1, 1024, 17, 4096, 256, 3), None),        # resident and ordinary kernels in turn, on the same states
     ("lowpass 2k 0.707 :0 eq 300 1.5 4 gain -2 : add 0.001 highshelf 6k 0.7 2 mult 0.5", 3, (128, 64, 500), None),   # gains, an add, an op that skips channels
     (BIQ, 8, (256, 64), (3,)),                                           # eight channels: two waves
@@ -47,7 +47,7 @@ def stream(chain, C, x, blocks, variant, pause_at=None):
 ])
 def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
     rng = np.random.Generator(np.random.PCG64(99))
-    x = rng.uniform(-0.5, 0.5, size=(40000, C))
+    x = rng.uniform(-0.5, 0.5, size=(200000 if blocks == (64,) else 40000, C))
     x[100:110] = 0.0                                                     # (and some exact zeros of both signs: gains keep the sign of zero)
     x[105] = -0.0
     got = stream(chain, C, x, blocks, "_gpu", pause)
