@@ -1129,6 +1129,16 @@ CascadeStage *Pipeline::sole_cascade() const
 	return (c && !c->ring.base && c->write_interleaved) ? c : nullptr;
 }
 
+bool Pipeline::remix_then_cascade(RemixStage **r, CascadeStage **c) const
+{
+	if (stages.size() != 2 || S != 1) return false;
+	RemixStage *rm = dynamic_cast<RemixStage *>(stages[0].get());
+	CascadeStage *cs = dynamic_cast<CascadeStage *>(stages[1].get());
+	if (!rm || !cs || !rm->device_idx() || rm->sources_per_row() > 8 || cs->ring.base || !cs->write_interleaved || rm->ch_out != cs->ch_in) return false;
+	*r = rm; *c = cs;
+	return true;
+}
+
 ssize_t Pipeline::run(const double *d_in, ssize_t frames, double *d_out, long out_stride, hipStream_t st, long in_stride)
 {
 	if (in_stride <= 0) in_stride = frames;

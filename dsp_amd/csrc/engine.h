@@ -201,6 +201,8 @@ public:
 	int n_stages() const { return (int) stages.size(); }
 	// the pipeline's only stage when that is a cascade writing interleaved frames (what the resident small-block path of plugin.cpp serves), or nullptr
 	class CascadeStage *sole_cascade() const;
+	// ... or a plain remix followed by such a cascade (the crossover shape): both stages, else false
+	bool remix_then_cascade(class RemixStage **r, class CascadeStage **c) const;
 	size_t device_bytes() const;
 private:
 	Pipeline() {}
@@ -225,7 +227,10 @@ struct ResidentParams {
 	ResidentCtl *ctl;
 	const double *in;                                // mapped staging buffers of the segment: [frames][C]
 	double *out;
-	int C, n_ops;
+	int C, n_ops;                                    // channels of the cascade (= of the output), ops per channel
+	int Cin;                                         // channels of the input block: C, or the input side of a plain remix in front of the cascade
+	const int *remix_idx;                            // [C][remix_max_n] source channels of every cascade channel, -1 terminated (remix.c:39-101), or nullptr
+	int remix_max_n, out_off;                        // out_off: doubles from the block's input to its output in LDS (0: in place)
 	const OpDesc *ops;                               // [C][n_ops]
 	double *state;                                   // [C][n_ops][2]
 	unsigned long long lifetime_ticks;               // of the 100 MHz wall clock, without a block

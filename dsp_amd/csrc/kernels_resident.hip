@@ -59,6 +59,11 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		else if (od.kind == OP_MUL) a = od.g;
 		else if (od.kind == OP_ADD) b = od.g;
 	}
+	// a plain remix in front (the crossover shape): this row's channel is the sum of up to eight input channels, in ascending order from 0.0 (remix.c:39-101)
+	const int Cin = p.Cin;
+	int src[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) src[k] = (p.remix_idx && ch < C && k < p.remix_max_n) ? p.remix_idx[(size_t) ch * p.remix_max_n + k] : -1;
 	double *stp = p.state + ((size_t) ch * n_ops + j) * 2;
 	unsigned done = p.done0;
 	unsigned long long t_last = wall_clock64();
@@ -81,7 +86,8 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		if (frames == RESIDENT_STOP) break;
 		if (seq == done) { __builtin_amdgcn_s_sleep(8); continue; }
 		// ---- a block: in (mapped host memory, [frames][C]) -> LDS, the ops, LDS -> out
-		const int n = (int) frames * C;
+		const int n = (int) frames * Cin, n_out = (int) frames * C;
+		double *bout = buf + p.out_off;                              // the block's output: in place, or behind the input when a remix changes the channel count
 		double m0 = 0.0, m1 = 0.0;
 		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }      // (asked for in front of the block's trip over PCIe, not behind it)
 		// (host memory is a PCIe round trip away: sixteen bytes per lane and eight loads in flight before the first one is waited for -- one
@@ -104,14 +110,21 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		if (ch < C) {
 			const int nf = (int) frames, steps = nf + n_ops - 1;
 			const bool upd = mine && biq, wr = mine && j == n_ops - 1;
-			const double *rd = buf + ch;                                 // frame t of this row's channel at rd[t C]
+			// frame t of this row's channel: buf[t C + ch], or the remix of the input frame
+			auto frame_in = [&](int t) -> double {
+				if (!p.remix_idx) return buf[t * C + ch];
+				double acc = 0.0;
+#pragma unroll
+				for (int k = 0; k < 8; ++k) if (src[k] >= 0) acc = __dadd_rn(acc, buf[t * Cin + src[k]]);      // (one rounding per sum, in the reference's order: bit-exact)
+				return acc;
+			};
 			double s0 = biq ? m0 : b;                                    // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
 			// frames are asked for FOUR steps ahead of their use, by every lane of the row (one address, no branch), in a loop unrolled four times so that a
 			// loaded frame is used from the register it landed in: the wave is alone on its SIMD and would otherwise sit out an LDS round trip per step
 			// (with a rotating pair of registers the load was needed half a step after it had been asked for: 0.11 us per step)
 			double xq[4];
 #pragma unroll
-			for (int k = 0; k < 4; ++k) xq[k] = rd[(k < nf ? k : nf - 1) * C];
+			for (int k = 0; k < 4; ++k) xq[k] = frame_in(k < nf ? k : nf - 1);
 			double prev = 0.0;
 			auto step = [&](int t, double xin) {
 				const double below = row_shr1(prev);
@@ -123,14 +136,14 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 				const double n0 = fma(-c3, r, tt), n1 = fma(-c4, r, u);
 				if (active && upd) { s0 = n0; m1 = n1; }
 				prev = r;
-				if (active && wr) buf[(t - j) * C + ch] = r;
+				if (active && wr) bout[(t - j) * C + ch] = r;
 			};
 			for (int t = 0; t < steps; t += 4) {
 #pragma unroll
 				for (int k = 0; k < 4; ++k) {
 					if (t + k < steps) step(t + k, xq[k]);
 					const int tn = (t + k + 4 < nf) ? t + k + 4 : nf - 1;
-					xq[k] = rd[tn * C];
+					xq[k] = frame_in(tn);
 				}
 			}
 			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
@@ -139,10 +152,10 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		{
 			typedef double res_d2 __attribute__((ext_vector_type(2)));
 			res_d2 *dst = reinterpret_cast<res_d2 *>(p.out);
-			const res_d2 *src = reinterpret_cast<const res_d2 *>(buf);
-			const int n2 = n >> 1;
-			for (int e = tid; e < n2; e += nth) __builtin_nontemporal_store(src[e], dst + e);
-			if ((n & 1) && tid == 0) __builtin_nontemporal_store(buf[n - 1], p.out + n - 1);
+			const res_d2 *so = reinterpret_cast<const res_d2 *>(bout);
+			const int n2 = n_out >> 1;
+			for (int e = tid; e < n2; e += nth) __builtin_nontemporal_store(so[e], dst + e);
+			if ((n_out & 1) && tid == 0) __builtin_nontemporal_store(bout[n_out - 1], p.out + n_out - 1);
 		}
 		__threadfence_system();                                      // the block's output and states are out before the word that says so
 		__syncthreads();
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st)
 {
-	if (p.C < 1 || p.C > 64 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) p.buf_doubles * sizeof(double) + 16 > lds_bytes) return false;
+	if (p.C < 1 || p.C > 64 || p.Cin < 1 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) p.buf_doubles * sizeof(double) + 16 > lds_bytes || (p.out_off & 1)) return false;
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident), lds_bytes);
 	const int waves = (p.C + 3) / 4;
 	hipLaunchKernelGGL(cascade_resident, dim3(1), dim3(64 * waves), lds_bytes, st, p);

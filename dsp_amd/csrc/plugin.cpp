@@ -84,9 +84,11 @@ static bool ensure_segment(struct effect *e, Node *n)
 	{
 		static const bool resident_on = [] { const char *v = getenv("DSP_AMD_PLUGIN_RESIDENT"); return !v || atoi(v) != 0; }();
 		CascadeStage *casc = resident_on ? seg->pipe->sole_cascade() : nullptr;
+		RemixStage *rmx = nullptr;
+		if (resident_on && !casc && !seg->pipe->remix_then_cascade(&rmx, &casc)) { rmx = nullptr; casc = nullptr; }
 		if (casc && seg->mapped.bytes) {
 			seg->resident.reset(new Resident);
-			if (!seg->resident->init(casc, seg->mapped)) seg->resident.reset();
+			if (!seg->resident->init(rmx, casc, seg->mapped)) seg->resident.reset();
 		}
 	}
 	if (seg->members.size() > 1) log_msg(LL_VERBOSE, "%s: info: %zu effects fused into one device segment: %s", e->name, seg->members.size(), seg->pipe->plan().c_str());
@@ -168,7 +170,7 @@ Segment::~Segment() { resident.reset(); unpin_all(); }
 // ---- the resident small-block wave (see plugin.h) ----
 static inline double res_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 
-bool Resident::init(CascadeStage *c, const MappedPair &mp)
+bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 {
 	if (!c || c->n_ops < 1 || c->n_ops > 16 || c->ch_in < 1 || c->ch_in > 64 || !mp.bytes) return false;
 	void *m = nullptr;
@@ -179,12 +181,17 @@ bool Resident::init(CascadeStage *c, const MappedPair &mp)
 	memset(&rp, 0, sizeof(rp));
 	rp.ctl = ctl; rp.in = mp.in; rp.out = mp.out;
 	rp.C = c->ch_in; rp.n_ops = c->n_ops;
+	rp.Cin = r ? r->ch_in : c->ch_in;
+	rp.remix_idx = r ? r->device_idx() : nullptr;
+	rp.remix_max_n = r ? r->sources_per_row() : 0;
 	rp.ops = c->device_ops(); rp.state = c->device_state();
 	rp.lifetime_ticks = 300000ull;           // 3 ms of the 100 MHz clock: more than two periods of a 64-frame block at 48 kHz
 	rp.max_life_ticks = 2000000ull;          // 20 ms in all: what a hipDeviceSynchronize() on another thread waits at the very most while this segment plays
 	rp.max_polls = 1u << 18;                 // (a turn of the loop is a round trip to host memory: about a second at the very most)
 	const size_t block_bytes = std::min<size_t>(mp.bytes, (size_t) 64 << 10);
 	rp.buf_doubles = (int) (block_bytes / sizeof(double));
+	// with a remix the output of a block lies behind its input (the channel count changes): the input's share of the buffer by channel counts, on an even index
+	rp.out_off = r ? (int) (((long) rp.buf_doubles * rp.Cin / (rp.Cin + rp.C)) & ~1L) : 0;
 	lds = block_bytes + 16;
 	sections = 1;
 	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of three dependent trips over PCIe (doorbell, block,

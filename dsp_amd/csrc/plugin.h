@@ -25,8 +25,8 @@ struct Resident {
 	long max_work = 0;                       // frames x sections a block may have (beyond it the ordinary, parallel kernels are faster)
 	int sections = 1;
 	bool off = false;
-	bool init(class CascadeStage *c, const MappedPair &mp);
-	bool takes(ssize_t frames) const { return !off && ctl && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * rp.C <= (size_t) rp.buf_doubles; }
+	bool init(class RemixStage *r, class CascadeStage *c, const MappedPair &mp);       // r: a plain remix in front of the cascade, or nullptr
+	bool takes(ssize_t frames) const { return !off && ctl && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? rp.Cin + rp.C : rp.C) + 2 <= (size_t) rp.buf_doubles; }
 	bool serve(ssize_t frames);              // the block is in the mapped input buffer; true: its output is in the mapped output buffer
 	void stop();
 	~Resident();

@@ -84,6 +84,9 @@ public:
 	bool wire_in_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
 	bool wire_out_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
 	size_t device_bytes() const override { return d_idx.bytes + d_w.bytes + d_post.bytes; }
+	// a plain remix (sums from 0.0 in ascending input order) for the resident small-block wave: [ch_out][max_n] source channels, -1 terminated
+	const int *device_idx() const { return weighted ? nullptr : d_idx.as<int>(); }
+	int sources_per_row() const { return max_n; }
 private:
 	DevBuf d_idx, d_w, d_post;           // d_w / d_post: weighted rows (Kind::Mix)
 	int max_n = 1;

@@ -44,6 +44,9 @@ def stream(chain, C, x, blocks, variant, pause_at=None):
     ("lowpass 2k 0.707 :0 eq 300 1.5 4 gain -2 : add 0.001 highshelf 6k 0.7 2 mult 0.5", 3, (128, 64, 500), None),   # gains, an add, an op that skips channels
     (BIQ, 8, (256, 64), (3,)),                                           # eight channels: two waves
     ("gain -6 mult 1.5 add 0.25", 2, (64, 200), None),                   # no section at all: bit-exact ops only
+    # the crossover shape (examples/crossover_lr4_2kHz): a remix 2 -> 4 in front of per-band sections -- the remix inside the wave too
+    ("remix 0 1 0 1 :0,1 lowpass 2k 0.707 lowpass 2k 0.707 :2,3 highpass 2k 0.707 highpass 2k 0.707 : gain -1", 2, (64, 128, 1000), (4,)),
+    ("remix 0,1 0 1 gain -3 add 0.001", 2, (64, 96), None),              # a mono sum beside the two channels, then bit-exact ops only
 ])
 def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
     rng = np.random.Generator(np.random.PCG64(99))
@@ -53,6 +56,7 @@ def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
     got = stream(chain, C, x, blocks, "_gpu", pause)
     ref = stream(chain, C, x, blocks, "")
     assert got.shape == ref.shape
+    assert got.shape[1] == (3 if chain.startswith("remix 0,1") else 4 if chain.startswith("remix") else C)
     if "eq" not in chain and "pass" not in chain:
         assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
     else:
