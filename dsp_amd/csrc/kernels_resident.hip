@@ -59,11 +59,7 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		else if (od.kind == OP_MUL) a = od.g;
 		else if (od.kind == OP_ADD) b = od.g;
 	}
-	// a plain remix in front (the crossover shape): this row's channel is the sum of up to eight input channels, in ascending order from 0.0 (remix.c:39-101)
-	const int Cin = p.Cin;
-	int src[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k) src[k] = (p.remix_idx && ch < C && k < p.remix_max_n) ? p.remix_idx[(size_t) ch * p.remix_max_n + k] : -1;
+	const int Cin = p.Cin, rmx_n = p.remix_idx ? p.remix_max_n : 0;
 	double *stp = p.state + ((size_t) ch * n_ops + j) * 2;
 	unsigned done = p.done0;
 	unsigned long long t_last = wall_clock64();
@@ -107,17 +103,23 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			if ((n & 1) && tid == 0) buf[n - 1] = __builtin_nontemporal_load(p.in + n - 1);
 		}
 		__syncthreads();
+		if (rmx_n) {
+			// a plain remix in front (the crossover shape): every output channel the sum of its input channels, in ascending order from 0.0, one rounding per
+			// sum (remix.c:39-101: bit-exact) -- a pass of its own over the block in LDS, into the region the cascade then works on in place
+			for (int e = tid; e < n_out; e += nth) {
+				const int t = e / C, c = e - t * C;
+				const int *idx = p.remix_idx + (size_t) c * rmx_n;
+				double acc = 0.0;
+				for (int k = 0; k < rmx_n; ++k) { const int sc = idx[k]; if (sc < 0) break; acc = __dadd_rn(acc, buf[t * Cin + sc]); }
+				bout[e] = acc;
+			}
+			__syncthreads();
+		}
 		if (ch < C) {
 			const int nf = (int) frames, steps = nf + n_ops - 1;
 			const bool upd = mine && biq, wr = mine && j == n_ops - 1;
-			// frame t of this row's channel: buf[t C + ch], or the remix of the input frame
-			auto frame_in = [&](int t) -> double {
-				if (!p.remix_idx) return buf[t * C + ch];
-				double acc = 0.0;
-#pragma unroll
-				for (int k = 0; k < 8; ++k) if (src[k] >= 0) acc = __dadd_rn(acc, buf[t * Cin + src[k]]);      // (one rounding per sum, in the reference's order: bit-exact)
-				return acc;
-			};
+			const double *rd = bout + ch;                                // frame t of this row's channel at rd[t C] (the remix, if any, has been through)
+			auto frame_in = [&](int t) -> double { return rd[t * C]; };
 			double s0 = biq ? m0 : b;                                    // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
 			// frames are asked for FOUR steps ahead of their use, by every lane of the row (one address, no branch), in a loop unrolled four times so that a
 			// loaded frame is used from the register it landed in: the wave is alone on its SIMD and would otherwise sit out an LDS round trip per step

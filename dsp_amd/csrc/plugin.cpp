@@ -196,8 +196,9 @@ bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 	sections = 1;
 	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of three dependent trips over PCIe (doorbell, block,
 	// completion): profiles/r05_ladspa_rate.txt -- 12.1 us at 64 frames, about 30 at 256; a launch of the ordinary, time-parallel kernels costs 24 ... 26 us
-	// whatever the block: the wave takes blocks of up to 160 frames
-	max_work = 160;
+	// whatever the block (18 ... 21 us for the two launches of a short remix + cascade segment): the wave takes blocks of up to 128 frames
+	// (2 -> 4 crossover: 12.3 us at 64 frames against 17.6, 20.2 against 20.1 at 128: profiles/r05_ladspa_rate.txt)
+	max_work = 128;
 	return true;
 }
 
