@@ -3,5 +3,5 @@
 mkdir -p gpurun_out/r05final
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r05final/pytest.log 2>&1; echo "pytest all rc $?"; tail -4 gpurun_out/r05final/pytest.log | cut -c1-300
-bash scripts/profile_round.sh r05b > gpurun_out/r05final/profile.log 2>&1; tail -3 gpurun_out/r05final/profile.log
+bash scripts/profile_round.sh r05c > gpurun_out/r05final/profile.log 2>&1; tail -3 gpurun_out/r05final/profile.log
 bash scripts/exp_scale2.sh 2>&1 | tail -6
