@@ -190,8 +190,8 @@ bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 	rp.max_polls = 1u << 18;                 // (a turn of the loop is a round trip to host memory: about a second at the very most)
 	const size_t block_bytes = std::min<size_t>(mp.bytes, (size_t) 64 << 10);
 	rp.buf_doubles = (int) (block_bytes / sizeof(double));
-	// with a remix the output of a block lies behind its input (the channel count changes): the input's share of the buffer by channel counts, on an even index
-	rp.out_off = r ? (int) (((long) rp.buf_doubles * rp.Cin / (rp.Cin + rp.C)) & ~1L) : 0;
+	// with a remix the output of a block lies behind its input (the channel count changes): one half of the buffer each
+	rp.out_off = r ? (rp.buf_doubles / 2) & ~1 : 0;
 	lds = block_bytes + 16;
 	sections = 1;
 	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of three dependent trips over PCIe (doorbell, block,

@@ -1,5 +1,6 @@
 // plugin.h -- the `struct effect` objects handed to a host through the reference's plugin ABI.
 #pragma once
+#include <algorithm>
 #include <memory>
 #include "dsp_effect_abi.h"
 #include "effects.h"
@@ -26,7 +27,7 @@ struct Resident {
 	int sections = 1;
 	bool off = false;
 	bool init(class RemixStage *r, class CascadeStage *c, const MappedPair &mp);       // r: a plain remix in front of the cascade, or nullptr
-	bool takes(ssize_t frames) const { return !off && ctl && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? rp.Cin + rp.C : rp.C) + 2 <= (size_t) rp.buf_doubles; }
+	bool takes(ssize_t frames) const { return !off && ctl && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles; }
 	bool serve(ssize_t frames);              // the block is in the mapped input buffer; true: its output is in the mapped output buffer
 	void stop();
 	~Resident();
