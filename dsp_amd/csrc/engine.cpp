@@ -15,6 +15,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <thread>
+#include <vector>
 #include <sched.h>
 #include <unistd.h>
 
@@ -38,6 +39,16 @@ void grant_dynamic_lds(const void *kernel, size_t bytes)
 	if (bytes <= g) return;
 	if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) == hipSuccess) g = bytes;
 	else (void) hipGetLastError();   // the launch itself will report the failure
+}
+
+// DSP_AMD_TRACE_MEM=<file>: one line per device / page-locked allocation, release and host-buffer registration of this library (what, address, bytes,
+// microseconds) -- the map a GPU memory fault's address is looked up in (scripts/r05_hunt_suite.sh); off and free of cost otherwise
+void trace_mem(const char *what, const void *p, size_t n)
+{
+	static FILE *f = [] { const char *e = getenv("DSP_AMD_TRACE_MEM"); FILE *h = (e && *e) ? fopen(e, "a") : nullptr; if (h) setvbuf(h, nullptr, _IOLBF, 0); return h; }();
+	if (!f) return;
+	timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+	fprintf(f, "%s %p %zu %lld pid %d\n", what, p, n, (long long) t.tv_sec * 1000000 + t.tv_nsec / 1000, (int) getpid());
 }
 
 int device_count()
@@ -85,12 +96,63 @@ Profiler::~Profiler()
 	for (Rec &r : recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
 }
 
+static const size_t CANARY = 4096, DEVBUF_SLACK = 4096;
+static int guard_mode() { static const int m = [] { const char *e = getenv("DSP_AMD_GUARD"); return e ? atoi(e) : 0; }(); return m; }
+
+static bool guarded_alloc(DevBuf &b, size_t n)
+{
+	int dev = 0;
+	(void) hipGetDevice(&dev);
+	hipMemAllocationProp prop;
+	memset(&prop, 0, sizeof(prop));
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = dev;
+	size_t gran = 0;
+	if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return false;
+	const size_t slack = guard_mode() == 4 ? ((size_t) 64 << 10) : 0;        // (mode 4: the same kind of memory with room behind the buffer -- tells an overrun from the mapping itself)
+	const size_t map = (n + slack + gran - 1) / gran * gran;
+	void *base = nullptr;
+	if (hipMemAddressReserve(&base, map + 2 * gran, gran, nullptr, 0) != hipSuccess) return false;
+	hipMemGenericAllocationHandle_t h;
+	if (hipMemCreate(&h, map, &prop, 0) != hipSuccess) { (void) hipMemAddressFree(base, map + 2 * gran); return false; }
+	char *at = static_cast<char *>(base) + gran;
+	hipMemAccessDesc acc;
+	memset(&acc, 0, sizeof(acc));
+	acc.location = prop.location;
+	acc.flags = hipMemAccessFlagsProtReadWrite;
+	if (hipMemMap(at, map, 0, h, 0) != hipSuccess) { (void) hipMemRelease(h); (void) hipMemAddressFree(base, map + 2 * gran); return false; }
+	if (hipMemSetAccess(at, map, &acc, 1) != hipSuccess) { (void) hipMemUnmap(at, map); (void) hipMemRelease(h); (void) hipMemAddressFree(base, map + 2 * gran); return false; }
+	b.vm_base = base; b.vm_size = map + 2 * gran; b.vm_map = map; b.vm_gran = gran; b.vm_handle = (void *) h;
+	b.p = guard_mode() == 2 ? at : at + (map - (n + 255) / 256 * 256);     // (hipMalloc's alignment, which the kernels rely on: 256 bytes)
+	return true;
+}
+
 bool DevBuf::alloc(size_t n, bool zero)
 {
 	release();
 	if (n == 0) n = 16;
-	if (!hip_ok(hipMalloc(&p, n), "hipMalloc")) { p = nullptr; return false; }
+	if (guard_mode() == 3) {
+		// canaries: a page of a pattern on both sides, looked at when the buffer goes (writes beyond the buffer, found where they land)
+		char *base = nullptr;
+		if (hipMalloc((void **) &base, n + 2 * CANARY) == hipSuccess && hipMemset(base, 0xA5, n + 2 * CANARY) == hipSuccess) {
+			p = base + CANARY; canary = true; site = __builtin_return_address(0);
+		}
+		else (void) hipGetLastError();
+	}
+	else if (guard_mode()) {
+		if (!guarded_alloc(*this, n)) {
+			(void) hipGetLastError();
+			static bool said = false;
+			if (!said) { said = true; fprintf(stderr, "dsp_amd: DSP_AMD_GUARD: the virtual-memory calls failed, plain hipMalloc from here on\n"); }
+		}
+	}
+	// (a page of slack behind every buffer, as a defence: no kernel is known to read past the end of one -- DSP_AMD_GUARD=3 finds no write outside
+	// any buffer in the whole GPU suite -- but a vector load that did would fault or not depending on what the allocator has put next to the buffer,
+	// which is how the round-5 fault behaves: DESIGN.md section 5)
+	if (!p && !hip_ok(hipMalloc(&p, n + DEVBUF_SLACK), "hipMalloc")) { p = nullptr; return false; }
 	bytes = n;
+	trace_mem("dev+", p, n);
 	if (zero && !hip_ok(hipMemset(p, 0, n), "hipMemset")) return false;
 	return true;
 }
@@ -103,6 +165,7 @@ void MappedPair::alloc()
 	// (coherent = fine-grained: a wave that stays on the device across blocks -- kernels_resident.hip -- must see what the host wrote a moment ago, not an L2 line)
 	if (hipHostMalloc(&a, (size_t) kb << 10, hipHostMallocCoherent) == hipSuccess && hipHostMalloc(&b, (size_t) kb << 10, hipHostMallocCoherent) == hipSuccess) {
 		in = static_cast<double *>(a); out = static_cast<double *>(b); bytes = (size_t) kb << 10;
+		trace_mem("map+", a, bytes); trace_mem("map+", b, bytes);
 		void *f = nullptr;
 		static const bool spin = !getenv("DSP_AMD_PLUGIN_NO_SPIN");
 		if (spin && hipHostMalloc(&f, 64, hipHostMallocDefault) == hipSuccess) { flag = static_cast<volatile unsigned *>(f); *flag = 0; }
@@ -115,8 +178,8 @@ void MappedPair::alloc()
 
 MappedPair::~MappedPair()
 {
-	if (in) (void) hipHostFree(in);
-	if (out) (void) hipHostFree(out);
+	if (in) { trace_mem("map-", in, bytes); (void) hipHostFree(in); }
+	if (out) { trace_mem("map-", out, bytes); (void) hipHostFree(out); }
 	if (flag) (void) hipHostFree(const_cast<unsigned *>(flag));
 }
 
@@ -226,8 +289,8 @@ bool PinnedStage::ensure(size_t in_bytes, size_t out_bytes)
 	if (std::max(in_bytes, out_bytes) > ((size_t) 64 << 20)) return false;
 	if (done[0]) (void) hipDeviceSynchronize();           // (buffers that may still be in flight are about to be replaced)
 	for (int i = 0; i < 2; ++i) {
-		if (in[i]) (void) hipHostFree(in[i]);
-		if (out[i]) (void) hipHostFree(out[i]);
+		if (in[i]) { trace_mem("stage-", in[i], in_cap); (void) hipHostFree(in[i]); }
+		if (out[i]) { trace_mem("stage-", out[i], out_cap); (void) hipHostFree(out[i]); }
 		in[i] = out[i] = nullptr;
 	}
 	in_cap = out_cap = 0;
@@ -246,14 +309,15 @@ bool PinnedStage::ensure(size_t in_bytes, size_t out_bytes)
 		return false;
 	}
 	in_cap = std::max<size_t>(in_bytes, 4096); out_cap = std::max<size_t>(out_bytes, 4096);
+	for (int i = 0; i < 2; ++i) { trace_mem("stage+", in[i], in_cap); trace_mem("stage+", out[i], out_cap); }
 	return true;
 }
 
 PinnedStage::~PinnedStage()
 {
 	for (int i = 0; i < 2; ++i) {
-		if (in[i]) (void) hipHostFree(in[i]);
-		if (out[i]) (void) hipHostFree(out[i]);
+		if (in[i]) { trace_mem("stage-", in[i], in_cap); (void) hipHostFree(in[i]); }
+		if (out[i]) { trace_mem("stage-", out[i], out_cap); (void) hipHostFree(out[i]); }
 		if (done[i]) (void) hipEventDestroy(done[i]);
 		if (copied[i]) (void) hipEventDestroy(copied[i]);
 	}
@@ -293,7 +357,31 @@ bool DevBuf::upload(const void *src, size_t n)
 
 void DevBuf::release()
 {
-	if (p) (void) hipFree(p);
+	if (p && vm_base) {
+		trace_mem("dev-", p, bytes);
+		(void) hipDeviceSynchronize();
+		(void) hipMemUnmap(static_cast<char *>(vm_base) + vm_gran, vm_map);
+		(void) hipMemRelease((hipMemGenericAllocationHandle_t) vm_handle);
+		(void) hipMemAddressFree(vm_base, vm_size);
+		vm_base = nullptr; vm_handle = nullptr; vm_size = vm_map = vm_gran = 0;
+	}
+	else if (p && canary) {
+		std::vector<unsigned char> h(bytes + 2 * CANARY);
+		char *base = static_cast<char *>(p) - CANARY;
+		if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), base, h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+			long lo = -1, hi = -1, n_bad = 0;
+			for (size_t i = 0; i < h.size(); ++i) {
+				if (i >= CANARY && i < CANARY + bytes) continue;
+				if (h[i] != 0xA5) { if (lo < 0) lo = (long) i; hi = (long) i; ++n_bad; }
+			}
+			if (n_bad) fprintf(stderr, "dsp_amd: CANARY: buffer of %zu bytes allocated at %p: %ld bytes written outside, offsets %ld ... %ld relative to its start\n",
+			                   bytes, site, n_bad, lo - (long) CANARY, hi - (long) CANARY);
+		}
+		else (void) hipGetLastError();
+		(void) hipFree(base);
+		canary = false;
+	}
+	else if (p) { trace_mem("dev-", p, bytes); (void) hipFree(p); }
 	p = nullptr;
 	bytes = 0;
 }

@@ -107,7 +107,8 @@ void Segment::unpin_all()
 	if (pins.empty()) return;
 	(void) hipDeviceSynchronize();
 	for (const Pin &r : pins)
-		if (hipHostUnregister(r.base) != hipSuccess) {
+		if (trace_mem("reg-", r.base, r.bytes), hipHostUnregister(r.base) != hipSuccess) {
+			trace_mem("reg-failed", r.base, r.bytes);
 			// (a range the host has unmapped in the meantime: nothing to undo, but worth a line -- see INTEGRATION.md, "host buffers")
 			log_msg(LL_VERBOSE, "info: host buffer %p could not be unregistered (%s)", (void *) r.base, hipGetErrorString(hipGetLastError()));
 		}
@@ -149,7 +150,8 @@ bool Segment::pinned(int which, const void *p, size_t n)
 		const Pin r = pins[i];
 		if (lo <= r.base + r.bytes && hi >= r.base) {
 			lo = std::min(lo, r.base); hi = std::max(hi, r.base + r.bytes);
-			if (hipHostUnregister(r.base) != hipSuccess) (void) hipGetLastError();
+			trace_mem("reg-", r.base, r.bytes);
+			if (hipHostUnregister(r.base) != hipSuccess) { trace_mem("reg-failed", r.base, r.bytes); (void) hipGetLastError(); }
 			pins.erase(pins.begin() + i);
 		}
 		else ++i;
@@ -161,6 +163,7 @@ bool Segment::pinned(int which, const void *p, size_t n)
 		return false;
 	}
 	pins.push_back(Pin{ lo, (size_t) (hi - lo) });
+	trace_mem("reg+", lo, (size_t) (hi - lo));
 	log_msg(LL_VERBOSE, "info: host buffer %p (%zu KiB) registered for DMA", (void *) lo, (size_t) (hi - lo) >> 10);
 	return true;
 }
@@ -176,6 +179,7 @@ bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 	void *m = nullptr;
 	if (hipHostMalloc(&m, sizeof(ResidentCtl), hipHostMallocCoherent) != hipSuccess) { (void) hipGetLastError(); return false; }
 	ctl = static_cast<ResidentCtl *>(m);
+	trace_mem("ctl+", ctl, sizeof(*ctl));
 	memset(ctl, 0, sizeof(*ctl));
 	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); (void) hipHostFree(ctl); ctl = nullptr; st = nullptr; return false; }
 	memset(&rp, 0, sizeof(rp));
@@ -243,7 +247,7 @@ Resident::~Resident()
 {
 	stop();
 	if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
-	if (ctl) (void) hipHostFree(ctl);
+	if (ctl) { trace_mem("ctl-", ctl, sizeof(*ctl)); (void) hipHostFree(ctl); }
 }
 
 static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, sample_t *obuf)
