@@ -96,7 +96,7 @@ Profiler::~Profiler()
 	for (Rec &r : recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
 }
 
-static const size_t CANARY = 4096, DEVBUF_SLACK = 4096;
+static const size_t CANARY = 4096, DEVBUF_SLACK = (size_t) 64 << 10;     // (64 KB: one 4096-point row of a transform)
 static int guard_mode() { static const int m = [] { const char *e = getenv("DSP_AMD_GUARD"); return e ? atoi(e) : 0; }(); return m; }
 
 static bool guarded_alloc(DevBuf &b, size_t n)
@@ -147,7 +147,7 @@ bool DevBuf::alloc(size_t n, bool zero)
 			if (!said) { said = true; fprintf(stderr, "dsp_amd: DSP_AMD_GUARD: the virtual-memory calls failed, plain hipMalloc from here on\n"); }
 		}
 	}
-	// (a page of slack behind every buffer, as a defence: no kernel is known to read past the end of one -- DSP_AMD_GUARD=3 finds no write outside
+	// (64 KB of slack behind every buffer, as a defence: no kernel is known to read past the end of one -- DSP_AMD_GUARD=3 finds no write outside
 	// any buffer in the whole GPU suite -- but a vector load that did would fault or not depending on what the allocator has put next to the buffer,
 	// which is how the round-5 fault behaves: DESIGN.md section 5)
 	if (!p && !hip_ok(hipMalloc(&p, n + DEVBUF_SLACK), "hipMalloc")) { p = nullptr; return false; }
