@@ -52,6 +52,23 @@ def _isolated(item):
     return (not CHILD_REPORT) and (not ONE_PROCESS) and item.get_closest_marker(ISOLATE_MARK) is not None
 
 
+class _Done:
+    def __init__(self, returncode, stdout):
+        self.returncode, self.stdout = returncode, stdout
+
+
+def _run(cmd, cwd, env, limit=float(os.environ.get("DSP_AMD_TESTS_MODULE_SECONDS", "1500"))):
+    """a child that outlives `limit` seconds (a hung kernel) is ended; it stays in this process's group, so whatever ends the suite ends it too"""
+    proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, errors="replace")
+    try:
+        out, _ = proc.communicate(timeout=limit)
+        return _Done(proc.returncode, out)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        return _Done(-9, (out or "") + f"\n[tests/conftest.py: the module's test process was ended after {limit:.0f} s]\n")
+
+
 def _run_module(item):
     global _native_loaded
     if ISOLATE_MARK == "gpu" and not _native_loaded:
@@ -71,7 +88,7 @@ def _run_module(item):
         os.close(fd)
         env = dict(os.environ, DSP_AMD_TESTS_CHILD_REPORT=path)
         cmd = [sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", "--rootdir", str(item.config.rootpath), "-m", ISOLATE_MARK, f"--maxfail={maxfail}"] + todo
-        p = subprocess.run(cmd, cwd=str(item.config.rootpath), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, errors="replace")
+        p = _run(cmd, str(item.config.rootpath), env)
         with open(path) as f:
             for line in f:
                 rec = json.loads(line)

@@ -29,4 +29,6 @@ def test_dies():
 
 
 def test_after_the_death():
-    pass
+    if os.environ.get("ISOLATION_SAMPLE_HANG") == "1":
+        import time
+        time.sleep(600)

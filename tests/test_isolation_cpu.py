@@ -39,3 +39,10 @@ def test_a_child_that_dies_fails_its_tests_and_not_the_others():
 def test_one_process_switch():
     r = inner("-q", DSP_AMD_TESTS_ONE_PROCESS="1")
     assert r.returncode == 1 and re.search(r"2 failed, 4 passed, 1 skipped", r.stdout), r.stdout[-2000:]   # (test_in_a_child is not in one)
+
+
+def test_a_child_that_hangs_is_ended():
+    r = inner("-q", ISOLATION_SAMPLE_HANG="1", DSP_AMD_TESTS_MODULE_SECONDS="3")
+    assert r.returncode == 1, r.stdout[-2000:]
+    assert re.search(r"2 failed, 4 passed, 1 skipped", r.stdout), r.stdout[-2000:]
+    assert "was ended after 3 s" in r.stdout
