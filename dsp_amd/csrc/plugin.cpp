@@ -176,14 +176,9 @@ static inline double res_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &
 bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 {
 	if (!c || c->n_ops < 1 || c->n_ops > 16 || c->ch_in < 1 || c->ch_in > 64 || !mp.bytes) return false;
-	void *m = nullptr;
-	if (hipHostMalloc(&m, sizeof(ResidentCtl), hipHostMallocCoherent) != hipSuccess) { (void) hipGetLastError(); return false; }
-	ctl = static_cast<ResidentCtl *>(m);
-	trace_mem("ctl+", ctl, sizeof(*ctl));
-	memset(ctl, 0, sizeof(*ctl));
-	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); (void) hipHostFree(ctl); ctl = nullptr; st = nullptr; return false; }
+	// (the doorbell and the stream of its own are made by the first block the wave takes -- open(): a segment driven with larger blocks never has them)
 	memset(&rp, 0, sizeof(rp));
-	rp.ctl = ctl; rp.in = mp.in; rp.out = mp.out;
+	rp.in = mp.in; rp.out = mp.out;
 	rp.C = c->ch_in; rp.n_ops = c->n_ops;
 	rp.Cin = r ? r->ch_in : c->ch_in;
 	rp.remix_idx = r ? r->device_idx() : nullptr;
@@ -203,6 +198,19 @@ bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 	// whatever the block (18 ... 21 us for the two launches of a short remix + cascade segment): the wave takes blocks of up to 128 frames
 	// (2 -> 4 crossover: 12.3 us at 64 frames against 17.6, 20.2 against 20.1 at 128: profiles/r05_ladspa_rate.txt)
 	max_work = 128;
+	ready = true;
+	return true;
+}
+
+bool Resident::open()
+{
+	void *m = nullptr;
+	if (hipHostMalloc(&m, sizeof(ResidentCtl), hipHostMallocCoherent) != hipSuccess) { (void) hipGetLastError(); return false; }
+	ctl = static_cast<ResidentCtl *>(m);
+	trace_mem("ctl+", ctl, sizeof(*ctl));
+	memset(ctl, 0, sizeof(*ctl));
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); trace_mem("ctl-", ctl, sizeof(*ctl)); (void) hipHostFree(ctl); ctl = nullptr; st = nullptr; return false; }
+	rp.ctl = ctl;
 	return true;
 }
 
@@ -216,6 +224,7 @@ bool Resident::launch()
 
 bool Resident::serve(ssize_t frames)
 {
+	if (!ctl && !open()) { off = true; return false; }
 	++seq;
 	__atomic_store_n(&ctl->req, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames, __ATOMIC_RELEASE);
 	const double t0 = res_now_us();

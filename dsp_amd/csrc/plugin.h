@@ -26,12 +26,14 @@ struct Resident {
 	long max_work = 0;                       // frames x sections a block may have (beyond it the ordinary, parallel kernels are faster)
 	int sections = 1;
 	bool off = false;
+	bool ready = false;                      // init() has accepted the segment; the doorbell and the stream come with the first small block (open())
 	bool init(class RemixStage *r, class CascadeStage *c, const MappedPair &mp);       // r: a plain remix in front of the cascade, or nullptr
-	bool takes(ssize_t frames) const { return !off && ctl && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles; }
+	bool takes(ssize_t frames) const { return !off && ready && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles; }
 	bool serve(ssize_t frames);              // the block is in the mapped input buffer; true: its output is in the mapped output buffer
 	void stop();
 	~Resident();
 private:
+	bool open();
 	bool launch();
 };
 
