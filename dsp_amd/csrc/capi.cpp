@@ -2,6 +2,7 @@
 #include "dsp_amd.h"
 #include "chain.h"
 #include "engine.h"
+#include "plugin.h"
 #include "pcm_params.h"
 #include <cstring>
 #include <cstdio>
@@ -273,6 +274,17 @@ const char *dspamd_chain_effect_name(dspamd_chain *c, int i)
 {
 	if (i < 0 || i >= (int) c->b->plan.effects.size()) return nullptr;
 	return c->b->plan.effects[i]->name;
+}
+
+// ---------------------------------------------------------------- how the plugin path served its blocks
+
+int dspamd_plugin_counters(long long *out, int n)
+{
+	const PluginCounters &c = g_plugin_counters;
+	const long long v[7] = { c.wave_blocks.load(), c.mapped_blocks.load(), c.copied_blocks.load(), c.wave_launches.load(), c.wave_timeouts.load(), c.wave_off.load(), c.registrations.load() };
+	int k = 0;
+	for (; k < n && k < 7; ++k) out[k] = v[k];
+	return k;
 }
 
 // ---------------------------------------------------------------- per-kernel HIP-event timing

@@ -748,12 +748,16 @@ const CascadeStage::FuseTables &CascadeStage::fuse_tables()
 	// section slots: the ops that are a section in any channel (a selector makes them OP_SKIP in the others); gains have no slot
 	std::vector<int> sec_op;
 	for (int j = 0; j < n_ops; ++j) {
-		bool section = false;
+		bool section = false, gain_here = false;
 		for (int c = 0; c < ch_in; ++c) {
 			const int k = host_ops[(size_t) c * n_ops + j].kind;
 			if (k == OP_BIQUAD) section = true;
-			else if (k != OP_MUL && k != OP_SKIP) return ft;          // (`add` is not linear in the state)
+			else if (k == OP_MUL) gain_here = true;
+			else if (k != OP_SKIP) return ft;                         // (`add` is not linear in the state)
 		}
+		// an op that is a section on some channels and a gain on others has no slot form (the table loop below would come out an entry short
+		// for the pairs it is a gain for): such a chain keeps the separate kernels
+		if (section && gain_here) return ft;
 		if (section) sec_op.push_back(j);
 	}
 	const int slots = fused_section_slots((int) sec_op.size());
@@ -778,6 +782,7 @@ const CascadeStage::FuseTables &CascadeStage::fuse_tables()
 		gains.push_back(gain);
 	}
 	while ((int) sec_op.size() < slots) sec_op.push_back(-1);
+	if (sec.size() != (size_t) tables * slots * 6) return ft;         // (what the fused kernels index with sec_stride)
 	if (!ft.sec.upload(sec.data(), sec.size() * sizeof(double)) || !ft.sec_op.upload(sec_op.data(), sec_op.size() * sizeof(int))) return ft;
 	if (tables > 1 && !ft.gain_tab.upload(gains.data(), gains.size() * sizeof(double))) return ft;
 	ft.n_sec = slots;

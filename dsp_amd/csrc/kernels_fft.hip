@@ -263,35 +263,42 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 	if (tid < 64) tlo[twpad(tid)] = p.tw_nf[tid];
 	else if (tid < 64 + NF / 64) thi[tid - 64] = p.tw_nf[(tid - 64) * 64];
 	const bool active = pair < p.n_pairs;
-	const cplx *ring = p.ring + (active ? pair : 0) * p.ring_row_stride;
+	// Rows of at least 1024 points belong to whole waves (P >= 64): the pair is wave-uniform -- said to the compiler (readfirstlane), so that the
+	// stream, the channels and every base address derived from it live in scalar registers across the loop over the sub-blocks (as per-lane
+	// values they cost the 4096-point instance 6 spilled registers until round 6)
+	constexpr bool BUF = (P >= 64);
+	const long pair_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) ((active ? pair : 0) >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) (active ? pair : 0))) : 0;
+	const long pair_e = BUF ? pair_u : (active ? pair : 0);
+	const cplx *ring = p.ring + pair_e * p.ring_row_stride;
 	const TwRow<NF> tw{ t256, tlo, thi };
 	const RowMap map{ rw * Cfg::PITCH };
-	const long s = (active ? pair : 0) / p.pairs_per_stream;
-	const int qs = (int) ((active ? pair : 0) % p.pairs_per_stream);
+	// (a 64-bit division runs on the vector unit: its result is told to be uniform once more)
+	const long s_v = pair_e / p.pairs_per_stream;
+	const long s = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) (s_v >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) s_v)) : s_v;
+	const int qs = (int) (pair_e - s * p.pairs_per_stream);
 	const int cha = p.pair_out_ch ? p.pair_out_ch[2 * qs] : -1, chb = p.pair_out_ch ? p.pair_out_ch[2 * qs + 1] : -1;
-	double *out = p.out + (size_t) s * p.out_stride_frames * p.C;
-	const double *tail = p.tail ? p.tail + ((size_t) s * p.tail_stride_frames + p.tail_off) * p.C : nullptr;
+	// (64-bit products of uniform values still come out of the vector unit: the two base addresses are told to be uniform as well)
+	auto uni64 = [](long v) { return BUF ? (((long) __builtin_amdgcn_readfirstlane((int) (v >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) v)) : v; };
+	double *out = reinterpret_cast<double *>(uni64(reinterpret_cast<long>(p.out + (size_t) s * p.out_stride_frames * p.C)));
+	const double *tail = p.tail ? reinterpret_cast<const double *>(uni64(reinterpret_cast<long>(p.tail + ((size_t) s * p.tail_stride_frames + p.tail_off) * p.C))) : nullptr;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0) && (!tail || (((size_t) tail) & 15) == 0);
 	const size_t slot_stride = (size_t) p.n_pairs * NF;
-	// Rows of at least 1024 points belong to whole waves (P >= 64): the pair is wave-uniform and every array is addressed as
-	// SGPR base (buffer descriptor) + ONE per-lane offset register + a scalar offset per access.  With plain pointers the 16
-	// strided accesses per array (4 KB and more apart: beyond the instruction's immediate) each hold a 64-bit address pair:
-	// 87 scratch instructions at NF = 4096, two workgroups per CU.
-	constexpr bool BUF = (P >= 64);
+	// With whole-wave rows every array is addressed as SGPR base (buffer descriptor) + ONE per-lane offset register + a scalar offset per
+	// access.  With plain pointers the 16 strided accesses per array (4 KB and more apart: beyond the instruction's immediate) each hold a
+	// 64-bit address pair: 87 scratch instructions at NF = 4096, two workgroups per CU.
 	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-	const long pair_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) ((active ? pair : 0) >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) (active ? pair : 0))) : 0;
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
 	const __amdgpu_buffer_rsrc_t r_fdl = __builtin_amdgcn_make_buffer_rsrc(p.fdl + (BUF ? pair_u * NF : 0), 0, 0x7fffffff, RSRC_FLAGS);
 	// the pair's filter (wave-uniform where the descriptors are used: rows of whole waves)
-	const long h_off = (p.pair_h && active) ? (long) p.pair_h[pair] * p.P1 * NF : 0;
+	const long h_off = (p.pair_h && active) ? (long) p.pair_h[pair_e] * p.P1 * NF : 0;
 	const long h_off_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) (h_off >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) h_off)) : 0;
 	const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.Hf) + h_off_u, 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.ring) + (BUF ? pair_u * p.ring_row_stride : 0), 0, 0x7fffffff, RSRC_FLAGS);
 	// (32-bit byte offsets: the host only enters this regime when the delay line of a pair's slots and a ring row stay below 2 GB)
 	const int jb = j * 16;
-	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (BUF ? (size_t) (pair_u / p.pairs_per_stream) * p.out_stride_frames * p.C : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (BUF ? (size_t) s * p.out_stride_frames * p.C : 0), 0, 0x7fffffff, RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_tail = __builtin_amdgcn_make_buffer_rsrc(
-		const_cast<double *>(p.tail ? p.tail + ((BUF ? (size_t) (pair_u / p.pairs_per_stream) : 0) * p.tail_stride_frames + p.tail_off) * p.C : p.out), 0, 0x7fffffff, RSRC_FLAGS);
+		const_cast<double *>(p.tail ? p.tail + ((BUF ? (size_t) s : 0) * p.tail_stride_frames + p.tail_off) * p.C : p.out), 0, 0x7fffffff, RSRC_FLAGS);
 	const bool out_small = (double) p.out_stride_frames * p.C * 8 < 2.0e9 && (double) p.n_sub * B * p.C * 8 < 2.0e9;
 	const int vo_out = (j * p.C + cha) * 8;
 	__syncthreads();

@@ -190,29 +190,45 @@ __global__ __launch_bounds__(256) void resample_gemm_kernel(ResampleGemmParams p
 	const bool dither = p.sink.on && p.sink.dither_mult != 0.0;
 	double sink_peak = 0.0;
 	unsigned long long sink_clipped = 0;
+	// one 16 x 16 tile: C[row = (lane >> 4) + 4 reg][col = lane & 15]
+	auto store_tile = [&](int a, int b, const v4d tile, bool to_sink) {
+		const int r = 16 * (pt0 + b) + (lane & 15);             // position inside the block
+		if (pt0 + b >= ptiles || r >= p.NB) return;
 #pragma unroll
-	for (int a = 0; a < 2; ++a)
-#pragma unroll
-		for (int b = 0; b < PT; ++b) {
-			const int r = 16 * (pt0 + b) + (lane & 15);             // position inside the block
-			if (pt0 + b >= ptiles || r >= p.NB) continue;
-#pragma unroll
-			for (int reg = 0; reg < 4; ++reg) {
-				const int R = 16 * (2 * wr + a) + (lane >> 4) + 4 * reg;
-				const int il = R >> p.log2cp, c = R & (CP - 1);
-				const long m = (long) p.NB * (i0 + il) + r - p.out_delay - p.m_first;   // visible output frame of this call
-				if (c < p.C && m >= 0 && m < p.m_count) {
-					const long idx = (p.out_frame0 + m) * p.C + c;
-					if (p.sink.on) {
-						// (every sample finds its place in the dither sequences by itself: see resample_kernel)
-						const uint64_t nn = (uint64_t) (p.sink.samples_before + idx) + 1;
-						const double y = sink_sample(acc[a][b][reg], dither, dither ? pm_pow<0>(nn) : 0u, dither ? pm_pow<1>(nn) : 0u, p.sink.dither_mult, sink_peak, sink_clipped);
-						pcm_store(wout, p.sink.fmt, idx, y);
-					}
-					else out[idx] = acc[a][b][reg];
+		for (int reg = 0; reg < 4; ++reg) {
+			const int R = 16 * (2 * wr + a) + (lane >> 4) + 4 * reg;
+			const int il = R >> p.log2cp, c = R & (CP - 1);
+			const long m = (long) p.NB * (i0 + il) + r - p.out_delay - p.m_first;   // visible output frame of this call
+			if (c < p.C && m >= 0 && m < p.m_count) {
+				const long idx = (p.out_frame0 + m) * p.C + c;
+				if (to_sink) {
+					// (every sample finds its place in the dither sequences by itself: see resample_kernel)
+					const uint64_t nn = (uint64_t) (p.sink.samples_before + idx) + 1;
+					const double y = sink_sample(tile[reg], dither, dither ? pm_pow<0>(nn) : 0u, dither ? pm_pow<1>(nn) : 0u, p.sink.dither_mult, sink_peak, sink_clipped);
+					pcm_store(wout, p.sink.fmt, idx, y);
 				}
+				else out[idx] = tile[reg];
 			}
 		}
+	};
+	if (!p.sink.on) {
+#pragma unroll
+		for (int a = 0; a < 2; ++a)
+#pragma unroll
+			for (int b = 0; b < PT; ++b) store_tile(a, b, acc[a][b], false);
+	}
+	else {
+		// the sink's code (dither sequences, clipping, five wire formats) ONCE, in a loop over the tiles that picks its accumulator by a wave-uniform
+		// select: unrolled 2 x PT x 4 times it is too large for the unroller at PT = 6, which then left the loop over a / b rolled and the accumulators
+		// in scratch -- 416 bytes per lane until round 6
+#pragma unroll 1
+		for (int ab = 0; ab < 2 * PT; ++ab) {
+			v4d tile = acc[0][0];
+#pragma unroll
+			for (int k = 1; k < 2 * PT; ++k) if (ab == k) tile = acc[k / PT][k % PT];
+			store_tile(ab / PT, ab % PT, tile, true);
+		}
+	}
 	if (p.sink.on && p.sink.stats) sink_stats_block(p.sink.stats, s, sink_peak, sink_clipped);
 }
 

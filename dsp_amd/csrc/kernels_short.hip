@@ -85,7 +85,9 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 	lds_barrier();                                                       // tables visible
 	const TwRow<N> tw{ t256, tlo, thi };
 	const RowMap map{ 0 };
-	const long s = pair / p.pairs_per_stream, qs = pair % p.pairs_per_stream;
+	// (the division runs on the vector unit; its result is uniform all the same and is said to be: with a per-lane stream index the slab and output
+	// descriptors are per-lane values and every load through them becomes a loop over their distinct values -- 16 such loops per block until round 6)
+	const long s = __builtin_amdgcn_readfirstlane((int) (pair / p.pairs_per_stream)), qs = pair - s * p.pairs_per_stream;
 	const int fb = p.C * (int) sizeof(double);                          // bytes per fp64 output frame
 	const int fbi = p.C * BS;                                           // bytes per slab frame
 	const WordFormat wf_slab = word_format(p.slab_fmt);

@@ -16,6 +16,7 @@
 namespace dspamd {
 
 static std::once_flag g_dev_once;
+PluginCounters g_plugin_counters;
 
 static void select_device_once()
 {
@@ -105,6 +106,7 @@ static inline char *page_hi(const void *p, size_t n) { return (char *) (((uintpt
 void Segment::unpin_all()
 {
 	if (pins.empty()) return;
+	if (resident) resident->stop();          // (the device-wide wait would otherwise sit out the wave's lifetime)
 	(void) hipDeviceSynchronize();
 	for (const Pin &r : pins)
 		if (trace_mem("reg-", r.base, r.bytes), hipHostUnregister(r.base) != hipSuccess) {
@@ -125,6 +127,27 @@ void Segment::before_copy(const void *p, size_t n)
 	}
 }
 
+void Segment::unpin_role(int which)
+{
+	bool any = false;
+	for (const Pin &r : pins) if (r.roles & (1u << which)) any = true;
+	if (!any) return;
+	if (resident) resident->stop();
+	(void) hipDeviceSynchronize();
+	for (size_t i = 0; i < pins.size();) {
+		const Pin r = pins[i];
+		if (!(r.roles & (1u << which))) { ++i; continue; }
+		trace_mem("reg-", r.base, r.bytes);
+		if (hipHostUnregister(r.base) != hipSuccess) {
+			trace_mem("reg-failed", r.base, r.bytes);
+			log_msg(LL_VERBOSE, "info: host buffer %p could not be unregistered (%s)", (void *) r.base, hipGetErrorString(hipGetLastError()));
+		}
+		// (a range the other role shares is gone with it: that role counts its sightings again before it registers anything)
+		for (int o = 0; o < 2; ++o) if (o != which && (r.roles & (1u << o))) seen[o] = 0;
+		pins.erase(pins.begin() + i);
+	}
+}
+
 bool Segment::pinned(int which, const void *p, size_t n)
 {
 	// on by default since round 4 (DSP_AMD_PLUGIN_PIN=0: off).  Registering takes milliseconds once -- only blocks that do not fit the
@@ -137,19 +160,23 @@ bool Segment::pinned(int which, const void *p, size_t n)
 	if (p != last_ptr[which]) {
 		// the host hands over another buffer in this role: the one before may be gone (the reference frees its block buffers on
 		// REALLOC_BUFS while a crossfading chain still holds this segment, effects_chain.c:1241-1274) -- a registration must not outlive
-		// the memory it pins, so every range is dropped and the count starts again
-		if (last_ptr[which]) unpin_all();
+		// the memory it pins, so this ROLE's ranges are dropped and its count starts again (the other role's buffer has not changed: a host that
+		// rotates one buffer and keeps the other does not pay a device-wide wait and a re-registration of the one it keeps on every block)
+		if (last_ptr[which]) unpin_role(which);
 		last_ptr[which] = p; seen[which] = 1;
 		return false;
 	}
-	for (const Pin &r : pins) if (lo >= r.base && hi <= r.base + r.bytes) return true;
+	for (Pin &r : pins) if (lo >= r.base && hi <= r.base + r.bytes) { r.roles |= 1u << which; return true; }
 	if (++seen[which] < 4) return false;
 	// grow over every registration this range touches
+	if (resident) resident->stop();
 	(void) hipDeviceSynchronize();
+	unsigned roles = 1u << which;
 	for (size_t i = 0; i < pins.size();) {
 		const Pin r = pins[i];
 		if (lo <= r.base + r.bytes && hi >= r.base) {
 			lo = std::min(lo, r.base); hi = std::max(hi, r.base + r.bytes);
+			roles |= r.roles;
 			trace_mem("reg-", r.base, r.bytes);
 			if (hipHostUnregister(r.base) != hipSuccess) { trace_mem("reg-failed", r.base, r.bytes); (void) hipGetLastError(); }
 			pins.erase(pins.begin() + i);
@@ -162,7 +189,8 @@ bool Segment::pinned(int which, const void *p, size_t n)
 		pin_off = true;
 		return false;
 	}
-	pins.push_back(Pin{ lo, (size_t) (hi - lo) });
+	pins.push_back(Pin{ lo, (size_t) (hi - lo), roles });
+	g_plugin_counters.registrations.fetch_add(1, std::memory_order_relaxed);
 	trace_mem("reg+", lo, (size_t) (hi - lo));
 	log_msg(LL_VERBOSE, "info: host buffer %p (%zu KiB) registered for DMA", (void *) lo, (size_t) (hi - lo) >> 10);
 	return true;
@@ -219,12 +247,13 @@ bool Resident::launch()
 	__atomic_store_n(&ctl->alive, 1u, __ATOMIC_RELEASE);
 	rp.done0 = __atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE);
 	if (!launch_cascade_resident(rp, lds, st)) { (void) hipGetLastError(); __atomic_store_n(&ctl->alive, 0u, __ATOMIC_RELEASE); return false; }
+	g_plugin_counters.wave_launches.fetch_add(1, std::memory_order_relaxed);
 	return true;
 }
 
 bool Resident::serve(ssize_t frames)
 {
-	if (!ctl && !open()) { off = true; return false; }
+	if (!ctl && !open()) { off = true; g_plugin_counters.wave_off.fetch_add(1, std::memory_order_relaxed); return false; }
 	++seq;
 	__atomic_store_n(&ctl->req, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames, __ATOMIC_RELEASE);
 	const double t0 = res_now_us();
@@ -237,8 +266,14 @@ bool Resident::serve(ssize_t frames)
 	// not served in time: ask the wave to leave, wait for it (bounded by its own loop), and see whether it got the block done after all
 	stop();
 	if (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) == seq) return true;
-	off = true;
-	log_msg(LL_VERBOSE, "info: resident small-block path switched off for this segment (a block was not served in time)");
+	// this block goes through a launch (the wave is gone, the states are where it left them).  One late block -- the wave's first launch queued behind
+	// another chain's kernels on a busy device -- is not a reason to give the path up for good: the third one is
+	g_plugin_counters.wave_timeouts.fetch_add(1, std::memory_order_relaxed);
+	if (++timeouts >= 3) {
+		off = true;
+		g_plugin_counters.wave_off.fetch_add(1, std::memory_order_relaxed);
+		log_msg(LL_VERBOSE, "info: resident small-block path switched off for this segment (three blocks were not served in time)");
+	}
 	return false;
 }
 
@@ -294,14 +329,17 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 		if (sg.resident && sg.resident->takes(total) && sg.resident->serve(total)) {
 			// (one cascade, a block the resident wave finishes sooner than a launch: no launch at all)
 			memcpy(dst, sg.mapped.out, (size_t) total * sg.ch_out * sizeof(double));
+			g_plugin_counters.wave_blocks.fetch_add(1, std::memory_order_relaxed);
 			return dst;
 		}
+		g_plugin_counters.mapped_blocks.fetch_add(1, std::memory_order_relaxed);
 		const ssize_t f = sg.pipe->run(sg.mapped.in, total, sg.mapped.out, (ssize_t) (sg.mapped.bytes / (sg.ch_out * sizeof(double))), nullptr);
 		(void) sg.mapped.wait_block(nullptr);
 		if (f > 0) memcpy(dst, sg.mapped.out, (size_t) f * sg.ch_out * sizeof(double));
 		*frames = f < 0 ? 0 : f;
 		return dst;
 	}
+	g_plugin_counters.copied_blocks.fetch_add(1, std::memory_order_relaxed);
 	// larger blocks: the host's own buffers once they are registered for DMA (they are after coming back four times), until then -- and
 	// for buffers that never come back -- this library's page-locked staging buffers when the block is several pipeline calls long
 	const bool reg_in = sg.pinned(0, ibuf, in_bytes);

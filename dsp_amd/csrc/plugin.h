@@ -1,6 +1,7 @@
 // plugin.h -- the `struct effect` objects handed to a host through the reference's plugin ABI.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include "dsp_effect_abi.h"
 #include "effects.h"
@@ -26,6 +27,7 @@ struct Resident {
 	long max_work = 0;                       // frames x sections a block may have (beyond it the ordinary, parallel kernels are faster)
 	int sections = 1;
 	bool off = false;
+	int timeouts = 0;                        // blocks the wave did not serve in time (the third one switches the path off for the segment)
 	bool ready = false;                      // init() has accepted the segment; the doorbell and the stream come with the first small block (open())
 	bool init(class RemixStage *r, class CascadeStage *c, const MappedPair &mp);       // r: a plain remix in front of the cascade, or nullptr
 	bool takes(ssize_t frames) const { return !off && ready && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles; }
@@ -50,7 +52,7 @@ struct Segment {
 	PinnedStage staged;                      // page-locked staging for larger ones (engine.h)
 	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the
 	// HIP runtime after a few sightings: the copies then run as DMA instead of through the runtime's pageable-memory staging.
-	struct Pin { char *base; size_t bytes; };
+	struct Pin { char *base; size_t bytes; unsigned roles; };     // roles: bit 0 = the input buffer lies in it, bit 1 = the output buffer
 	std::vector<Pin> pins;
 	const void *last_ptr[2] = { nullptr, nullptr };
 	int seen[2] = { 0, 0 };
@@ -60,8 +62,21 @@ struct Segment {
 	bool pinned(int which, const void *p, size_t n);     // which: 0 = input, 1 = output buffer of run()
 	void before_copy(const void *p, size_t n);           // a range half inside a registration cannot be copied: drop all of them
 	void unpin_all();
+	void unpin_role(int which);                          // the registrations role `which` lies in (a range both roles share goes too: the other role starts counting again)
 	~Segment();
 };
+
+// How the plugin path served its blocks, process-wide (dspamd_plugin_counters, include/dsp_amd.h): what tests/test_gpu_resident.py asserts on
+struct PluginCounters {
+	std::atomic<long long> wave_blocks { 0 };        // blocks served by a resident wave (no launch)
+	std::atomic<long long> mapped_blocks { 0 };      // small blocks through the mapped staging buffers and a launch
+	std::atomic<long long> copied_blocks { 0 };      // larger blocks: copies (registered, staged or pageable) and launches
+	std::atomic<long long> wave_launches { 0 };      // resident kernels started
+	std::atomic<long long> wave_timeouts { 0 };      // blocks a wave did not serve in time (served by a launch instead)
+	std::atomic<long long> wave_off { 0 };           // segments whose resident path was switched off
+	std::atomic<long long> registrations { 0 };      // hipHostRegister calls that succeeded
+};
+extern PluginCounters g_plugin_counters;
 
 // what e->data points to for every effect this library creates
 struct Node {

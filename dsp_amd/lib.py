@@ -56,7 +56,7 @@ API_SYMBOLS = [
     "dspamd_batch_out_channels", "dspamd_batch_max_out_frames", "dspamd_batch_drain_frames", "dspamd_batch_run", "dspamd_batch_run_strided",
     "dspamd_batch_drain", "dspamd_batch_reset", "dspamd_batch_destroy", "dspamd_batch_plan", "dspamd_batch_n_stages",
     "dspamd_sgen_sine", "dspamd_sgen_sweep", "dspamd_sgen_delta", "dspamd_digest", "dspamd_copy_probe", "dspamd_pcm_sample_bytes", "dspamd_pcm_read", "dspamd_pcm_write", "dspamd_profile_enable", "dspamd_profile_collect",
-    "dspamd_batch_run_wire", "dspamd_batch_drain_wire", "dspamd_batch_wire_fused",
+    "dspamd_batch_run_wire", "dspamd_batch_drain_wire", "dspamd_batch_wire_fused", "dspamd_plugin_counters",
 ]
 
 
@@ -113,6 +113,7 @@ def load_library():
         "dspamd_sgen_delta": (i, [vp, i, ssize_t, i, ssize_t, ssize_t, ssize_t, vp]),
         "dspamd_digest": (i, [vp, i, ssize_t, ssize_t, i, vp, vp]),
         "dspamd_copy_probe": (i, [vp, vp, C.c_size_t, vp]),
+        "dspamd_plugin_counters": (i, [C.POINTER(C.c_longlong), i]),
         "dspamd_pcm_sample_bytes": (C.c_size_t, [i]),
         "dspamd_pcm_read": (i, [i, vp, vp, ssize_t, vp]),
         "dspamd_pcm_write": (i, [i, vp, ssize_t, vp, i, ssize_t, i, i, ssize_t, vp, vp]),
@@ -132,6 +133,16 @@ def load_library():
         f.argtypes = init_sig
     _LIB = L
     return L
+
+
+PLUGIN_COUNTERS = ("wave_blocks", "mapped_blocks", "copied_blocks", "wave_launches", "wave_timeouts", "wave_off", "registrations")
+
+
+def plugin_counters():
+    """how the plugin path has served its blocks in this process (dspamd_plugin_counters, include/dsp_amd.h)"""
+    buf = (C.c_longlong * len(PLUGIN_COUNTERS))()
+    n = load_library().dspamd_plugin_counters(buf, len(PLUGIN_COUNTERS))
+    return {k: int(buf[j]) for j, k in enumerate(PLUGIN_COUNTERS[:n])}
 
 
 def last_error():

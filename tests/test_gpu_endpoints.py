@@ -430,3 +430,35 @@ def test_bench_launches_its_own_ranks():
         r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         assert r.returncode != 0 and "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
+
+
+@pytest.mark.gpu
+def test_bench_as_a_scale_run_launches_it_eight_ranks_at_the_headline():
+    """The exact configuration a SCALE run launches at N = 8: `python bench.py --gpus 8` on the headline workload, here as eight
+    ranks sharing the one GPU over gloo, two steps.  One line, n_gpus == 8, eight disjoint contiguous 32-stream ranges, one communicator of eight,
+    and rank 0's plan is the fused one at a per-rank shape (32 streams: 960 chunks of 1024 frames)."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("eight ranks of the headline shape on one device need about 110 GB")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DSP_AMD_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["output_finite"] and d["scaling"] == "strong"
+    assert d["config"]["streams"] == 256 and d["config"]["block_frames"] == 983040 and d["config"]["taps"] == 65536
+    assert d["config"]["ranks"] == [{"rank": k, "streams": [32 * k, 32 * k + 32]} for k in range(8)]
+    assert d["config"]["communicator"]["ranks"] == 8 and d["config"]["communicator"]["backend"] == "gloo"
+    assert "cascade-fused(960 chunks of 1024)" in d["config"]["plan"], d["config"]["plan"]
+    assert "fused_col_fwd" in d["roofline"]["kernels"]
+    assert d["digest"]["streams"] == 256
+    # whole-job samples over the max-over-ranks time
+    assert abs(d["value"] - 256 * 8 * 983040 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]

@@ -53,8 +53,26 @@ def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
     x = rng.uniform(-0.5, 0.5, size=(200000 if blocks == (64,) else 40000, C))
     x[100:110] = 0.0                                                     # (and some exact zeros of both signs: gains keep the sign of zero)
     x[105] = -0.0
+    from dsp_amd.lib import plugin_counters
+    c0 = plugin_counters()
     got = stream(chain, C, x, blocks, "_gpu", pause)
+    c1 = plugin_counters()
     ref = stream(chain, C, x, blocks, "")
+    # the wave really served every block it is meant for (a dead wave falls back to launches and gives the same samples: outputs alone prove nothing)
+    n_blocks, small, pos, k = 0, 0, 0, 0
+    while pos < x.shape[0]:
+        n = min(blocks[k % len(blocks)], x.shape[0] - pos)
+        small += n <= 128
+        n_blocks += 1
+        pos += n
+        k += 1
+    d = {key: c1[key] - c0[key] for key in c1}
+    assert d["wave_blocks"] == small, (d, small, n_blocks)
+    assert d["wave_timeouts"] == 0 and d["wave_off"] == 0, d
+    assert d["wave_blocks"] + d["mapped_blocks"] + d["copied_blocks"] == n_blocks, (d, n_blocks)
+    assert 1 <= d["wave_launches"] <= small, d
+    if pause:
+        assert d["wave_launches"] >= 1 + len(pause), d           # (every pause outlasts the wave: the block behind it started another one)
     assert got.shape == ref.shape
     assert got.shape[1] == (3 if chain.startswith("remix 0,1") else 4 if chain.startswith("remix") else C)
     if "eq" not in chain and "pass" not in chain:
