@@ -870,7 +870,7 @@ void ConvStage::convolve_short(long q_lo, long q_hi, long k_origin, long out_cou
 	p.ring = ring_dev; p.ring_row_stride = ring_stride; p.ring_mask = ring_len - 1;
 	p.q0 = q_lo; p.lat = lat; p.n_in = q_hi - q_lo + 1;
 	p.slab_fmt = PCM_DOUBLE;
-	if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_q0 = cur_q0; p.file_from = cur_q0 + cur_frames - first_n; p.slab_fmt = wire_in_fmt; }
+	if (cur_slab) { p.slab = cur_slab; p.slab_stride_frames = cur_slab_stride; p.slab_frames = cur_frames; p.slab_q0 = cur_q0; p.file_from = cur_q0 + cur_frames - first_n; p.slab_fmt = wire_in_fmt; }
 	p.sink = wire_sink;
 	p.C = ch_in; p.pairs_per_stream = pps;
 	p.pair_out_ch = pair_out_ch.as<int>(); p.pair_h = pair_h.as<int>();

@@ -97,62 +97,29 @@ Profiler::~Profiler()
 }
 
 static const size_t CANARY = 4096, DEVBUF_SLACK = (size_t) 64 << 10;     // (64 KB: one 4096-point row of a transform)
+// DSP_AMD_GUARD (debugging, read once): 3 = a page of a pattern on both sides of every device buffer, looked at when the buffer goes (writes outside a
+// buffer, found where they land); 5 = every buffer that is not asked to be zero, and the slack behind every buffer, filled with 0xFF bytes (a NaN in every
+// double and float): a kernel that USES memory nobody has written -- or what lies behind a buffer -- shows up as a NaN in a parity test, whatever the
+// allocator happened to leave there.  (Modes 1 / 2 / 4 of round 5, buffers in hipMemCreate mappings of their own, are gone: memory mapped that way gave
+// wrong values in large-buffer tests whatever the placement, so they said nothing about over-reads.)
 static int guard_mode() { static const int m = [] { const char *e = getenv("DSP_AMD_GUARD"); return e ? atoi(e) : 0; }(); return m; }
-
-static bool guarded_alloc(DevBuf &b, size_t n)
-{
-	int dev = 0;
-	(void) hipGetDevice(&dev);
-	hipMemAllocationProp prop;
-	memset(&prop, 0, sizeof(prop));
-	prop.type = hipMemAllocationTypePinned;
-	prop.location.type = hipMemLocationTypeDevice;
-	prop.location.id = dev;
-	size_t gran = 0;
-	if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return false;
-	const size_t slack = guard_mode() == 4 ? ((size_t) 64 << 10) : 0;        // (mode 4: the same kind of memory with room behind the buffer -- tells an overrun from the mapping itself)
-	const size_t map = (n + slack + gran - 1) / gran * gran;
-	void *base = nullptr;
-	if (hipMemAddressReserve(&base, map + 2 * gran, gran, nullptr, 0) != hipSuccess) return false;
-	hipMemGenericAllocationHandle_t h;
-	if (hipMemCreate(&h, map, &prop, 0) != hipSuccess) { (void) hipMemAddressFree(base, map + 2 * gran); return false; }
-	char *at = static_cast<char *>(base) + gran;
-	hipMemAccessDesc acc;
-	memset(&acc, 0, sizeof(acc));
-	acc.location = prop.location;
-	acc.flags = hipMemAccessFlagsProtReadWrite;
-	if (hipMemMap(at, map, 0, h, 0) != hipSuccess) { (void) hipMemRelease(h); (void) hipMemAddressFree(base, map + 2 * gran); return false; }
-	if (hipMemSetAccess(at, map, &acc, 1) != hipSuccess) { (void) hipMemUnmap(at, map); (void) hipMemRelease(h); (void) hipMemAddressFree(base, map + 2 * gran); return false; }
-	b.vm_base = base; b.vm_size = map + 2 * gran; b.vm_map = map; b.vm_gran = gran; b.vm_handle = (void *) h;
-	b.p = guard_mode() == 2 ? at : at + (map - (n + 255) / 256 * 256);     // (hipMalloc's alignment, which the kernels rely on: 256 bytes)
-	return true;
-}
 
 bool DevBuf::alloc(size_t n, bool zero)
 {
 	release();
 	if (n == 0) n = 16;
 	if (guard_mode() == 3) {
-		// canaries: a page of a pattern on both sides, looked at when the buffer goes (writes beyond the buffer, found where they land)
 		char *base = nullptr;
 		if (hipMalloc((void **) &base, n + 2 * CANARY) == hipSuccess && hipMemset(base, 0xA5, n + 2 * CANARY) == hipSuccess) {
 			p = base + CANARY; canary = true; site = __builtin_return_address(0);
 		}
 		else (void) hipGetLastError();
 	}
-	else if (guard_mode()) {
-		if (!guarded_alloc(*this, n)) {
-			(void) hipGetLastError();
-			static bool said = false;
-			if (!said) { said = true; fprintf(stderr, "dsp_amd: DSP_AMD_GUARD: the virtual-memory calls failed, plain hipMalloc from here on\n"); }
-		}
-	}
-	// (64 KB of slack behind every buffer, as a defence: no kernel is known to read past the end of one -- DSP_AMD_GUARD=3 finds no write outside
-	// any buffer in the whole GPU suite -- but a vector load that did would fault or not depending on what the allocator has put next to the buffer,
-	// which is how the round-5 fault behaves: DESIGN.md section 5)
+	// (64 KB of slack behind every buffer, as a defence: DESIGN.md section 5)
 	if (!p && !hip_ok(hipMalloc(&p, n + DEVBUF_SLACK), "hipMalloc")) { p = nullptr; return false; }
 	bytes = n;
 	trace_mem("dev+", p, n);
+	if (guard_mode() == 5 && !canary && !hip_ok(hipMemset(p, 0xFF, n + DEVBUF_SLACK), "hipMemset")) return false;
 	if (zero && !hip_ok(hipMemset(p, 0, n), "hipMemset")) return false;
 	return true;
 }
@@ -357,15 +324,7 @@ bool DevBuf::upload(const void *src, size_t n)
 
 void DevBuf::release()
 {
-	if (p && vm_base) {
-		trace_mem("dev-", p, bytes);
-		(void) hipDeviceSynchronize();
-		(void) hipMemUnmap(static_cast<char *>(vm_base) + vm_gran, vm_map);
-		(void) hipMemRelease((hipMemGenericAllocationHandle_t) vm_handle);
-		(void) hipMemAddressFree(vm_base, vm_size);
-		vm_base = nullptr; vm_handle = nullptr; vm_size = vm_map = vm_gran = 0;
-	}
-	else if (p && canary) {
+	if (p && canary) {
 		std::vector<unsigned char> h(bytes + 2 * CANARY);
 		char *base = static_cast<char *>(p) - CANARY;
 		if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), base, h.size(), hipMemcpyDeviceToHost) == hipSuccess) {

@@ -20,11 +20,6 @@ void trace_mem(const char *what, const void *p, size_t n);      // DSP_AMD_TRACE
 struct DevBuf {
 	void *p = nullptr;
 	size_t bytes = 0;
-	// DSP_AMD_GUARD=1|2 (a debugging switch, engine.cpp): every buffer in a reservation of its own with unmapped pages on both sides, its end (1) or its
-	// start (2) on a page boundary -- an access one element beyond it faults in the kernel that makes it instead of landing in whatever lies next to it
-	void *vm_base = nullptr;
-	size_t vm_size = 0, vm_map = 0, vm_gran = 0;
-	void *vm_handle = nullptr;
 	bool canary = false;                        // DSP_AMD_GUARD=3: a page of a pattern on both sides, checked when the buffer is released
 	const void *site = nullptr;
 	DevBuf() = default;

@@ -160,6 +160,7 @@ struct ShortParams {
 	long q0, lat, n_in;                 // first input index of block 0, the stage's latency, input indices covered (blocks of hop frames, the last one shorter)
 	const double *slab;                 // direct mode: [S][slab_stride_frames][C], frame 0 = input index slab_q0; nullptr = everything from the rings
 	long slab_stride_frames, slab_q0, file_from;   // slab frames with input index >= file_from are filed in the ring on the way (the history later calls look back at)
+	long slab_frames;                   // frames of the current call in every stream's slab (what the slab descriptor lets the kernel read)
 	int slab_fmt;                       // PCM_DOUBLE, or the fusable wire format the slab holds (first kernel of a pipeline run in wire formats; the rings keep fp64)
 	WireSink sink;                      // last kernel of such a pipeline: `out` holds samples of sink.fmt (dither, clip, conversion in the stores)
 	int C, pairs_per_stream;

@@ -92,9 +92,10 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 	const int fbi = p.C * BS;                                           // bytes per slab frame
 	const WordFormat wf_slab = word_format(p.slab_fmt);
 	const int mask = (int) p.ring_mask, omask = (int) p.ring_out_mask;
-	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(p.ring) + pair * p.ring_row_stride, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(p.ring) + pair * p.ring_row_stride, 0, rsrc_records((p.ring_mask + 1) * 16), 0x00020000);
 	// direct mode: the pair's two channels of a slab frame are 16 contiguous bytes (channels 2 qs, 2 qs + 1: the host checked)
-	const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.slab ? reinterpret_cast<const char *>(p.slab) + ((size_t) s * p.slab_stride_frames * p.C + 2 * qs) * BS : nullptr), 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.slab ? reinterpret_cast<const char *>(p.slab) + ((size_t) s * p.slab_stride_frames * p.C + 2 * qs) * BS : nullptr), 0,
+		p.slab ? rsrc_records((p.slab_frames * p.C - 2 * qs) * BS) : 0, 0x00020000);
 	auto slab_ld = [&](int vo) -> cplx {
 		if constexpr (BS == 8) return buf_ldc(r_slab, vo, 0);
 		else if constexpr (BS == 4) { const sh_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r_slab, vo, 0, 0); return mkc(pcm_from_word(w.x, wf_slab), pcm_from_word(w.y, wf_slab)); }
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 	const int cha = p.pair_out_ch[2 * qs], chb = p.pair_out_ch[2 * qs + 1];
 	double *out = p.out ? p.out + (size_t) s * p.out_stride_frames * p.C : nullptr;
 	const bool wide = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) out) & 15) == 0);
-	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, 0x7fffffff, 0x00020000);
-	const __amdgpu_buffer_rsrc_t r_rout = __builtin_amdgcn_make_buffer_rsrc(p.ring_out ? p.ring_out + pair * p.ring_out_stride : nullptr, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (out && !p.sink.on) ? rsrc_records(p.out_count * p.C * (long) sizeof(double)) : 0, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_rout = __builtin_amdgcn_make_buffer_rsrc(p.ring_out ? p.ring_out + pair * p.ring_out_stride : nullptr, 0, p.ring_out ? rsrc_records((p.ring_out_mask + 1) * 16) : 0, 0x00020000);
 	const int first_n = (int) p.first_n;
 	for (long b = b0; b < b1; ++b) {
 		const long q_blk = p.q0 + b * p.hop;

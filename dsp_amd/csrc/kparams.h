@@ -27,6 +27,12 @@ struct WireSink {
 	double *stats;             // optional [S][2]: clipped samples (as a 64-bit count), peak |sample|
 };
 
+// num_records of a raw buffer descriptor (__builtin_amdgcn_make_buffer_rsrc): the bytes a kernel is MEANT to touch from the descriptor's base.  Beyond
+// them the hardware answers a load with zeros and drops a store -- an access outside the buffer becomes a wrong VALUE a parity test sees, not a read of
+// whatever the allocator put next to the buffer (or of nothing: a memory fault that depends on the allocator's mood).  Until round 6 every descriptor
+// said 0x7fffffff: the check was switched off.  Descriptors address at most 2 GB (32-bit offsets: the host keeps rings, slabs and outputs below that).
+constexpr int rsrc_records(long bytes) { return bytes <= 0 ? 0 : (bytes > 0x7fffffffL ? 0x7fffffff : (int) bytes); }
+
 // ---- cascade (gain / add / biquad sections fused into one pass) ----
 
 enum : int { OP_MUL = 0, OP_ADD = 1, OP_BIQUAD = 2, OP_SKIP = 3 };
