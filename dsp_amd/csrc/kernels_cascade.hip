@@ -811,11 +811,13 @@ void cascade_rows(CascadeParams p, const double *__restrict__ frows, const doubl
 	const bool sink_on = WOUT;
 	const WordFormat wf_in = word_format(in_fmt), wf_out = word_format(out_fmt);
 	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
-		const_cast<char *>(reinterpret_cast<const char *>(p.in) + ((size_t) s * p.in_stride_frames * p.C + c0) * in_bs), 0, 0x7fffffff, RSRC_FLAGS);
+		const_cast<char *>(reinterpret_cast<const char *>(p.in) + ((size_t) s * p.in_stride_frames * p.C + c0) * in_bs), 0, rsrc_records(((long) p.frames * p.C - c0) * in_bs), RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-		reinterpret_cast<char *>(p.out) + ((size_t) s * p.out_stride_frames * p.C + c0) * out_bs, 0, 0x7fffffff, RSRC_FLAGS);
+		reinterpret_cast<char *>(p.out) + ((size_t) s * p.out_stride_frames * p.C + c0) * out_bs, 0, rsrc_records(((long) p.frames * p.C - c0) * out_bs), RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(
-		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) + ((G == 1) ? (c0 & 1) : 0) : p.out, 0, 0x7fffffff, RSRC_FLAGS);
+		p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c0 >> 1)) * p.ring.row_stride) + ((G == 1) ? (c0 & 1) : 0) : p.out, 0,
+		// (G = 4: the rows of the group's two pairs; G = 2: one row; G = 1: one channel's half of the row's elements)
+		p.ring.base ? rsrc_records(((G == 4) ? p.ring.row_stride : 0) * 16 + (p.ring.mask + 1) * 16 - ((G == 1) ? (c0 & 1) * 8 : 0)) : 0, RSRC_FLAGS);
 	const bool has_ring = p.ring.base != nullptr;
 	const int ring_row_bytes = (int) (p.ring.row_stride * 16);
 	// slab order: slot k of a lane = (frame f0 + FPS k, pair pr).  G = 4: 64 lanes cover 32 frames x 2 pairs (32 contiguous

@@ -288,17 +288,18 @@ __global__ __launch_bounds__(NT, 2) void conv_fdl(FdlParams p)
 	// 64-bit address pair: 87 scratch instructions at NF = 4096, two workgroups per CU.
 	typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 	constexpr int RSRC_FLAGS = 0x00020000;                      // raw buffer, 32-bit offsets
-	const __amdgpu_buffer_rsrc_t r_fdl = __builtin_amdgcn_make_buffer_rsrc(p.fdl + (BUF ? pair_u * NF : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	// (num_records: what the kernel is meant to touch from each base -- kparams.h rsrc_records; beyond it a load gives zeros, a store is dropped)
+	const __amdgpu_buffer_rsrc_t r_fdl = __builtin_amdgcn_make_buffer_rsrc(p.fdl + (BUF ? pair_u * NF : 0), 0, rsrc_records((((long) p.P1 - 1) * p.n_pairs + 1) * NF * 16), RSRC_FLAGS);
 	// the pair's filter (wave-uniform where the descriptors are used: rows of whole waves)
 	const long h_off = (p.pair_h && active) ? (long) p.pair_h[pair_e] * p.P1 * NF : 0;
 	const long h_off_u = BUF ? (((long) __builtin_amdgcn_readfirstlane((int) (h_off >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) h_off)) : 0;
-	const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.Hf) + h_off_u, 0, 0x7fffffff, RSRC_FLAGS);
-	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.ring) + (BUF ? pair_u * p.ring_row_stride : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_H = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.Hf) + h_off_u, 0, rsrc_records((long) p.P1 * NF * 16), RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_ring = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(p.ring) + (BUF ? pair_u * p.ring_row_stride : 0), 0, rsrc_records((p.ring_mask + 1) * 16), RSRC_FLAGS);
 	// (32-bit byte offsets: the host only enters this regime when the delay line of a pair's slots and a ring row stay below 2 GB)
 	const int jb = j * 16;
-	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (BUF ? (size_t) s * p.out_stride_frames * p.C : 0), 0, 0x7fffffff, RSRC_FLAGS);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out + (BUF ? (size_t) s * p.out_stride_frames * p.C : 0), 0, rsrc_records((long) p.n_sub * B * p.C * 8), RSRC_FLAGS);
 	const __amdgpu_buffer_rsrc_t r_tail = __builtin_amdgcn_make_buffer_rsrc(
-		const_cast<double *>(p.tail ? p.tail + ((BUF ? (size_t) s : 0) * p.tail_stride_frames + p.tail_off) * p.C : p.out), 0, 0x7fffffff, RSRC_FLAGS);
+		const_cast<double *>(p.tail ? p.tail + ((BUF ? (size_t) s : 0) * p.tail_stride_frames + p.tail_off) * p.C : p.out), 0, p.tail ? rsrc_records((long) p.n_sub * B * p.C * 8) : 0, RSRC_FLAGS);
 	const bool out_small = (double) p.out_stride_frames * p.C * 8 < 2.0e9 && (double) p.n_sub * B * p.C * 8 < 2.0e9;
 	const int vo_out = (j * p.C + cha) * 8;
 	__syncthreads();

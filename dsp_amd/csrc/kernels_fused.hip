@@ -131,7 +131,7 @@ void fused_prepass(FuseParams f, const double *__restrict__ sec_all, long N2, in
 	const long row = c / f.seg;
 	const int sg = (int) (c - row * f.seg);
 	const long frame0 = row * N2 + (long) sg * f.len;
-	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(f.in) + (size_t) s * f.in_stride_frames * f.C, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(f.in) + (size_t) s * f.in_stride_frames * f.C, 0, rsrc_records(f.K * f.len * f.C * (long) sizeof(double)), 0x00020000);   // (the call's frames: K chunks of len)
 	const int fb = f.C * (int) sizeof(double);                      // bytes per frame
 	int vo = (int) ((frame0 * f.C + 2 * q) * (long) sizeof(double));
 	double2 m0[NSEC], m1[NSEC];
@@ -389,7 +389,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec_al
 	constexpr int bs = BS;
 	const WordFormat wf = word_format(f.in_fmt);
 	const int fb = f.C * bs;
-	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(f.in)) + (size_t) s * f.in_stride_frames * f.C * bs, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(f.in)) + (size_t) s * f.in_stride_frames * f.C * bs, 0, rsrc_records(f.K * f.len * f.C * (long) bs), 0x00020000);   // (the call's frames: K chunks of len)
 	const int vs = (int) ((((long) lj * N2 + lt) * f.C + 4 * grp + 2 * lq) * (long) bs);
 	const int hr = HR > 0 ? HR : f.hist_rows;        // (a constant in the HR > 0 instances)
 	const int vs0 = vs - (int) (hr * N2 * fb);       // row lj itself (looked at when hr <= lj: hr < 32)
@@ -407,7 +407,7 @@ void fused_col_fwd(ConvParams p, FuseParams f, const double *__restrict__ sec_al
 	};
 	const bool hist_row = lj < hr;                   // row lj (m = 0) is history: the pair rings (wave-uniform when hr is a multiple of 4)
 	// W of the group's two pairs through one descriptor
-	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, 0x7fffffff, 0x00020000);
+	const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(WBUF(p.W) + (pair0 - p.pair0) * p.w_stride, 0, rsrc_records((p.w_stride + p.N) * (long) sizeof(cplx)), 0x00020000);   // (the group's two pairs)
 	const int vw = (int) (((long) q * p.w_stride + (long) j * N2 + t) * (long) sizeof(cplx));
 	const int w_step = (int) (32 * N2 * (long) sizeof(cplx));
 	const double2 *ring0 = p.ring + pair0 * p.ring_row_stride;

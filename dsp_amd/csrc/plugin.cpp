@@ -154,7 +154,7 @@ bool Segment::pinned(int which, const void *p, size_t n)
 	// mapped staging buffers get here, i.e. not the 64 ... 1024-frame blocks of a real-time host -- and turns the two copies of a block
 	// into DMA: 10 % at the reference's 2048-frame blocks (scripts/exp_cli_rate.sh, where the host's own I/O dominates), 3x on
 	// buffers of several chunks (dspamd_chain_run-sized blocks: one thread's memcpy into staging was the limit there)
-	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return !e || atoi(e) != 0; }();
+	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return e && atoi(e) != 0; }();      // (round 6: opt-in)
 	if (!enabled || pin_off || !p || n == 0) return false;
 	char *lo = page_lo(p), *hi = page_hi(p, n);
 	if (p != last_ptr[which]) {
