@@ -246,7 +246,7 @@ ConvParams ConvStage::base_params() const
 	p.ring_out_round_f32 = feed_round;
 	// non-temporal hints: K1's ring loads and W stores (data touched once per launch): 5.95 -> 5.55 ms at the headline shape; on
 	// K2 and K3 they measured nothing (scripts/exp_nt.sh)
-	{ static const char *e = getenv("DSP_AMD_CONV_NT"); p.nt = e ? atoi(e) : 3; }
+	p.nt = 3;      // (non-temporal K1 ring loads and W stores: docs/history.md section 4.2)
 	return p;
 }
 
@@ -378,7 +378,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		ring_dev = ring_parent->ring_dev;
 	}
 	else {
-		{ static const long pad = [] { const char *e = getenv("DSP_AMD_CONV_RPAD"); return e ? atol(e) : 272L; }(); ring_stride = ring_len + pad; }
+		ring_stride = ring_len + 272;       // (4352 bytes: pair rows off power-of-two distances, profiles/r02_tcc_padding.json)
 		if (!ring.alloc((size_t) S * pps * ring_stride * sizeof(double2))) return false;
 		ring_dev = ring.as<double2>();
 	}
@@ -432,7 +432,7 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	}
 
 	pairs_per_chunk = (long) S * pps;
-	{ static const long pad = [] { const char *e = getenv("DSP_AMD_CONV_WPAD"); return e ? atol(e) : 272L; }(); w_stride = N + pad; }
+	w_stride = N + 272;                     // (the same padding between the pairs of W)
 	// (at least one fp64 row set: the filter spectra of a float32 stage are computed by the fp64 kernels in this buffer)
 	if (!W.alloc(std::max((size_t) nph * pairs_per_chunk * w_stride * elem(), (size_t) nph * w_stride * sizeof(double2)), false)) return false;
 	if (!H.alloc((size_t) (upc_P ? (size_t) upc_P * n_filters : (size_t) n_filters * nph) * N * elem(), false)) return false;
@@ -523,8 +523,6 @@ bool ConvStage::fuse_accepts(const void *in, long in_stride, ssize_t frames, int
 	else {
 		// a wire format (the cascade is the first stage of a pipeline run from format to format): read by the matrix-core prepass and by the first
 		// pass themselves -- 8 channels, naturally aligned pairs
-		const char *me = getenv("DSP_AMD_FUSE_MM");
-		if (me && atoi(me) == 0) return false;
 		if (!(wire_fusion_on() && pcm_fusable(in_fmt) && ch_in == 8 && feeder_->fuse_tables().n_real <= 16 && feeder_->fuse_tables().pairs == 1 && (((size_t) in) & 7) == 0)) return false;
 	}
 	// everything run_fused() will need exists before the answer is yes (the chunk plan's state buffers scale with S K C D; a plan is built
@@ -592,9 +590,8 @@ bool ConvStage::fused_first_pass(const ConvParams &p, ssize_t frames, hipStream_
 	f.n_streams = S;
 	{
 		// the chunks' end states from zero state: as a product on the matrix cores where the shape allows (8 channels), else by the recurrence
-		const char *me = getenv("DSP_AMD_FUSE_MM");
 		ProfScope ps("fused_prepass", st);
-		if ((me && atoi(me) == 0) || !feeder_->fuse_gtable(*plan) || !launch_fused_prepass_mm(f, plan->G.as<double>(), N2, plan->g_states, st)) {
+		if (!feeder_->fuse_gtable(*plan) || !launch_fused_prepass_mm(f, plan->G.as<double>(), N2, plan->g_states, st)) {
 			if (f.in_fmt != PCM_DOUBLE || !launch_fused_prepass(f, ft.sec.as<double>(), N2, pps, st)) return false;       // (fuse_accepts lets a wire format through only where the matrix-core form serves it)
 		}
 		else ps.rename("fused_prepass_mm");
@@ -812,7 +809,6 @@ bool ConvStage::spectrum_of(const std::vector<double> &src, long n_taps, int str
 	}
 	if (!hip_ok(hipMemcpy(tring.p, taps.data(), (size_t) N * sizeof(double2), hipMemcpyHostToDevice), "H2D taps")) return false;
 	ConvParams p = base_params();
-	p.no_split = (f32 || upc_P) ? 1 : 0;       // (the delay-line form runs the generic row kernel: its spectrum order)
 	p.f32 = 0;                                   // always the fp64 kernels and tables (a float32 stage rounds the result: spectrum_f32)
 	p.tw_n1 = tw_n1.as<double2>(); p.tw_n2 = tw_n2.as<double2>(); p.tw_col = tw_col.as<double2>();
 	p.ring = tring.as<double2>();

@@ -41,14 +41,18 @@ void grant_dynamic_lds(const void *kernel, size_t bytes)
 	else (void) hipGetLastError();   // the launch itself will report the failure
 }
 
-// DSP_AMD_TRACE_MEM=<file>: one line per device / page-locked allocation, release and host-buffer registration of this library (what, address, bytes,
-// microseconds) -- the map a GPU memory fault's address is looked up in (scripts/r05_hunt_suite.sh); off and free of cost otherwise
+// A build with -DDSP_AMD_TRACE_MEM (make TRACE_MEM=1): DSP_AMD_TRACE_MEM=<file> gets one line per device / page-locked allocation and release of this
+// library (what, address, bytes, microseconds) -- the map a GPU memory fault's address is looked up in.  Not in the product build.
 void trace_mem(const char *what, const void *p, size_t n)
 {
+#ifndef DSP_AMD_TRACE_MEM
+	(void) what; (void) p; (void) n;
+#else
 	static FILE *f = [] { const char *e = getenv("DSP_AMD_TRACE_MEM"); FILE *h = (e && *e) ? fopen(e, "a") : nullptr; if (h) setvbuf(h, nullptr, _IOLBF, 0); return h; }();
 	if (!f) return;
 	timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 	fprintf(f, "%s %p %zu %lld pid %d\n", what, p, n, (long long) t.tv_sec * 1000000 + t.tv_nsec / 1000, (int) getpid());
+#endif
 }
 
 int device_count()
@@ -134,8 +138,7 @@ void MappedPair::alloc()
 		in = static_cast<double *>(a); out = static_cast<double *>(b); bytes = (size_t) kb << 10;
 		trace_mem("map+", a, bytes); trace_mem("map+", b, bytes);
 		void *f = nullptr;
-		static const bool spin = !getenv("DSP_AMD_PLUGIN_NO_SPIN");
-		if (spin && hipHostMalloc(&f, 64, hipHostMallocDefault) == hipSuccess) { flag = static_cast<volatile unsigned *>(f); *flag = 0; }
+		if (hipHostMalloc(&f, 64, hipHostMallocDefault) == hipSuccess) { flag = static_cast<volatile unsigned *>(f); *flag = 0; }
 		else (void) hipGetLastError();
 		return;
 	}
@@ -205,9 +208,8 @@ struct CopyCrew {
 	}
 	bool start()
 	{
-		static const bool enabled = [] { const char *e = getenv("DSP_AMD_COPY_CREW"); return !e || atoi(e) != 0; }();
 		cpu_set_t set;
-		if (!enabled || sched_getaffinity(0, sizeof set, &set) != 0 || CPU_COUNT(&set) < HELPERS + 1) { state = -1; return false; }
+		if (sched_getaffinity(0, sizeof set, &set) != 0 || CPU_COUNT(&set) < HELPERS + 1) { state = -1; return false; }
 		try {
 			for (int i = 0; i < HELPERS; ++i) std::thread([this] { helper(); }).detach();
 		} catch (...) { state = -1; return false; }      // (helpers already started stay asleep: gen never moves)
@@ -439,7 +441,7 @@ bool CascadeStage::finalize()
 	// gains.  A gain in front of a section is folded into that section's b coefficients (same states, the product rounds
 	// differently in the last bit -- the sections are not bit-exact anyway), gains behind the last section become one factor
 	// applied to the finished tile ([1] of the last op's entry); `add`, unselected channels and chains without any section
-	// stay with cascade_wave / cascade_fast (a pure gain chain must remain bit-exact).
+	// stay with cascade_fast (a pure gain chain must remain bit-exact).
 	rows4_ok = false;
 	if (ch_in % 2 == 0) {
 		bool uniform = true, any_biquad = false, quad = (ch_in % 4 == 0);
@@ -504,7 +506,7 @@ std::string CascadeStage::describe() const
 }
 
 // K chunks of len frames each, or false: not worth it / not possible.  The chunks must be whole tiles of whichever kernel
-// launch_cascade will pick for S K C channels (cascade_rows<4>: 512 frames, <2>: 1024, <1>: 2048; cascade_wave / _fast: 1024).
+// launch_cascade will pick for S K C channels (cascade_rows<4>: 512 frames, <2>: 1024, <1>: 2048; cascade_fast: 1024).
 bool CascadeStage::choose_chunks(long frames, int *K_out, long *len_out) const
 {
 	const char *env_s = getenv("DSP_AMD_CASCADE_CHUNKS");        // 0 = never, K = force up to K chunks (read per plan: tests switch it)
@@ -1119,7 +1121,7 @@ std::unique_ptr<Pipeline> Pipeline::compile(const std::vector<const Spec *> &spe
 			{
 				bool only_discard = sp->discard > 0 && !pl->stages.empty();
 				for (ssize_t len : sp->delay) if (len != 0) only_discard = false;
-				if (only_discard && !getenv("DSP_AMD_NO_DISCARD_FOLD") && pl->stages.back()->absorb_discard((long) sp->discard)) break;
+				if (only_discard && pl->stages.back()->absorb_discard((long) sp->discard)) break;
 			}
 			DelayStage *d = new DelayStage;
 			base(d, *sp);

@@ -219,18 +219,24 @@ private:
 };
 
 // ---- small plugin blocks through a wave that stays on the device for a bounded time (kernels_resident.hip, plugin.cpp) ----
+// The mailbox protocol (round 6).  Both directions are arrays of 16-byte units { value, word }: word = request ^ bits(value), request = (sequence number << 32) |
+// frames -- a unit proves by itself that it belongs to the current request (a stale value under a new word does not decode to the request, and the other way
+// round), so neither side needs a second, dependent trip behind a doorbell and neither side waits for its stores to be acknowledged:
+//   host -> wave: mail_in[0] = the control unit { 0.0, request }, mail_in[1 + e] = sample e of the block.  In DEVICE memory where the CPU can store into it (large
+//                 BAR: posted writes over PCIe, the wave polls and reads local memory -- scripts/ubench/barprobe.hip: 3.2 us against 5.6 for the round trip
+//                 with a 1 KB block), else in page-locked host memory;
+//   wave -> host: mail_out[e] = output sample e, in page-locked host memory (posted writes again); the host reads the units until every one decodes.
 constexpr unsigned RESIDENT_STOP = 0xffffffffu;      // `frames` of a request that tells the wave to leave
-struct ResidentCtl {                                 // page-locked, device-mapped host memory: one 64-byte line per direction
-	unsigned long long req;                          // (sequence number << 32) | frames: written by the host once the block is in the staging buffer
-	unsigned long long pad0[7];
-	unsigned done;                                   // sequence number of the last block whose output is complete (the wave)
+constexpr int RESIDENT_UNITS = 4096;                 // payload units per direction (64 KB): frames x channels of a block the wave takes
+struct ResidentUnit { double v; unsigned long long w; };
+struct ResidentCtl {                                 // page-locked, device-mapped host memory
 	unsigned alive;                                  // set by the host before a launch, cleared by the wave as its last store
-	unsigned pad1[14];
+	unsigned pad[15];
 };
 struct ResidentParams {
 	ResidentCtl *ctl;
-	const double *in;                                // mapped staging buffers of the segment: [frames][C]
-	double *out;
+	const ResidentUnit *mail_in;                     // [1 + RESIDENT_UNITS]
+	ResidentUnit *mail_out;                          // [RESIDENT_UNITS]
 	int C, n_ops;                                    // channels of the cascade (= of the output), ops per channel
 	int Cin;                                         // channels of the input block: C, or the input side of a plain remix in front of the cascade
 	const int *remix_idx;                            // [C][remix_max_n] source channels of every cascade channel, -1 terminated (remix.c:39-101), or nullptr
@@ -241,6 +247,7 @@ struct ResidentParams {
 	unsigned long long max_life_ticks;               // ... since the launch, blocks or not (the wave leaves between two blocks; the host starts another)
 	unsigned max_polls, done0;                       // hard bound on the polling loop; the sequence number already served
 	int buf_doubles;                                 // doubles of the block buffer in LDS (a block is at most that many samples)
+	int spec_units;                                  // payload units per lane asked for together with the control unit (the blocks the host expects to send)
 };
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st);
 

@@ -59,7 +59,6 @@ struct ConvParams {
 	double2 *fdl;
 	long fdl_slot_stride;
 	int fdl_P, fdl_slot;
-	int no_split;                       // filter preparation of a float32 stage: keep the generic row kernel's spectrum order (the split-row kernels are fp64 only)
 	int f32;                            // 1: W, H and the twiddle tables hold float2 (the float32 instance, kernels_fft32.hip); rings / slabs / outputs stay fp64
 	WireSink sink;                      // K3 of a plain convolution at the end of a pipeline: `out` holds samples of sink.fmt (kparams.h)
 };

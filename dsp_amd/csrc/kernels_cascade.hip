@@ -9,7 +9,7 @@
 // Four kernels share the arithmetic below and differ in how they spread it over the chip (launch_cascade picks):
 //   cascade_rows   a wave = 4 channels (one per DPP row), 32 frames per lane, time axis shared by skewed waves -- many
 //                  channels with identical sections (the headline kernel)
-//   cascade_wave   a wave = 1 channel, 16 frames per lane, time axis shared by up to 10 skewed waves -- few channels
+//   (cascade_wave, one channel per wave with the time axis shared by up to 10 skewed waves, served few channels until the chunked time axis did: removed in round 6)
 //   cascade_fast   a wave = 1 channel, cooperative workgroup I/O -- per-channel coefficients, add, unselected channels
 //   cascade_kernel generic: any channel count, remainders shorter than a tile (L = 4 and L = 1 tail steps)
 //
@@ -640,9 +640,9 @@ static long launch_cascade_fast(const CascadeParams &p, int n_streams, hipStream
 // 4-step row scan, which then spreads it -- and twice as many frames per lane halve what is left per sample:
 // (256 + ~50) instructions per 4 x 512 samples against 4 x (128 + ~90) per 4 x 1024 (scripts/ubench/secbench: 304 ns of
 // SIMD time per 1024 samples against 540).  Four channels per wave leave a quarter of the waves, so the time axis is
-// shared as in cascade_wave (below).  The constants stay wave-uniform scalars: the four channels of a group must run
+// shared between skewed waves.  The constants stay wave-uniform scalars: the four channels of a group must run
 // identical biquad sections (gains among them are folded into the sections by the host: frows table, engine.cpp);
-// anything else goes to cascade_wave / cascade_fast.
+// anything else goes to cascade_fast.
 constexpr int RW_L = ROWS_L, RW_ROW = 16 * (RW_L + 1);
 // value of lane 15 of row 0 / 2 in every lane of row 1 / 3; rows 0 and 2 read 0.0 (two v_readlane pairs and a select)
 __device__ __forceinline__ double bcast15_f64(double v, int lane)
@@ -742,7 +742,7 @@ __device__ __forceinline__ double2 rw_as_d2(rw_u32x4 v) { return __builtin_bit_c
 __device__ __forceinline__ rw_u32x4 rw_as_u4(double2 v) { return __builtin_bit_cast(rw_u32x4, v); }
 
 // cascade_rows<G>: workgroup = (stream, group of G channels) x P waves.  The P waves share the TIME axis of the group the way
-// cascade_wave does (wave w owns the tiles w, w + P, ..., one section per step, one LDS barrier per step, the 16-byte
+// round 2's cascade_wave did (wave w owns the tiles w, w + P, ..., one section per step, one LDS barrier per step, the 16-byte
 // section states of the channels travel from wave to wave through LDS), so that 2048 channels still give 2048 waves.
 // G = 4: one DPP row and 512 frames per channel and tile -- 1024 channels and more.  G = 2: two rows and 1024 frames per
 // channel (one extra carry step from the lower to the upper row, per-lane matrices from an LDS table) -- twice the
@@ -1139,8 +1139,7 @@ template <int G> static long try_launch_rows(const CascadeParams &p, int n_strea
 	if (lds > 160 * 1024) return 0;
 	// point-to-point ordering for long calls (at least 16 tiles per wave); short ones keep the workgroup barrier per step: the
 	// polling costs more than it saves there (config 2's chunks of 8 tiles: 0.052 against 0.064 ms; 2048-frame calls 0.031 / 0.035)
-	static const int p2p_env = [] { const char *e = getenv("DSP_AMD_CASCADE_P2P"); return e ? atoi(e) : -1; }();
-	const int p2p = (p2p_env >= 0) ? p2p_env : (n_full / P >= 16 ? 1 : 0);
+	const int p2p = n_full / P >= 16 ? 1 : 0;
 	dim3 grid(n_streams, p.C / G), block(64 * P);
 	const int wire = (p.in_fmt != PCM_DOUBLE ? 1 : 0) | (p.sink.on ? 2 : 0);
 	if (wire) {
@@ -1206,166 +1205,6 @@ static long launch_cascade_rows(const CascadeParams &p, int n_streams, hipStream
 	return (G == 4) ? try_launch_rows<4>(p, n_streams, P, stream) : (G == 2) ? try_launch_rows<2>(p, n_streams, P, stream) : try_launch_rows<1>(p, n_streams, P, stream);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Wavefront variant for FEW streams (strong scaling: 256 streams over 8 GPUs leave 32 per GPU = 256 channels).
-//
-// cascade_fast runs one wave per channel through all sections of a tile before the next tile: 192 tiles x 10 sections in
-// series per channel, 2.4 ms per launch however few channels there are.  With fewer than ~2000 channels on the GPU the
-// time axis of a channel has to be shared between waves: here the P waves of a channel own the tiles t = w, w + P,
-// w + 2 P, ... and each runs ALL sections on its tile, skewed by one step: at step sigma wave w is at unit sigma - w of
-// its sequence, (tile m, section j) = divmod(unit, n_ops).  Section j of tile t needs the state that section j left
-// after tile t - 1 -- produced by wave w - 1 exactly one step earlier (by wave P - 1, n_ops - P + 1 steps earlier, for
-// w = 0), so ONE LDS barrier per step orders everything, and because P <= n_ops no two waves of a channel ever touch
-// the same section in the same step.  The tiles stay in registers for all their sections; what moves between waves is
-// the 16-byte section state.  Every wave loads and stores its own tiles, one per n_ops steps, prefetched a whole tile
-// period ahead and naturally staggered across the waves.  (A first version handed the TILES from wave to wave through
-// LDS, one section per wave: 16 KB of LDS traffic per wave and step and two barriers -- 0.59 ms at 32 streams against
-// 0.45 ms for this one.)
-template <int CG, int P>
-__global__ __launch_bounds__(64 * CG * P) void cascade_wave(CascadeParams p, const double *__restrict__ fops)
-{
-	constexpr int L = CASCADE_L, TILE = 64 * L, NTH = 64 * CG * P;
-	extern __shared__ __attribute__((aligned(16))) double smem[];
-	int s, grp;
-	stream_and_group_of_block(p.xcd_map, s, grp);
-	const int c0 = p.cg0 + grp * CG;
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int w = wave / CG, cc = wave % CG, c = c0 + cc;
-	double *st = smem;                                               // [CG][n_ops][2]
-	double *qt = st + (size_t) CG * p.n_ops * 2;                     // [CG][n_ops][FQ_DOUBLES]
-	const int n_st = CG * p.n_ops * 2;
-	double *gstate = p.state + ((size_t) s * p.C + c0) * p.n_ops * 2;
-	for (int i = tid; i < n_st; i += NTH) st[i] = gstate[i];
-	for (int i = tid; i < CG * p.n_ops * FQ_DOUBLES; i += NTH) qt[i] = p.fq[(size_t) c0 * p.n_ops * FQ_DOUBLES + i];
-
-	const long n_full = p.frames / TILE;
-	const int n_ops = p.n_ops;
-	// HBM is accessed frame-major (element i of a lane = frame 64 i + lane of the tile: consecutive lanes on consecutive
-	// frames / ring elements), the recurrence wants lane-major (lane = L consecutive frames): each wave transposes through
-	// its own padded LDS tile (frame f at f + f / L), twice per tile -- no barrier, a wave's LDS operations are in order
-	double *tb = qt + (size_t) CG * p.n_ops * FQ_DOUBLES + (size_t) wave * (TILE + TILE / L);
-	const int fm_off = lane + (lane >> 4), lm_off = lane * (L + 1);      // + (64 + 64 / L) i  /  + i
-	const double *in = p.in + ((size_t) s * p.in_stride_frames + lane) * p.C + c;
-	double *out = p.out + ((size_t) s * p.out_stride_frames + lane) * p.C + c;
-	double *ringc = p.ring.base ? p.ring.base + 2 * (((size_t) s * p.ring.rows_per_stream + (c >> 1)) * p.ring.row_stride) + (c & 1) : nullptr;
-	const double *__restrict__ cf = fops + (size_t) c * n_ops * FOP_DOUBLES;
-	const double *wq = qt + (size_t) cc * n_ops * FQ_DOUBLES;
-	double *cst = st + cc * n_ops * 2;
-
-	// the last tile's owner finishes last: wave wl after its tiles
-	const int wl = (int) ((n_full - 1) % P);
-	const long n_steps = wl + ((n_full - 1) / P + 1) * n_ops;
-	long steps = 0;                                                  // barriers passed so far (every wave passes n_steps of them)
-	OpHead cur = load_head(cf);
-	__syncthreads();
-
-	auto load_raw = [&](double (&r)[L], long t) {
-		const double *src = in + (size_t) t * TILE * p.C;
-#pragma unroll
-		for (int i = 0; i < L; ++i) r[i] = src[(size_t) i * 64 * p.C];
-	};
-	// all sections on the tile in x (one step each), then the tile goes out
-	auto process = [&](double (&x)[L], long t) {
-		PendingFix fix = { 0.0, 0.0, 0.0, 0.0 };
-		bool pending = false;
-		for (int j = 0; j < n_ops; ++j) {
-			const long long kind = cur.kind;                 // before the next head is requested (see run_ops_fast)
-			__builtin_amdgcn_sched_barrier(0);
-			const OpHead nxt = load_head(cf + ((j + 1 < n_ops) ? j + 1 : 0) * FOP_DOUBLES);     // in flight during this op
-			run_op_fast<L>(x, kind, cur, cf + j * FOP_DOUBLES, wq, j, cst, lane, fix, pending);
-			cur = nxt;
-			if (j + 1 == n_ops) {
-				if (pending) apply_fix<L>(x, fix);
-#pragma unroll
-				for (int i = 0; i < L; ++i) tb[lm_off + i] = x[i];
-#pragma unroll
-				for (int i = 0; i < L; ++i) x[i] = tb[fm_off + (64 + 64 / L) * i];
-				{
-					const size_t f0 = (size_t) t * TILE;
-					if (p.write_interleaved) {
-#pragma unroll
-						for (int i = 0; i < L; ++i) out[(f0 + 64 * i) * p.C] = x[i];
-					}
-					if (ringc) {
-						const long e0 = p.ring.pos + (long) f0 + lane;
-#pragma unroll
-						for (int i = 0; i < L; ++i) ringc[2 * (size_t) ((e0 + 64 * i) & p.ring.mask)] = x[i];
-					}
-				}
-			}
-			lds_barrier();
-		}
-		steps += n_ops;
-	};
-
-	for (int i = 0; i < w; ++i) lds_barrier();                       // the skew: wave w starts at step w
-	steps = w;
-	if (w < n_full) {
-		double raw[L], x[L];
-		load_raw(raw, w);
-		for (long t = w; t < n_full; t += P) {
-			// the wait for this tile's loads sits here, BEFORE the next tile's loads are issued (vmcnt counts in order)
-#pragma unroll
-			for (int i = 0; i < L; ++i) tb[fm_off + (64 + 64 / L) * i] = raw[i];
-#pragma unroll
-			for (int i = 0; i < L; ++i) x[i] = tb[lm_off + i];
-			// unconditional (the last one re-reads this tile): a conditional load would have to select between old and new
-			// registers, which costs a wait right behind the loads
-			load_raw(raw, (t + P < n_full) ? t + P : t);
-			process(x, t);
-		}
-	}
-	for (; steps < n_steps; ++steps) lds_barrier();
-	__syncthreads();
-	for (int i = tid; i < n_st; i += NTH) gstate[i] = st[i];
-}
-
-template <int CG, int P> static bool try_launch_wave(const CascadeParams &p, int n_streams, hipStream_t stream)
-{
-	const size_t lds = ((size_t) CG * p.n_ops * 2 + (size_t) CG * p.n_ops * FQ_DOUBLES + (size_t) CG * P * (CASCADE_TILE + 64)) * sizeof(double);
-	if (lds > 160 * 1024 || p.n_ops < P || (p.C % CG)) return false;
-	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_wave<CG, P>), lds);
-	dim3 grid(n_streams, p.C / CG), block(64 * CG * P);
-	hipLaunchKernelGGL((cascade_wave<CG, P>), grid, block, lds, stream, p, p.fops);
-	return true;
-}
-
-// few streams: the tiles of a channel are dealt out to P waves (see cascade_wave) so that the chip stays full
-static long launch_cascade_wave(const CascadeParams &p, int n_streams, hipStream_t stream)
-{
-	static const int env = [] { const char *e = getenv("DSP_AMD_CASCADE_WAVE"); return e ? atoi(e) : -1; }();   // 0 = never, CG*100+P = force
-	if (env == 0 || p.cg0 != 0 || !p.fops || p.n_ops < 1) return 0;
-	if (p.ring.base && !p.ring.consecutive_pairs) return 0;
-	const long n_full = p.frames / CASCADE_TILE;
-	if (n_full < 4) return 0;
-	const long channels = (long) n_streams * p.C;
-	int cg, pp;
-	if (env > 0) { cg = env / 100; pp = env % 100; }
-	else {
-		if (channels > 1024) return 0;                      // enough channels: one wave per channel already fills the chip
-		// about 256 workgroups of 10 - 12 waves
-		cg = (channels > 512 && p.C % 4 == 0) ? 4 : (channels > 256 && p.C % 2 == 0) ? 2 : 1;
-		pp = (cg == 4) ? 3 : (cg == 2) ? 5 : 10;
-		while (pp > p.n_ops || pp > n_full) pp = (pp == 10) ? 5 : (pp == 5) ? 3 : (pp == 3) ? 2 : 1;
-	}
-	bool ok = false;
-	if (cg == 1 && pp == 10) ok = try_launch_wave<1, 10>(p, n_streams, stream);
-	else if (cg == 1 && pp == 5) ok = try_launch_wave<1, 5>(p, n_streams, stream);
-	else if (cg == 1 && pp == 3) ok = try_launch_wave<1, 3>(p, n_streams, stream);
-	else if (cg == 1 && pp == 2) ok = try_launch_wave<1, 2>(p, n_streams, stream);
-	else if (cg == 1 && pp == 1) ok = try_launch_wave<1, 1>(p, n_streams, stream);
-	else if (cg == 2 && pp == 5) ok = try_launch_wave<2, 5>(p, n_streams, stream);
-	else if (cg == 2 && pp == 3) ok = try_launch_wave<2, 3>(p, n_streams, stream);
-	else if (cg == 2 && pp == 2) ok = try_launch_wave<2, 2>(p, n_streams, stream);
-	else if (cg == 2 && pp == 1) ok = try_launch_wave<2, 1>(p, n_streams, stream);
-	else if (cg == 4 && pp == 3) ok = try_launch_wave<4, 3>(p, n_streams, stream);
-	else if (cg == 4 && pp == 2) ok = try_launch_wave<4, 2>(p, n_streams, stream);
-	else if (cg == 4 && pp == 1) ok = try_launch_wave<4, 1>(p, n_streams, stream);
-	else if (cg == 8 && pp == 1) ok = try_launch_wave<8, 1>(p, n_streams, stream);
-	return ok ? n_full * CASCADE_TILE : 0;
-}
-
 size_t cascade_lds_bytes(int Cg, int n_ops)
 {
 	return ((size_t) Cg * CH_STRIDE + (size_t) Cg * n_ops * 2 + (size_t) Cg * n_ops * OPL_DOUBLES) * sizeof(double);
@@ -1373,15 +1212,13 @@ size_t cascade_lds_bytes(int Cg, int n_ops)
 
 const char *launch_cascade(const CascadeParams &p_in, int n_streams, hipStream_t stream)
 {
-	static const int xmap = [] { const char *e = getenv("DSP_AMD_CASCADE_XCDMAP"); return e ? atoi(e) : 1; }();   // 0: plain block order (for comparison)
 	CascadeParams p0 = p_in;
-	p0.xcd_map = xmap;
+	p0.xcd_map = 1;          // (the channel groups of a stream co-scheduled on one XCD: scripts/exp_xcdmap.sh, docs/history.md section 4.1)
 	CascadeParams p = p0;
 	const char *name = "cascade_rows";
 	// a call in wire formats: cascade_rows and the generic kernel speak them (the host asks cascade_rows_takes() first)
 	const bool wire = p0.in_fmt != PCM_DOUBLE || p0.sink.on;
 	long done = launch_cascade_rows(p0, n_streams, stream);
-	if (done == 0 && !wire) { name = "cascade_wave"; done = launch_cascade_wave(p0, n_streams, stream); }
 	if (done == 0 && !wire) { name = "cascade_fast"; done = launch_cascade_fast(p0, n_streams, stream); }
 	if (done > 0) {
 		// the generic kernel continues the streams (state is in HBM) on whatever is left of the block

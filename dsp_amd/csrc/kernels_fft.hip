@@ -141,97 +141,6 @@ __global__ __launch_bounds__(NT) void conv_row_pipe(ConvParams p, int pairs_per_
 	}
 }
 
-// K2 for rows of N2 = WV * 1024 points (WV = 2, 4): the row FFT is itself split 4-step style so that all but one
-// exchange per direction stay inside a wave.  With n2 = a + 1024 b and k2 = WV ka + kb:
-//   forward   Z_kb[a] = w_N2^(a kb) sum_b x[a + 1024 b] w_WV^(b kb)      radix-WV butterflies on registers (a thread
-//                                                                        loads its own WV blocks), then ONE
-//                                                                        cross-wave exchange: wave kb collects Z_kb
-//             X[WV ka + kb] = sum_a Z_kb[a] w_1024^(a ka)                1024-point FFT inside wave kb (no barriers)
-//   multiply by H, which filter preparation (MODE 1) stores in this kernel's own (kb, ka) order
-//   inverse   the mirror image: 1024-point IFFT inside the wave, conj twiddle, ONE cross-wave exchange, radix-WV
-//             butterflies, y[a + 1024 b] leaves in contiguous runs.
-// Two workgroup barriers per row instead of the seven of the generic 3-pass kernel.
-template <int WV, int MODE>
-__global__ __launch_bounds__(NT) void conv_row_big(ConvParams p)
-{
-	using C10 = RowCfg<10>;
-	constexpr int N2 = 1024 * WV, AV = 16 / WV, TR = 64 * WV, ROWS = 4 / WV, PITCH = C10::PITCH;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *data = reinterpret_cast<cplx *>(smem_raw);                 // [4 sub-rows][PITCH]
-	cplx *t256 = data + 4 * PITCH, *tlo = t256 + C10::T256, *thi = tlo + 64, *t1lo = thi + 64, *t1hi = t1lo + C10::TLO;   // t256, t1lo: padded (twpad)
-	const int tid = threadIdx.x;
-	const int lane = tid & 63, wq = tid >> 6;                        // wq: wave of the workgroup = sub-row buffer
-	const int rw = wq / WV, w = wq % WV, tr = w * 64 + lane;
-	const long k1 = (long) blockIdx.x * ROWS + rw;
-	const long pair = p.pair0 + blockIdx.y;
-	cplx *W = p.W + (pair - p.pair0) * p.w_stride + k1 * N2;
-	cplx v[16];
-#pragma unroll
-	for (int i = 0; i < AV; ++i)
-#pragma unroll
-		for (int b = 0; b < WV; ++b) v[i * WV + b] = W[tr + TR * i + 1024 * b];
-	// tables: W_256, W_N2 two-level (cross-wave twiddles), W_1024 two-level (in-wave FFT)
-	t256[twpad(tid)] = p.tw_n2[tid * (N2 / 256)];
-	if (tid < 64) { tlo[tid] = p.tw_n2[tid]; t1lo[twpad(tid)] = p.tw_n2[tid * WV]; }
-	else if (tid < 128) { thi[tid - 64] = (tid - 64 < N2 / 64) ? p.tw_n2[(tid - 64) * 64] : make_double2(0.0, 0.0); }
-	else if (tid < 144) t1hi[tid - 128] = p.tw_n2[(tid - 128) * 64 * WV];
-	lds_barrier();
-	const TwRow<1024> tw1{ t256, t1lo, t1hi };
-	const int rbase = rw * WV * PITCH;
-	const RowMap mymap{ wq * PITCH };
-	// ---- forward: radix-WV over the blocks, twiddle, hand Z_kb to wave kb ----
-#pragma unroll
-	for (int i = 0; i < AV; ++i) {
-		cplx u[WV];
-#pragma unroll
-		for (int b = 0; b < WV; ++b) u[b] = v[i * WV + b];
-		dftR<WV, false>(u);
-		const int a = tr + TR * i;
-#pragma unroll
-		for (int kb = 0; kb < WV; ++kb) {
-			if (kb > 0) { const int e = a * kb; u[kb] = cmul(u[kb], cmul(thi[e >> 6], tlo[e & 63])); }
-			RowMap{ rbase + kb * PITCH }.store(data, a, u[kb]);
-		}
-	}
-	lds_barrier();
-	gather16<10>(v, lane, data, mymap);
-	row_sync<true>();
-	row_fft<10, false>(v, lane, data, mymap, tw1);
-	if (MODE == 1) {
-		cplx *H = p.Hout + k1 * N2 + w * 1024 + lane;
-#pragma unroll
-		for (int m = 0; m < 16; ++m) H[64 * m] = make_double2(v[m].x * p.h_scale, v[m].y * p.h_scale);
-		return;
-	}
-	{
-		const cplx *H = p.H + p.pair_h[pair] * p.N + k1 * N2 + w * 1024 + lane;
-#pragma unroll
-		for (int m = 0; m < 16; ++m) v[m] = cmul(v[m], H[64 * m]);
-	}
-	// ---- inverse ----
-	row_sync<true>();
-	row_fft<10, true>(v, lane, data, mymap, tw1);
-	row_sync<true>();
-#pragma unroll
-	for (int m = 0; m < 16; ++m) {
-		const int a = lane + 64 * m;
-		cplx z = v[m];
-		if (w > 0) { const int e = a * w; z = cmulc(z, cmul(thi[e >> 6], tlo[e & 63])); }
-		mymap.store(data, a, z);
-	}
-	lds_barrier();
-#pragma unroll
-	for (int i = 0; i < AV; ++i) {
-		const int a = tr + TR * i;
-		cplx u[WV];
-#pragma unroll
-		for (int kb = 0; kb < WV; ++kb) RowMap{ rbase + kb * PITCH }.load(data, a, u[kb]);
-		dftR<WV, true>(u);
-#pragma unroll
-		for (int b = 0; b < WV; ++b) W[a + 1024 * b] = u[b];
-	}
-}
-
 // ------------------------------------------------------------------ small calls: partitioned head with a delay line
 //
 // One row of NF = 2 B points per pair: window = [previous block | this block] of the pair's ring, forward transform (kept:
@@ -557,15 +466,6 @@ __global__ __launch_bounds__(NT) void fir_direct_kernel(FirDirectParams p)
 
 // ------------------------------------------------------------------ launchers
 
-template <int WV> static void launch_row_big(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
-{
-	constexpr size_t LDS = ((size_t) 4 * RowCfg<10>::PITCH + RowCfg<10>::T256 + 3 * 64 + RowCfg<10>::TLO) * sizeof(cplx);
-	if (mode) grant_lds(conv_row_big<WV, 1>, LDS); else grant_lds(conv_row_big<WV, 0>, LDS);
-	dim3 grid((unsigned) (p.N1 / (4 / WV)), n_pairs), block(NT);
-	if (mode == 1) hipLaunchKernelGGL((conv_row_big<WV, 1>), grid, block, LDS, st, p);
-	else hipLaunchKernelGGL((conv_row_big<WV, 0>), grid, block, LDS, st, p);
-}
-
 static void pipe_grid(int groups, int n_pairs, int *ranges, int *per)
 {
 	// one workgroup per CU (LDS): the row groups times as many pair ranges as it takes to give every CU two workgroups in turn
@@ -593,56 +493,29 @@ template <int L2> static void launch_row_pipe(const ConvParams &p, int n_pairs, 
 	hipLaunchKernelGGL((conv_row_pipe<L2, 1>), dim3((unsigned) groups, (unsigned) ranges), dim3(NT), LDS, st, p, per, n_pairs);
 }
 
-// Which row-kernel family serves a plan -- decided from the plan alone (never from the number of pairs in a launch): the
-// filter spectra are stored in the family's own order by its preparation mode.
-//   persistent three-pass kernel (conv_row_pipe; conv_row for launches of a few pairs): single-phase plans with one shared filter;
-//   split rows (conv_row_big: the row FFT itself four-step, all but one exchange inside a wave): the other 2048-point plans
-//   (a persistent form of it was measured: 5.4 against 4.4 ms at 2048-point rows, 11.1 against 8.9 at 4096 -- its two extra
-//   exchanges per row are exposed when a SIMD holds a single wave);
-//   everything else the generic three-pass kernel
-static const int g_pipe_env = [] { const char *e = getenv("DSP_AMD_ROW_PIPE"); return e ? atoi(e) : 1; }();
-static bool plan_is_pipe(const ConvParams &p) { return g_pipe_env && p.nph <= 2 && p.shared_h; }
-static bool rows_are_split(const ConvParams &p)
-{
-	static const int big_env = [] { const char *e = getenv("DSP_AMD_ROW_BIG"); return e ? atoi(e) : 1; }();
-	if (!big_env || p.nph > 1 || plan_is_pipe(p) || p.no_split || p.f32) return false;          // (a multi-phase plan uses the generic kernel for preparation too)
-	return p.log2N2 == 11 || (big_env > 1 && p.log2N2 == 12);            // (measured: the 3-pass kernel is ahead at 4096)
-}
+// Which row kernel serves a plan -- decided from the plan alone (never from the number of pairs in a launch beyond "a few"):
+//   rows of 2048 / 4096 points of one shared filter: the two-workgroup persistent kernel (conv_row_duo: plain convolution with the filter row in
+//   registers; the 2x resampler's two branches with the rows from L2);
+//   rows of 512 / 1024 points of one shared filter: the persistent kernel with the landing zone (conv_row_pipe);
+//   everything else -- one filter per channel, the delay-line form (mode 3), filter preparation (mode 1), launches of a few pairs -- the one-shot kernel.
+// (Round 6 removed the split-row kernel conv_row_big -- per-channel filters at 2048-point rows, 10 % ahead of the one-shot kernel there and nowhere
+// the default of a BASELINE plan -- and the A/B switches DSP_AMD_ROW_PIPE / _ROW_BIG / _ROW_DUO / _ROW_DUO2: their measurements are in docs/history.md.)
+static bool plan_is_shared(const ConvParams &p) { return p.nph <= 2 && p.shared_h; }
 
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st)
 {
 	if (mode == 3) { if (p.f32) p32::core_launch_row(p, 3, n_pairs, st); else core_launch_row(p, 3, n_pairs, st); return; }     // delay-line form: the generic row kernel
+	const bool persistent = plan_is_shared(p) && n_pairs >= 8 && ((mode == 0 && p.nph == 1) || (mode == 2 && p.nph == 2));
 	if (p.f32) {
 		// the float32 instance: the persistent two-workgroup kernel for the long rows of a shared filter, else the one-shot kernel
-		if (plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= 11) p32::core_launch_row_duo(p, n_pairs, st);
+		if (persistent && p.nph == 1 && p.log2N2 >= 11) p32::core_launch_row_duo(p, n_pairs, st);
 		else p32::core_launch_row(p, mode, n_pairs, st);
 		return;
 	}
-	if (rows_are_split(p)) {
-		if (p.log2N2 == 11) launch_row_big<2>(p, mode, n_pairs, st); else launch_row_big<4>(p, mode, n_pairs, st);
-		return;
-	}
-	// (the two-branch form holds both filter rows in registers: at 2048- / 4096-point rows it spills 100 VGPRs and is behind the
-	// one-shot kernel, 16.7 against 15.0 ms; at 1024-point rows ahead, 3.26 against 3.53)
-	static const int duo_env = [] { const char *e = getenv("DSP_AMD_ROW_DUO"); return e ? atoi(e) : 1; }();
-	if (duo_env && plan_is_pipe(p) && mode == 0 && p.nph == 1 && n_pairs >= 8 && p.log2N2 >= 11 && (duo_env == 1 || p.log2N2 == 10 + duo_env)) {
-		core_launch_row_duo(p, n_pairs, st);
-		return;
-	}
-	// (round 5) the 2x resampler's two branches at 2048- / 4096-point rows: the two-workgroup kernel with the filter rows from L2
-	static const int duo2_env = [] { const char *e = getenv("DSP_AMD_ROW_DUO2"); return e ? atoi(e) : 1; }();
-	if (duo2_env && plan_is_pipe(p) && mode == 2 && p.nph == 2 && n_pairs >= 8 && p.log2N2 >= 11) {
-		core_launch_row_duo(p, n_pairs, st);
-		return;
-	}
-	if (plan_is_pipe(p) && (mode == 0 || (mode == 2 && p.nph == 2)) && n_pairs >= 8) {
-		switch (p.log2N2) {
-		case 9: launch_row_pipe<9>(p, n_pairs, st); return;
-		case 10: launch_row_pipe<10>(p, n_pairs, st); return;
-		case 11: launch_row_pipe<11>(p, n_pairs, st); return;
-		case 12: launch_row_pipe<12>(p, n_pairs, st); return;
-		default: break;
-		}
+	if (persistent && p.log2N2 >= 11) { core_launch_row_duo(p, n_pairs, st); return; }
+	if (persistent) {
+		if (p.log2N2 == 9) { launch_row_pipe<9>(p, n_pairs, st); return; }
+		if (p.log2N2 == 10) { launch_row_pipe<10>(p, n_pairs, st); return; }
 	}
 	core_launch_row(p, mode, n_pairs, st);
 }

@@ -1,16 +1,25 @@
-// kernels_resident.hip -- small plugin blocks without a launch per block (round 5).
+// kernels_resident.hip -- small plugin blocks without a launch per block (round 5; the mailbox protocol: round 6).
 //
 // What it serves: the reference's LADSPA frontend and CLI drive a chain with run() calls of 64 ... 1024 frames (ladspa_dsp.c:316-355, dsp.h:38); a
 // kernel launch plus its completion costs 25 us on this platform whatever the block, the reference's own loop 3 us at 64 frames x 2 ch x 10 sections.
-// For a device segment that is ONE cascade of gains / adds / sections (the equaliser shape) a single wave stays on the device for a bounded time,
-// polls a doorbell in page-locked host memory, runs the block -- the reference's recurrence as written (biquad.h:76-92), sample by sample, one lane per op
-// per channel, states and coefficients in registers -- out of and into the mapped staging buffers, and says so in host memory.
+// For a device segment that is ONE cascade of gains / adds / sections (the equaliser shape), or a plain remix in front of one (the crossover shape), a
+// single workgroup stays on the device for a bounded time, polls a mailbox the host writes the block into, runs the block -- the reference's recurrence as
+// written (biquad.h:76-92), sample by sample, one lane per op per channel, states and coefficients in registers -- and writes the output into a mailbox
+// the host polls.
+//
+// The mailboxes (engine.h: ResidentUnit, ResidentParams): 16-byte units { value, request ^ bits(value) } that validate themselves, so the wave asks for the
+// control unit AND the units of the block it expects in ONE burst of loads and neither side waits for an acknowledgement of its stores.  Round 5 had a
+// doorbell word and plain staging buffers in host memory: a PCIe read round trip for the doorbell, a second, dependent one for the block, and a
+// system-scope fence (a third round trip's worth) between the output and the completion word -- 12.1 us per 64-frame stereo block of ten sections.  The
+// request mailbox now lives in device memory the CPU stores into over the BAR (page-locked host memory where it cannot): every PCIe transfer on the path is a
+// posted write.
 //
 // Bounded lifetime: the wave leaves after `lifetime` ticks of the 100 MHz clock without a block, `max_life` ticks after its launch however busy it is kept
-// (between two blocks), when the host asks it to (frames = RESIDENT_STOP), or after `max_polls` turns of its loop whatever the clock says -- so a hipDeviceSynchronize() anywhere in the process waits a few milliseconds at
-// most, and no failure of the host can leave a kernel behind.  Its last store is alive = 0; the host starts another one with the next block.
-// The states live in device memory between blocks (loaded and stored around every block, past the L1: the ordinary kernels may have run in between),
-// so a block of any other size simply takes the ordinary path on the same states.
+// (between two blocks), when the host asks it to (frames = RESIDENT_STOP), or after `max_polls` turns of its loop whatever the clock says -- so a
+// hipDeviceSynchronize() anywhere in the process waits a few milliseconds at most, and no failure of the host can leave a kernel behind.  Its last store
+// is alive = 0 behind a system-scope fence; the host starts another one with the next block.
+// The states live in device memory between blocks (loaded and stored around every block, past the L1).  They are NOT fenced per block: before anything
+// else touches them (the ordinary kernels at another block size, reset, destroy) the host asks the wave to leave and waits for it (Resident::quiesce).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "kparams.h"
@@ -37,6 +46,28 @@ __device__ __forceinline__ double row_shr1(double v)
 	return __hiloint2double(hi, lo);
 }
 
+typedef unsigned int res_u4 __attribute__((ext_vector_type(4)));
+// sc0 | sc1 (system scope: the access goes to memory whatever a cache holds) | the compiler's volatile bit (a poll is not hoisted out of its loop)
+constexpr int RES_AUX = (int) 0x80000011u;
+__device__ __forceinline__ ResidentUnit ld_unit(__amdgpu_buffer_rsrc_t r, int unit)
+{
+	const res_u4 q = __builtin_amdgcn_raw_buffer_load_b128(r, unit * 16, 0, RES_AUX);
+	ResidentUnit u;
+	u.v = __hiloint2double((int) q.y, (int) q.x);
+	u.w = ((unsigned long long) q.w << 32) | q.z;
+	return u;
+}
+__device__ __forceinline__ void st_unit(__amdgpu_buffer_rsrc_t r, int unit, double v, unsigned long long rq)
+{
+	const unsigned long long b = (unsigned long long) __double_as_longlong(v), w = rq ^ b;
+	const res_u4 q = { (unsigned) b, (unsigned) (b >> 32), (unsigned) w, (unsigned) (w >> 32) };
+	__builtin_amdgcn_raw_buffer_store_b128(q, r, unit * 16, 0, 0x11);
+}
+__device__ __forceinline__ unsigned long long unit_request(const ResidentUnit &u) { return u.w ^ (unsigned long long) __double_as_longlong(u.v); }
+
+constexpr int RES_SPEC = 4;                  // payload units per lane asked for together with the control unit, at most
+constexpr unsigned RES_SPINS = 1u << 17;     // re-reads of a unit that does not decode before the wave gives up (the host wrote the block BEFORE the control unit)
+
 // Workgroup = ceil(C / 4) waves; a wave = 4 channels, one per 16-lane DPP row; lane j of a row = op j of its channel (n_ops <= 16).  A block runs as a
 // systolic array: at step t lane j works on frame t - j, its input the result lane j - 1 had a step earlier (one DPP move), lane 0 reads the frame from
 // the block buffer, the channel's last op writes it back -- frames + n_ops - 1 steps of one dependent fma each instead of frames x n_ops of them (the
@@ -45,7 +76,7 @@ __device__ __forceinline__ double row_shr1(double v)
 // sign of zero), an add (a = 1, b = v) or a pass (a = 1, b = -0.0), bit for bit what __dmul_rn / __dadd_rn give; only sections update (m0, m1).
 __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 {
-	extern __shared__ __attribute__((aligned(16))) double buf[];      // the block: [frames][C]; behind it one word for the request
+	extern __shared__ __attribute__((aligned(16))) double buf[];      // the block: [frames][C]; behind it two words: the request, a failure flag
 	const int tid = threadIdx.x, nth = blockDim.x, C = p.C, n_ops = p.n_ops;
 	const int j = tid & 15, ch = tid >> 4;                             // op and channel of this lane
 	const bool mine = ch < C && j < n_ops;
@@ -61,48 +92,67 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 	}
 	const int Cin = p.Cin, rmx_n = p.remix_idx ? p.remix_max_n : 0;
 	double *stp = p.state + ((size_t) ch * n_ops + j) * 2;
+	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<ResidentUnit *>(p.mail_in), 0, (1 + RESIDENT_UNITS) * 16, 0x00020000);
+	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.mail_out, 0, RESIDENT_UNITS * 16, 0x00020000);
+	const int spec = p.spec_units < RES_SPEC ? p.spec_units : RES_SPEC;
 	unsigned done = p.done0;
 	unsigned long long t_last = wall_clock64();
 	const unsigned long long t_start = t_last;
+	if (tid == 0) req_w[1] = 0;
 	for (unsigned it = 0; it < p.max_polls; ++it) {
-		// thread 0 reads the doorbell and the clock and decides for everybody (the waves meet at barriers below: one decision, not one per wave)
+		// one burst: the control unit and the units of the block this lane expects (offsets beyond the mailbox read as zeros and do not decode)
+		const ResidentUnit cu = ld_unit(r_in, 0);
+		ResidentUnit pu[RES_SPEC];
+#pragma unroll
+		for (int k = 0; k < RES_SPEC; ++k) if (k < spec) pu[k] = ld_unit(r_in, 1 + tid + k * nth);
+		// thread 0 reads the clock and decides for everybody (the waves meet at barriers below: one decision, not one per wave)
 		if (tid == 0) {
-			unsigned long long rq0 = __hip_atomic_load(&p.ctl->req, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+			unsigned long long rq0 = unit_request(cu);
 			// nothing for a lifetime: leave.  And leave between two blocks once max_life_ticks have gone by however busy the host keeps the wave: another
 			// thread's hipDeviceSynchronize() (a second chain being built while this one plays) must not wait for the audio to stop
 			const unsigned long long now = wall_clock64();
 			if ((unsigned) (rq0 >> 32) == done && (unsigned) (rq0 & 0xffffffffu) != RESIDENT_STOP && (now - t_last > p.lifetime_ticks || now - t_start > p.max_life_ticks))
 				rq0 = ((unsigned long long) done << 32) | RESIDENT_STOP;
-			*req_w = rq0;
+			req_w[0] = rq0;
 		}
 		__syncthreads();
-		const unsigned long long rq = *req_w;
+		const unsigned long long rq = req_w[0];
 		__syncthreads();
 		const unsigned seq = (unsigned) (rq >> 32), frames = (unsigned) (rq & 0xffffffffu);
 		if (frames == RESIDENT_STOP) break;
-		if (seq == done) { __builtin_amdgcn_s_sleep(8); continue; }
-		// ---- a block: in (mapped host memory, [frames][C]) -> LDS, the ops, LDS -> out
+		if (seq == done) { __builtin_amdgcn_s_sleep(4); continue; }
+		// ---- a block: the mailbox -> LDS, the ops, LDS -> the host's mailbox
 		const int n = (int) frames * Cin, n_out = (int) frames * C;
+		if (n > RESIDENT_UNITS || n_out > RESIDENT_UNITS || n > p.buf_doubles) break;      // (a request the host never makes: leave rather than touch anything)
 		double *bout = buf + p.out_off;                              // the block's output: in place, or behind the input when a remix changes the channel count
 		double m0 = 0.0, m1 = 0.0;
-		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }      // (asked for in front of the block's trip over PCIe, not behind it)
-		// (host memory is a PCIe round trip away: sixteen bytes per lane and eight loads in flight before the first one is waited for -- one
-		// 8-byte load per turn, as this loop first read, was 80 of the 157 us of a 1024-frame block)
+		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }
 		{
-			typedef double res_d2 __attribute__((ext_vector_type(2)));
-			const res_d2 *src = reinterpret_cast<const res_d2 *>(p.in);
-			res_d2 *dst = reinterpret_cast<res_d2 *>(buf);
-			const int n2 = n >> 1;
-			for (int base = 0; base < n2; base += 8 * nth) {
-				res_d2 v[8];
+			// a unit that does not decode to this request has not arrived yet (or was not asked for with the control unit): read it again.  The host
+			// wrote every unit of the block before the control unit, so this is the exception; a bound all the same
+			bool lost = false;
+			auto settle = [&](ResidentUnit u, bool have, int e) -> double {
+				unsigned spins = 0;
+				while (!have || unit_request(u) != rq) {
+					if (++spins > RES_SPINS) { lost = true; break; }
+					u = ld_unit(r_in, 1 + e);
+					have = true;
+				}
+				return u.v;
+			};
 #pragma unroll
-				for (int k = 0; k < 8; ++k) { const int e = base + k * nth + tid; if (e < n2) v[k] = __builtin_nontemporal_load(src + e); }
+			for (int k = 0; k < RES_SPEC; ++k) { const int e = tid + k * nth; if (e < n) buf[e] = settle(pu[k], k < spec, e); }
+			for (int base = RES_SPEC * nth; base < n; base += 4 * nth) {
+				ResidentUnit v[4];
 #pragma unroll
-				for (int k = 0; k < 8; ++k) { const int e = base + k * nth + tid; if (e < n2) dst[e] = v[k]; }
+				for (int k = 0; k < 4; ++k) { const int e = base + k * nth + tid; if (e < n) v[k] = ld_unit(r_in, 1 + e); }
+#pragma unroll
+				for (int k = 0; k < 4; ++k) { const int e = base + k * nth + tid; if (e < n) buf[e] = settle(v[k], true, e); }
 			}
-			if ((n & 1) && tid == 0) buf[n - 1] = __builtin_nontemporal_load(p.in + n - 1);
+			if (lost) req_w[1] = 1;
 		}
 		__syncthreads();
+		if (req_w[1]) break;                                         // (the host times out and takes the block through a launch)
 		if (rmx_n) {
 			// a plain remix in front (the crossover shape): every output channel the sum of its input channels, in ascending order from 0.0, one rounding per
 			// sum (remix.c:39-101: bit-exact) -- a pass of its own over the block in LDS, into the region the cascade then works on in place
@@ -151,28 +201,19 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
 		}
 		__syncthreads();
-		{
-			typedef double res_d2 __attribute__((ext_vector_type(2)));
-			res_d2 *dst = reinterpret_cast<res_d2 *>(p.out);
-			const res_d2 *so = reinterpret_cast<const res_d2 *>(bout);
-			const int n2 = n_out >> 1;
-			for (int e = tid; e < n2; e += nth) __builtin_nontemporal_store(so[e], dst + e);
-			if ((n_out & 1) && tid == 0) __builtin_nontemporal_store(bout[n_out - 1], p.out + n_out - 1);
-		}
-		__threadfence_system();                                      // the block's output and states are out before the word that says so
-		__syncthreads();
+		for (int e = tid; e < n_out; e += nth) st_unit(r_out, e, bout[e], rq);
+		__syncthreads();                                             // (the block buffer is free for the next block)
 		done = seq;
-		if (tid == 0) __hip_atomic_store(&p.ctl->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		t_last = wall_clock64();
 	}
-	__threadfence_system();
+	__threadfence_system();                                          // states (and whatever output is still on its way) are out before the word that says so
 	__syncthreads();
 	if (tid == 0) __hip_atomic_store(&p.ctl->alive, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st)
 {
-	if (p.C < 1 || p.C > 64 || p.Cin < 1 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) p.buf_doubles * sizeof(double) + 16 > lds_bytes || (p.out_off & 1)) return false;
+	if (p.C < 1 || p.C > 64 || p.Cin < 1 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) p.buf_doubles * sizeof(double) + 16 > lds_bytes || !p.mail_in || !p.mail_out || (p.out_off & 1)) return false;
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident), lds_bytes);
 	const int waves = (p.C + 3) / 4;
 	hipLaunchKernelGGL(cascade_resident, dim3(1), dim3(64 * waves), lds_bytes, st, p);

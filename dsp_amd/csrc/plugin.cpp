@@ -87,9 +87,9 @@ static bool ensure_segment(struct effect *e, Node *n)
 		CascadeStage *casc = resident_on ? seg->pipe->sole_cascade() : nullptr;
 		RemixStage *rmx = nullptr;
 		if (resident_on && !casc && !seg->pipe->remix_then_cascade(&rmx, &casc)) { rmx = nullptr; casc = nullptr; }
-		if (casc && seg->mapped.bytes) {
+		if (casc) {
 			seg->resident.reset(new Resident);
-			if (!seg->resident->init(rmx, casc, seg->mapped)) seg->resident.reset();
+			if (!seg->resident->init(rmx, casc)) seg->resident.reset();
 		}
 	}
 	if (seg->members.size() > 1) log_msg(LL_VERBOSE, "%s: info: %zu effects fused into one device segment: %s", e->name, seg->members.size(), seg->pipe->plan().c_str());
@@ -201,12 +201,11 @@ Segment::~Segment() { resident.reset(); unpin_all(); }
 // ---- the resident small-block wave (see plugin.h) ----
 static inline double res_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 
-bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
+bool Resident::init(RemixStage *r, CascadeStage *c)
 {
-	if (!c || c->n_ops < 1 || c->n_ops > 16 || c->ch_in < 1 || c->ch_in > 64 || !mp.bytes) return false;
-	// (the doorbell and the stream of its own are made by the first block the wave takes -- open(): a segment driven with larger blocks never has them)
+	if (!c || c->n_ops < 1 || c->n_ops > 16 || c->ch_in < 1 || c->ch_in > 64) return false;
+	// (the mailboxes and the stream of its own are made by the first block the wave takes -- open(): a segment driven with larger blocks never has them)
 	memset(&rp, 0, sizeof(rp));
-	rp.in = mp.in; rp.out = mp.out;
 	rp.C = c->ch_in; rp.n_ops = c->n_ops;
 	rp.Cin = r ? r->ch_in : c->ch_in;
 	rp.remix_idx = r ? r->device_idx() : nullptr;
@@ -214,17 +213,16 @@ bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 	rp.ops = c->device_ops(); rp.state = c->device_state();
 	rp.lifetime_ticks = 300000ull;           // 3 ms of the 100 MHz clock: more than two periods of a 64-frame block at 48 kHz
 	rp.max_life_ticks = 2000000ull;          // 20 ms in all: what a hipDeviceSynchronize() on another thread waits at the very most while this segment plays
-	rp.max_polls = 1u << 18;                 // (a turn of the loop is a round trip to host memory: about a second at the very most)
-	const size_t block_bytes = std::min<size_t>(mp.bytes, (size_t) 64 << 10);
+	rp.max_polls = 1u << 18;                 // (a turn of the loop is a trip to the mailbox: about a second at the very most)
+	const size_t block_bytes = (size_t) 64 << 10;
 	rp.buf_doubles = (int) (block_bytes / sizeof(double));
 	// with a remix the output of a block lies behind its input (the channel count changes): one half of the buffer each
 	rp.out_off = r ? (rp.buf_doubles / 2) & ~1 : 0;
 	lds = block_bytes + 16;
 	sections = 1;
-	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of three dependent trips over PCIe (doorbell, block,
-	// completion): profiles/r05_ladspa_rate.txt -- 12.1 us at 64 frames, about 30 at 256; a launch of the ordinary, time-parallel kernels costs 24 ... 26 us
-	// whatever the block (18 ... 21 us for the two launches of a short remix + cascade segment): the wave takes blocks of up to 128 frames
-	// (2 -> 4 crossover: 12.3 us at 64 frames against 17.6, 20.2 against 20.1 at 128: profiles/r05_ladspa_rate.txt)
+	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of the trips of the block and of its output; a launch of the
+	// ordinary, time-parallel kernels costs 24 ... 26 us whatever the block (18 ... 21 us for the two launches of a short remix + cascade segment): the wave
+	// takes blocks of up to 128 frames (profiles/r06_ladspa_rate.txt)
 	max_work = 128;
 	ready = true;
 	return true;
@@ -232,42 +230,122 @@ bool Resident::init(RemixStage *r, CascadeStage *c, const MappedPair &mp)
 
 bool Resident::open()
 {
-	void *m = nullptr;
-	if (hipHostMalloc(&m, sizeof(ResidentCtl), hipHostMallocCoherent) != hipSuccess) { (void) hipGetLastError(); return false; }
-	ctl = static_cast<ResidentCtl *>(m);
+	void *c = nullptr, *mo = nullptr, *mi = nullptr;
+	const size_t in_bytes = (size_t) (1 + RESIDENT_UNITS) * sizeof(ResidentUnit), out_bytes = (size_t) RESIDENT_UNITS * sizeof(ResidentUnit);
+	auto fail = [&] {
+		(void) hipGetLastError();
+		if (mi) { if (in_device) (void) hipFree(mi); else (void) hipHostFree(mi); }
+		if (mo) (void) hipHostFree(mo);
+		if (c) (void) hipHostFree(c);
+		ctl = nullptr; mail_in = mail_out = nullptr; st = nullptr;
+		return false;
+	};
+	if (hipHostMalloc(&c, sizeof(ResidentCtl), hipHostMallocCoherent) != hipSuccess) { c = nullptr; return fail(); }
+	if (hipHostMalloc(&mo, out_bytes, hipHostMallocCoherent) != hipSuccess) { mo = nullptr; return fail(); }
+	memset(c, 0, sizeof(ResidentCtl));
+	memset(mo, 0, out_bytes);
+	// the request mailbox in device memory where the CPU can store into it (every byte of device memory visible through the BAR): uncached on the device side,
+	// write-combined from here.  DSP_AMD_PLUGIN_MAILBOX=host keeps it in page-locked host memory (what a device without a large BAR gets anyway)
+	static const bool want_device = [] { const char *v = getenv("DSP_AMD_PLUGIN_MAILBOX"); return !v || strcmp(v, "host") != 0; }();
+	int dev = 0, large_bar = 0;
+	(void) hipGetDevice(&dev);
+	if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) { (void) hipGetLastError(); large_bar = 0; }
+	in_device = false;
+	if (want_device && large_bar && hipExtMallocWithFlags(&mi, in_bytes, hipDeviceMallocUncached) == hipSuccess) {
+		// (trust, but verify once: what the CPU stores must be what the device holds)
+		in_device = true;
+		volatile unsigned long long *q = static_cast<volatile unsigned long long *>(mi);
+		for (size_t k = 0; k < in_bytes / 8; ++k) q[k] = 0;
+		q[2] = 0x0123456789abcdefull;
+		__builtin_ia32_sfence();
+		unsigned long long back = 0;
+		if (hipMemcpy(&back, static_cast<char *>(mi) + 16, 8, hipMemcpyDeviceToHost) != hipSuccess || back != 0x0123456789abcdefull) {
+			(void) hipGetLastError(); (void) hipFree(mi); mi = nullptr; in_device = false;
+		}
+		else { q[2] = 0; __builtin_ia32_sfence(); }
+	}
+	else (void) hipGetLastError();
+	if (!mi) {
+		if (hipHostMalloc(&mi, in_bytes, hipHostMallocCoherent) != hipSuccess) { mi = nullptr; return fail(); }
+		memset(mi, 0, in_bytes);
+	}
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail();
+	ctl = static_cast<ResidentCtl *>(c);
+	mail_in = static_cast<ResidentUnit *>(mi);
+	mail_out = static_cast<ResidentUnit *>(mo);
 	trace_mem("ctl+", ctl, sizeof(*ctl));
-	memset(ctl, 0, sizeof(*ctl));
-	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); trace_mem("ctl-", ctl, sizeof(*ctl)); (void) hipHostFree(ctl); ctl = nullptr; st = nullptr; return false; }
-	rp.ctl = ctl;
+	rp.ctl = ctl; rp.mail_in = mail_in; rp.mail_out = mail_out;
+	log_msg(LL_VERBOSE, "info: resident small-block path: request mailbox in %s memory", in_device ? "device" : "page-locked host");
 	return true;
 }
 
 bool Resident::launch()
 {
 	__atomic_store_n(&ctl->alive, 1u, __ATOMIC_RELEASE);
-	rp.done0 = __atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE);
 	if (!launch_cascade_resident(rp, lds, st)) { (void) hipGetLastError(); __atomic_store_n(&ctl->alive, 0u, __ATOMIC_RELEASE); return false; }
 	g_plugin_counters.wave_launches.fetch_add(1, std::memory_order_relaxed);
 	return true;
 }
 
-bool Resident::serve(ssize_t frames)
+static inline void res_store_unit(ResidentUnit *u, double v, unsigned long long rq)
+{
+	unsigned long long b;
+	memcpy(&b, &v, 8);
+	// (one 16-byte store: value and word travel together)
+	typedef long long res_v2 __attribute__((vector_size(16), aligned(16)));
+	const res_v2 q = { (long long) b, (long long) (rq ^ b) };
+	*reinterpret_cast<volatile res_v2 *>(u) = q;
+}
+
+bool Resident::serve(const double *in, ssize_t frames, double *out)
 {
 	if (!ctl && !open()) { off = true; g_plugin_counters.wave_off.fetch_add(1, std::memory_order_relaxed); return false; }
+	const unsigned served = seq;
 	++seq;
-	__atomic_store_n(&ctl->req, ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames, __ATOMIC_RELEASE);
+	const unsigned long long rq = ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames;
+	const size_t n = (size_t) frames * rp.Cin, n_out = (size_t) frames * rp.C;
+	// the block first, the control unit behind it (write-combined stores leave the core in any order: a fence in between)
+	for (size_t e = 0; e < n; ++e) res_store_unit(mail_in + 1 + e, in[e], rq);
+	if (in_device) __builtin_ia32_sfence();
+	res_store_unit(mail_in, 0.0, rq);
+	if (in_device) __builtin_ia32_sfence();
+	// (the units a lane asks for together with the control unit: what this block needed -- the next one is most likely the same size)
+	rp.spec_units = (int) std::min<size_t>(4, (n + 63) / 64);
+	dirty = true;
 	const double t0 = res_now_us();
-	for (long spins = 0;; ++spins) {
-		if (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) == seq) return true;
-		if (__atomic_load_n(&ctl->alive, __ATOMIC_ACQUIRE) == 0 && !launch()) break;       // no wave (the first block, or the last one left): start one -- it finds the request
+	size_t got = 0;
+	bool late = false;
+	for (long spins = 0; got < n_out; ++spins) {
+		// the reply: every unit decodes to this request once it has arrived
+		while (got < n_out) {
+			const volatile ResidentUnit *u = mail_out + got;
+			const unsigned long long w = __atomic_load_n(&u->w, __ATOMIC_ACQUIRE);
+			double v;
+			{ const unsigned long long bv = *reinterpret_cast<const volatile unsigned long long *>(&u->v); memcpy(&v, &bv, 8); if ((w ^ bv) != rq) break; }
+			out[got++] = v;
+		}
+		if (got == n_out) break;
+		if (__atomic_load_n(&ctl->alive, __ATOMIC_ACQUIRE) == 0) {
+			// no wave (the first block, or the last one left): start one -- it finds the request waiting.  done0 = the last request served
+			rp.done0 = served;
+			if (!launch()) { late = true; break; }
+		}
 		__builtin_ia32_pause();
-		if ((spins & 255) == 255 && res_now_us() - t0 > 20000.0) break;                   // 20 ms: something is wrong
+		if ((spins & 255) == 255 && res_now_us() - t0 > 20000.0) { late = true; break; }      // 20 ms: something is wrong
 	}
-	// not served in time: ask the wave to leave, wait for it (bounded by its own loop), and see whether it got the block done after all
+	if (!late) return true;
+	// not served in time: ask the wave to leave and wait for it (bounded by its own loop).  The block goes through a launch, on the states as the wave left
+	// them -- unless the wave wrote some of the reply: then it ran the block, and what is missing of the reply is on its way
 	stop();
-	if (__atomic_load_n(&ctl->done, __ATOMIC_ACQUIRE) == seq) return true;
-	// this block goes through a launch (the wave is gone, the states are where it left them).  One late block -- the wave's first launch queued behind
-	// another chain's kernels on a busy device -- is not a reason to give the path up for good: the third one is
+	dirty = false;
+	for (int tries = 0; got > 0 && got < n_out && tries < 1000; ++tries) {
+		const volatile ResidentUnit *u = mail_out + got;
+		const unsigned long long w = __atomic_load_n(&u->w, __ATOMIC_ACQUIRE), bv = *reinterpret_cast<const volatile unsigned long long *>(&u->v);
+		if ((w ^ bv) == rq) { double v; memcpy(&v, &bv, 8); out[got++] = v; }
+	}
+	if (got == n_out) return true;
+	// (a partial reply that never completes cannot happen once the wave has left behind its fence; if it did, the states have advanced: say so loudly)
+	if (got > 0) log_msg(LL_ERROR, "error: resident wave left a block half answered");
 	g_plugin_counters.wave_timeouts.fetch_add(1, std::memory_order_relaxed);
 	if (++timeouts >= 3) {
 		off = true;
@@ -281,7 +359,10 @@ void Resident::stop()
 {
 	if (!ctl) return;
 	if (__atomic_load_n(&ctl->alive, __ATOMIC_ACQUIRE)) {
-		__atomic_store_n(&ctl->req, ((unsigned long long) seq << 32) | (unsigned long long) RESIDENT_STOP, __ATOMIC_RELEASE);
+		// (a request of its own sequence number: a wave that has served block `seq` sees a new request, one that has not sees STOP in its place -- serve() only
+		// stops a wave whose block it then takes through a launch)
+		res_store_unit(mail_in, 0.0, ((unsigned long long) seq << 32) | (unsigned long long) RESIDENT_STOP);
+		if (in_device) __builtin_ia32_sfence();
 		(void) hipStreamSynchronize(st);
 		(void) hipGetLastError();
 	}
@@ -291,6 +372,8 @@ Resident::~Resident()
 {
 	stop();
 	if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+	if (mail_in) { if (in_device) (void) hipFree(mail_in); else (void) hipHostFree(mail_in); }
+	if (mail_out) (void) hipHostFree(mail_out);
 	if (ctl) { trace_mem("ctl-", ctl, sizeof(*ctl)); (void) hipHostFree(ctl); }
 }
 
@@ -323,15 +406,17 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 		log_msg(LL_VERBOSE, "%s: info: blocks of %zd frames x %d ch through %zu effects: below about 20000 channel-sample-effects per block a device round trip "
 		        "(about 25 us per block) is slower than the host's own loop; larger blocks (-b) or more channels per chain amortise it", e->name, total, sg.ch_in, sg.members.size());
 	}
+	if (sg.resident && sg.resident->takes(total) && sg.resident->serve(ibuf, total, dst)) {
+		// (one cascade, a block the resident wave finishes sooner than a launch: no launch at all -- the block goes from the host's buffer into the
+		// wave's mailbox and its output from the reply mailbox into the host's buffer)
+		g_plugin_counters.wave_blocks.fetch_add(1, std::memory_order_relaxed);
+		return dst;
+	}
+	// (the ordinary kernels are about to work on the cascade's states: a wave that has served blocks is asked to leave first -- it does not fence per block)
+	if (sg.resident) sg.resident->quiesce();
 	if (total <= sg.pipe_frames && sg.mapped.fits(in_bytes, out_bytes)) {
 		// small block: the kernels work on the mapped staging buffers themselves
 		memcpy(sg.mapped.in, ibuf, in_bytes);
-		if (sg.resident && sg.resident->takes(total) && sg.resident->serve(total)) {
-			// (one cascade, a block the resident wave finishes sooner than a launch: no launch at all)
-			memcpy(dst, sg.mapped.out, (size_t) total * sg.ch_out * sizeof(double));
-			g_plugin_counters.wave_blocks.fetch_add(1, std::memory_order_relaxed);
-			return dst;
-		}
 		g_plugin_counters.mapped_blocks.fetch_add(1, std::memory_order_relaxed);
 		const ssize_t f = sg.pipe->run(sg.mapped.in, total, sg.mapped.out, (ssize_t) (sg.mapped.bytes / (sg.ch_out * sizeof(double))), nullptr);
 		(void) sg.mapped.wait_block(nullptr);
@@ -387,6 +472,7 @@ static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1
 	Node *n = node_of(e);
 	if (!n || !n->seg || !n->seg->pipe) { *frames = -1; return buf1; }
 	Segment &sg = *n->seg;
+	if (sg.resident) sg.resident->quiesce();
 	const ssize_t want = std::min<ssize_t>(*frames, sg.pipe_frames);
 	const ssize_t f = sg.pipe->drain2(want, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 	if (f < 0) { *frames = -1; return buf1; }
@@ -404,6 +490,7 @@ static void plugin_reset(struct effect *e)
 	// stateless effects carry no reset callback (gain.c, remix.c, st2ms.c set none) and may head a segment: whichever
 	// member with state the host resets first clears the whole segment, the others find it clean
 	if (n && n->seg && n->seg->pipe && n->seg->touched) {
+		if (n->seg->resident) n->seg->resident->quiesce();
 		n->seg->pipe->reset(nullptr);
 		(void) hipStreamSynchronize(nullptr);
 		n->seg->touched = false;

@@ -15,24 +15,35 @@ constexpr unsigned NODE_MAGIC = 0x44535041u;   // "DSPA"
 // e->next when the first of them runs) compiled into ONE fused pipeline -- one H2D copy at the head, the whole
 // segment on the device (cascade fusion, LTI merges, convolvers feeding each other, exactly as in the batch API),
 // one D2H copy; the other members' run() hand the result through.  SURVEY.md section 7 step 4 / section 8(f).
-// Small blocks of a segment that is one cascade (the equaliser shape) through a wave that stays on the device for a few milliseconds and polls a
-// doorbell in host memory -- no launch per block (kernels_resident.hip).  The wave leaves by itself (clock, loop bound) or when asked
-// to; the next block starts another one.  Any failure switches the mechanism off for the segment: the ordinary path works on the same states.
+// Small blocks of a segment that is one cascade (the equaliser shape), or a plain remix in front of one, through a workgroup that stays on the device for a
+// few milliseconds and polls a mailbox -- no launch per block (kernels_resident.hip; the mailbox protocol: engine.h).  The wave leaves by itself (clock, loop
+// bound) or when asked to; the next block starts another one.  A block it does not serve in time goes through a launch (the third such block switches the
+// mechanism off for the segment).  The wave does not fence the states per block: whoever else is about to touch them calls quiesce() first.
 struct Resident {
-	ResidentCtl *ctl = nullptr;
+	ResidentCtl *ctl = nullptr;              // page-locked host memory: the wave's alive word
+	ResidentUnit *mail_in = nullptr;         // request mailbox: device memory the CPU stores into (large BAR), else page-locked host memory
+	ResidentUnit *mail_out = nullptr;        // reply mailbox: page-locked host memory
+	bool in_device = false;                  // mail_in is device memory (write-combined from here: fences around the control unit)
 	hipStream_t st = nullptr;
 	ResidentParams rp;
 	size_t lds = 0;
-	unsigned seq = 0;
+	unsigned seq = 0;                        // sequence number of the last request made
 	long max_work = 0;                       // frames x sections a block may have (beyond it the ordinary, parallel kernels are faster)
 	int sections = 1;
 	bool off = false;
+	bool dirty = false;                      // the wave has served blocks since it was last waited for: the states in device memory may still be on their way
 	int timeouts = 0;                        // blocks the wave did not serve in time (the third one switches the path off for the segment)
-	bool ready = false;                      // init() has accepted the segment; the doorbell and the stream come with the first small block (open())
-	bool init(class RemixStage *r, class CascadeStage *c, const MappedPair &mp);       // r: a plain remix in front of the cascade, or nullptr
-	bool takes(ssize_t frames) const { return !off && ready && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles; }
-	bool serve(ssize_t frames);              // the block is in the mapped input buffer; true: its output is in the mapped output buffer
-	void stop();
+	bool ready = false;                      // init() has accepted the segment; mailboxes and the stream come with the first small block (open())
+	bool init(class RemixStage *r, class CascadeStage *c);       // r: a plain remix in front of the cascade, or nullptr
+	bool takes(ssize_t frames) const
+	{
+		return !off && ready && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * std::max(rp.Cin, rp.C) <= (size_t) RESIDENT_UNITS
+		       && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles;
+	}
+	// the block at `in` ([frames][Cin]) through the wave into `out` ([frames][C]); false: not served (the caller takes the ordinary path, on the same states)
+	bool serve(const double *in, ssize_t frames, double *out);
+	void stop();                             // ask the wave to leave and wait for it
+	void quiesce() { if (dirty) { stop(); dirty = false; } }     // before anything else reads or writes the cascade's states
 	~Resident();
 private:
 	bool open();

@@ -79,3 +79,45 @@ def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
         assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
     else:
         assert rms(got - ref) < 1e-12, rms(got - ref)
+
+
+_SWITCH_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import dsp_amd
+from dsp_amd.lib import plugin_counters
+dsp_amd.load_library()
+from oracle_api import RefChain, rms
+chain = {chain!r}
+rng = np.random.Generator(np.random.PCG64(5))
+x = rng.uniform(-0.5, 0.5, size=(64 * 300, 2))
+def stream(variant):
+    r = RefChain(chain, 48000, 2, variant=variant)
+    y = np.concatenate([r.run(x[p:p + 64]) for p in range(0, x.shape[0], 64)])
+    r.close()
+    return y
+got, c, ref = stream("_gpu"), plugin_counters(), stream("")
+assert got.shape == ref.shape and rms(got - ref) < 1e-12, rms(got - ref)
+print("COUNTERS", c["wave_blocks"], c["mapped_blocks"], c["wave_timeouts"], c["wave_off"])
+"""
+
+
+@pytest.mark.skipif(not RefChain.available("_gpu"), reason="oracle/_ref/libdspref_gpu.so not present")
+@pytest.mark.parametrize("env,wave", [({"DSP_AMD_PLUGIN_MAILBOX": "host"}, True), ({"DSP_AMD_PLUGIN_RESIDENT": "0"}, False), ({}, True)])
+def test_the_mailbox_in_host_memory_and_the_path_without_a_wave(env, wave):
+    """the two ways round the default (the switches are read once per process: a process each): the request mailbox in page-locked host memory -- what a
+    device without a large BAR gets -- and no resident wave at all (a launch per block); both against the reference, and the counters say which ran"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _SWITCH_SCRIPT.format(root=root, tests=os.path.join(root, "tests"), chain="gain -3 " + BIQ)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DSP_AMD_LOGLEVEL="4", **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    wb, mb, to, off = [int(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("COUNTERS")][0].split()[1:]]
+    assert to == 0 and off == 0
+    if wave:
+        assert wb == 300 and mb == 0
+        assert ("request mailbox in page-locked host memory" if env else "request mailbox in device memory") in r.stderr, r.stderr[-1500:]
+    else:
+        assert wb == 0 and mb == 300
