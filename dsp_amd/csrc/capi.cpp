@@ -281,9 +281,9 @@ const char *dspamd_chain_effect_name(dspamd_chain *c, int i)
 int dspamd_plugin_counters(long long *out, int n)
 {
 	const PluginCounters &c = g_plugin_counters;
-	const long long v[7] = { c.wave_blocks.load(), c.mapped_blocks.load(), c.copied_blocks.load(), c.wave_launches.load(), c.wave_timeouts.load(), c.wave_off.load(), c.registrations.load() };
+	const long long v[6] = { c.wave_blocks.load(), c.mapped_blocks.load(), c.copied_blocks.load(), c.wave_launches.load(), c.wave_timeouts.load(), c.wave_off.load() };
 	int k = 0;
-	for (; k < n && k < 7; ++k) out[k] = v[k];
+	for (; k < n && k < 6; ++k) out[k] = v[k];
 	return k;
 }
 

@@ -96,107 +96,13 @@ static bool ensure_segment(struct effect *e, Node *n)
 	return true;
 }
 
-// true when [p, p + n) is registered (DMA-able).  A buffer is registered the fourth time in a row the host hands over the
-// same pointer in the same role; buffers that share pages (the reference's two block buffers are small neighbouring heap
-// allocations) are registered as ONE range, because a copy may not straddle registered and pageable memory; at most 4
-// ranges; any failure drops every registration and switches the mechanism off for this segment.
-static inline char *page_lo(const void *p) { return (char *) ((uintptr_t) p & ~(uintptr_t) 4095); }
-static inline char *page_hi(const void *p, size_t n) { return (char *) (((uintptr_t) p + n + 4095) & ~(uintptr_t) 4095); }
-
-void Segment::unpin_all()
-{
-	if (pins.empty()) return;
-	if (resident) resident->stop();          // (the device-wide wait would otherwise sit out the wave's lifetime)
-	(void) hipDeviceSynchronize();
-	for (const Pin &r : pins)
-		if (trace_mem("reg-", r.base, r.bytes), hipHostUnregister(r.base) != hipSuccess) {
-			trace_mem("reg-failed", r.base, r.bytes);
-			// (a range the host has unmapped in the meantime: nothing to undo, but worth a line -- see INTEGRATION.md, "host buffers")
-			log_msg(LL_VERBOSE, "info: host buffer %p could not be unregistered (%s)", (void *) r.base, hipGetErrorString(hipGetLastError()));
-		}
-	pins.clear();
-}
-
-void Segment::before_copy(const void *p, size_t n)
-{
-	if (pins.empty() || !p || n == 0) return;
-	char *lo = page_lo(p), *hi = page_hi(p, n);
-	for (const Pin &r : pins) {
-		const bool inside = lo >= r.base && hi <= r.base + r.bytes, apart = hi <= r.base || lo >= r.base + r.bytes;
-		if (!inside && !apart) { unpin_all(); pin_off = true; return; }
-	}
-}
-
-void Segment::unpin_role(int which)
-{
-	bool any = false;
-	for (const Pin &r : pins) if (r.roles & (1u << which)) any = true;
-	if (!any) return;
-	if (resident) resident->stop();
-	(void) hipDeviceSynchronize();
-	for (size_t i = 0; i < pins.size();) {
-		const Pin r = pins[i];
-		if (!(r.roles & (1u << which))) { ++i; continue; }
-		trace_mem("reg-", r.base, r.bytes);
-		if (hipHostUnregister(r.base) != hipSuccess) {
-			trace_mem("reg-failed", r.base, r.bytes);
-			log_msg(LL_VERBOSE, "info: host buffer %p could not be unregistered (%s)", (void *) r.base, hipGetErrorString(hipGetLastError()));
-		}
-		// (a range the other role shares is gone with it: that role counts its sightings again before it registers anything)
-		for (int o = 0; o < 2; ++o) if (o != which && (r.roles & (1u << o))) seen[o] = 0;
-		pins.erase(pins.begin() + i);
-	}
-}
-
-bool Segment::pinned(int which, const void *p, size_t n)
-{
-	// on by default since round 4 (DSP_AMD_PLUGIN_PIN=0: off).  Registering takes milliseconds once -- only blocks that do not fit the
-	// mapped staging buffers get here, i.e. not the 64 ... 1024-frame blocks of a real-time host -- and turns the two copies of a block
-	// into DMA: 10 % at the reference's 2048-frame blocks (scripts/exp_cli_rate.sh, where the host's own I/O dominates), 3x on
-	// buffers of several chunks (dspamd_chain_run-sized blocks: one thread's memcpy into staging was the limit there)
-	static const bool enabled = []() { const char *e = getenv("DSP_AMD_PLUGIN_PIN"); return e && atoi(e) != 0; }();      // (round 6: opt-in)
-	if (!enabled || pin_off || !p || n == 0) return false;
-	char *lo = page_lo(p), *hi = page_hi(p, n);
-	if (p != last_ptr[which]) {
-		// the host hands over another buffer in this role: the one before may be gone (the reference frees its block buffers on
-		// REALLOC_BUFS while a crossfading chain still holds this segment, effects_chain.c:1241-1274) -- a registration must not outlive
-		// the memory it pins, so this ROLE's ranges are dropped and its count starts again (the other role's buffer has not changed: a host that
-		// rotates one buffer and keeps the other does not pay a device-wide wait and a re-registration of the one it keeps on every block)
-		if (last_ptr[which]) unpin_role(which);
-		last_ptr[which] = p; seen[which] = 1;
-		return false;
-	}
-	for (Pin &r : pins) if (lo >= r.base && hi <= r.base + r.bytes) { r.roles |= 1u << which; return true; }
-	if (++seen[which] < 4) return false;
-	// grow over every registration this range touches
-	if (resident) resident->stop();
-	(void) hipDeviceSynchronize();
-	unsigned roles = 1u << which;
-	for (size_t i = 0; i < pins.size();) {
-		const Pin r = pins[i];
-		if (lo <= r.base + r.bytes && hi >= r.base) {
-			lo = std::min(lo, r.base); hi = std::max(hi, r.base + r.bytes);
-			roles |= r.roles;
-			trace_mem("reg-", r.base, r.bytes);
-			if (hipHostUnregister(r.base) != hipSuccess) { trace_mem("reg-failed", r.base, r.bytes); (void) hipGetLastError(); }
-			pins.erase(pins.begin() + i);
-		}
-		else ++i;
-	}
-	if (pins.size() >= 4 || hipHostRegister(lo, (size_t) (hi - lo), hipHostRegisterDefault) != hipSuccess) {
-		(void) hipGetLastError();
-		unpin_all();
-		pin_off = true;
-		return false;
-	}
-	pins.push_back(Pin{ lo, (size_t) (hi - lo), roles });
-	g_plugin_counters.registrations.fetch_add(1, std::memory_order_relaxed);
-	trace_mem("reg+", lo, (size_t) (hi - lo));
-	log_msg(LL_VERBOSE, "info: host buffer %p (%zu KiB) registered for DMA", (void *) lo, (size_t) (hi - lo) >> 10);
-	return true;
-}
-
-Segment::~Segment() { resident.reset(); unpin_all(); }
+// Host buffers are never registered with the HIP runtime (round 6).  Rounds 4 and 5 page-locked a block buffer the host kept handing over
+// (hipHostRegister after four sightings: DMA instead of the runtime's pageable-memory staging, 10 % at the reference's 2048-frame blocks).  That is
+// memory this library does not own -- the host may free it, the C library may trim or remap the heap under it -- and with the registration in the
+// process a LATER, unrelated pageable copy of the same process (a torch .cpu(), an upload from a std::vector) faulted with hipErrorIllegalAddress in 3 of
+// 13 one-process runs of the GPU suite; without it, in 0 of 32 (profiles/r06_ab_one_process_suite.txt, r06_one_process_runs.txt).
+// Blocks that do not fit the mapped staging buffers take pageable copies (one pipeline call) or this library's own page-locked double buffers (longer ones).
+Segment::~Segment() { resident.reset(); }
 
 // ---- the resident small-block wave (see plugin.h) ----
 static inline double res_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
@@ -425,11 +331,8 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 		return dst;
 	}
 	g_plugin_counters.copied_blocks.fetch_add(1, std::memory_order_relaxed);
-	// larger blocks: the host's own buffers once they are registered for DMA (they are after coming back four times), until then -- and
-	// for buffers that never come back -- this library's page-locked staging buffers when the block is several pipeline calls long
-	const bool reg_in = sg.pinned(0, ibuf, in_bytes);
-	const bool reg_out = (dst == ibuf) ? reg_in : sg.pinned(1, dst, out_bytes);
-	if (!(reg_in && reg_out)) {
+	// larger blocks: this library's page-locked staging buffers when the block is several pipeline calls long, else pageable copies
+	{
 		const ssize_t chunk = sg.pipe_frames;
 		// (one chunk alone gains nothing: the thread's two copies simply add to the call -- 1.45 against 1.24 ms at 4 MB -- so those keep the
 		// copy commands; from two chunks on the copies hide behind the GPU's work: 8 ch x 2^20 frames 168 -> 469 Msamples/s)
@@ -442,15 +345,12 @@ static sample_t *plugin_run(struct effect *e, ssize_t *frames, sample_t *ibuf, s
 			return dst;
 		}
 	}
-	sg.before_copy(ibuf, in_bytes);
-	sg.before_copy(dst, out_bytes);
 	while (done < total) {
 		const ssize_t nb = std::min<ssize_t>(total - done, sg.pipe_frames);
-		// (a copy that fails on a registered buffer: the registration is suspect -- dropped for good, later blocks use pageable copies / staging)
-		if (!hip_ok(hipMemcpyAsync(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice, nullptr), "H2D")) { if (reg_in) { sg.unpin_all(); sg.pin_off = true; } break; }
+		if (!hip_ok(hipMemcpyAsync(sg.d_in.p, ibuf + done * sg.ch_in, (size_t) nb * sg.ch_in * sizeof(double), hipMemcpyHostToDevice, nullptr), "H2D")) break;
 		const ssize_t f = sg.pipe->run(sg.d_in.as<double>(), nb, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 		if (f < 0) break;
-		if (f > 0 && !hip_ok(hipMemcpyAsync(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost, nullptr), "D2H")) { if (reg_out) { sg.unpin_all(); sg.pin_off = true; } break; }
+		if (f > 0 && !hip_ok(hipMemcpyAsync(dst + produced * sg.ch_out, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost, nullptr), "D2H")) break;
 		produced += f;
 		done += nb;
 	}
@@ -477,7 +377,6 @@ static sample_t *plugin_drain2(struct effect *e, ssize_t *frames, sample_t *buf1
 	const ssize_t f = sg.pipe->drain2(want, sg.d_out.as<double>(), sg.out_cap_frames, nullptr);
 	if (f < 0) { *frames = -1; return buf1; }
 	if (f > 0) {
-		sg.before_copy(buf2, (size_t) f * sg.ch_out * sizeof(double));
 		(void) hip_ok(hipMemcpy(buf2, sg.d_out.p, (size_t) f * sg.ch_out * sizeof(double), hipMemcpyDeviceToHost), "D2H");
 	}
 	*frames = f;

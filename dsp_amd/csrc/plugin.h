@@ -61,19 +61,8 @@ struct Segment {
 	MappedPair mapped;                       // staging for small blocks (engine.h)
 	std::unique_ptr<Resident> resident;      // ... and, for a segment that is one cascade, the wave that serves them without a launch
 	PinnedStage staged;                      // page-locked staging for larger ones (engine.h)
-	// Host buffers that keep coming back (the reference allocates its two block buffers once, dsp.c) are registered with the
-	// HIP runtime after a few sightings: the copies then run as DMA instead of through the runtime's pageable-memory staging.
-	struct Pin { char *base; size_t bytes; unsigned roles; };     // roles: bit 0 = the input buffer lies in it, bit 1 = the output buffer
-	std::vector<Pin> pins;
-	const void *last_ptr[2] = { nullptr, nullptr };
-	int seen[2] = { 0, 0 };
-	bool pin_off = false;
 	long calls = 0, small_calls = 0;         // run() calls so far / of those, blocks that a host loop would have finished sooner (the advisory below)
 	bool advised = false;
-	bool pinned(int which, const void *p, size_t n);     // which: 0 = input, 1 = output buffer of run()
-	void before_copy(const void *p, size_t n);           // a range half inside a registration cannot be copied: drop all of them
-	void unpin_all();
-	void unpin_role(int which);                          // the registrations role `which` lies in (a range both roles share goes too: the other role starts counting again)
 	~Segment();
 };
 
@@ -85,7 +74,6 @@ struct PluginCounters {
 	std::atomic<long long> wave_launches { 0 };      // resident kernels started
 	std::atomic<long long> wave_timeouts { 0 };      // blocks a wave did not serve in time (served by a launch instead)
 	std::atomic<long long> wave_off { 0 };           // segments whose resident path was switched off
-	std::atomic<long long> registrations { 0 };      // hipHostRegister calls that succeeded
 };
 extern PluginCounters g_plugin_counters;
 

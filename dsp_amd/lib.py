@@ -135,7 +135,7 @@ def load_library():
     return L
 
 
-PLUGIN_COUNTERS = ("wave_blocks", "mapped_blocks", "copied_blocks", "wave_launches", "wave_timeouts", "wave_off", "registrations")
+PLUGIN_COUNTERS = ("wave_blocks", "mapped_blocks", "copied_blocks", "wave_launches", "wave_timeouts", "wave_off")
 
 
 def plugin_counters():

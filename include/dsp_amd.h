@@ -150,7 +150,7 @@ int dspamd_batch_wire_fused(dspamd_batch *);
 /* How the plugin path (effect->run() on host buffers, effect.h:47) has served its blocks in this process, for tests and field reports:
  * out[0] blocks served by a resident wave (no launch: kernels_resident.hip), [1] small blocks through the mapped staging buffers and a launch,
  * [2] larger blocks (copies + launches), [3] resident kernels started, [4] blocks a wave did not serve in time, [5] segments whose resident
- * path was switched off, [6] host-buffer registrations made.  Returns the number of values written (<= n). */
+ * path was switched off.  Returns the number of values written (<= n). */
 int dspamd_plugin_counters(long long *out, int n);
 
 /* plain device copy kernel: measured HBM ceiling next to the 8 TB/s spec (bytes must be a multiple of 16) */

@@ -6,13 +6,13 @@ import numpy as np
 np.random.default_rng(1).uniform(-0.5, 0.5, size=(48000 * 600, 8)).astype('<f8').tofile('/dev/shm/in8.raw')
 PY
 for exe in dsp_ref dsp_gpu; do for b in 2048 65536; do
-  for pin in 1 0 m; do   # registered host buffers / pageable copies / mapped staging forced up to 256 KB (default: up to 32 KB)
-  [ $exe = dsp_ref ] && [ $pin != 1 ] && continue
-  kb=0; [ $pin = m ] && kb=256
+  for pin in d 0 m; do   # the default (mapped staging up to 32 KB, else pageable copies) / pageable copies only / mapped staging forced up to 256 KB
+  [ $exe = dsp_ref ] && [ $pin != d ] && continue
+  kb=32; [ $pin = 0 ] && kb=0; [ $pin = m ] && kb=256
   s=$(date +%s.%N)
-  DSP_AMD_PLUGIN_PIN=$pin DSP_AMD_PLUGIN_MAPPED_KB=$kb oracle/_ref/$exe -q -b $b -t pcm -e double -r 48k -c 8 /dev/shm/in8.raw -o -t null null $B10
+  DSP_AMD_PLUGIN_MAPPED_KB=$kb oracle/_ref/$exe -q -b $b -t pcm -e double -r 48k -c 8 /dev/shm/in8.raw -o -t null null $B10
   e=$(date +%s.%N)
-  python -c "print('$exe block $b pin $pin: %.2f s -> %.0f Msamples/s' % ($e - $s, 48000 * 600 * 8 / ($e - $s) / 1e6))"
+  python -c "print('$exe block $b staging $pin: %.2f s -> %.0f Msamples/s' % ($e - $s, 48000 * 600 * 8 / ($e - $s) / 1e6))"
   done
 done; done
 rm -f /dev/shm/in8.raw

@@ -100,19 +100,19 @@ def test_plot_coefficients_identical():
     assert "H0_1(w)=" in a and a == b
 
 
-def test_registered_host_buffers(tmp_path):
-    # DSP_AMD_PLUGIN_PIN=1: the host's block buffers are registered with the HIP runtime after a few blocks (the reference's
-    # two buffers share pages: one union range) -- in place, out of place with a rate change, and a drain at the end
+def test_host_buffers_through_the_copy_path(tmp_path):
+    # no mapped staging: every block of the unmodified CLI goes through copy commands on the host's own (pageable, never registered: round 6) block
+    # buffers -- in place, out of place with a rate change, and a drain at the end
     rng = np.random.Generator(np.random.PCG64(79))
     x = rng.uniform(-0.3, 0.3, size=(40000, 2))
     xin = os.path.join(str(tmp_path), "in.raw"); x.astype("<f8").tofile(xin)
-    env = dict(os.environ, DSP_AMD_PLUGIN_PIN="1", DSP_AMD_PLUGIN_MAPPED_KB="0", DSP_AMD_LOGLEVEL="4")   # (no mapped staging: the copy path)
+    env = dict(os.environ, DSP_AMD_PLUGIN_MAPPED_KB="0", DSP_AMD_LOGLEVEL="4")
     for chain, tol in ((f"gain -3 {BIQ}", 1e-12), ("hilbert -p 1023 :1 gain -2 : resample 44.1k", 1e-11)):
         ro, go = os.path.join(str(tmp_path), "r.raw"), os.path.join(str(tmp_path), "g.raw")
         args = ["-q", "-t", "pcm", "-e", "double", "-r", "48k", "-c", "2", xin, "-o", "-t", "pcm", "-e", "double"]
         run_cli(REF, args + [ro] + chain.split())
         r = run_cli(GPU, args + [go] + chain.split(), env=env)
-        assert "registered for DMA" in r.stderr, r.stderr[-800:]
+        assert "registered for DMA" not in r.stderr
         ref, gpu = np.fromfile(ro).reshape(-1, 2), np.fromfile(go).reshape(-1, 2)
         assert ref.shape == gpu.shape, (chain, ref.shape, gpu.shape)
         assert rms(ref - gpu) < tol, (chain, rms(ref - gpu))
