@@ -100,11 +100,11 @@ Profiler::~Profiler()
 	for (Rec &r : recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
 }
 
-static const size_t CANARY = 4096, DEVBUF_SLACK = (size_t) 64 << 10;     // (64 KB: one 4096-point row of a transform)
+static const size_t CANARY = 4096, GUARD_SLACK = (size_t) 64 << 10;      // (64 KB of poison behind a buffer in mode 5: one 4096-point row of a transform)
 // DSP_AMD_GUARD (debugging, read once): 3 = a page of a pattern on both sides of every device buffer, looked at when the buffer goes (writes outside a
 // buffer, found where they land); 5 = every buffer that is not asked to be zero, and the slack behind every buffer, filled with 0xFF bytes (a NaN in every
-// double and float): a kernel that USES memory nobody has written -- or what lies behind a buffer -- shows up as a NaN in a parity test, whatever the
-// allocator happened to leave there.  (Modes 1 / 2 / 4 of round 5, buffers in hipMemCreate mappings of their own, are gone: memory mapped that way gave
+// double and float; the slack: 64 KB that only this mode allocates): a kernel that USES memory nobody has written -- or what lies behind a buffer -- shows
+// up as a NaN in a parity test, whatever the allocator happened to leave there.  (Modes 1 / 2 / 4 of round 5, buffers in hipMemCreate mappings of their own, are gone: memory mapped that way gave
 // wrong values in large-buffer tests whatever the placement, so they said nothing about over-reads.)
 static int guard_mode() { static const int m = [] { const char *e = getenv("DSP_AMD_GUARD"); return e ? atoi(e) : 0; }(); return m; }
 
@@ -119,11 +119,13 @@ bool DevBuf::alloc(size_t n, bool zero)
 		}
 		else (void) hipGetLastError();
 	}
-	// (64 KB of slack behind every buffer, as a defence: DESIGN.md section 5)
-	if (!p && !hip_ok(hipMalloc(&p, n + DEVBUF_SLACK), "hipMalloc")) { p = nullptr; return false; }
+	// (round 5 put 64 KB of slack behind every buffer as a defence against an over-read nobody had found; the fault it was meant for was not an over-read
+	// -- DESIGN.md section 5 -- and the slack is gone: a buffer is what was asked for, and the descriptors the kernels address it through say so)
+	const size_t slack = (guard_mode() == 5) ? GUARD_SLACK : 0;
+	if (!p && !hip_ok(hipMalloc(&p, n + slack), "hipMalloc")) { p = nullptr; return false; }
 	bytes = n;
 	trace_mem("dev+", p, n);
-	if (guard_mode() == 5 && !canary && !hip_ok(hipMemset(p, 0xFF, n + DEVBUF_SLACK), "hipMemset")) return false;
+	if (guard_mode() == 5 && !canary && !hip_ok(hipMemset(p, 0xFF, n + slack), "hipMemset")) return false;
 	if (zero && !hip_ok(hipMemset(p, 0, n), "hipMemset")) return false;
 	return true;
 }

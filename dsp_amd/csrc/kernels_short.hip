@@ -18,6 +18,8 @@
 // per CU (139 KB of LDS).  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 #include "kparams.h"
 #include "fft_params.h"
 #include "pcm_device.h"
@@ -31,9 +33,11 @@ typedef double real;
 #undef FFT_CORE_NO_LAUNCHERS
 #undef FFT_F32
 
-constexpr int SH_LOG2N = 13, SH_N = 1 << SH_LOG2N, SH_P = SH_N / 16, SH_THREADS = SH_P;
+constexpr int SH_LOG2N = 13, SH_N = 1 << SH_LOG2N, SH_P = SH_N / 16;
 constexpr int SH_T256 = 272, SH_TLO = 68, SH_THI = SH_N / 64;
-constexpr size_t SH_LDS = ((size_t) SH_N + SH_T256 + SH_TLO + SH_THI) * sizeof(cplx);
+// VT = points sets per thread: 1 -> 512 threads, the exchanges carry complex points (128 KB: one workgroup per CU); 2 -> 256 threads with two sets each,
+// the exchanges carry the real and the imaginary parts one after the other through a buffer of doubles (64 KB: TWO independent workgroups per CU)
+template <int VT> constexpr size_t sh_lds() { return (size_t) SH_N * (VT == 1 ? sizeof(cplx) : sizeof(double)) + ((size_t) SH_T256 + SH_TLO + SH_THI) * sizeof(cplx); }
 
 template <bool INV, class Tw>
 __device__ __forceinline__ void short_fft(cplx (&v)[16], int j, cplx *lds, const RowMap &map, const Tw &tw)
@@ -57,30 +61,77 @@ __device__ __forceinline__ void short_fft(cplx (&v)[16], int j, cplx *lds, const
 	pass16<SH_LOG2N, 2, 4096, INV, true>(v, j, lds, map, tw);
 }
 
+// The same transform for a thread that holds TWO sets of 16 points (the points of "virtual threads" j and j + 256), with every exchange done in halves: the
+// real parts through a buffer of 8192 doubles, then the imaginary parts through the same buffer.  Twice the barriers and LDS instructions for the same
+// bytes -- but half the LDS, so a second, independent workgroup fits the CU and issues its butterflies while this one waits at a barrier or for the LDS
+// (round 5's form keeps all eight waves of a CU in lock-step: 7.5 us of fp64 issue + 6 us of exchanges per block, one after the other).
+// Slots: an element is 8 bytes = 2 banks of 64; a ds_read / ds_write_b64 is served in two groups of 32 lanes, conflict-free when the 32 slots differ
+// mod 32: slot = pos ^ ((pos >> 4) & 31) makes them for both access shapes of every pass (stores 16 j + r, (j - k) 16 + k + NS r; gathers j + P m).
+__device__ __forceinline__ int sh_slotd(int pos) { return pos ^ ((pos >> 4) & 31); }
+template <int NS> __device__ __forceinline__ int sh_out_pos(int jv, int r) { const int k = jv & (NS - 1); return (jv - k) * 16 + k + NS * r; }
+
+template <bool INV, class Tw>
+__device__ __forceinline__ void short_fft2(cplx (&va)[16], cplx (&vb)[16], int j, double *lds, const Tw &tw)
+{
+	constexpr int P = SH_P, H = SH_P / 2;
+	const RowMap nomap{ 0 };
+	auto exchange = [&](auto ns_tag, bool last) {
+		constexpr int NS = decltype(ns_tag)::value;
+		asm volatile("" : "+v"(j));
+		// butterflies in place: v[r] = output r of the thread's radix-16 butterfly (pass16 with LAST leaves them in v)
+		pass16<SH_LOG2N, 16, NS, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
+		pass16<SH_LOG2N, 16, NS, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
+#pragma unroll
+		for (int r = 0; r < 16; ++r) { lds[sh_slotd(sh_out_pos<NS>(j, r))] = va[r].x; lds[sh_slotd(sh_out_pos<NS>(j + H, r))] = vb[r].x; }
+		lds_barrier();
+		double xa[16], xb[16];
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { xa[m] = lds[sh_slotd(j + P * m)]; xb[m] = lds[sh_slotd(j + H + P * m)]; }
+		lds_barrier();
+#pragma unroll
+		for (int r = 0; r < 16; ++r) { lds[sh_slotd(sh_out_pos<NS>(j, r))] = va[r].y; lds[sh_slotd(sh_out_pos<NS>(j + H, r))] = vb[r].y; }
+		lds_barrier();
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { va[m] = mkc(xa[m], lds[sh_slotd(j + P * m)]); vb[m] = mkc(xb[m], lds[sh_slotd(j + H + P * m)]); }
+		if (!last) lds_barrier();            // (behind the last exchange the caller's own barrier stands in front of the next store)
+	};
+	exchange(std::integral_constant<int, 1>{}, false);
+	exchange(std::integral_constant<int, 16>{}, false);
+	exchange(std::integral_constant<int, 256>{}, true);
+	asm volatile("" : "+v"(j));
+	pass16<SH_LOG2N, 2, 4096, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
+	pass16<SH_LOG2N, 2, 4096, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
+}
+
 // (every address is a buffer descriptor + a 32-bit offset: the host checks that rings, slabs and outputs stay below 2 GB per stream / pair -- sixteen
 // 64-bit address pairs per direction do not fit beside the 64 registers of the window and the 64 of the filter row)
 typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
 // BS: bytes per sample of the slab in direct mode (8: fp64; 4: s24 / s32 / float; 2: s16 -- read_buf_<fmt> of pcm_device.h in the loads)
-template <int BS>
-__global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
+template <int BS, int VT>
+__global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
 {
-	constexpr int N = SH_N, P = SH_P;
+	constexpr int N = SH_N, P = SH_P, NTH = SH_P / VT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *data = reinterpret_cast<cplx *>(smem_raw);
-	cplx *t256 = data + N, *tlo = t256 + SH_T256, *thi = tlo + SH_TLO;
+	cplx *data = reinterpret_cast<cplx *>(smem_raw);                     // VT = 1: the exchange row of complex points
+	double *datad = reinterpret_cast<double *>(smem_raw);                // VT = 2: ... of doubles
+	cplx *t256 = reinterpret_cast<cplx *>(smem_raw + (size_t) N * (VT == 1 ? sizeof(cplx) : sizeof(double))), *tlo = t256 + SH_T256, *thi = tlo + SH_TLO;
 	int j = threadIdx.x;
 	const long pair = blockIdx.x;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long b0 = (long) blockIdx.y * p.blocks_per_wg, b1 = (b0 + p.blocks_per_wg < n_blocks) ? b0 + p.blocks_per_wg : n_blocks;
 	if (b0 >= b1) return;
-	if (j < 256) t256[twpad(j)] = TAB(p.tw)[j * (N / 256)];
-	else if (j < 256 + 64) tlo[twpad(j - 256)] = TAB(p.tw)[j - 256];
-	else if (j < 256 + 64 + SH_THI) thi[j - 320] = TAB(p.tw)[(j - 320) * 64];
-	cplx h[16];
-	if (!p.Hout) {
-		const cplx *H = TAB(p.H) + (long) p.pair_h[pair] * N + j;
+	for (int e = j; e < 256 + 64 + SH_THI; e += NTH) {
+		if (e < 256) t256[twpad(e)] = TAB(p.tw)[e * (N / 256)];
+		else if (e < 256 + 64) tlo[twpad(e - 256)] = TAB(p.tw)[e - 256];
+		else thi[e - 320] = TAB(p.tw)[(e - 320) * 64];
+	}
+	const cplx *Hrow = p.Hout ? nullptr : TAB(p.H) + (long) p.pair_h[pair] * N;
+	cplx h[VT == 1 ? 16 : 1];
+	if constexpr (VT == 1) {
+		if (!p.Hout) {
 #pragma unroll
-		for (int m = 0; m < 16; ++m) h[m] = H[P * m];
+			for (int m = 0; m < 16; ++m) h[m] = Hrow[j + P * m];
+		}
 	}
 	lds_barrier();                                                       // tables visible
 	const TwRow<N> tw{ t256, tlo, thi };
@@ -118,30 +169,58 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 		const int n_slab = !p.slab ? N : (d_slab <= 0 ? 0 : (d_slab < N ? (int) d_slab : N));
 		const int n_file = (d_file <= first_n) ? first_n : (d_file < N ? (int) d_file : N);
 		const int so = (int) (-d_slab * fbi);                        // byte offset of element 0 in the stream's slab (negative while it lies in older calls)
-		cplx v[16];
+		cplx v[VT][16];
 		asm volatile("" : "+v"(j));                                  // (addresses are recomputed per block: kept across blocks they are 40 registers nobody has)
 #pragma unroll
-		for (int m = 0; m < 16; ++m) {
-			const int n = j + P * m;
-			if (n >= valid) v[m] = mkc(0.0, 0.0);
-			else if (n >= n_slab) {
-				v[m] = slab_ld(so + n * fbi);
-				if (n >= n_file) buf_stc(v[m], r_ring, ((r0 + n) & mask) * 16);
+		for (int t = 0; t < VT; ++t) {
+			const int jv = j + NTH * t;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) {
+				const int n = jv + P * m;
+				if (n >= valid) v[t][m] = mkc(0.0, 0.0);
+				else if (n >= n_slab) {
+					v[t][m] = slab_ld(so + n * fbi);
+					if (n >= n_file) buf_stc(v[t][m], r_ring, ((r0 + n) & mask) * 16);
+				}
+				else v[t][m] = buf_ldc(r_ring, ((r0 + n) & mask) * 16, 0);
 			}
-			else v[m] = buf_ldc(r_ring, ((r0 + n) & mask) * 16, 0);
 		}
 		if (b > b0) lds_barrier();                                   // the previous block's last gather is done
-		short_fft<false>(v, j, data, map, tw);
+		if constexpr (VT == 1) short_fft<false>(v[0], j, data, map, tw);
+		else short_fft2<false>(v[0], v[VT - 1], j, datad, tw);
 		if (p.Hout) {
-			cplx *Ho = reinterpret_cast<cplx *>(p.Hout) + pair * N + j;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) Ho[P * m] = mkc(v[m].x * p.h_scale, v[m].y * p.h_scale);
+			for (int t = 0; t < VT; ++t) {
+				cplx *Ho = reinterpret_cast<cplx *>(p.Hout) + pair * N + j + NTH * t;
+#pragma unroll
+				for (int m = 0; m < 16; ++m) Ho[P * m] = mkc(v[t][m].x * p.h_scale, v[t][m].y * p.h_scale);
+			}
 			return;
 		}
+		if constexpr (VT == 1) {
 #pragma unroll
-		for (int m = 0; m < 16; ++m) { v[m] = cmul(v[m], h[m]); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+			for (int m = 0; m < 16; ++m) { v[0][m] = cmul(v[0][m], h[m]); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+		}
+		else {
+			// (no room for the filter row beside two sets of points: it comes from L2 where it is used -- the same 128 KB for every pair of a filter;
+			// asked for HERE, from an index the compiler cannot see through: hoisted above the forward transform the loads are 32 spilled registers)
+			int jh = j;
+			asm volatile("" : "+v"(jh));
+#pragma unroll
+			for (int t = 0; t < VT; ++t)
+#pragma unroll
+				for (int g = 0; g < 2; ++g) {
+					cplx hh[8];
+#pragma unroll
+					for (int m = 0; m < 8; ++m) hh[m] = Hrow[jh + NTH * t + P * (8 * g + m)];
+#pragma unroll
+					for (int m = 0; m < 8; ++m) v[t][8 * g + m] = cmul(v[t][8 * g + m], hh[m]);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+		}
 		lds_barrier();                                               // every gather of the forward transform is done
-		short_fft<true>(v, j, data, map, tw);
+		if constexpr (VT == 1) short_fft<true>(v[0], j, data, map, tw);
+		else short_fft2<true>(v[0], v[VT - 1], j, datad, tw);
 		// window sample first_n + f -> output frame mo0 + f, for f in [f_lo, f_hi)
 		const long mo0 = q_blk - p.k_origin;
 		const int f_lo = (mo0 >= 0) ? 0 : (-mo0 < in_count ? (int) -mo0 : in_count);
@@ -158,60 +237,69 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 			const WordFormat wf_sink = word_format(p.sink.fmt);
 			char *wout = reinterpret_cast<char *>(p.out) + (size_t) s * p.out_stride_frames * p.C * bs;
 			const bool wpair = (chb == cha + 1) && ((cha & 1) == 0) && ((p.C & 1) == 0) && ((((size_t) wout) & 15) == 0);
-			int m_first = 16;
-#pragma unroll
-			for (int m = 15; m >= 0; --m) { const int f = j + P * m - first_n; if (f >= f_lo && f < f_hi) m_first = m; }
-			uint32_t ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0, j0 = 1, j1 = 1;
-			if (dither && m_first < 16) {
-				const long mo = mo0 + (j + P * m_first - first_n);
-				const uint64_t na = (uint64_t) (p.sink.samples_before + mo * p.C + (cha >= 0 ? cha : 0)) + 1;
-				const uint64_t nb = (uint64_t) (p.sink.samples_before + mo * p.C + (chb >= 0 ? chb : 0)) + 1;
-				ua0 = pm_pow<0>(na); ua1 = pm_pow<1>(na);
-				if (chb == cha + 1) { ub0 = pm_mul(ua0, PM_A0); ub1 = pm_mul(ua1, PM_A1); }
-				else { ub0 = pm_pow<0>(nb); ub1 = pm_pow<1>(nb); }
-				j0 = pm_pow<0>((uint64_t) P * p.C); j1 = pm_pow<1>((uint64_t) P * p.C);
-			}
 			double peak = 0.0;
 			unsigned long long clipped = 0;
+			// (a lambda called once per set: as a loop over the sets the body is too large for the unroller, and a rolled loop indexes v by a variable)
+			auto sink_set = [&](cplx (&vv)[16], const int jv) {
+				int m_first = 16;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) {
-				const int f = j + P * m - first_n;
-				if (f < f_lo || f >= f_hi) continue;
-				const long mo = mo0 + f;
-				double ya = v[m].x, yb = v[m].y;
-				if (p.round_f32) { ya = (double) (float) ya; yb = (double) (float) yb; }
-				if (cha >= 0) ya = sink_sample(ya, dither, ua0, ua1, p.sink.dither_mult, peak, clipped);
-				if (chb >= 0) yb = sink_sample(yb, dither, ub0, ub1, p.sink.dither_mult, peak, clipped);
-				if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
-				if (wpair) {
-					char *dst = wout + (mo * p.C + cha) * bs;
-					if (bs == 8) *reinterpret_cast<double2 *>(dst) = make_double2(ya, yb);
-					else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, wf_sink), pcm_to_word(yb, wf_sink));
-					else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+				for (int m = 15; m >= 0; --m) { const int f = jv + P * m - first_n; if (f >= f_lo && f < f_hi) m_first = m; }
+				uint32_t ua0 = 0, ua1 = 0, ub0 = 0, ub1 = 0, j0 = 1, j1 = 1;
+				if (dither && m_first < 16) {
+					const long mo = mo0 + (jv + P * m_first - first_n);
+					const uint64_t na = (uint64_t) (p.sink.samples_before + mo * p.C + (cha >= 0 ? cha : 0)) + 1;
+					const uint64_t nb = (uint64_t) (p.sink.samples_before + mo * p.C + (chb >= 0 ? chb : 0)) + 1;
+					ua0 = pm_pow<0>(na); ua1 = pm_pow<1>(na);
+					if (chb == cha + 1) { ub0 = pm_mul(ua0, PM_A0); ub1 = pm_mul(ua1, PM_A1); }
+					else { ub0 = pm_pow<0>(nb); ub1 = pm_pow<1>(nb); }
+					j0 = pm_pow<0>((uint64_t) P * p.C); j1 = pm_pow<1>((uint64_t) P * p.C);
 				}
-				else {
-					if (cha >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + cha, ya);
-					if (chb >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + chb, yb);
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					const int f = jv + P * m - first_n;
+					if (f < f_lo || f >= f_hi) continue;
+					const long mo = mo0 + f;
+					double ya = vv[m].x, yb = vv[m].y;
+					if (p.round_f32) { ya = (double) (float) ya; yb = (double) (float) yb; }
+					if (cha >= 0) ya = sink_sample(ya, dither, ua0, ua1, p.sink.dither_mult, peak, clipped);
+					if (chb >= 0) yb = sink_sample(yb, dither, ub0, ub1, p.sink.dither_mult, peak, clipped);
+					if (dither) { ua0 = pm_mul(ua0, j0); ua1 = pm_mul(ua1, j1); ub0 = pm_mul(ub0, j0); ub1 = pm_mul(ub1, j1); }
+					if (wpair) {
+						char *dst = wout + (mo * p.C + cha) * bs;
+						if (bs == 8) *reinterpret_cast<double2 *>(dst) = make_double2(ya, yb);
+						else if (bs == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(pcm_to_word(ya, wf_sink), pcm_to_word(yb, wf_sink));
+						else *reinterpret_cast<uint32_t *>(dst) = pcm_to_s16(ya) | (pcm_to_s16(yb) << 16);
+					}
+					else {
+						if (cha >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + cha, ya);
+						if (chb >= 0) pcm_store(wout, p.sink.fmt, mo * p.C + chb, yb);
+					}
 				}
-			}
+			};
+			sink_set(v[0], j);
+			if constexpr (VT == 2) sink_set(v[VT - 1], j + NTH);
 			if (p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
 			continue;
 		}
 #pragma unroll
-		for (int m = 0; m < 16; ++m) {
-			const int f = j + P * m - first_n;
-			if (f < f_lo || f >= f_hi) continue;
-			cplx y = v[m];
-			if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
-			if (p.ring_out) {
-				if (p.ring_out_round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
-				if (chb < 0) y.y = 0.0;
-				buf_stc(y, r_rout, ((rp0 + f) & omask) * 16);
-			}
-			else if (wide) buf_stc(y, r_out, ob + f * fb);
-			else {
-				if (cha >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.x), r_out, ob + f * fb, 0, 0);
-				if (chb >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.y), r_out, ob2 + f * fb, 0, 0);
+		for (int t = 0; t < VT; ++t) {
+			const int jv = j + NTH * t;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) {
+				const int f = jv + P * m - first_n;
+				if (f < f_lo || f >= f_hi) continue;
+				cplx y = v[t][m];
+				if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+				if (p.ring_out) {
+					if (p.ring_out_round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+					if (chb < 0) y.y = 0.0;
+					buf_stc(y, r_rout, ((rp0 + f) & omask) * 16);
+				}
+				else if (wide) buf_stc(y, r_out, ob + f * fb);
+				else {
+					if (cha >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.x), r_out, ob + f * fb, 0, 0);
+					if (chb >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.y), r_out, ob2 + f * fb, 0, 0);
+				}
 			}
 		}
 	}
@@ -219,16 +307,23 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 }  // namespace psh
 
+template <int BS, int VT> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
+{
+	constexpr size_t LDS = psh::sh_lds<VT>();
+	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<BS, VT>), LDS);
+	hipLaunchKernelGGL((psh::conv_short<BS, VT>), grid, dim3(psh::SH_P / VT), LDS, st, p);
+}
+
 void launch_conv_short(const ShortParams &p, hipStream_t st)
 {
 	if (p.N != psh::SH_N || p.n_pairs < 1 || p.n_in < 1) return;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
-	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges), block(psh::SH_THREADS);
+	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges);
 	const int bs = (!p.slab || p.slab_fmt == PCM_DOUBLE) ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
-	if (bs == 8) { grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<8>), psh::SH_LDS); hipLaunchKernelGGL(psh::conv_short<8>, grid, block, psh::SH_LDS, st, p); }
-	else if (bs == 4) { grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<4>), psh::SH_LDS); hipLaunchKernelGGL(psh::conv_short<4>, grid, block, psh::SH_LDS, st, p); }
-	else { grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<2>), psh::SH_LDS); hipLaunchKernelGGL(psh::conv_short<2>, grid, block, psh::SH_LDS, st, p); }
+	static const int vt = [] { const char *e = getenv("DSP_AMD_SHORT_VT"); return e ? atoi(e) : 1; }();       // (A/B while round 6 measures the two forms)
+	if (vt == 2) { if (bs == 8) launch_short_t<8, 2>(p, grid, st); else if (bs == 4) launch_short_t<4, 2>(p, grid, st); else launch_short_t<2, 2>(p, grid, st); }
+	else { if (bs == 8) launch_short_t<8, 1>(p, grid, st); else if (bs == 4) launch_short_t<4, 1>(p, grid, st); else launch_short_t<2, 1>(p, grid, st); }
 }
 
 }  // namespace dspamd

@@ -1,10 +1,10 @@
 """Test configuration.
 
-GPU test modules run ONE PROCESS EACH (round 5): `pytest -m gpu` hands every module's selected tests to a child pytest and replays the child's reports,
-so a module starts on a fresh HIP context and a fresh heap, and a fault in one module cannot take the others' results with it.  Why: DESIGN.md section 5,
-"the memory fault late in a long test process" -- three of seven whole-suite runs in one process ended in a GPU memory fault between 850 and 900 tests in,
-in a different conv test each time; no module has ever shown it in a process of its own (about sixty module runs), and its cause is not found.
-DSP_AMD_TESTS_ONE_PROCESS=1 runs everything in the calling process as before (scripts/r05_hunt_suite.sh does, to look for the fault)."""
+`pytest -m gpu` runs in ONE process again (round 6): the fault that made round 5 give every GPU test module a process of its own is found and gone
+(host-buffer registrations, DESIGN.md section 5: 0 faults in 32 one-process runs of the suite without them, 3 in 13 with them), and
+tests/test_gpu_soak.py builds and destroys 500 chains in the suite's own process.  The mechanism stays as an option: DSP_AMD_TESTS_ISOLATE_MARK=gpu hands
+every module's selected tests to a child pytest and replays the child's reports, so a module starts on a fresh HIP context and a fault in one module
+cannot take the others' results with it (a child that dies fails its test; CPU self-test: tests/test_isolation_cpu.py)."""
 import json
 import os
 import subprocess
@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 CHILD_REPORT = os.environ.get("DSP_AMD_TESTS_CHILD_REPORT")              # set in a child: where its reports go
 ONE_PROCESS = os.environ.get("DSP_AMD_TESTS_ONE_PROCESS") == "1"
-ISOLATE_MARK = os.environ.get("DSP_AMD_TESTS_ISOLATE_MARK", "gpu")        # (the CPU test of this mechanism isolates another mark)
+ISOLATE_MARK = os.environ.get("DSP_AMD_TESTS_ISOLATE_MARK")               # None: no isolation (the default); "gpu": the GPU modules; the CPU self-test isolates another mark
 
 
 def pytest_configure(config):
@@ -49,7 +49,7 @@ _native_loaded = False
 
 
 def _isolated(item):
-    return (not CHILD_REPORT) and (not ONE_PROCESS) and item.get_closest_marker(ISOLATE_MARK) is not None
+    return bool(ISOLATE_MARK) and (not CHILD_REPORT) and (not ONE_PROCESS) and item.get_closest_marker(ISOLATE_MARK) is not None
 
 
 class _Done:
