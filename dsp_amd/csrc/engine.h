@@ -231,7 +231,9 @@ constexpr int RESIDENT_UNITS = 4096;                 // payload units per direct
 struct ResidentUnit { double v; unsigned long long w; };
 struct ResidentCtl {                                 // page-locked, device-mapped host memory
 	unsigned alive;                                  // set by the host before a launch, cleared by the wave as its last store
-	unsigned pad[15];
+	unsigned settled;                                // sequence number of the last block whose states (and output) are known to be out: written by the wave when it
+	                                                 // finds nothing to do, behind a wait for its stores -- never on the path of a block (Resident::quiesce)
+	unsigned pad[14];
 };
 struct ResidentParams {
 	ResidentCtl *ctl;

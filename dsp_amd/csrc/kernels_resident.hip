@@ -18,8 +18,9 @@
 // (between two blocks), when the host asks it to (frames = RESIDENT_STOP), or after `max_polls` turns of its loop whatever the clock says -- so a
 // hipDeviceSynchronize() anywhere in the process waits a few milliseconds at most, and no failure of the host can leave a kernel behind.  Its last store
 // is alive = 0 behind a system-scope fence; the host starts another one with the next block.
-// The states live in device memory between blocks (loaded and stored around every block, past the L1).  They are NOT fenced per block: before anything
-// else touches them (the ordinary kernels at another block size, reset, destroy) the host asks the wave to leave and waits for it (Resident::quiesce).
+// The states live in device memory between blocks (loaded and stored around every block, past the L1).  They are NOT fenced on the path of a block: when
+// the wave finds nothing to do it waits for its stores and says so (ctl->settled), and before anything else touches the states (the ordinary kernels at
+// another block size, reset, destroy) the host waits for that word (Resident::quiesce) -- the wave stays.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "kparams.h"
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<ResidentUnit *>(p.mail_in), 0, (1 + RESIDENT_UNITS) * 16, 0x00020000);
 	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.mail_out, 0, RESIDENT_UNITS * 16, 0x00020000);
 	const int spec = p.spec_units < RES_SPEC ? p.spec_units : RES_SPEC;
-	unsigned done = p.done0;
+	unsigned done = p.done0, settled = p.done0;
 	unsigned long long t_last = wall_clock64();
 	const unsigned long long t_start = t_last;
 	if (tid == 0) req_w[1] = 0;
@@ -120,7 +121,18 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		__syncthreads();
 		const unsigned seq = (unsigned) (rq >> 32), frames = (unsigned) (rq & 0xffffffffu);
 		if (frames == RESIDENT_STOP) break;
-		if (seq == done) { __builtin_amdgcn_s_sleep(4); continue; }
+		if (seq == done) {
+			// nothing to do: the moment to say that the last block's states are out (a wait for this wave's stores, then a word in host memory) -- the host
+			// looks at it before it lets anything else touch the states, and a block never waits for it
+			if (settled != done) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				__syncthreads();
+				if (tid == 0) __hip_atomic_store(&p.ctl->settled, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				settled = done;
+			}
+			__builtin_amdgcn_s_sleep(4);
+			continue;
+		}
 		// ---- a block: the mailbox -> LDS, the ops, LDS -> the host's mailbox
 		const int n = (int) frames * Cin, n_out = (int) frames * C;
 		if (n > RESIDENT_UNITS || n_out > RESIDENT_UNITS || n > p.buf_doubles) break;      // (a request the host never makes: leave rather than touch anything)

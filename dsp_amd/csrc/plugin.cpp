@@ -261,6 +261,21 @@ bool Resident::serve(const double *in, ssize_t frames, double *out)
 	return false;
 }
 
+void Resident::quiesce()
+{
+	if (!dirty || !ctl) return;
+	// the wave says `settled == seq` the first time it finds nothing to do behind block seq (a trip of its poll loop and a wait for its stores: a few
+	// microseconds); a wave that has left fenced on its way out.  Anything else: ask it to leave and wait for it
+	const double t0 = res_now_us();
+	for (long spins = 0;; ++spins) {
+		if (__atomic_load_n(&ctl->settled, __ATOMIC_ACQUIRE) == seq || __atomic_load_n(&ctl->alive, __ATOMIC_ACQUIRE) == 0) { dirty = false; return; }
+		__builtin_ia32_pause();
+		if ((spins & 255) == 255 && res_now_us() - t0 > 2000.0) break;
+	}
+	stop();
+	dirty = false;
+}
+
 void Resident::stop()
 {
 	if (!ctl) return;

@@ -18,7 +18,7 @@ constexpr unsigned NODE_MAGIC = 0x44535041u;   // "DSPA"
 // Small blocks of a segment that is one cascade (the equaliser shape), or a plain remix in front of one, through a workgroup that stays on the device for a
 // few milliseconds and polls a mailbox -- no launch per block (kernels_resident.hip; the mailbox protocol: engine.h).  The wave leaves by itself (clock, loop
 // bound) or when asked to; the next block starts another one.  A block it does not serve in time goes through a launch (the third such block switches the
-// mechanism off for the segment).  The wave does not fence the states per block: whoever else is about to touch them calls quiesce() first.
+// mechanism off for the segment).  The wave does not fence the states on the path of a block: whoever else is about to touch them calls quiesce() first.
 struct Resident {
 	ResidentCtl *ctl = nullptr;              // page-locked host memory: the wave's alive word
 	ResidentUnit *mail_in = nullptr;         // request mailbox: device memory the CPU stores into (large BAR), else page-locked host memory
@@ -43,7 +43,7 @@ struct Resident {
 	// the block at `in` ([frames][Cin]) through the wave into `out` ([frames][C]); false: not served (the caller takes the ordinary path, on the same states)
 	bool serve(const double *in, ssize_t frames, double *out);
 	void stop();                             // ask the wave to leave and wait for it
-	void quiesce() { if (dirty) { stop(); dirty = false; } }     // before anything else reads or writes the cascade's states
+	void quiesce();                          // before anything else reads or writes the cascade's states: wait until the wave says they are out (it stays)
 	~Resident();
 private:
 	bool open();
