@@ -100,6 +100,9 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 	unsigned long long t_last = wall_clock64();
 	const unsigned long long t_start = t_last;
 	if (tid == 0) req_w[1] = 0;
+#ifdef RES_TIMING
+	unsigned it_last = 0;
+#endif
 	for (unsigned it = 0; it < p.max_polls; ++it) {
 		// one burst: the control unit and the units of the block this lane expects (offsets beyond the mailbox read as zeros and do not decode)
 		const ResidentUnit cu = ld_unit(r_in, 0);
@@ -134,6 +137,9 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			continue;
 		}
 		// ---- a block: the mailbox -> LDS, the ops, LDS -> the host's mailbox
+#ifdef RES_TIMING
+		const unsigned long long tt0 = wall_clock64();
+#endif
 		const int n = (int) frames * Cin, n_out = (int) frames * C;
 		if (n > RESIDENT_UNITS || n_out > RESIDENT_UNITS || n > p.buf_doubles) break;      // (a request the host never makes: leave rather than touch anything)
 		double *bout = buf + p.out_off;                              // the block's output: in place, or behind the input when a remix changes the channel count
@@ -164,6 +170,9 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			if (lost) req_w[1] = 1;
 		}
 		__syncthreads();
+#ifdef RES_TIMING
+		const unsigned long long tt1 = wall_clock64();
+#endif
 		if (req_w[1]) break;                                         // (the host times out and takes the block through a launch)
 		if (rmx_n) {
 			// a plain remix in front (the crossover shape): every output channel the sum of its input channels, in ascending order from 0.0, one rounding per
@@ -213,7 +222,15 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
 		}
 		__syncthreads();
+#ifdef RES_TIMING
+		const unsigned long long tt2 = wall_clock64();
+#endif
 		for (int e = tid; e < n_out; e += nth) st_unit(r_out, e, bout[e], rq);
+#ifdef RES_TIMING
+		// (an experimental build, scripts/r06_resident_timing.sh: where a block's time goes, in ticks of the 100 MHz clock, summed in the control block)
+		if (tid == 0) { const unsigned long long tt3 = wall_clock64(); p.ctl->pad[0] += (unsigned) (tt1 - tt0); p.ctl->pad[1] += (unsigned) (tt2 - tt1); p.ctl->pad[2] += (unsigned) (tt3 - tt2); p.ctl->pad[3] += 1; p.ctl->pad[4] += it - it_last; }
+		it_last = it;
+#endif
 		__syncthreads();                                             // (the block buffer is free for the next block)
 		done = seq;
 		t_last = wall_clock64();

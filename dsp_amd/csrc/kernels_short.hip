@@ -7,18 +7,18 @@
 // write of hop outputs: (N + hop) / hop units of 16 bytes per pair and frame -- 3 at 4095 taps, 2.3 at 1000 -- against 6.4 for three trips of a
 // 65536-point transform.  BASELINE config 5's `hilbert -p 4095` stage was 22 of its 35 ms.
 //
-// What bounds it (round 5, BASELINE config 5's hilbert stage: 1024 pairs x 224 blocks, 44 GB in 15.6 ms = 2.8 TB/s, where the four-step path took 22 ms for
-// 97 GB): not memory -- a block is two 8192-point transforms for 4096 outputs, about 7.5 us of fp64 issue and 6 us of LDS exchange traffic (six exchanges of
-// 128 KB each way) per CU against 9 us of HBM time, in one workgroup whose eight waves meet at a barrier between every two of those phases.  The next window
-// prefetched into a second register set (the filter row then read from L2 where it is used: 255 registers) measures 16.9 ms against 16.2 for the same
-// code without it (profiles/r05_conv_short_prefetch_ab.txt, scripts/conv_short_prefetch_r05.patch): there is no idle memory time to fill.
+// What bounds it (BASELINE config 5's hilbert stage: 1024 pairs x 224 blocks, 44 GB): not memory -- a block is two 8192-point transforms for 4096
+// outputs, about 7.5 us of fp64 issue and 6 us of LDS exchange traffic per CU against 9 us of HBM time.  Counters (profiles/r06_conv_short_config5_
+// counters.json, round 5's one-workgroup form): waves parked at a barrier or a counter 42 % of their time, issuing VALU 27 %, stalled on an
+// instruction's operands 20 %, LDS bank conflicts 18 % of the LDS cycles.  Round 5: 15.6 - 17.5 ms; with the per-lane descriptors gone (16 loops per
+// block over one value) 16.4 - 16.7; round 6's form below 15.9.  A prefetched next window measured slower (profiles/r05_conv_short_prefetch_ab.txt).
 //
-// Workgroup = one channel pair (z = x_a + i x_b, exact: h is real), 512 threads x 16 points, walking the pair's blocks with the filter row in registers;
-// radix 16 / 16 / 16 / 2 Stockham passes through the row buffer (the XOR-swizzled slots of conv_row: the same store and gather shapes).  One workgroup
-// per CU (139 KB of LDS).  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
+// Workgroup = one channel pair (z = x_a + i x_b, exact: h is real), 256 threads x two sets of 16 points, walking the pair's blocks; radix 16 / 16 / 16 / 2
+// Stockham passes whose exchanges go through a buffer of 8192 DOUBLES -- real parts, then imaginary parts -- so that two independent workgroups fit a CU
+// (72 KB of LDS each) and one issues butterflies while the other waits; conflict-free slots for both access shapes (short_fft2).  The filter row comes from
+// L2 where it is used.  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
 #include <hip/hip_runtime.h>
 #include <cstdint>
-#include <cstdlib>
 #include <type_traits>
 #include "kparams.h"
 #include "fft_params.h"
@@ -35,33 +35,13 @@ typedef double real;
 
 constexpr int SH_LOG2N = 13, SH_N = 1 << SH_LOG2N, SH_P = SH_N / 16;
 constexpr int SH_T256 = 272, SH_TLO = 68, SH_THI = SH_N / 64;
-// VT = points sets per thread: 1 -> 512 threads, the exchanges carry complex points (128 KB: one workgroup per CU); 2 -> 256 threads with two sets each,
-// the exchanges carry the real and the imaginary parts one after the other through a buffer of doubles (64 KB: TWO independent workgroups per CU)
-template <int VT> constexpr size_t sh_lds() { return (size_t) SH_N * (VT == 1 ? sizeof(cplx) : sizeof(double)) + ((size_t) SH_T256 + SH_TLO + SH_THI) * sizeof(cplx); }
+// 256 threads with two point sets each; the exchanges carry the real and the imaginary parts one after the other through a buffer of doubles (64 KB: TWO
+// independent workgroups per CU).  (Round 5's form -- 512 threads, complex points through 128 KB, one workgroup per CU, the filter row in registers -- measured
+// 16.65 ms on BASELINE config 5's hilbert stage against 15.9 for this one.)
+constexpr int SH_VT = 2, SH_THREADS = SH_P / SH_VT;
+constexpr size_t SH_LDS = (size_t) SH_N * sizeof(double) + ((size_t) SH_T256 + SH_TLO + SH_THI) * sizeof(cplx);
 
-template <bool INV, class Tw>
-__device__ __forceinline__ void short_fft(cplx (&v)[16], int j, cplx *lds, const RowMap &map, const Tw &tw)
-{
-	// (j made opaque per pass: the thread's twiddle and exchange addresses depend on j alone and would all be computed once and kept)
-	asm volatile("" : "+v"(j));
-	pass16<SH_LOG2N, 16, 1, INV, false>(v, j, lds, map, tw);
-	lds_barrier();
-	gather16<SH_LOG2N>(v, j, lds, map);
-	lds_barrier();
-	asm volatile("" : "+v"(j));
-	pass16<SH_LOG2N, 16, 16, INV, false>(v, j, lds, map, tw);
-	lds_barrier();
-	gather16<SH_LOG2N>(v, j, lds, map);
-	lds_barrier();
-	asm volatile("" : "+v"(j));
-	pass16<SH_LOG2N, 16, 256, INV, false>(v, j, lds, map, tw);
-	lds_barrier();
-	gather16<SH_LOG2N>(v, j, lds, map);
-	asm volatile("" : "+v"(j));
-	pass16<SH_LOG2N, 2, 4096, INV, true>(v, j, lds, map, tw);
-}
-
-// The same transform for a thread that holds TWO sets of 16 points (the points of "virtual threads" j and j + 256), with every exchange done in halves: the
+// The 8192-point transform of a thread that holds TWO sets of 16 points (the points of "virtual threads" j and j + 256), with every exchange done in halves: the
 // real parts through a buffer of 8192 doubles, then the imaginary parts through the same buffer.  Twice the barriers and LDS instructions for the same
 // bytes -- but half the LDS, so a second, independent workgroup fits the CU and issues its butterflies while this one waits at a barrier or for the LDS
 // (round 5's form keeps all eight waves of a CU in lock-step: 7.5 us of fp64 issue + 6 us of exchanges per block, one after the other).
@@ -107,14 +87,13 @@ __device__ __forceinline__ void short_fft2(cplx (&va)[16], cplx (&vb)[16], int j
 // 64-bit address pairs per direction do not fit beside the 64 registers of the window and the 64 of the filter row)
 typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
 // BS: bytes per sample of the slab in direct mode (8: fp64; 4: s24 / s32 / float; 2: s16 -- read_buf_<fmt> of pcm_device.h in the loads)
-template <int BS, int VT>
-__global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
+template <int BS>
+__global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
 {
-	constexpr int N = SH_N, P = SH_P, NTH = SH_P / VT;
+	constexpr int N = SH_N, P = SH_P, NTH = SH_THREADS, VT = SH_VT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	cplx *data = reinterpret_cast<cplx *>(smem_raw);                     // VT = 1: the exchange row of complex points
-	double *datad = reinterpret_cast<double *>(smem_raw);                // VT = 2: ... of doubles
-	cplx *t256 = reinterpret_cast<cplx *>(smem_raw + (size_t) N * (VT == 1 ? sizeof(cplx) : sizeof(double))), *tlo = t256 + SH_T256, *thi = tlo + SH_TLO;
+	double *datad = reinterpret_cast<double *>(smem_raw);                // the exchange buffer: one half (real / imaginary parts) of the row at a time
+	cplx *t256 = reinterpret_cast<cplx *>(smem_raw + (size_t) N * sizeof(double)), *tlo = t256 + SH_T256, *thi = tlo + SH_TLO;
 	int j = threadIdx.x;
 	const long pair = blockIdx.x;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
@@ -126,16 +105,8 @@ __global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2)
 		else thi[e - 320] = TAB(p.tw)[(e - 320) * 64];
 	}
 	const cplx *Hrow = p.Hout ? nullptr : TAB(p.H) + (long) p.pair_h[pair] * N;
-	cplx h[VT == 1 ? 16 : 1];
-	if constexpr (VT == 1) {
-		if (!p.Hout) {
-#pragma unroll
-			for (int m = 0; m < 16; ++m) h[m] = Hrow[j + P * m];
-		}
-	}
 	lds_barrier();                                                       // tables visible
 	const TwRow<N> tw{ t256, tlo, thi };
-	const RowMap map{ 0 };
 	// (the division runs on the vector unit; its result is uniform all the same and is said to be: with a per-lane stream index the slab and output
 	// descriptors are per-lane values and every load through them becomes a loop over their distinct values -- 16 such loops per block until round 6)
 	const long s = __builtin_amdgcn_readfirstlane((int) (pair / p.pairs_per_stream)), qs = pair - s * p.pairs_per_stream;
@@ -186,8 +157,7 @@ __global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2)
 			}
 		}
 		if (b > b0) lds_barrier();                                   // the previous block's last gather is done
-		if constexpr (VT == 1) short_fft<false>(v[0], j, data, map, tw);
-		else short_fft2<false>(v[0], v[VT - 1], j, datad, tw);
+		short_fft2<false>(v[0], v[1], j, datad, tw);
 		if (p.Hout) {
 #pragma unroll
 			for (int t = 0; t < VT; ++t) {
@@ -197,11 +167,7 @@ __global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2)
 			}
 			return;
 		}
-		if constexpr (VT == 1) {
-#pragma unroll
-			for (int m = 0; m < 16; ++m) { v[0][m] = cmul(v[0][m], h[m]); if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
-		}
-		else {
+		{
 			// (no room for the filter row beside two sets of points: it comes from L2 where it is used -- the same 128 KB for every pair of a filter;
 			// asked for HERE, from an index the compiler cannot see through: hoisted above the forward transform the loads are 32 spilled registers)
 			int jh = j;
@@ -219,8 +185,7 @@ __global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2)
 				}
 		}
 		lds_barrier();                                               // every gather of the forward transform is done
-		if constexpr (VT == 1) short_fft<true>(v[0], j, data, map, tw);
-		else short_fft2<true>(v[0], v[VT - 1], j, datad, tw);
+		short_fft2<true>(v[0], v[1], j, datad, tw);
 		// window sample first_n + f -> output frame mo0 + f, for f in [f_lo, f_hi)
 		const long mo0 = q_blk - p.k_origin;
 		const int f_lo = (mo0 >= 0) ? 0 : (-mo0 < in_count ? (int) -mo0 : in_count);
@@ -277,7 +242,7 @@ __global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2)
 				}
 			};
 			sink_set(v[0], j);
-			if constexpr (VT == 2) sink_set(v[VT - 1], j + NTH);
+			sink_set(v[1], j + NTH);
 			if (p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
 			continue;
 		}
@@ -307,11 +272,10 @@ __global__ __launch_bounds__(SH_P / VT) __attribute__((amdgpu_waves_per_eu(2, 2)
 
 }  // namespace psh
 
-template <int BS, int VT> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
+template <int BS> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
 {
-	constexpr size_t LDS = psh::sh_lds<VT>();
-	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<BS, VT>), LDS);
-	hipLaunchKernelGGL((psh::conv_short<BS, VT>), grid, dim3(psh::SH_P / VT), LDS, st, p);
+	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<BS>), psh::SH_LDS);
+	hipLaunchKernelGGL((psh::conv_short<BS>), grid, dim3(psh::SH_THREADS), psh::SH_LDS, st, p);
 }
 
 void launch_conv_short(const ShortParams &p, hipStream_t st)
@@ -321,9 +285,7 @@ void launch_conv_short(const ShortParams &p, hipStream_t st)
 	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
 	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges);
 	const int bs = (!p.slab || p.slab_fmt == PCM_DOUBLE) ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
-	static const int vt = [] { const char *e = getenv("DSP_AMD_SHORT_VT"); return e ? atoi(e) : 1; }();       // (A/B while round 6 measures the two forms)
-	if (vt == 2) { if (bs == 8) launch_short_t<8, 2>(p, grid, st); else if (bs == 4) launch_short_t<4, 2>(p, grid, st); else launch_short_t<2, 2>(p, grid, st); }
-	else { if (bs == 8) launch_short_t<8, 1>(p, grid, st); else if (bs == 4) launch_short_t<4, 1>(p, grid, st); else launch_short_t<2, 1>(p, grid, st); }
+	if (bs == 8) launch_short_t<8>(p, grid, st); else if (bs == 4) launch_short_t<4>(p, grid, st); else launch_short_t<2>(p, grid, st);
 }
 
 }  // namespace dspamd

@@ -206,6 +206,9 @@ static inline void res_store_unit(ResidentUnit *u, double v, unsigned long long 
 bool Resident::serve(const double *in, ssize_t frames, double *out)
 {
 	if (!ctl && !open()) { off = true; g_plugin_counters.wave_off.fetch_add(1, std::memory_order_relaxed); return false; }
+#ifdef RES_TIMING
+	const double t_enter = res_now_us();
+#endif
 	const unsigned served = seq;
 	++seq;
 	const unsigned long long rq = ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames;
@@ -219,6 +222,9 @@ bool Resident::serve(const double *in, ssize_t frames, double *out)
 	rp.spec_units = (int) std::min<size_t>(4, (n + 63) / 64);
 	dirty = true;
 	const double t0 = res_now_us();
+#ifdef RES_TIMING
+	t_write_us += t0 - t_enter;
+#endif
 	size_t got = 0;
 	bool late = false;
 	for (long spins = 0; got < n_out; ++spins) {
@@ -239,6 +245,9 @@ bool Resident::serve(const double *in, ssize_t frames, double *out)
 		__builtin_ia32_pause();
 		if ((spins & 255) == 255 && res_now_us() - t0 > 20000.0) { late = true; break; }      // 20 ms: something is wrong
 	}
+#ifdef RES_TIMING
+	t_wait_us += res_now_us() - t0;
+#endif
 	if (!late) return true;
 	// not served in time: ask the wave to leave and wait for it (bounded by its own loop).  The block goes through a launch, on the states as the wave left
 	// them -- unless the wave wrote some of the reply: then it ran the block, and what is missing of the reply is on its way
@@ -292,6 +301,13 @@ void Resident::stop()
 Resident::~Resident()
 {
 	stop();
+#ifdef RES_TIMING
+	if (ctl && ctl->pad[3]) {
+		const double n = ctl->pad[3];
+		fprintf(stderr, "resident timing: %.0f blocks; wave: mailbox -> LDS %.2f us, ops %.2f us, reply stores issued %.2f us, polls between blocks %.1f; host: block written %.2f us, reply complete %.2f us after that\n",
+		        n, ctl->pad[0] / n * 0.01, ctl->pad[1] / n * 0.01, ctl->pad[2] / n * 0.01, ctl->pad[4] / n, t_write_us / n, t_wait_us / n);
+	}
+#endif
 	if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
 	if (mail_in) { if (in_device) (void) hipFree(mail_in); else (void) hipHostFree(mail_in); }
 	if (mail_out) (void) hipHostFree(mail_out);

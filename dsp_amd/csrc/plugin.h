@@ -33,6 +33,9 @@ struct Resident {
 	bool off = false;
 	bool dirty = false;                      // the wave has served blocks since it was last waited for: the states in device memory may still be on their way
 	int timeouts = 0;                        // blocks the wave did not serve in time (the third one switches the path off for the segment)
+#ifdef RES_TIMING
+	double t_write_us = 0.0, t_wait_us = 0.0;
+#endif
 	bool ready = false;                      // init() has accepted the segment; mailboxes and the stream come with the first small block (open())
 	bool init(class RemixStage *r, class CascadeStage *c);       // r: a plain remix in front of the cascade, or nullptr
 	bool takes(ssize_t frames) const
