@@ -23,6 +23,7 @@
 // another block size, reset, destroy) the host waits for that word (Resident::quiesce) -- the wave stays.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <type_traits>
 #include "kparams.h"
 #include "engine.h"
 
@@ -38,12 +39,12 @@ __device__ __forceinline__ void st_agent(double *p, double v)
 {
 	__hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long) __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the value of the lane below in the 16-lane row (lane 0 of a row keeps its own)
-__device__ __forceinline__ double row_shr1(double v)
+// the value `v` of the lane below in the 16-lane row; lane 0 of a row (no lane below: the move is disabled there and the destination keeps its `old`) gets `first`
+__device__ __forceinline__ double row_shr1_or(double v, double first)
 {
 	int lo = __double2loint(v), hi = __double2hiint(v);
-	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x111, 0xf, 0xf, false);
-	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x111, 0xf, 0xf, false);
+	lo = __builtin_amdgcn_update_dpp(__double2loint(first), lo, 0x111, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(__double2hiint(first), hi, 0x111, 0xf, 0xf, false);
 	return __hiloint2double(hi, lo);
 }
 
@@ -192,33 +193,52 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			const double *rd = bout + ch;                                // frame t of this row's channel at rd[t C] (the remix, if any, has been through)
 			auto frame_in = [&](int t) -> double { return rd[t * C]; };
 			double s0 = biq ? m0 : b;                                    // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
-			// frames are asked for FOUR steps ahead of their use, by every lane of the row (one address, no branch), in a loop unrolled four times so that a
-			// loaded frame is used from the register it landed in: the wave is alone on its SIMD and would otherwise sit out an LDS round trip per step
-			// (with a rotating pair of registers the load was needed half a step after it had been asked for: 0.11 us per step)
-			double xq[4];
-#pragma unroll
-			for (int k = 0; k < 4; ++k) xq[k] = frame_in(k < nf ? k : nf - 1);
+			// the channel's last op writes frame t - j at step t; every other lane writes into a word of its own behind the block (no branch around the store)
+			double *wr_base = wr ? bout + ch - j * C : buf + p.buf_doubles + 2 + tid;
+			const int wr_stride = wr ? C : 0;
 			double prev = 0.0;
-			auto step = [&](int t, double xin) {
-				const double below = row_shr1(prev);
-				const double x = (j == 0) ? xin : below;
-				const bool active = t >= j && t < j + nf;
-				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
+			// One step.  The wave is alone on its SIMD: a step costs what it ISSUES (round 6 measured 91 ns per step for round 5's 17 vector and 10 scalar
+			// instructions -- 6.7 of the 10.9 us of a 64-frame block), so the steps between the array's fill and its drain -- n_ops - 1 ... frames - 1, when
+			// every lane has a frame -- are kept short: the input arrives by ONE dpp move per half whose `old` operand is the frame from LDS (lane 0 of a
+			// row has no lane below: it keeps `old`), sections update their states under the execution mask (a branch the compiler may not turn into four
+			// selects: the empty asm), every lane stores (no branch), nobody asks who is active, and the frames come from LDS four steps ahead.
+			auto step_any = [&](int t) {                                 // fill and drain: lane j has a frame while 0 <= t - j < frames
+				const double x = row_shr1_or(prev, frame_in(t < nf ? t : nf - 1));
 				const double r = fma(a, x, s0);
-				const double tt = fma(c1, x, m1), u = c2 * x;
-				const double n0 = fma(-c3, r, tt), n1 = fma(-c4, r, u);
-				if (active && upd) { s0 = n0; m1 = n1; }
+				const bool active = (unsigned) (t - j) < (unsigned) nf;
+				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
+				if (active && upd) { const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
+				if (active && wr) wr_base[t * wr_stride] = r;
 				prev = r;
-				if (active && wr) bout[(t - j) * C + ch] = r;
 			};
-			for (int t = 0; t < steps; t += 4) {
+			const int t_fill = (n_ops - 1 < steps) ? n_ops - 1 : steps;
+			int t = 0;
+			for (; t < t_fill; ++t) step_any(t);
+			if (t < nf) {
+				double xq[4];
 #pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					if (t + k < steps) step(t + k, xq[k]);
-					const int tn = (t + k + 4 < nf) ? t + k + 4 : nf - 1;
-					xq[k] = frame_in(tn);
+				for (int k = 0; k < 4; ++k) xq[k] = frame_in(t + k < nf ? t + k : nf - 1);
+				auto step_full = [&](int tt_, double xin) {
+					const double x = row_shr1_or(prev, xin);
+					const double r = fma(a, x, s0);
+					if (upd) { asm volatile(""); const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
+					wr_base[tt_ * wr_stride] = r;
+					prev = r;
+				};
+				// (the frame four steps ahead by a running pointer, not clamped to the block: what it reads behind the last frame -- LDS, at worst beyond the
+				// allocation, where a read gives zeros -- belongs to steps this loop does not run)
+				const double *ahead = rd + (size_t) (t + 4) * C;
+				for (; t + 4 <= nf; t += 4) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						step_full(t + k, xq[k]);
+						xq[k] = ahead[k * C];
+					}
+					ahead += 4 * C;
 				}
+				for (; t < nf; ++t) step_any(t);
 			}
+			for (; t < steps; ++t) step_any(t);
 			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
 		}
 		__syncthreads();
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st)
 {
-	if (p.C < 1 || p.C > 64 || p.Cin < 1 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) p.buf_doubles * sizeof(double) + 16 > lds_bytes || !p.mail_in || !p.mail_out || (p.out_off & 1)) return false;
+	if (p.C < 1 || p.C > 64 || p.Cin < 1 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) (p.buf_doubles + 2 + 1024) * sizeof(double) > lds_bytes || !p.mail_in || !p.mail_out || (p.out_off & 1)) return false;
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident), lds_bytes);
 	const int waves = (p.C + 3) / 4;
 	hipLaunchKernelGGL(cascade_resident, dim3(1), dim3(64 * waves), lds_bytes, st, p);

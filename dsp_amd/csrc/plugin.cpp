@@ -124,7 +124,7 @@ bool Resident::init(RemixStage *r, CascadeStage *c)
 	rp.buf_doubles = (int) (block_bytes / sizeof(double));
 	// with a remix the output of a block lies behind its input (the channel count changes): one half of the buffer each
 	rp.out_off = r ? (rp.buf_doubles / 2) & ~1 : 0;
-	lds = block_bytes + 16;
+	lds = block_bytes + (2 + 1024) * sizeof(double);      // the block, two control words, a word per lane for the stores of the lanes that are not a channel's last op
 	sections = 1;
 	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of the trips of the block and of its output; a launch of the
 	// ordinary, time-parallel kernels costs 24 ... 26 us whatever the block (18 ... 21 us for the two launches of a short remix + cascade segment): the wave
