@@ -28,7 +28,7 @@ for d in sorted(glob.glob(f"{O}/p*/")):
         if "dspamd" not in r["Kernel_Name"]: continue
         per[(r["Kernel_Name"].split("(")[0][-44:], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
     for (k, di), cs in per.items():
-        if dur.get(di, 0) < 5e5: continue
+        if dur.get(di, 0) < float(__import__("os").environ.get("MIN_NS", "5e5")): continue
         agg[k]["ns"].append(dur[di])
         for c, v in cs.items(): agg[k][c].append(v)
 out = {k: {c: sum(v) / len(v) for c, v in a.items()} for k, a in agg.items()}
