@@ -1155,11 +1155,24 @@ public:
 	ssize_t run(const double *in, long in_stride, ssize_t frames, double *out, long out_stride, hipStream_t st) override;
 	void reset(hipStream_t st) override { (void) hipMemsetAsync(hist.p, 0, hist.bytes, st); phase = 0; }
 	size_t device_bytes() const override { return hist.bytes + taps.bytes; }
+	friend bool fir_direct_view(Stage *s, ResidentPass *ps, const int **phase);
 private:
 	int T = 0, phase = 0;
 	std::string name;
 	DevBuf taps, foc, hist;
 };
+
+bool fir_direct_view(Stage *s, ResidentPass *ps, const int **phase)
+{
+	FirDirectStage *f = dynamic_cast<FirDirectStage *>(s);
+	if (!f || f->S != 1 || f->ch_in > RES_FIR_MAX_CH || f->T < 1 || f->T > RES_FIR_TAPS) return false;
+	static_assert(RES_FIR_TAPS == FIR_DIRECT_MAX, "the wave reads the stage's own tables");
+	memset(ps, 0, sizeof(*ps));
+	ps->kind = RES_PASS_FIR; ps->c_in = ps->c_out = f->ch_in;
+	ps->T = f->T; ps->taps = f->taps.as<double>(); ps->foc = f->foc.as<int>(); ps->hist = f->hist.as<double>();
+	*phase = &f->phase;
+	return true;
+}
 
 bool FirDirectStage::init(const Spec &sp)
 {

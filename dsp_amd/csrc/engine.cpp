@@ -1178,20 +1178,33 @@ ssize_t Pipeline::max_out_frames(ssize_t in_frames) const
 	return f;
 }
 
-CascadeStage *Pipeline::sole_cascade() const
+bool Pipeline::resident_plan(ResidentParams *rp, const int *fir_phase[]) const
 {
-	if (stages.size() != 1 || S != 1) return nullptr;
-	CascadeStage *c = dynamic_cast<CascadeStage *>(stages[0].get());
-	return (c && !c->ring.base && c->write_interleaved) ? c : nullptr;
-}
-
-bool Pipeline::remix_then_cascade(RemixStage **r, CascadeStage **c) const
-{
-	if (stages.size() != 2 || S != 1) return false;
-	RemixStage *rm = dynamic_cast<RemixStage *>(stages[0].get());
-	CascadeStage *cs = dynamic_cast<CascadeStage *>(stages[1].get());
-	if (!rm || !cs || !rm->device_idx() || rm->sources_per_row() > 8 || cs->ring.base || !cs->write_interleaved || rm->ch_out != cs->ch_in) return false;
-	*r = rm; *c = cs;
+	if (S != 1 || stages.empty() || stages.size() > (size_t) RES_MAX_PASSES) return false;
+	memset(rp, 0, sizeof(*rp));
+	rp->Cin = ch_in; rp->Cout = ch_out;
+	int c = ch_in;
+	for (size_t k = 0; k < stages.size(); ++k) {
+		ResidentPass &ps = rp->pass[k];
+		fir_phase[k] = nullptr;
+		Stage *st = stages[k].get();
+		if (RemixStage *rm = dynamic_cast<RemixStage *>(st)) {
+			if (rm->ch_in != c || rm->sources_per_row() > 16 || rm->ch_out > 64) return false;
+			memset(&ps, 0, sizeof(ps));
+			ps.kind = RES_PASS_REMIX; ps.c_in = rm->ch_in; ps.c_out = rm->ch_out;
+			ps.idx = rm->device_idx(); ps.w = rm->device_w(); ps.post = rm->device_post(); ps.max_n = rm->sources_per_row();
+		}
+		else if (CascadeStage *cs = dynamic_cast<CascadeStage *>(st)) {
+			if (rp->n_casc >= RES_MAX_CASCADES || cs->ch_in != c || cs->ring.base || !cs->write_interleaved || cs->n_ops < 1 || cs->n_ops > 16 || cs->ch_in > 32) return false;
+			memset(&ps, 0, sizeof(ps));
+			ps.kind = RES_PASS_CASCADE; ps.c_in = ps.c_out = cs->ch_in; ps.casc = rp->n_casc;
+			rp->cs[rp->n_casc++] = ResidentParams::Casc{ cs->ch_in, cs->n_ops, cs->device_ops(), cs->device_state() };
+		}
+		else if (!fir_direct_view(st, &ps, &fir_phase[k]) || ps.c_in != c) return false;
+		c = ps.c_out;
+	}
+	if (c != ch_out) return false;
+	rp->n_pass = (int) stages.size();
 	return true;
 }
 

@@ -203,10 +203,10 @@ public:
 	void reset(hipStream_t st);
 	std::string plan() const;
 	int n_stages() const { return (int) stages.size(); }
-	// the pipeline's only stage when that is a cascade writing interleaved frames (what the resident small-block path of plugin.cpp serves), or nullptr
-	class CascadeStage *sole_cascade() const;
-	// ... or a plain remix followed by such a cascade (the crossover shape): both stages, else false
-	bool remix_then_cascade(class RemixStage **r, class CascadeStage **c) const;
+	// what a resident small-block wave (kernels_resident.hip, plugin.cpp) would do with a block of this single-stream pipeline: its stages as passes over the
+	// block in LDS -- plain or weighted remixes, at most one cascade, direct FIRs -- or false when a stage is of another kind.  fir_phase[k]: where the host
+	// finds, per request, which half of pass k's FIR history is current (the stage's own member), or nullptr
+	bool resident_plan(struct ResidentParams *rp, const int *fir_phase[]) const;
 	size_t device_bytes() const;
 private:
 	Pipeline() {}
@@ -235,22 +235,42 @@ struct ResidentCtl {                                 // page-locked, device-mapp
 	                                                 // finds nothing to do, behind a wait for its stores -- never on the path of a block (Resident::quiesce)
 	unsigned pad[14];
 };
+// What the wave does with a block is a short list of passes over it in LDS (round 6; round 5: one cascade, or a plain remix in front of one):
+//   remix / mix   every output channel a sum of input channels (remix.c:39-101), or a weighted one (st2ms.c:28-54, crossfeed.c:41-46), bit-exact
+//   cascade       gains / adds / sections as a systolic array over the lanes of a row (at most two such passes per segment: their ops live in registers)
+//   direct FIR    filters of up to 32 taps in the reference's own summation order (fir.c:43-62, fir_p.c:131-148), bit-exact; history in device memory
+enum : int { RES_PASS_REMIX = 1, RES_PASS_CASCADE = 2, RES_PASS_FIR = 3 };
+constexpr int RES_MAX_PASSES = 4, RES_MAX_CASCADES = 2, RES_FIR_MAX_CH = 16, RES_FIR_TAPS = 32;
+struct ResidentPass {
+	int kind, c_in, c_out;
+	int casc;                                        // cascade: which of the segment's cascades (ResidentParams::cs)
+	const int *idx;                                  // remix: [c_out][max_n] source channels, -1 terminated
+	const double *w, *post;                          // a weighted mix: [c_out][max_n] weights, [c_out] factors applied to the sums (or nullptr)
+	int max_n;
+	int T;                                           // direct FIR: taps
+	const double *taps;                              // [n_filters][RES_FIR_TAPS]
+	const int *foc;                                  // [c] filter of the channel, -1 = the channel passes through
+	double *hist;                                    // [2][c][RES_FIR_TAPS]: x[-(q + 1)] of the block's first frame; which half holds it comes with the request
+};
+// a request's low word: frames in bits 0 ... 15, bit 16 + k = the half of pass k's FIR history that is current (the ordinary kernel alternates them)
+constexpr unsigned RES_FRAMES_MASK = 0xffffu;
 struct ResidentParams {
 	ResidentCtl *ctl;
 	const ResidentUnit *mail_in;                     // [1 + RESIDENT_UNITS]
 	ResidentUnit *mail_out;                          // [RESIDENT_UNITS]
-	int C, n_ops;                                    // channels of the cascade (= of the output), ops per channel
-	int Cin;                                         // channels of the input block: C, or the input side of a plain remix in front of the cascade
-	const int *remix_idx;                            // [C][remix_max_n] source channels of every cascade channel, -1 terminated (remix.c:39-101), or nullptr
-	int remix_max_n, out_off;                        // out_off: doubles from the block's input to its output in LDS (0: in place)
-	const OpDesc *ops;                               // [C][n_ops]
-	double *state;                                   // [C][n_ops][2]
+	int Cin, Cout;                                   // channels of the block as it comes and as it goes
+	int n_pass;
+	ResidentPass pass[RES_MAX_PASSES];
+	int n_casc;
+	struct Casc { int C, n_ops; const OpDesc *ops; double *state; } cs[RES_MAX_CASCADES];     // channels, ops per channel, [C][n_ops] ops, [C][n_ops][2] states
 	unsigned long long lifetime_ticks;               // of the 100 MHz wall clock, without a block
 	unsigned long long max_life_ticks;               // ... since the launch, blocks or not (the wave leaves between two blocks; the host starts another)
 	unsigned max_polls, done0;                       // hard bound on the polling loop; the sequence number already served
-	int buf_doubles;                                 // doubles of the block buffer in LDS (a block is at most that many samples)
+	int buf_doubles;                                 // doubles of the block buffer in LDS: two halves, a pass that cannot work in place goes from one to the other
 	int spec_units;                                  // payload units per lane asked for together with the control unit (the blocks the host expects to send)
 };
+// LDS of the wave: the block buffer, two control words, a word per lane (the stores of lanes that are not a channel's last op), the FIR histories
+constexpr size_t resident_lds_bytes(int buf_doubles) { return ((size_t) buf_doubles + 2 + 1024 + (size_t) RES_MAX_PASSES * RES_FIR_MAX_CH * RES_FIR_TAPS) * sizeof(double); }
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st);
 
 // kernel launchers (kernels_*.hip)

@@ -76,24 +76,33 @@ constexpr unsigned RES_SPINS = 1u << 17;     // re-reads of a unit that does not
 // first form of this kernel, one lane per channel: 116 us per 64-frame block of a stereo ten-section chain on a GPU that idles at a low clock).
 // Every lane runs the same instructions: r = fma(a, x, b) is the section's output (a = c0, b = m0), a gain (a = g, b = -0.0: the product keeps its
 // sign of zero), an add (a = 1, b = v) or a pass (a = 1, b = -0.0), bit for bit what __dmul_rn / __dadd_rn give; only sections update (m0, m1).
-__global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
+__global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 {
-	extern __shared__ __attribute__((aligned(16))) double buf[];      // the block: [frames][C]; behind it two words: the request, a failure flag
-	const int tid = threadIdx.x, nth = blockDim.x, C = p.C, n_ops = p.n_ops;
-	const int j = tid & 15, ch = tid >> 4;                             // op and channel of this lane
-	const bool mine = ch < C && j < n_ops;
+	extern __shared__ __attribute__((aligned(16))) double buf[];      // two halves of the block buffer; behind them two words (the request, a failure flag), a word per lane, the FIR histories
+	const int tid = threadIdx.x, nth = blockDim.x;
+	const int j = tid & 15, ch = tid >> 4;                             // op and channel of this lane in a cascade pass
+	const int half = p.buf_doubles / 2;
 	unsigned long long *req_w = reinterpret_cast<unsigned long long *>(buf + p.buf_doubles);
-	// this lane's op, in registers for the kernel's lifetime
-	double a = 1.0, b = -0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0;
-	bool biq = false;
-	if (mine) {
-		const OpDesc &od = p.ops[(size_t) ch * n_ops + j];
-		if (od.kind == OP_BIQUAD) { biq = true; a = od.c[0]; c1 = od.c[1]; c2 = od.c[2]; c3 = od.c[3]; c4 = od.c[4]; }
-		else if (od.kind == OP_MUL) a = od.g;
-		else if (od.kind == OP_ADD) b = od.g;
-	}
-	const int Cin = p.Cin, rmx_n = p.remix_idx ? p.remix_max_n : 0;
-	double *stp = p.state + ((size_t) ch * n_ops + j) * 2;
+	double *lane_word = buf + p.buf_doubles + 2 + tid;
+	double *hist_lds = buf + p.buf_doubles + 2 + 1024;                 // [pass][channel][RES_FIR_TAPS]
+	// this lane's op in each of the segment's cascades, in registers for the kernel's lifetime
+	struct LaneOp { double a, b, c1, c2, c3, c4; bool biq, mine; double *stp; };
+	auto lane_op = [&](int q) {
+		LaneOp o{ 1.0, -0.0, 0.0, 0.0, 0.0, 0.0, false, false, nullptr };
+		if (q < p.n_casc) {
+			const int C = p.cs[q].C, n_ops = p.cs[q].n_ops;
+			o.mine = ch < C && j < n_ops;
+			o.stp = p.cs[q].state + ((size_t) ch * n_ops + j) * 2;
+			if (o.mine) {
+				const OpDesc &od = p.cs[q].ops[(size_t) ch * n_ops + j];
+				if (od.kind == OP_BIQUAD) { o.biq = true; o.a = od.c[0]; o.c1 = od.c[1]; o.c2 = od.c[2]; o.c3 = od.c[3]; o.c4 = od.c[4]; }
+				else if (od.kind == OP_MUL) o.a = od.g;
+				else if (od.kind == OP_ADD) o.b = od.g;
+			}
+		}
+		return o;
+	};
+	const LaneOp op0 = lane_op(0), op1 = lane_op(1);
 	const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<ResidentUnit *>(p.mail_in), 0, (1 + RESIDENT_UNITS) * 16, 0x00020000);
 	const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.mail_out, 0, RESIDENT_UNITS * 16, 0x00020000);
 	const int spec = p.spec_units < RES_SPEC ? p.spec_units : RES_SPEC;
@@ -123,8 +132,8 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		__syncthreads();
 		const unsigned long long rq = req_w[0];
 		__syncthreads();
-		const unsigned seq = (unsigned) (rq >> 32), frames = (unsigned) (rq & 0xffffffffu);
-		if (frames == RESIDENT_STOP) break;
+		const unsigned seq = (unsigned) (rq >> 32), low = (unsigned) (rq & 0xffffffffu);
+		if (low == RESIDENT_STOP) break;
 		if (seq == done) {
 			// nothing to do: the moment to say that the last block's states are out (a wait for this wave's stores, then a word in host memory) -- the host
 			// looks at it before it lets anything else touch the states, and a block never waits for it
@@ -137,15 +146,24 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 			__builtin_amdgcn_s_sleep(4);
 			continue;
 		}
-		// ---- a block: the mailbox -> LDS, the ops, LDS -> the host's mailbox
+		// ---- a block: the mailbox -> LDS, the passes, LDS -> the host's mailbox
 #ifdef RES_TIMING
 		const unsigned long long tt0 = wall_clock64();
 #endif
-		const int n = (int) frames * Cin, n_out = (int) frames * C;
-		if (n > RESIDENT_UNITS || n_out > RESIDENT_UNITS || n > p.buf_doubles) break;      // (a request the host never makes: leave rather than touch anything)
-		double *bout = buf + p.out_off;                              // the block's output: in place, or behind the input when a remix changes the channel count
-		double m0 = 0.0, m1 = 0.0;
-		if (mine && biq) { m0 = ld_agent(stp); m1 = ld_agent(stp + 1); }
+		const int frames = (int) (low & RES_FRAMES_MASK);
+		const int n = frames * p.Cin, n_out = frames * p.Cout;
+		if (frames < 1 || n > half || n_out > half || n > RESIDENT_UNITS || n_out > RESIDENT_UNITS) break;      // (a request the host never makes: leave rather than touch anything)
+		double *cur = buf, *oth = buf + half;                       // a pass that cannot work in place reads `cur`, writes `oth`, and they change places
+		double m0a = 0.0, m1a = 0.0, m0b = 0.0, m1b = 0.0;               // the states of this lane's section in the first / second cascade
+		if (op0.mine && op0.biq) { m0a = ld_agent(op0.stp); m1a = ld_agent(op0.stp + 1); }
+		if (op1.mine && op1.biq) { m0b = ld_agent(op1.stp); m1b = ld_agent(op1.stp + 1); }
+		// the histories of the FIR passes, asked for now (device memory: they arrive while the block does)
+		for (int k = 0; k < p.n_pass; ++k) {
+			const ResidentPass &ps = p.pass[k];
+			if (ps.kind != RES_PASS_FIR) continue;
+			const double *hd = ps.hist + (size_t) ((low >> (16 + k)) & 1u) * ps.c_in * RES_FIR_TAPS;
+			for (int e = tid; e < ps.c_in * RES_FIR_TAPS; e += nth) hist_lds[k * RES_FIR_MAX_CH * RES_FIR_TAPS + e] = ld_agent(hd + e);
+		}
 		{
 			// a unit that does not decode to this request has not arrived yet (or was not asked for with the control unit): read it again.  The host
 			// wrote every unit of the block before the control unit, so this is the exception; a bound all the same
@@ -160,13 +178,13 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 				return u.v;
 			};
 #pragma unroll
-			for (int k = 0; k < RES_SPEC; ++k) { const int e = tid + k * nth; if (e < n) buf[e] = settle(pu[k], k < spec, e); }
+			for (int k = 0; k < RES_SPEC; ++k) { const int e = tid + k * nth; if (e < n) cur[e] = settle(pu[k], k < spec, e); }
 			for (int base = RES_SPEC * nth; base < n; base += 4 * nth) {
 				ResidentUnit v[4];
 #pragma unroll
 				for (int k = 0; k < 4; ++k) { const int e = base + k * nth + tid; if (e < n) v[k] = ld_unit(r_in, 1 + e); }
 #pragma unroll
-				for (int k = 0; k < 4; ++k) { const int e = base + k * nth + tid; if (e < n) buf[e] = settle(v[k], true, e); }
+				for (int k = 0; k < 4; ++k) { const int e = base + k * nth + tid; if (e < n) cur[e] = settle(v[k], true, e); }
 			}
 			if (lost) req_w[1] = 1;
 		}
@@ -175,77 +193,128 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 		const unsigned long long tt1 = wall_clock64();
 #endif
 		if (req_w[1]) break;                                         // (the host times out and takes the block through a launch)
-		if (rmx_n) {
-			// a plain remix in front (the crossover shape): every output channel the sum of its input channels, in ascending order from 0.0, one rounding per
-			// sum (remix.c:39-101: bit-exact) -- a pass of its own over the block in LDS, into the region the cascade then works on in place
-			for (int e = tid; e < n_out; e += nth) {
-				const int t = e / C, c = e - t * C;
-				const int *idx = p.remix_idx + (size_t) c * rmx_n;
-				double acc = 0.0;
-				for (int k = 0; k < rmx_n; ++k) { const int sc = idx[k]; if (sc < 0) break; acc = __dadd_rn(acc, buf[t * Cin + sc]); }
-				bout[e] = acc;
-			}
-			__syncthreads();
-		}
-		if (ch < C) {
-			const int nf = (int) frames, steps = nf + n_ops - 1;
-			const bool upd = mine && biq, wr = mine && j == n_ops - 1;
-			const double *rd = bout + ch;                                // frame t of this row's channel at rd[t C] (the remix, if any, has been through)
-			auto frame_in = [&](int t) -> double { return rd[t * C]; };
-			double s0 = biq ? m0 : b;                                    // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
-			// the channel's last op writes frame t - j at step t; every other lane writes into a word of its own behind the block (no branch around the store)
-			double *wr_base = wr ? bout + ch - j * C : buf + p.buf_doubles + 2 + tid;
-			const int wr_stride = wr ? C : 0;
-			double prev = 0.0;
-			// One step.  The wave is alone on its SIMD: a step costs what it ISSUES (round 6 measured 91 ns per step for round 5's 17 vector and 10 scalar
-			// instructions -- 6.7 of the 10.9 us of a 64-frame block), so the steps between the array's fill and its drain -- n_ops - 1 ... frames - 1, when
-			// every lane has a frame -- are kept short: the input arrives by ONE dpp move per half whose `old` operand is the frame from LDS (lane 0 of a
-			// row has no lane below: it keeps `old`), sections update their states under the execution mask (a branch the compiler may not turn into four
-			// selects: the empty asm), every lane stores (no branch), nobody asks who is active, and the frames come from LDS four steps ahead.
-			auto step_any = [&](int t) {                                 // fill and drain: lane j has a frame while 0 <= t - j < frames
-				const double x = row_shr1_or(prev, frame_in(t < nf ? t : nf - 1));
-				const double r = fma(a, x, s0);
-				const bool active = (unsigned) (t - j) < (unsigned) nf;
-				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
-				if (active && upd) { const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
-				if (active && wr) wr_base[t * wr_stride] = r;
-				prev = r;
-			};
-			const int t_fill = (n_ops - 1 < steps) ? n_ops - 1 : steps;
-			int t = 0;
-			for (; t < t_fill; ++t) step_any(t);
-			if (t < nf) {
-				double xq[4];
-#pragma unroll
-				for (int k = 0; k < 4; ++k) xq[k] = frame_in(t + k < nf ? t + k : nf - 1);
-				auto step_full = [&](int tt_, double xin) {
-					const double x = row_shr1_or(prev, xin);
-					const double r = fma(a, x, s0);
-					if (upd) { asm volatile(""); const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
-					wr_base[tt_ * wr_stride] = r;
-					prev = r;
-				};
-				// (the frame four steps ahead by a running pointer, not clamped to the block: what it reads behind the last frame -- LDS, at worst beyond the
-				// allocation, where a read gives zeros -- belongs to steps this loop does not run)
-				const double *ahead = rd + (size_t) (t + 4) * C;
-				for (; t + 4 <= nf; t += 4) {
-#pragma unroll
-					for (int k = 0; k < 4; ++k) {
-						step_full(t + k, xq[k]);
-						xq[k] = ahead[k * C];
+		for (int k = 0; k < p.n_pass; ++k) {
+			const ResidentPass &ps = p.pass[k];
+			if (ps.kind == RES_PASS_REMIX) {
+				// every output channel the sum of its input channels, in ascending order from 0.0, one rounding per sum (remix.c:39-101) -- or, weighted
+				// (st2ms.c:34-38, crossfeed.c:41-46), the first product starts the sum and every operation rounds once: bit-exact either way
+#pragma clang fp contract(off)
+				const int ci = ps.c_in, co = ps.c_out, mn = ps.max_n;
+				for (int e = tid; e < frames * co; e += nth) {
+					const int t = e / co, c = e - t * co;
+					const int *idx = ps.idx + (size_t) c * mn;
+					double acc = 0.0;
+					if (ps.w) {
+						const double *w = ps.w + (size_t) c * mn;
+						if (idx[0] >= 0) acc = cur[t * ci + idx[0]] * w[0];
+						for (int q = 1; q < mn; ++q) { const int sc = idx[q]; if (sc < 0) break; const double prod = cur[t * ci + sc] * w[q]; acc = acc + prod; }
+						if (ps.post) acc = acc * ps.post[c];
 					}
-					ahead += 4 * C;
+					else for (int q = 0; q < mn; ++q) { const int sc = idx[q]; if (sc < 0) break; acc = acc + cur[t * ci + sc]; }
+					oth[e] = acc;
 				}
-				for (; t < nf; ++t) step_any(t);
+				double *sw = cur; cur = oth; oth = sw;
+				__syncthreads();
 			}
-			for (; t < steps; ++t) step_any(t);
-			if (upd) { st_agent(stp, s0); st_agent(stp + 1, m1); }
+			else if (ps.kind == RES_PASS_FIR) {
+				// direct form in the reference's order (fir.c:43-62): ((0 + x[t-T+1] h[T-1]) + ...) + x[t] h[0], products and sums rounded one by one
+#pragma clang fp contract(off)
+				const int cc = ps.c_in, T = ps.T;
+				const double *hl = hist_lds + k * RES_FIR_MAX_CH * RES_FIR_TAPS;
+				for (int e = tid; e < frames * cc; e += nth) {
+					const int t = e / cc, c = e - t * cc;
+					const int fc = ps.foc[c];
+					double acc = cur[e];
+					if (fc >= 0) {
+						const double *h = ps.taps + (size_t) fc * RES_FIR_TAPS;
+						acc = 0.0;
+						for (int m = T - 1; m >= 0; --m) {
+							const int ti = t - m;
+							const double x = (ti >= 0) ? cur[ti * cc + c] : hl[c * RES_FIR_TAPS + (-ti - 1)];
+							const double prod = x * h[m];
+							acc = acc + prod;
+						}
+					}
+					oth[e] = acc;
+				}
+				// the history the next block starts from: slot q = x[-(q + 1)] of its first frame, i.e. the last T - 1 inputs of [old history | this block]
+				double *hd = ps.hist + (size_t) ((low >> (16 + k)) & 1u) * cc * RES_FIR_TAPS;
+				for (int e = tid; e < cc * (T - 1); e += nth) {
+					const int c = e / (T - 1), q = e - c * (T - 1);
+					if (ps.foc[c] < 0) continue;
+					st_agent(hd + c * RES_FIR_TAPS + q, (q < frames) ? cur[(frames - 1 - q) * cc + c] : hl[c * RES_FIR_TAPS + (q - frames)]);
+				}
+				double *sw = cur; cur = oth; oth = sw;
+				__syncthreads();
+			}
+			else if (ps.kind == RES_PASS_CASCADE) {
+				auto cascade = [&](const LaneOp &o, const int C, const int n_ops, double m0, double m1) {
+					const bool mine = o.mine, biq = o.biq;
+					const double a = o.a, b = o.b, c1 = o.c1, c2 = o.c2, c3 = o.c3, c4 = o.c4;
+					if (ch >= C) return;
+					{
+					const int nf = frames, steps = nf + n_ops - 1;
+					const bool upd = mine && biq, wr = mine && j == n_ops - 1;
+					const double *rd = cur + ch;                             // frame t of this row's channel at rd[t C]
+					auto frame_in = [&](int t) -> double { return rd[t * C]; };
+					double s0 = biq ? m0 : b;                                // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
+					// the channel's last op writes frame t - j at step t; every other lane writes into a word of its own behind the block (no branch around the store)
+					double *wr_base = wr ? cur + ch - j * C : lane_word;
+					const int wr_stride = wr ? C : 0;
+					double prev = 0.0;
+					// One step.  The wave is alone on its SIMD: a step costs what it ISSUES (round 6 measured 91 ns per step for round 5's 17 vector and 10 scalar
+					// instructions -- 6.7 of the 10.9 us of a 64-frame block), so the steps between the array's fill and its drain -- n_ops - 1 ... frames - 1, when
+					// every lane has a frame -- are kept short: the input arrives by ONE dpp move per half whose `old` operand is the frame from LDS (lane 0 of a
+					// row has no lane below: it keeps `old`), sections update their states under the execution mask (a branch the compiler may not turn into four
+					// selects: the empty asm), every lane stores (no branch), nobody asks who is active, and the frames come from LDS four steps ahead.
+					auto step_any = [&](int t) {                             // fill and drain: lane j has a frame while 0 <= t - j < frames
+						const double x = row_shr1_or(prev, frame_in(t < nf ? t : nf - 1));
+						const double r = fma(a, x, s0);
+						const bool active = (unsigned) (t - j) < (unsigned) nf;
+						// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
+						if (active && upd) { const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
+						if (active && wr) wr_base[t * wr_stride] = r;
+						prev = r;
+					};
+					const int t_fill = (n_ops - 1 < steps) ? n_ops - 1 : steps;
+					int t = 0;
+					for (; t < t_fill; ++t) step_any(t);
+					if (t < nf) {
+						double xq[4];
+#pragma unroll
+						for (int q = 0; q < 4; ++q) xq[q] = frame_in(t + q < nf ? t + q : nf - 1);
+						auto step_full = [&](int tt_, double xin) {
+							const double x = row_shr1_or(prev, xin);
+							const double r = fma(a, x, s0);
+							if (upd) { asm volatile(""); const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
+							wr_base[tt_ * wr_stride] = r;
+							prev = r;
+						};
+						// (the frame four steps ahead by a running pointer, not clamped to the block: what it reads behind the last frame -- LDS, at worst beyond the
+						// allocation, where a read gives zeros -- belongs to steps this loop does not run)
+						const double *ahead = rd + (size_t) (t + 4) * C;
+						for (; t + 4 <= nf; t += 4) {
+#pragma unroll
+							for (int q = 0; q < 4; ++q) {
+								step_full(t + q, xq[q]);
+								xq[q] = ahead[q * C];
+							}
+							ahead += 4 * C;
+						}
+						for (; t < nf; ++t) step_any(t);
+					}
+					for (; t < steps; ++t) step_any(t);
+					if (upd) { st_agent(o.stp, s0); st_agent(o.stp + 1, m1); }
+					}
+				};
+				if (ps.casc == 0) cascade(op0, p.cs[0].C, p.cs[0].n_ops, m0a, m1a); else cascade(op1, p.cs[1].C, p.cs[1].n_ops, m0b, m1b);
+				__syncthreads();
+			}
 		}
-		__syncthreads();
 #ifdef RES_TIMING
 		const unsigned long long tt2 = wall_clock64();
 #endif
-		for (int e = tid; e < n_out; e += nth) st_unit(r_out, e, bout[e], rq);
+		for (int e = tid; e < n_out; e += nth) st_unit(r_out, e, cur[e], rq);
 #ifdef RES_TIMING
 		// (an experimental build, scripts/r06_resident_timing.sh: where a block's time goes, in ticks of the 100 MHz clock, summed in the control block)
 		if (tid == 0) { const unsigned long long tt3 = wall_clock64(); p.ctl->pad[0] += (unsigned) (tt1 - tt0); p.ctl->pad[1] += (unsigned) (tt2 - tt1); p.ctl->pad[2] += (unsigned) (tt3 - tt2); p.ctl->pad[3] += 1; p.ctl->pad[4] += it - it_last; }
@@ -262,9 +331,15 @@ __global__ __launch_bounds__(1024) void cascade_resident(ResidentParams p)
 
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st)
 {
-	if (p.C < 1 || p.C > 64 || p.Cin < 1 || p.n_ops < 1 || p.n_ops > RES_MAX_OPS || (size_t) (p.buf_doubles + 2 + 1024) * sizeof(double) > lds_bytes || !p.mail_in || !p.mail_out || (p.out_off & 1)) return false;
+	if (p.Cin < 1 || p.Cout < 1 || p.n_pass < 1 || p.n_pass > RES_MAX_PASSES || p.n_casc < 0 || p.n_casc > RES_MAX_CASCADES
+	    || resident_lds_bytes(p.buf_doubles) > lds_bytes || (p.buf_doubles & 3) || !p.mail_in || !p.mail_out) return false;
+	for (int q = 0; q < p.n_casc; ++q) if (p.cs[q].C < 1 || p.cs[q].C > 32 || p.cs[q].n_ops < 1 || p.cs[q].n_ops > RES_MAX_OPS) return false;
 	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident), lds_bytes);
-	const int waves = (p.C + 3) / 4;
+	// a wave per four channels of a cascade pass (a 16-lane row per channel); the other passes share the block out over whatever threads there are
+	int widest = 1;
+	for (int q = 0; q < p.n_casc; ++q) widest = p.cs[q].C > widest ? p.cs[q].C : widest;
+	for (int k = 0; k < p.n_pass; ++k) if (p.pass[k].kind != RES_PASS_CASCADE && p.pass[k].c_out > widest && p.pass[k].c_out <= 16) widest = p.pass[k].c_out;
+	const int waves = (widest + 3) / 4;
 	hipLaunchKernelGGL(cascade_resident, dim3(1), dim3(64 * waves), lds_bytes, st, p);
 	return hipGetLastError() == hipSuccess;
 }

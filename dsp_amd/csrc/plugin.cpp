@@ -84,12 +84,9 @@ static bool ensure_segment(struct effect *e, Node *n)
 	seg->mapped.alloc();
 	{
 		static const bool resident_on = [] { const char *v = getenv("DSP_AMD_PLUGIN_RESIDENT"); return !v || atoi(v) != 0; }();
-		CascadeStage *casc = resident_on ? seg->pipe->sole_cascade() : nullptr;
-		RemixStage *rmx = nullptr;
-		if (resident_on && !casc && !seg->pipe->remix_then_cascade(&rmx, &casc)) { rmx = nullptr; casc = nullptr; }
-		if (casc) {
+		if (resident_on) {
 			seg->resident.reset(new Resident);
-			if (!seg->resident->init(rmx, casc)) seg->resident.reset();
+			if (!seg->resident->init(*seg->pipe)) seg->resident.reset();
 		}
 	}
 	if (seg->members.size() > 1) log_msg(LL_VERBOSE, "%s: info: %zu effects fused into one device segment: %s", e->name, seg->members.size(), seg->pipe->plan().c_str());
@@ -107,28 +104,21 @@ Segment::~Segment() { resident.reset(); }
 // ---- the resident small-block wave (see plugin.h) ----
 static inline double res_now_us() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 
-bool Resident::init(RemixStage *r, CascadeStage *c)
+bool Resident::init(const Pipeline &pipe)
 {
-	if (!c || c->n_ops < 1 || c->n_ops > 16 || c->ch_in < 1 || c->ch_in > 64) return false;
+	// the segment's stages as passes of the wave (remixes, at most one cascade, direct FIRs: Pipeline::resident_plan), or no wave for this segment
+	if (!pipe.resident_plan(&rp, fir_phase)) return false;
 	// (the mailboxes and the stream of its own are made by the first block the wave takes -- open(): a segment driven with larger blocks never has them)
-	memset(&rp, 0, sizeof(rp));
-	rp.C = c->ch_in; rp.n_ops = c->n_ops;
-	rp.Cin = r ? r->ch_in : c->ch_in;
-	rp.remix_idx = r ? r->device_idx() : nullptr;
-	rp.remix_max_n = r ? r->sources_per_row() : 0;
-	rp.ops = c->device_ops(); rp.state = c->device_state();
 	rp.lifetime_ticks = 300000ull;           // 3 ms of the 100 MHz clock: more than two periods of a 64-frame block at 48 kHz
 	rp.max_life_ticks = 2000000ull;          // 20 ms in all: what a hipDeviceSynchronize() on another thread waits at the very most while this segment plays
 	rp.max_polls = 1u << 18;                 // (a turn of the loop is a trip to the mailbox: about a second at the very most)
-	const size_t block_bytes = (size_t) 64 << 10;
-	rp.buf_doubles = (int) (block_bytes / sizeof(double));
-	// with a remix the output of a block lies behind its input (the channel count changes): one half of the buffer each
-	rp.out_off = r ? (rp.buf_doubles / 2) & ~1 : 0;
-	lds = block_bytes + (2 + 1024) * sizeof(double);      // the block, two control words, a word per lane for the stores of the lanes that are not a channel's last op
-	sections = 1;
-	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel on top of the trips of the block and of its output; a launch of the
-	// ordinary, time-parallel kernels costs 24 ... 26 us whatever the block (18 ... 21 us for the two launches of a short remix + cascade segment): the wave
-	// takes blocks of up to 128 frames (profiles/r06_ladspa_rate.txt)
+	rp.buf_doubles = 8192;                   // 64 KB: two halves of 4096 samples (a pass that cannot work in place goes from one to the other)
+	lds = resident_lds_bytes(rp.buf_doubles);
+	widest = std::max(rp.Cin, rp.Cout);
+	for (int k = 0; k < rp.n_pass; ++k) widest = std::max(widest, std::max(rp.pass[k].c_in, rp.pass[k].c_out));
+	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel (or a pass of a few taps per sample) on top of the trips of the block
+	// and of its output: 8.6 us at 64 frames, 12.8 at 128 for a stereo ten-section chain; a launch of the ordinary, time-parallel kernels costs 20 ... 26 us
+	// whatever the block: the wave takes blocks of up to 128 frames (profiles/r06_ladspa_rate.txt)
 	max_work = 128;
 	ready = true;
 	return true;
@@ -211,8 +201,11 @@ bool Resident::serve(const double *in, ssize_t frames, double *out)
 #endif
 	const unsigned served = seq;
 	++seq;
-	const unsigned long long rq = ((unsigned long long) seq << 32) | (unsigned long long) (unsigned) frames;
-	const size_t n = (size_t) frames * rp.Cin, n_out = (size_t) frames * rp.C;
+	// the low word: the frames, and for every FIR pass which half of its history is current (the ordinary kernel alternates them, conv.cpp FirDirectStage)
+	unsigned low = (unsigned) frames;
+	for (int k = 0; k < rp.n_pass; ++k) if (fir_phase[k] && *fir_phase[k]) low |= 1u << (16 + k);
+	const unsigned long long rq = ((unsigned long long) seq << 32) | (unsigned long long) low;
+	const size_t n = (size_t) frames * rp.Cin, n_out = (size_t) frames * rp.Cout;
 	// the block first, the control unit behind it (write-combined stores leave the core in any order: a fence in between)
 	for (size_t e = 0; e < n; ++e) res_store_unit(mail_in + 1 + e, in[e], rq);
 	if (in_device) __builtin_ia32_sfence();

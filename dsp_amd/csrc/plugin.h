@@ -15,7 +15,8 @@ constexpr unsigned NODE_MAGIC = 0x44535041u;   // "DSPA"
 // e->next when the first of them runs) compiled into ONE fused pipeline -- one H2D copy at the head, the whole
 // segment on the device (cascade fusion, LTI merges, convolvers feeding each other, exactly as in the batch API),
 // one D2H copy; the other members' run() hand the result through.  SURVEY.md section 7 step 4 / section 8(f).
-// Small blocks of a segment that is one cascade (the equaliser shape), or a plain remix in front of one, through a workgroup that stays on the device for a
+// Small blocks of a segment made of remixes / mixes, direct FIRs and at most one cascade (the equaliser, the crossover, a crossover with correction FIRs, st2ms ...)
+// through a workgroup that stays on the device for a
 // few milliseconds and polls a mailbox -- no launch per block (kernels_resident.hip; the mailbox protocol: engine.h).  The wave leaves by itself (clock, loop
 // bound) or when asked to; the next block starts another one.  A block it does not serve in time goes through a launch (the third such block switches the
 // mechanism off for the segment).  The wave does not fence the states on the path of a block: whoever else is about to touch them calls quiesce() first.
@@ -28,8 +29,9 @@ struct Resident {
 	ResidentParams rp;
 	size_t lds = 0;
 	unsigned seq = 0;                        // sequence number of the last request made
-	long max_work = 0;                       // frames x sections a block may have (beyond it the ordinary, parallel kernels are faster)
-	int sections = 1;
+	long max_work = 0;                       // frames a block may have (beyond it the ordinary, time-parallel kernels are faster)
+	int widest = 1;                          // channels of the widest point of the segment (a block's frames x that many samples fit a half of the wave's buffer)
+	const int *fir_phase[RES_MAX_PASSES] = { nullptr, nullptr, nullptr, nullptr };     // per FIR pass: the stage's own "which half of the history is current"
 	bool off = false;
 	bool dirty = false;                      // the wave has served blocks since it was last waited for: the states in device memory may still be on their way
 	int timeouts = 0;                        // blocks the wave did not serve in time (the third one switches the path off for the segment)
@@ -37,12 +39,8 @@ struct Resident {
 	double t_write_us = 0.0, t_wait_us = 0.0;
 #endif
 	bool ready = false;                      // init() has accepted the segment; mailboxes and the stream come with the first small block (open())
-	bool init(class RemixStage *r, class CascadeStage *c);       // r: a plain remix in front of the cascade, or nullptr
-	bool takes(ssize_t frames) const
-	{
-		return !off && ready && frames >= 1 && (long) frames * sections <= max_work && (size_t) frames * std::max(rp.Cin, rp.C) <= (size_t) RESIDENT_UNITS
-		       && (size_t) frames * (rp.remix_idx ? 2 * std::max(rp.Cin, rp.C) : rp.C) + 4 <= (size_t) rp.buf_doubles;
-	}
+	bool init(const Pipeline &pipe);         // false: the segment's stages are not all passes the wave knows
+	bool takes(ssize_t frames) const { return !off && ready && frames >= 1 && (long) frames <= max_work && (size_t) frames * widest <= (size_t) rp.buf_doubles / 2 && (size_t) frames * widest <= (size_t) RESIDENT_UNITS; }
 	// the block at `in` ([frames][Cin]) through the wave into `out` ([frames][C]); false: not served (the caller takes the ordinary path, on the same states)
 	bool serve(const double *in, ssize_t frames, double *out);
 	void stop();                             // ask the wave to leave and wait for it

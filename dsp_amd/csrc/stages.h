@@ -84,8 +84,10 @@ public:
 	bool wire_in_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
 	bool wire_out_ok(int, const void *, long, ssize_t, bool, int) const override { return wire_fusion_on(); }
 	size_t device_bytes() const override { return d_idx.bytes + d_w.bytes + d_post.bytes; }
-	// a plain remix (sums from 0.0 in ascending input order) for the resident small-block wave: [ch_out][max_n] source channels, -1 terminated
-	const int *device_idx() const { return weighted ? nullptr : d_idx.as<int>(); }
+	// for the resident small-block wave: [ch_out][max_n] source channels, -1 terminated; of a weighted mix also the weights and the factors behind the sums
+	const int *device_idx() const { return d_idx.as<int>(); }
+	const double *device_w() const { return weighted ? d_w.as<double>() : nullptr; }
+	const double *device_post() const { return (weighted && d_post.p) ? d_post.as<double>() : nullptr; }
 	int sources_per_row() const { return max_n; }
 private:
 	DevBuf d_idx, d_w, d_post;           // d_w / d_post: weighted rows (Kind::Mix)
@@ -122,5 +124,7 @@ void resample_polyphase_table(const Spec &sp, int *J, long *out_delay, std::vect
 // convolver on the same channel pairs its K3 writes this stage's ring directly.  `feeder` (may be null) is the cascade stage immediately before,
 // which can write straight into the convolver's planar ring instead of an interleaved slab.
 Stage *make_conv_stage(const Spec &sp, int n_streams, ssize_t max_frames, CascadeStage *feeder, Stage *prev);
+// a direct-form FIR stage (conv.cpp) as a pass of the resident small-block wave: taps, filter of every channel, history; *phase: which half of the history is current
+bool fir_direct_view(Stage *s, struct ResidentPass *ps, const int **phase);
 
 }  // namespace dspamd

@@ -47,6 +47,16 @@ def stream(chain, C, x, blocks, variant, pause_at=None):
     # the crossover shape (examples/crossover_lr4_2kHz): a remix 2 -> 4 in front of per-band sections -- the remix inside the wave too
     ("remix 0 1 0 1 :0,1 lowpass 2k 0.707 lowpass 2k 0.707 :2,3 highpass 2k 0.707 highpass 2k 0.707 : gain -1", 2, (64, 128, 1000), (4,)),
     ("remix 0,1 0 1 gain -3 add 0.001", 2, (64, 96), None),              # a mono sum beside the two channels, then bit-exact ops only
+    # round 6: direct FIRs (<= 32 taps, fir.c:43-62 / fir_p.c:131-148: bit-exact, history carried in device memory across blocks AND across the two paths)
+    ("fir_p coefs:0.9,0.05,-0.02,0.01,0.003 gain -2", 2, (64, 3, 33, 128, 2048, 64), None),
+    ("highpass 30 0.707 fir_p coefs:0.9,0.05,-0.02,0.01,0.003 gain -1", 2, (64, 17, 128, 5), (2,)),
+    ("fir coefs:0.5,0.25,0.125 :0 eq 300 1.5 4", 2, (64, 96), None),
+    # ... the crossover with a correction FIR behind the sections, and FIRs either side of the cascade
+    ("remix 0 1 0 1 :0,1 lowpass 2k 0.707 lowpass 2k 0.707 :2,3 highpass 2k 0.707 highpass 2k 0.707 : fir_p coefs:1.0,0.1,-0.05", 2, (64, 128, 700), (3,)),
+    ("fir_p coefs:0.8,0.1 eq 1k 1.0 3 fir_p coefs:1.0,-0.2,0.04", 2, (64, 20), None),
+    # ... and weighted mixes: mid / side around an equaliser, the two ends of a crossfeed (st2ms.c:28-54, crossfeed.c:41-46)
+    ("st2ms eq 1k 1.0 3 ms2st", 2, (64, 100), None),
+    ("crossfeed 700 4.5", 2, (64, 128), None),
 ])
 def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
     rng = np.random.Generator(np.random.PCG64(99))
@@ -75,7 +85,7 @@ def test_small_blocks_through_the_resident_wave(chain, C, blocks, pause):
         assert d["wave_launches"] >= 1 + len(pause), d           # (every pause outlasts the wave: the block behind it started another one)
     assert got.shape == ref.shape
     assert got.shape[1] == (3 if chain.startswith("remix 0,1") else 4 if chain.startswith("remix") else C)
-    if "eq" not in chain and "pass" not in chain:
+    if not any(w in chain for w in ("eq", "pass", "shelf", "crossfeed")):          # no section anywhere: gains, adds, remixes and direct FIRs are bit-exact
         assert np.array_equal(got, ref) and np.array_equal(np.signbit(got), np.signbit(ref))
     else:
         assert rms(got - ref) < 1e-12, rms(got - ref)
