@@ -1189,7 +1189,8 @@ bool Pipeline::resident_plan(ResidentParams *rp, const int *fir_phase[]) const
 		fir_phase[k] = nullptr;
 		Stage *st = stages[k].get();
 		if (RemixStage *rm = dynamic_cast<RemixStage *>(st)) {
-			if (rm->ch_in != c || rm->sources_per_row() > 16 || rm->ch_out > 64) return false;
+			// (its tables -- weights, factors, sources -- have 8 KB of the wave's LDS)
+			if (rm->ch_in != c || (size_t) rm->ch_out * rm->sources_per_row() * 12 + (size_t) rm->ch_out * 8 > (size_t) RES_TAB_DOUBLES * 8) return false;
 			memset(&ps, 0, sizeof(ps));
 			ps.kind = RES_PASS_REMIX; ps.c_in = rm->ch_in; ps.c_out = rm->ch_out;
 			ps.idx = rm->device_idx(); ps.w = rm->device_w(); ps.post = rm->device_post(); ps.max_n = rm->sources_per_row();

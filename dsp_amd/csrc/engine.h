@@ -269,8 +269,11 @@ struct ResidentParams {
 	int buf_doubles;                                 // doubles of the block buffer in LDS: two halves, a pass that cannot work in place goes from one to the other
 	int spec_units;                                  // payload units per lane asked for together with the control unit (the blocks the host expects to send)
 };
-// LDS of the wave: the block buffer, two control words, a word per lane (the stores of lanes that are not a channel's last op), the FIR histories
-constexpr size_t resident_lds_bytes(int buf_doubles) { return ((size_t) buf_doubles + 2 + 1024 + (size_t) RES_MAX_PASSES * RES_FIR_MAX_CH * RES_FIR_TAPS) * sizeof(double); }
+// LDS of the wave: the block buffer, two control words, a word per lane (the stores of lanes that are not a channel's last op), the FIR histories ...
+// ... and a copy of every pass's tables (8 KB per pass: a FIR's taps and channel map, a remix's sources, weights and factors -- read per tap / per source,
+// they must not be a trip to memory each time)
+constexpr int RES_TAB_DOUBLES = 1024;
+constexpr size_t resident_lds_bytes(int buf_doubles) { return ((size_t) buf_doubles + 2 + 1024 + (size_t) RES_MAX_PASSES * (RES_FIR_MAX_CH * RES_FIR_TAPS + RES_TAB_DOUBLES)) * sizeof(double); }
 bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStream_t st);
 
 // kernel launchers (kernels_*.hip)

@@ -76,6 +76,8 @@ constexpr unsigned RES_SPINS = 1u << 17;     // re-reads of a unit that does not
 // first form of this kernel, one lane per channel: 116 us per 64-frame block of a stereo ten-section chain on a GPU that idles at a low clock).
 // Every lane runs the same instructions: r = fma(a, x, b) is the section's output (a = c0, b = m0), a gain (a = g, b = -0.0: the product keeps its
 // sign of zero), an add (a = 1, b = v) or a pass (a = 1, b = -0.0), bit for bit what __dmul_rn / __dadd_rn give; only sections update (m0, m1).
+// GEN = false: the segment is ONE cascade (the equaliser at LADSPA block sizes: the shape the 9 us are asked of) -- no pass list, no tables, no histories
+template <bool GEN>
 __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) double buf[];      // two halves of the block buffer; behind them two words (the request, a failure flag), a word per lane, the FIR histories
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 	unsigned long long *req_w = reinterpret_cast<unsigned long long *>(buf + p.buf_doubles);
 	double *lane_word = buf + p.buf_doubles + 2 + tid;
 	double *hist_lds = buf + p.buf_doubles + 2 + 1024;                 // [pass][channel][RES_FIR_TAPS]
+	double *tab_lds = hist_lds + RES_MAX_PASSES * RES_FIR_MAX_CH * RES_FIR_TAPS;     // [pass][RES_TAB_DOUBLES]: the pass's tables, copied once (below)
 	// this lane's op in each of the segment's cascades, in registers for the kernel's lifetime
 	struct LaneOp { double a, b, c1, c2, c3, c4; bool biq, mine; double *stp; };
 	auto lane_op = [&](int q) {
@@ -110,6 +113,25 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 	unsigned long long t_last = wall_clock64();
 	const unsigned long long t_start = t_last;
 	if (tid == 0) req_w[1] = 0;
+	// every pass's tables into LDS, once per launch: a FIR's taps [16][32] and, behind them, its channel map [16] (ints); a remix's weights [c_out][max_n],
+	// factors [c_out] and sources [c_out][max_n] (ints, -1 terminated) -- the launcher checked that they fit
+	for (int k = 0; GEN && k < p.n_pass; ++k) {
+		const ResidentPass &ps = p.pass[k];
+		double *tb = tab_lds + k * RES_TAB_DOUBLES;
+		if (ps.kind == RES_PASS_FIR) {
+			for (int e = tid; e < RES_FIR_MAX_CH * RES_FIR_TAPS; e += nth) { const int f = e / RES_FIR_TAPS; bool used = false; for (int c = 0; c < ps.c_in; ++c) used |= ps.foc[c] == f; tb[e] = used ? ps.taps[e] : 0.0; }
+			int *fo = reinterpret_cast<int *>(tb + RES_FIR_MAX_CH * RES_FIR_TAPS);
+			for (int e = tid; e < RES_FIR_MAX_CH; e += nth) fo[e] = e < ps.c_in ? ps.foc[e] : -1;
+		}
+		else if (ps.kind == RES_PASS_REMIX) {
+			const int cells = ps.c_out * ps.max_n;
+			double *w = tb, *post = tb + cells;
+			int *idx = reinterpret_cast<int *>(tb + cells + ps.c_out);
+			for (int e = tid; e < cells; e += nth) { w[e] = ps.w ? ps.w[e] : 1.0; idx[e] = ps.idx[e]; }
+			for (int e = tid; e < ps.c_out; e += nth) post[e] = ps.post ? ps.post[e] : 1.0;
+		}
+	}
+	__syncthreads();
 #ifdef RES_TIMING
 	unsigned it_last = 0;
 #endif
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 		if (op0.mine && op0.biq) { m0a = ld_agent(op0.stp); m1a = ld_agent(op0.stp + 1); }
 		if (op1.mine && op1.biq) { m0b = ld_agent(op1.stp); m1b = ld_agent(op1.stp + 1); }
 		// the histories of the FIR passes, asked for now (device memory: they arrive while the block does)
-		for (int k = 0; k < p.n_pass; ++k) {
+		for (int k = 0; GEN && k < p.n_pass; ++k) {
 			const ResidentPass &ps = p.pass[k];
 			if (ps.kind != RES_PASS_FIR) continue;
 			const double *hd = ps.hist + (size_t) ((low >> (16 + k)) & 1u) * ps.c_in * RES_FIR_TAPS;
@@ -193,22 +215,85 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 		const unsigned long long tt1 = wall_clock64();
 #endif
 		if (req_w[1]) break;                                         // (the host times out and takes the block through a launch)
-		for (int k = 0; k < p.n_pass; ++k) {
+		auto cascade = [&](const LaneOp &o, const int C, const int n_ops, double m0, double m1) {
+			const bool mine = o.mine, biq = o.biq;
+			const double a = o.a, b = o.b, c1 = o.c1, c2 = o.c2, c3 = o.c3, c4 = o.c4;
+			if (ch >= C) return;
+			{
+			const int nf = frames, steps = nf + n_ops - 1;
+			const bool upd = mine && biq, wr = mine && j == n_ops - 1;
+			const double *rd = cur + ch;                             // frame t of this row's channel at rd[t C]
+			auto frame_in = [&](int t) -> double { return rd[t * C]; };
+			double s0 = biq ? m0 : b;                                // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
+			// the channel's last op writes frame t - j at step t; every other lane writes into a word of its own behind the block (no branch around the store)
+			double *wr_base = wr ? cur + ch - j * C : lane_word;
+			const int wr_stride = wr ? C : 0;
+			double prev = 0.0;
+			// One step.  The wave is alone on its SIMD: a step costs what it ISSUES (round 6 measured 91 ns per step for round 5's 17 vector and 10 scalar
+			// instructions -- 6.7 of the 10.9 us of a 64-frame block), so the steps between the array's fill and its drain -- n_ops - 1 ... frames - 1, when
+			// every lane has a frame -- are kept short: the input arrives by ONE dpp move per half whose `old` operand is the frame from LDS (lane 0 of a
+			// row has no lane below: it keeps `old`), sections update their states under the execution mask (a branch the compiler may not turn into four
+			// selects: the empty asm), every lane stores (no branch), nobody asks who is active, and the frames come from LDS four steps ahead.
+			auto step_any = [&](int t) {                             // fill and drain: lane j has a frame while 0 <= t - j < frames
+				const double x = row_shr1_or(prev, frame_in(t < nf ? t : nf - 1));
+				const double r = fma(a, x, s0);
+				const bool active = (unsigned) (t - j) < (unsigned) nf;
+				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
+				if (active && upd) { const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
+				if (active && wr) wr_base[t * wr_stride] = r;
+				prev = r;
+			};
+			const int t_fill = (n_ops - 1 < steps) ? n_ops - 1 : steps;
+			int t = 0;
+			for (; t < t_fill; ++t) step_any(t);
+			if (t < nf) {
+				double xq[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) xq[q] = frame_in(t + q < nf ? t + q : nf - 1);
+				auto step_full = [&](int tt_, double xin) {
+					const double x = row_shr1_or(prev, xin);
+					const double r = fma(a, x, s0);
+					if (upd) { asm volatile(""); const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
+					wr_base[tt_ * wr_stride] = r;
+					prev = r;
+				};
+				// (the frame four steps ahead by a running pointer, not clamped to the block: what it reads behind the last frame -- LDS, at worst beyond the
+				// allocation, where a read gives zeros -- belongs to steps this loop does not run)
+				const double *ahead = rd + (size_t) (t + 4) * C;
+				for (; t + 4 <= nf; t += 4) {
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						step_full(t + q, xq[q]);
+						xq[q] = ahead[q * C];
+					}
+					ahead += 4 * C;
+				}
+				for (; t < nf; ++t) step_any(t);
+			}
+			for (; t < steps; ++t) step_any(t);
+			if (upd) { st_agent(o.stp, s0); st_agent(o.stp + 1, m1); }
+			}
+		};
+		if constexpr (!GEN) { cascade(op0, p.cs[0].C, p.cs[0].n_ops, m0a, m1a); __syncthreads(); }
+		for (int k = 0; GEN && k < p.n_pass; ++k) {
 			const ResidentPass &ps = p.pass[k];
 			if (ps.kind == RES_PASS_REMIX) {
 				// every output channel the sum of its input channels, in ascending order from 0.0, one rounding per sum (remix.c:39-101) -- or, weighted
 				// (st2ms.c:34-38, crossfeed.c:41-46), the first product starts the sum and every operation rounds once: bit-exact either way
 #pragma clang fp contract(off)
 				const int ci = ps.c_in, co = ps.c_out, mn = ps.max_n;
+				const double *tw = tab_lds + k * RES_TAB_DOUBLES, *tpost = tw + co * mn;
+				const int *tidx = reinterpret_cast<const int *>(tw + co * mn + co);
+				const bool weighted = ps.w != nullptr, has_post = ps.post != nullptr;
 				for (int e = tid; e < frames * co; e += nth) {
 					const int t = e / co, c = e - t * co;
-					const int *idx = ps.idx + (size_t) c * mn;
+					const int *idx = tidx + c * mn;
 					double acc = 0.0;
-					if (ps.w) {
-						const double *w = ps.w + (size_t) c * mn;
+					if (weighted) {
+						const double *w = tw + c * mn;
 						if (idx[0] >= 0) acc = cur[t * ci + idx[0]] * w[0];
 						for (int q = 1; q < mn; ++q) { const int sc = idx[q]; if (sc < 0) break; const double prod = cur[t * ci + sc] * w[q]; acc = acc + prod; }
-						if (ps.post) acc = acc * ps.post[c];
+						if (has_post) acc = acc * tpost[c];
 					}
 					else for (int q = 0; q < mn; ++q) { const int sc = idx[q]; if (sc < 0) break; acc = acc + cur[t * ci + sc]; }
 					oth[e] = acc;
@@ -221,18 +306,28 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 #pragma clang fp contract(off)
 				const int cc = ps.c_in, T = ps.T;
 				const double *hl = hist_lds + k * RES_FIR_MAX_CH * RES_FIR_TAPS;
+				const double *taps = tab_lds + k * RES_TAB_DOUBLES;
+				const int *foc = reinterpret_cast<const int *>(taps + RES_FIR_MAX_CH * RES_FIR_TAPS);
 				for (int e = tid; e < frames * cc; e += nth) {
 					const int t = e / cc, c = e - t * cc;
-					const int fc = ps.foc[c];
+					const int fc = foc[c];
 					double acc = cur[e];
 					if (fc >= 0) {
-						const double *h = ps.taps + (size_t) fc * RES_FIR_TAPS;
+						const double *h = taps + fc * RES_FIR_TAPS;
 						acc = 0.0;
-						for (int m = T - 1; m >= 0; --m) {
-							const int ti = t - m;
-							const double x = (ti >= 0) ? cur[ti * cc + c] : hl[c * RES_FIR_TAPS + (-ti - 1)];
-							const double prod = x * h[m];
-							acc = acc + prod;
+						if (t >= T - 1) {
+							// (every tap's frame lies in the block: one pointer walking forward, no question asked per tap)
+							const double *xp = cur + (t - (T - 1)) * cc + c;
+#pragma unroll 4
+							for (int m = T - 1; m >= 0; --m) { const double prod = xp[0] * h[m]; acc = acc + prod; xp += cc; }
+						}
+						else {
+							for (int m = T - 1; m >= 0; --m) {
+								const int ti = t - m;
+								const double x = (ti >= 0) ? cur[ti * cc + c] : hl[c * RES_FIR_TAPS + (-ti - 1)];
+								const double prod = x * h[m];
+								acc = acc + prod;
+							}
 						}
 					}
 					oth[e] = acc;
@@ -241,72 +336,13 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 				double *hd = ps.hist + (size_t) ((low >> (16 + k)) & 1u) * cc * RES_FIR_TAPS;
 				for (int e = tid; e < cc * (T - 1); e += nth) {
 					const int c = e / (T - 1), q = e - c * (T - 1);
-					if (ps.foc[c] < 0) continue;
+					if (foc[c] < 0) continue;
 					st_agent(hd + c * RES_FIR_TAPS + q, (q < frames) ? cur[(frames - 1 - q) * cc + c] : hl[c * RES_FIR_TAPS + (q - frames)]);
 				}
 				double *sw = cur; cur = oth; oth = sw;
 				__syncthreads();
 			}
 			else if (ps.kind == RES_PASS_CASCADE) {
-				auto cascade = [&](const LaneOp &o, const int C, const int n_ops, double m0, double m1) {
-					const bool mine = o.mine, biq = o.biq;
-					const double a = o.a, b = o.b, c1 = o.c1, c2 = o.c2, c3 = o.c3, c4 = o.c4;
-					if (ch >= C) return;
-					{
-					const int nf = frames, steps = nf + n_ops - 1;
-					const bool upd = mine && biq, wr = mine && j == n_ops - 1;
-					const double *rd = cur + ch;                             // frame t of this row's channel at rd[t C]
-					auto frame_in = [&](int t) -> double { return rd[t * C]; };
-					double s0 = biq ? m0 : b;                                // the addend of r = fma(a, x, s0): a section's m0, or the op's constant
-					// the channel's last op writes frame t - j at step t; every other lane writes into a word of its own behind the block (no branch around the store)
-					double *wr_base = wr ? cur + ch - j * C : lane_word;
-					const int wr_stride = wr ? C : 0;
-					double prev = 0.0;
-					// One step.  The wave is alone on its SIMD: a step costs what it ISSUES (round 6 measured 91 ns per step for round 5's 17 vector and 10 scalar
-					// instructions -- 6.7 of the 10.9 us of a 64-frame block), so the steps between the array's fill and its drain -- n_ops - 1 ... frames - 1, when
-					// every lane has a frame -- are kept short: the input arrives by ONE dpp move per half whose `old` operand is the frame from LDS (lane 0 of a
-					// row has no lane below: it keeps `old`), sections update their states under the execution mask (a branch the compiler may not turn into four
-					// selects: the empty asm), every lane stores (no branch), nobody asks who is active, and the frames come from LDS four steps ahead.
-					auto step_any = [&](int t) {                             // fill and drain: lane j has a frame while 0 <= t - j < frames
-						const double x = row_shr1_or(prev, frame_in(t < nf ? t : nf - 1));
-						const double r = fma(a, x, s0);
-						const bool active = (unsigned) (t - j) < (unsigned) nf;
-						// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
-						if (active && upd) { const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
-						if (active && wr) wr_base[t * wr_stride] = r;
-						prev = r;
-					};
-					const int t_fill = (n_ops - 1 < steps) ? n_ops - 1 : steps;
-					int t = 0;
-					for (; t < t_fill; ++t) step_any(t);
-					if (t < nf) {
-						double xq[4];
-#pragma unroll
-						for (int q = 0; q < 4; ++q) xq[q] = frame_in(t + q < nf ? t + q : nf - 1);
-						auto step_full = [&](int tt_, double xin) {
-							const double x = row_shr1_or(prev, xin);
-							const double r = fma(a, x, s0);
-							if (upd) { asm volatile(""); const double tt = fma(c1, x, m1), u = c2 * x; s0 = fma(-c3, r, tt); m1 = fma(-c4, r, u); }
-							wr_base[tt_ * wr_stride] = r;
-							prev = r;
-						};
-						// (the frame four steps ahead by a running pointer, not clamped to the block: what it reads behind the last frame -- LDS, at worst beyond the
-						// allocation, where a read gives zeros -- belongs to steps this loop does not run)
-						const double *ahead = rd + (size_t) (t + 4) * C;
-						for (; t + 4 <= nf; t += 4) {
-#pragma unroll
-							for (int q = 0; q < 4; ++q) {
-								step_full(t + q, xq[q]);
-								xq[q] = ahead[q * C];
-							}
-							ahead += 4 * C;
-						}
-						for (; t < nf; ++t) step_any(t);
-					}
-					for (; t < steps; ++t) step_any(t);
-					if (upd) { st_agent(o.stp, s0); st_agent(o.stp + 1, m1); }
-					}
-				};
 				if (ps.casc == 0) cascade(op0, p.cs[0].C, p.cs[0].n_ops, m0a, m1a); else cascade(op1, p.cs[1].C, p.cs[1].n_ops, m0b, m1b);
 				__syncthreads();
 			}
@@ -334,13 +370,28 @@ bool launch_cascade_resident(const ResidentParams &p, size_t lds_bytes, hipStrea
 	if (p.Cin < 1 || p.Cout < 1 || p.n_pass < 1 || p.n_pass > RES_MAX_PASSES || p.n_casc < 0 || p.n_casc > RES_MAX_CASCADES
 	    || resident_lds_bytes(p.buf_doubles) > lds_bytes || (p.buf_doubles & 3) || !p.mail_in || !p.mail_out) return false;
 	for (int q = 0; q < p.n_casc; ++q) if (p.cs[q].C < 1 || p.cs[q].C > 32 || p.cs[q].n_ops < 1 || p.cs[q].n_ops > RES_MAX_OPS) return false;
-	grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident), lds_bytes);
+
 	// a wave per four channels of a cascade pass (a 16-lane row per channel); the other passes share the block out over whatever threads there are
 	int widest = 1;
 	for (int q = 0; q < p.n_casc; ++q) widest = p.cs[q].C > widest ? p.cs[q].C : widest;
-	for (int k = 0; k < p.n_pass; ++k) if (p.pass[k].kind != RES_PASS_CASCADE && p.pass[k].c_out > widest && p.pass[k].c_out <= 16) widest = p.pass[k].c_out;
-	const int waves = (widest + 3) / 4;
-	hipLaunchKernelGGL(cascade_resident, dim3(1), dim3(64 * waves), lds_bytes, st, p);
+	bool other = false;
+	for (int k = 0; k < p.n_pass; ++k) {
+		const ResidentPass &ps = p.pass[k];
+		if (ps.kind == RES_PASS_REMIX && (size_t) ps.c_out * ps.max_n * 12 + (size_t) ps.c_out * 8 > (size_t) RES_TAB_DOUBLES * 8) return false;
+		if (ps.kind == RES_PASS_FIR && (ps.c_in > RES_FIR_MAX_CH || ps.T > RES_FIR_TAPS)) return false;
+		other |= ps.kind != RES_PASS_CASCADE;
+	}
+	// (passes that are not a systolic array share the block out over the threads there are: four waves for them)
+	int waves = (widest + 3) / 4;
+	if (other && waves < 4) waves = 4;
+	if (!other && p.n_pass == 1) {
+		grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident<false>), lds_bytes);
+		hipLaunchKernelGGL(cascade_resident<false>, dim3(1), dim3(64 * waves), lds_bytes, st, p);
+	}
+	else {
+		grant_dynamic_lds(reinterpret_cast<const void *>(cascade_resident<true>), lds_bytes);
+		hipLaunchKernelGGL(cascade_resident<true>, dim3(1), dim3(64 * waves), lds_bytes, st, p);
+	}
 	return hipGetLastError() == hipSuccess;
 }
 

@@ -28,7 +28,7 @@ BASELINE_KERNELS = {
     "config 3 (fir_p 65536 alone)": ["fused_col_fwd<1, 16, 8>", "conv_row_duo<12, 1, true>", "conv_col_inv_pipe<8>"],
     "config 4 (+ resample 48k -> 96k)": ["fused_prepass_mm<2, 8>", "cascade_chunk_carry<10>", "fused_col_fwd<10, 17, 8>", "conv_row_duo<12, 2, false>", "conv_col_inv<8, 4, 2>"],
     "config 5 (hilbert + 131072-tap float32 contract)": ["conv_short<8>", "conv_col_fwd<8, false>", "conv_row_duo<12, 1, true>", "conv_col_inv<8, 1, 0>"],
-    "general n/d resampling, LADSPA-size blocks": ["resample_gemm_kernel<6>", "resample_gemm_kernel<1>", "cascade_resident"],
+    "general n/d resampling, LADSPA-size blocks": ["resample_gemm_kernel<6>", "resample_gemm_kernel<1>", "cascade_resident<false>", "cascade_resident<true>"],
 }
 
 # instances on no BASELINE plan that still carry a few spilled registers: name -> bytes of private memory per lane at the time of listing
