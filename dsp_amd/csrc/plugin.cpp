@@ -119,7 +119,10 @@ bool Resident::init(const Pipeline &pipe)
 	// a block is frames + n_ops - 1 steps of a systolic array over the ops of a channel (or a pass of a few taps per sample) on top of the trips of the block
 	// and of its output: 8.6 us at 64 frames, 12.8 at 128 for a stereo ten-section chain; a launch of the ordinary, time-parallel kernels costs 20 ... 26 us
 	// whatever the block: the wave takes blocks of up to 128 frames (profiles/r06_ladspa_rate.txt)
-	max_work = 128;
+	// ... 256 where the block is one systolic pass and nothing per tap (19 us there against 26 - 30)
+	bool taps = false;
+	for (int k = 0; k < rp.n_pass; ++k) taps |= rp.pass[k].kind == RES_PASS_FIR;
+	max_work = (!taps && rp.n_casc <= 1) ? 256 : 128;
 	ready = true;
 	return true;
 }
