@@ -733,3 +733,52 @@ def test_wav_filter_files(amd, tmp_path, fmt, ch, ext, extra):
     bad = os.path.join(str(tmp_path), "bad.wav"); open(bad, "wb").write(b"RIFX" + data[4:])
     with pytest.raises(ValueError):
         amd.EffectsChain(f"fir_p {bad}", 48000, 2)
+
+
+@pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
+def test_config4_at_full_size_on_the_fused_plan(amd, tmp_path):
+    """BASELINE config 4 at ITS size -- 256 streams x 8 ch, calls of 978944 frames -- on the plan bench.py measures (the S = 256 test above
+    runs another block on the unfused plan, the fused one was tested at S = 112): a first call (separate kernels) and a fused one, three streams drawn
+    from a printed seed against the real reference, and every stream fed stream 0's input agrees with stream 0 bit for bit.  Lean on memory: only the
+    picked streams' outputs are kept."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs about 150 GB of device memory")
+    taps, S, C, B = 65536, 256, 8, 978944
+    h = make_filter(taps)
+    p = write(tmp_path, h)
+    biq = ("lowpass 1k 0.707 highshelf 8k 0.7 -3 eq 100 1.0 3 eq 200 1.0 -2 eq 400 2.0 1.5 eq 800 1.0 -1 "
+           "eq 1600 1.4 2 eq 3200 1.0 -2.5 eq 6400 3.0 1 highpass 20 0.707")
+    chain = f"{biq} fir_p -t pcm -e double -c 1 {p} resample 96k"
+    b = amd.BatchChain(chain, 48000, C, S, B)
+    assert "fft-resample[" in b.plan() and "hop=978944" in b.plan() and "cascade-fused(239 chunks of 4096)" in b.plan(), b.plan()
+    picks, seed = pick_streams(S)
+    g = torch.Generator(device="cuda"); g.manual_seed(41)
+    L = amd.load_library()
+    xs, got = {s: [] for s in picks}, {s: [] for s in picks}
+    for call in range(2):
+        x = torch.rand((S, B, C), dtype=torch.float64, device="cuda", generator=g) - 0.5
+        x[S - 1] = x[0]                                            # (two streams with the same input: the same output, bit for bit)
+        L.dspamd_profile_enable(1)
+        y = b.run(x)
+        names = {ln.split()[0] for ln in L.dspamd_profile_collect().decode().splitlines()}
+        L.dspamd_profile_enable(0)
+        if call == 0:
+            assert "cascade_rows" in names and "fused_col_fwd" not in names, names
+        else:
+            assert "fused_col_fwd" in names and not (names & {"cascade_rows", "conv_col_fwd"}), names
+        assert torch.equal(y[0], y[S - 1])
+        for s in picks:
+            xs[s].append(x[s].cpu().numpy())
+            got[s].append(y[s].cpu().numpy())
+        del x, y
+    for s in picks:
+        if s == S - 1:
+            continue                                               # (fed stream 0's input above)
+        ref_c = RefChain(chain, 48000, C)
+        ref = np.concatenate([ref_c.run(xs[s][0]), ref_c.run(xs[s][1])])
+        ref_c.close()
+        g_ = np.concatenate(got[s])
+        n = min(ref.shape[0], g_.shape[0])
+        assert n > 3 * B and rms(ref[:n] - g_[:n]) < 1e-11, (s, ref.shape, g_.shape, rms(ref[:n] - g_[:n]), "pick seed", seed)
