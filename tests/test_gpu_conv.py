@@ -742,9 +742,12 @@ def test_config4_at_full_size_on_the_fused_plan(amd, tmp_path):
     from a printed seed against the real reference, and every stream fed stream 0's input agrees with stream 0 bit for bit.  Lean on memory: only the
     picked streams' outputs are kept."""
     import torch
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()                                       # (what earlier tests left in torch's cache counts as used)
     free, _ = torch.cuda.mem_get_info()
-    if free < 200e9:
-        pytest.skip("needs about 150 GB of device memory")
+    if free < 170e9:
+        pytest.skip(f"needs about 150 GB of device memory ({free / 1e9:.0f} GB free)")
     taps, S, C, B = 65536, 256, 8, 978944
     h = make_filter(taps)
     p = write(tmp_path, h)

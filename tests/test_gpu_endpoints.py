@@ -441,6 +441,9 @@ def test_bench_as_a_scale_run_launches_it_eight_ranks_at_the_headline():
     import subprocess
     import sys
     import torch
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 150e9:
         pytest.skip("eight ranks of the headline shape on one device need about 110 GB")
