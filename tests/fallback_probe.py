@@ -48,7 +48,7 @@ CASES = {
     "remix":    dict(chain="remix 0,1 2 . 1,2,3 :0 delay 37S", S=5, C=4, frames=3000, calls=(1000, 2000), pick=(0, 4)),
     # calls of exactly one hop of a 256 x 1024 transform whose history is 32 whole rows: the cascade fused into the convolver's first
     # pass (kernels_fused.hip; the separate kernels with DSP_AMD_FUSE=0; 8 channels: the chunks' end states on the
-    # matrix cores, by the recurrence with DSP_AMD_FUSE_MM=0), then a call off the grid, which the separate kernels take
+    # matrix cores, or by the recurrence where the shape is not served), then a call off the grid, which the separate kernels take
     "fused":    dict(chain="gain -1.5 " + BIQ + " fir_p -t pcm -e double -c 1 {F}", S=2, C=8, frames=2 * 229376 + 3000, calls=(229376, 229376, 3000), pick=(0, 1), taps=(32768, 15, 4000.0)),
 }
 HOST_CASES = {   # through dspamd_chain_run (host buffers: mapped staging / copy commands)
