@@ -42,7 +42,6 @@ public:
 	// the device tables a resident small-block wave works on (kernels_resident.hip): [C][n_ops] ops, [S][C][n_ops][2] states; sections per channel at most
 	const OpDesc *device_ops() const { return ops.as<OpDesc>(); }
 	double *device_state() { return state.as<double>(); }
-	int max_sections() const { int m = 0; for (int c = 0; c < ch_in; ++c) { int k = 0; for (int j = 0; j < n_ops; ++j) k += host_ops[(size_t) c * n_ops + j].kind == OP_BIQUAD; m = k > m ? k : m; } return m; }
 
 	friend class ConvStage;
 private:

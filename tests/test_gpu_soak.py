@@ -2,7 +2,7 @@
 effects_chain.c:1044-1081, watch.c:60-92 -- and a LADSPA host keeps the library loaded for days, ladspa_dsp.c:316-355).
 
 At least 500 chains of mixed kinds are built, driven and destroyed in THIS process, interleaved at random: plugin chains through the reference's chain
-runtime (the resident wave at 64-frame blocks, launches from the mapped staging buffers, blocks large enough for the host-buffer registrations),
+runtime (the resident wave at 64-frame blocks, launches from the mapped staging buffers, blocks that go through copy commands on the host's own buffers),
 batch chains on device slabs (cascades, the one-trip convolver, the four-step transforms at small / mid / whole-hop calls, the fused first pass, both
 resamplers, wire formats), with torch tensors of random sizes allocated and dropped in between so that slabs land wherever the caching allocator has
 room -- at the end of a segment too.  Every output is finite; a random fifth of the chains is compared with the real reference.  The process must
