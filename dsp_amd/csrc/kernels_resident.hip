@@ -2,10 +2,11 @@
 //
 // What it serves: the reference's LADSPA frontend and CLI drive a chain with run() calls of 64 ... 1024 frames (ladspa_dsp.c:316-355, dsp.h:38); a
 // kernel launch plus its completion costs 25 us on this platform whatever the block, the reference's own loop 3 us at 64 frames x 2 ch x 10 sections.
-// For a device segment that is ONE cascade of gains / adds / sections (the equaliser shape), or a plain remix in front of one (the crossover shape), a
-// single workgroup stays on the device for a bounded time, polls a mailbox the host writes the block into, runs the block -- the reference's recurrence as
-// written (biquad.h:76-92), sample by sample, one lane per op per channel, states and coefficients in registers -- and writes the output into a mailbox
-// the host polls.
+// For a device segment whose stages are remixes / weighted mixes, direct-form FIRs and at most two cascades of gains / adds / sections (the equaliser, the
+// crossover, a crossover with correction FIRs, a mid/side equaliser, crossfeed: engine.cpp Pipeline::resident_plan) a single workgroup stays on the device
+// for a bounded time, polls a mailbox the host writes the block into, runs the block through its passes in LDS -- a cascade as the reference's recurrence
+// as written (biquad.h:76-92), sample by sample, one lane per op per channel, states and coefficients in registers; a FIR in the reference's summation
+// order (fir.c:43-62); a remix as remix.c:39-101 -- and writes the output into a mailbox the host polls.
 //
 // The mailboxes (engine.h: ResidentUnit, ResidentParams): 16-byte units { value, request ^ bits(value) } that validate themselves, so the wave asks for the
 // control unit AND the units of the block it expects in ONE burst of loads and neither side waits for an acknowledgement of its stores.  Round 5 had a
