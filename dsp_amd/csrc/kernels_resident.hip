@@ -235,8 +235,8 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 			// every lane has a frame -- are kept short: the input arrives by ONE dpp move per half whose `old` operand is the frame from LDS (lane 0 of a
 			// row has no lane below: it keeps `old`), sections update their states under the execution mask (a branch the compiler may not turn into four
 			// selects: the empty asm), every lane stores (no branch), nobody asks who is active, and the frames come from LDS four steps ahead.
-			auto step_any = [&](int t) {                             // fill and drain: lane j has a frame while 0 <= t - j < frames
-				const double x = row_shr1_or(prev, frame_in(t < nf ? t : nf - 1));
+			auto step_any = [&](int t, double xin) {                 // fill and drain: lane j has a frame while 0 <= t - j < frames
+				const double x = row_shr1_or(prev, xin);
 				const double r = fma(a, x, s0);
 				const bool active = (unsigned) (t - j) < (unsigned) nf;
 				// biquad.h:76-92: r = c0 s + m0;  m0 = m1 + c1 s - c3 r;  m1 = c2 s - c4 r   (gain / add / pass: r = fma(a, x, b), no state)
@@ -244,9 +244,11 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 				if (active && wr) wr_base[t * wr_stride] = r;
 				prev = r;
 			};
+			// (fill and drain too ask for their frame a step ahead: a frame asked for where it is used is an LDS round trip per step -- 95 ns a step against 47)
 			const int t_fill = (n_ops - 1 < steps) ? n_ops - 1 : steps;
 			int t = 0;
-			for (; t < t_fill; ++t) step_any(t);
+			double xn = frame_in(0);
+			for (; t < t_fill; ++t) { const double xc = xn; xn = frame_in(t + 1 < nf ? t + 1 : nf - 1); step_any(t, xc); }
 			if (t < nf) {
 				double xq[4];
 #pragma unroll
@@ -269,9 +271,11 @@ __global__ __launch_bounds__(512) void cascade_resident(ResidentParams p)
 					}
 					ahead += 4 * C;
 				}
-				for (; t < nf; ++t) step_any(t);
+				xn = frame_in(t < nf ? t : nf - 1);
+				for (; t < nf; ++t) { const double xc = xn; xn = frame_in(t + 1 < nf ? t + 1 : nf - 1); step_any(t, xc); }
 			}
-			for (; t < steps; ++t) step_any(t);
+			// (behind the last frame lane 0 has nothing to take in: whatever it is handed is the input of steps nobody is active in)
+			for (; t < steps; ++t) step_any(t, xn);
 			if (upd) { st_agent(o.stp, s0); st_agent(o.stp + 1, m1); }
 			}
 		};
