@@ -22,7 +22,13 @@ SHAPES = {
     "FIR + equaliser + gain (two cascades)": "highpass 30 0.707 " + FIR16 + " eq 1k 1.0 3 gain -1",
     "mid/side equaliser (st2ms eq ms2st)": "st2ms eq 1k 1.0 3 eq 4k 1.0 -2 ms2st",
     "crossfeed": "crossfeed 700 4.5",
+    # what the wave does NOT take (an FFT convolver in the segment): the launch path whatever the switch says
+    "equaliser + 4095-tap fir_p (launches)": "gain -3 lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 /tmp/r06_shapes_h4095.raw",
+    "65536-tap fir_p (launches)": "fir_p -t pcm -e double -c 1 /tmp/r06_shapes_h65536.raw",
 }
+for _t in (4095, 65536):
+    _h = np.random.default_rng(_t).standard_normal(_t) * np.exp(-np.arange(_t) / (_t / 6.0))
+    np.asarray(_h / np.sqrt(np.sum(_h * _h)) / 4, dtype="<f8").tofile(f"/tmp/r06_shapes_h{_t}.raw")
 
 
 def measure(variant, frames):
