@@ -188,6 +188,7 @@ private:
 	// ---- short filters behind long calls (round 5, kernels_short.hip): taps - 1 <= 4096 and calls of at least 1024 frames -- the whole transform of a pair
 	// (8192 points) in one workgroup's LDS: a block is one read of the window and one write of the outputs instead of three trips of W through HBM
 	bool short_mode = false;
+	long short_N = CONV_SHORT_N;
 	long cur_frames = 0;
 	DevBuf tw_short;
 	bool prepare_short(const Spec &sp);
@@ -331,13 +332,18 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 
 	const char *env = getenv("DSP_AMD_CONV_LOG2N");
 	{
-		const char *se = getenv("DSP_AMD_CONV_SHORT");          // 0 = the four-step transforms whatever the filter's length (read per stage: the tests build both plans in one process)
-		const bool short_on = !se || atoi(se) != 0;
+		const char *se = getenv("DSP_AMD_CONV_SHORT");          // 0 = the four-step transforms whatever the filter's length; 13 / 14 = the 8192- / 16384-point window where either would do (read per stage: the tests build the plans in one process)
+		const int sv = se ? atoi(se) : 1;
+		const long fn = (T - 1 + 7) & ~7L;
 		// (calls of at least 1024 frames: below that a launch is all latency; 32-bit byte offsets inside a stream's slab / a pair's ring)
-		short_mode = short_on && !env && !resampler && !round_f32 && !ring_parent && !upc_block && !force_N && ((T - 1 + 7) & ~7L) <= CONV_SHORT_N / 2
+		short_mode = sv != 0 && !env && !resampler && !round_f32 && !ring_parent && !upc_block && !force_N && fn <= CONV_SHORT_N / 2
 		             && (long) max_frames >= 1024 && (long) max_frames <= (1L << 24) && (double) max_frames * sp.ch_in * sizeof(double) < 2.0e9;
+		// the window: a block of the 16384-point form is 14 / 13 of the transform work per point for (16384 - fn) instead of (8192 - fn) outputs, and
+		// (N + hop) / hop units of traffic -- from about 2000 taps on the larger window is less of both, provided the calls fill its blocks
+		short_N = CONV_SHORT_N;
+		if (short_mode && sv != 13 && (sv == 14 || (fn > 2048 && (long) max_frames >= 4 * (CONV_SHORT_N2 - fn)))) short_N = CONV_SHORT_N2;
 	}
-	N = short_mode ? CONV_SHORT_N : conv_plan(T, max_frames, resampler, nullptr);
+	N = short_mode ? short_N : conv_plan(T, max_frames, resampler, nullptr);
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
 	if (env && !is_tail_child) N = std::max(lo, 1L << atoi(env));
 	if (force_N) N = force_N;

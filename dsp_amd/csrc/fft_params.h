@@ -178,7 +178,7 @@ struct ShortParams {
 	int blocks_per_wg;
 };
 void launch_conv_short(const ShortParams &p, hipStream_t st);
-constexpr long CONV_SHORT_N = 8192;
+constexpr long CONV_SHORT_N = 8192, CONV_SHORT_N2 = 16384;   // the two window sizes of the one-trip convolver (kernels_short.hip)
 
 void launch_conv_col(const ConvParams &p, bool inverse, int grid_y, hipStream_t st);
 void launch_conv_row(const ConvParams &p, int mode, int n_pairs, hipStream_t st);

@@ -33,80 +33,131 @@ typedef double real;
 #undef FFT_CORE_NO_LAUNCHERS
 #undef FFT_F32
 
-constexpr int SH_LOG2N = 13, SH_N = 1 << SH_LOG2N, SH_P = SH_N / 16;
-constexpr int SH_T256 = 272, SH_TLO = 68, SH_THI = SH_N / 64;
-// 256 threads with two point sets each; the exchanges carry the real and the imaginary parts one after the other through a buffer of doubles (64 KB: TWO
-// independent workgroups per CU).  (Round 5's form -- 512 threads, complex points through 128 KB, one workgroup per CU, the filter row in registers -- measured
-// 16.65 ms on BASELINE config 5's hilbert stage against 15.9 for this one.)
-constexpr int SH_VT = 2, SH_THREADS = SH_P / SH_VT;
-constexpr size_t SH_LDS = (size_t) SH_N * sizeof(double) + ((size_t) SH_T256 + SH_TLO + SH_THI) * sizeof(cplx);
+// Geometry of an instance: N = 2^LOG2N points of a channel pair, N / 32 threads that hold TWO sets of 16 points each (the points of "virtual threads" j and
+// j + N / 32: v[t][m] <-> position j + (N / 32) (t + 2 m), the 32 inputs of the thread's radix-32 butterfly in EVERY pass), a direct twiddle table for the
+// middle pass (W_512 / W_1024) and the lo / hi pair for W_N.
+template <int LOG2N> struct ShCfg {
+	static constexpr int N = 1 << LOG2N, P = N / 16, NTH = N / 32;
+	static constexpr int TD = N / 16, TDP = TD + TD / 16, TLO = 68, THI = N / 64;
+	static constexpr size_t LDS = (size_t) N * sizeof(double) + ((size_t) TDP + TLO + THI) * sizeof(cplx);
+};
+// get<M>(e) = exp(-2 pi i e / M): M = N as hi[e >> 6] * lo[e & 63], M <= TD from the direct table (twpad: power-of-two strides conflict-free)
+template <int NSEQ, int TD> struct TwShort {
+	const cplx *td, *lo, *hi;
+	template <int M> __device__ __forceinline__ cplx get(int e) const
+	{
+		if constexpr (M == NSEQ) return cmul(hi[e >> 6], lo[twpad(e & 63)]);
+		else { static_assert(M <= TD, "no table for this pass"); return td[twpad(e * (TD / M))]; }
+	}
+};
 
-// The 8192-point transform of a thread that holds TWO sets of 16 points (the points of "virtual threads" j and j + 256), with every exchange done in halves: the
-// real parts through a buffer of 8192 doubles, then the imaginary parts through the same buffer.  Twice the barriers and LDS instructions for the same
-// bytes -- but half the LDS, so a second, independent workgroup fits the CU and issues its butterflies while this one waits at a barrier or for the LDS
-// (round 5's form keeps all eight waves of a CU in lock-step: 7.5 us of fp64 issue + 6 us of exchanges per block, one after the other).
-// Slots: an element is 8 bytes = 2 banks of 64; a ds_read / ds_write_b64 is served in two groups of 32 lanes, conflict-free when the 32 slots differ
-// mod 32: slot = pos ^ ((pos >> 4) & 31) makes them for both access shapes of every pass (stores 16 j + r, (j - k) 16 + k + NS r; gathers j + P m).
-__device__ __forceinline__ int sh_slotd(int pos) { return pos ^ ((pos >> 4) & 31); }
-template <int NS> __device__ __forceinline__ int sh_out_pos(int jv, int r) { const int k = jv & (NS - 1); return (jv - k) * 16 + k + NS * r; }
+// The exchanges carry the real and the imaginary parts one after the other through a buffer of N doubles: twice the barriers and LDS instructions for the
+// same bytes -- but half the LDS, so that two independent 8192-point workgroups fit a CU (one issues butterflies while the other waits), and a 16384-point
+// window fits a CU at all.  Slots: an element is 8 bytes = 2 banks of 64; a ds_read / ds_write_b64 is served in two groups of 32 lanes, conflict-free when
+// the 32 slots differ mod 32: slot = pos ^ ((pos >> 5) & 31) makes them for every access shape of the passes below (stores 32 j + r, (j - k) 32 + k + 32 r,
+// (j - k) 16 + k + 32 r; gathers j + (N / 32) m -- simulated over every pass before it ran).
+__device__ __forceinline__ int sh_slotd(int pos) { return pos ^ ((pos >> 5) & 31); }
 
-template <bool INV, class Tw>
+// One radix-32 Stockham pass on the thread's 32 points, u[2 m] = va[m], u[2 m + 1] = vb[m]: butterfly b = j, stride NS.  32 = 2 x 16: the two sets'
+// 16-point transforms, w_32^k2 on the odd set's results (constants), a radix-2 step across the sets.  Output r of the butterfly ends up in va[r] (r < 16) or
+// vb[r - 16]; its Stockham position is (j - k) 32 + k + NS r, k = j mod NS (sh_pos32).
+template <int NS, bool INV, class Tw>
+__device__ __forceinline__ void sh_pass32(cplx (&va)[16], cplx (&vb)[16], int j, const Tw &tw)
+{
+	if constexpr (NS > 1) {
+		const int k = j & (NS - 1);
+#pragma unroll
+		for (int m = 0; m < 16; ++m) {
+			if (m) { const cplx w = tw.template get<32 * NS>(2 * m * k); va[m] = INV ? cmulc(va[m], w) : cmul(va[m], w); }
+			const cplx w = tw.template get<32 * NS>((2 * m + 1) * k);
+			vb[m] = INV ? cmulc(vb[m], w) : cmul(vb[m], w);
+		}
+	}
+	dft16<INV>(va);
+	dft16<INV>(vb);
+	constexpr real c1 = 0.98078528040323044913, s1 = 0.19509032201612826785, c2 = 0.92387953251128675613, s2 = 0.38268343236508977173;
+	constexpr real c3 = 0.83146961230254523708, s3 = 0.55557023301960222474, h = 0.70710678118654752440;
+	// w_32^k2 = (cos(pi k2 / 16), -sin(pi k2 / 16))
+	vb[1] = mul_w<INV>(vb[1], c1, s1);   vb[2] = mul_w<INV>(vb[2], c2, s2);    vb[3] = mul_w<INV>(vb[3], c3, s3);
+	vb[4] = INV ? mkc((vb[4].x - vb[4].y) * h, (vb[4].x + vb[4].y) * h) : mkc((vb[4].x + vb[4].y) * h, (vb[4].y - vb[4].x) * h);
+	vb[5] = mul_w<INV>(vb[5], s3, c3);   vb[6] = mul_w<INV>(vb[6], s2, c2);    vb[7] = mul_w<INV>(vb[7], s1, c1);
+	vb[8] = mul_mi<INV>(vb[8]);
+	vb[9] = mul_w<INV>(vb[9], -s1, c1);  vb[10] = mul_w<INV>(vb[10], -s2, c2); vb[11] = mul_w<INV>(vb[11], -s3, c3);
+	vb[12] = INV ? mkc(-(vb[12].x + vb[12].y) * h, (vb[12].x - vb[12].y) * h) : mkc((vb[12].y - vb[12].x) * h, -(vb[12].x + vb[12].y) * h);
+	vb[13] = mul_w<INV>(vb[13], -c3, s3); vb[14] = mul_w<INV>(vb[14], -c2, s2); vb[15] = mul_w<INV>(vb[15], -c1, s1);
+#pragma unroll
+	for (int r = 0; r < 16; ++r) { const cplx a = va[r], b = vb[r]; va[r] = cadd(a, b); vb[r] = csub(a, b); }
+}
+template <int NS> __device__ __forceinline__ int sh_pos32(int j, int r) { const int k = j & (NS - 1); return (j - k) * 32 + k + NS * r; }
+template <int NS> __device__ __forceinline__ int sh_pos16(int jv, int r) { const int k = jv & (NS - 1); return (jv - k) * 16 + k + NS * r; }
+
+// The N-point transform of a pair's window: radix 32 / 16 / 16 at 8192 points, 32 / 32 / 16 at 16384 -- TWO exchanges (until round 6's second half: radix
+// 16 / 16 / 16 / 2 with three; a thread's 32 points are the same positions in every pass either way, so a radix-32 step costs no exchange of its own).
+// Results in natural order at the positions the thread loaded from.
+template <int LOG2N, bool INV, class Tw>
 __device__ __forceinline__ void short_fft2(cplx (&va)[16], cplx (&vb)[16], int j, double *lds, const Tw &tw)
 {
-	constexpr int P = SH_P, H = SH_P / 2;
+	constexpr int P = ShCfg<LOG2N>::P, H = ShCfg<LOG2N>::NTH;
 	const RowMap nomap{ 0 };
-	auto exchange = [&](auto ns_tag, bool last) {
-		constexpr int NS = decltype(ns_tag)::value;
-		asm volatile("" : "+v"(j));
-		// butterflies in place: v[r] = output r of the thread's radix-16 butterfly (pass16 with LAST leaves them in v)
-		pass16<SH_LOG2N, 16, NS, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
-		pass16<SH_LOG2N, 16, NS, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
+	// pa(r), pb(r): Stockham positions of va[r], vb[r]
+	auto exchange = [&](auto pa, auto pb, bool last) {
 #pragma unroll
-		for (int r = 0; r < 16; ++r) { lds[sh_slotd(sh_out_pos<NS>(j, r))] = va[r].x; lds[sh_slotd(sh_out_pos<NS>(j + H, r))] = vb[r].x; }
+		for (int r = 0; r < 16; ++r) { lds[sh_slotd(pa(r))] = va[r].x; lds[sh_slotd(pb(r))] = vb[r].x; }
 		lds_barrier();
 		double xa[16], xb[16];
 #pragma unroll
 		for (int m = 0; m < 16; ++m) { xa[m] = lds[sh_slotd(j + P * m)]; xb[m] = lds[sh_slotd(j + H + P * m)]; }
 		lds_barrier();
 #pragma unroll
-		for (int r = 0; r < 16; ++r) { lds[sh_slotd(sh_out_pos<NS>(j, r))] = va[r].y; lds[sh_slotd(sh_out_pos<NS>(j + H, r))] = vb[r].y; }
+		for (int r = 0; r < 16; ++r) { lds[sh_slotd(pa(r))] = va[r].y; lds[sh_slotd(pb(r))] = vb[r].y; }
 		lds_barrier();
 #pragma unroll
 		for (int m = 0; m < 16; ++m) { va[m] = mkc(xa[m], lds[sh_slotd(j + P * m)]); vb[m] = mkc(xb[m], lds[sh_slotd(j + H + P * m)]); }
 		if (!last) lds_barrier();            // (behind the last exchange the caller's own barrier stands in front of the next store)
 	};
-	exchange(std::integral_constant<int, 1>{}, false);
-	exchange(std::integral_constant<int, 16>{}, false);
-	exchange(std::integral_constant<int, 256>{}, true);
 	asm volatile("" : "+v"(j));
-	pass16<SH_LOG2N, 2, 4096, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
-	pass16<SH_LOG2N, 2, 4096, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
+	sh_pass32<1, INV>(va, vb, j, tw);
+	exchange([&](int r) { return sh_pos32<1>(j, r); }, [&](int r) { return sh_pos32<1>(j, r + 16); }, false);
+	asm volatile("" : "+v"(j));
+	if constexpr (LOG2N == 13) {
+		pass16<LOG2N, 16, 32, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
+		pass16<LOG2N, 16, 32, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
+		exchange([&](int r) { return sh_pos16<32>(j, r); }, [&](int r) { return sh_pos16<32>(j + H, r); }, true);
+	}
+	else {
+		sh_pass32<32, INV>(va, vb, j, tw);
+		exchange([&](int r) { return sh_pos32<32>(j, r); }, [&](int r) { return sh_pos32<32>(j, r + 16); }, true);
+	}
+	asm volatile("" : "+v"(j));
+	pass16<LOG2N, 16, P, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
+	pass16<LOG2N, 16, P, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
 }
 
 // (every address is a buffer descriptor + a 32-bit offset: the host checks that rings, slabs and outputs stay below 2 GB per stream / pair -- sixteen
 // 64-bit address pairs per direction do not fit beside the 64 registers of the window and the 64 of the filter row)
 typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
 // BS: bytes per sample of the slab in direct mode (8: fp64; 4: s24 / s32 / float; 2: s16 -- read_buf_<fmt> of pcm_device.h in the loads)
-template <int BS>
-__global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
+template <int LOG2N, int BS>
+__global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
 {
-	constexpr int N = SH_N, P = SH_P, NTH = SH_THREADS, VT = SH_VT;
+	typedef ShCfg<LOG2N> Cfg;
+	constexpr int N = Cfg::N, P = Cfg::P, NTH = Cfg::NTH, VT = 2;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 	double *datad = reinterpret_cast<double *>(smem_raw);                // the exchange buffer: one half (real / imaginary parts) of the row at a time
-	cplx *t256 = reinterpret_cast<cplx *>(smem_raw + (size_t) N * sizeof(double)), *tlo = t256 + SH_T256, *thi = tlo + SH_TLO;
+	cplx *td = reinterpret_cast<cplx *>(smem_raw + (size_t) N * sizeof(double)), *tlo = td + Cfg::TDP, *thi = tlo + Cfg::TLO;
 	int j = threadIdx.x;
 	const long pair = blockIdx.x;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long b0 = (long) blockIdx.y * p.blocks_per_wg, b1 = (b0 + p.blocks_per_wg < n_blocks) ? b0 + p.blocks_per_wg : n_blocks;
 	if (b0 >= b1) return;
-	for (int e = j; e < 256 + 64 + SH_THI; e += NTH) {
-		if (e < 256) t256[twpad(e)] = TAB(p.tw)[e * (N / 256)];
-		else if (e < 256 + 64) tlo[twpad(e - 256)] = TAB(p.tw)[e - 256];
-		else thi[e - 320] = TAB(p.tw)[(e - 320) * 64];
+	for (int e = j; e < Cfg::TD + 64 + Cfg::THI; e += NTH) {
+		if (e < Cfg::TD) td[twpad(e)] = TAB(p.tw)[e * (N / Cfg::TD)];
+		else if (e < Cfg::TD + 64) tlo[twpad(e - Cfg::TD)] = TAB(p.tw)[e - Cfg::TD];
+		else thi[e - Cfg::TD - 64] = TAB(p.tw)[(e - Cfg::TD - 64) * 64];
 	}
 	const cplx *Hrow = p.Hout ? nullptr : TAB(p.H) + (long) p.pair_h[pair] * N;
 	lds_barrier();                                                       // tables visible
-	const TwRow<N> tw{ t256, tlo, thi };
+	const TwShort<N, Cfg::TD> tw{ td, tlo, thi };
 	// (the division runs on the vector unit; its result is uniform all the same and is said to be: with a per-lane stream index the slab and output
 	// descriptors are per-lane values and every load through them becomes a loop over their distinct values -- 16 such loops per block until round 6)
 	const long s = __builtin_amdgcn_readfirstlane((int) (pair / p.pairs_per_stream)), qs = pair - s * p.pairs_per_stream;
@@ -157,7 +208,7 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 			}
 		}
 		if (b > b0) lds_barrier();                                   // the previous block's last gather is done
-		short_fft2<false>(v[0], v[1], j, datad, tw);
+		short_fft2<LOG2N, false>(v[0], v[1], j, datad, tw);
 		if (p.Hout) {
 #pragma unroll
 			for (int t = 0; t < VT; ++t) {
@@ -185,7 +236,7 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 				}
 		}
 		lds_barrier();                                               // every gather of the forward transform is done
-		short_fft2<true>(v[0], v[1], j, datad, tw);
+		short_fft2<LOG2N, true>(v[0], v[1], j, datad, tw);
 		// window sample first_n + f -> output frame mo0 + f, for f in [f_lo, f_hi)
 		const long mo0 = q_blk - p.k_origin;
 		const int f_lo = (mo0 >= 0) ? 0 : (-mo0 < in_count ? (int) -mo0 : in_count);
@@ -272,20 +323,21 @@ __global__ __launch_bounds__(SH_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 }  // namespace psh
 
-template <int BS> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
+template <int LOG2N, int BS> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
 {
-	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<BS>), psh::SH_LDS);
-	hipLaunchKernelGGL((psh::conv_short<BS>), grid, dim3(psh::SH_THREADS), psh::SH_LDS, st, p);
+	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<LOG2N, BS>), psh::ShCfg<LOG2N>::LDS);
+	hipLaunchKernelGGL((psh::conv_short<LOG2N, BS>), grid, dim3(psh::ShCfg<LOG2N>::NTH), psh::ShCfg<LOG2N>::LDS, st, p);
 }
 
 void launch_conv_short(const ShortParams &p, hipStream_t st)
 {
-	if (p.N != psh::SH_N || p.n_pairs < 1 || p.n_in < 1) return;
+	if ((p.N != CONV_SHORT_N && p.N != CONV_SHORT_N2) || p.n_pairs < 1 || p.n_in < 1) return;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
 	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges);
 	const int bs = (!p.slab || p.slab_fmt == PCM_DOUBLE) ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
-	if (bs == 8) launch_short_t<8>(p, grid, st); else if (bs == 4) launch_short_t<4>(p, grid, st); else launch_short_t<2>(p, grid, st);
+	if (p.N == CONV_SHORT_N) { if (bs == 8) launch_short_t<13, 8>(p, grid, st); else if (bs == 4) launch_short_t<13, 4>(p, grid, st); else launch_short_t<13, 2>(p, grid, st); }
+	else { if (bs == 8) launch_short_t<14, 8>(p, grid, st); else if (bs == 4) launch_short_t<14, 4>(p, grid, st); else launch_short_t<14, 2>(p, grid, st); }
 }
 
 }  // namespace dspamd

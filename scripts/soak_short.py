@@ -11,7 +11,7 @@ import dsp_amd
 
 
 def build(chain, C, S, B, short):
-    if not short: os.environ["DSP_AMD_CONV_SHORT"] = "0"
+    if short is not True: os.environ["DSP_AMD_CONV_SHORT"] = str(int(short))     # False: the four-step transforms; 13 / 14: that window of the one-trip form
     try: return dsp_amd.BatchChain(chain, 48000, C, S, B)
     finally: os.environ.pop("DSP_AMD_CONV_SHORT", None)
 
@@ -33,7 +33,8 @@ def main(n_seeds):
         post = " gain -1.5 highshelf 6k 0.7 2" if rng.random() < 0.3 else ""
         chain = f"{pre}{sel} {eff} -t pcm -e double -c {C if per_ch else 1} {f}{' :' if sel else ''}{post}".strip()
         B = int(rng.choice([1024, 4096, 20000, 65536]))
-        bo, bs = build(chain, C, S, B, True), build(chain, C, S, B, False)
+        window = [True, 13, 14][int(rng.integers(0, 3))]
+        bo, bs = build(chain, C, S, B, window), build(chain, C, S, B, False)
         one_trip = "one-trip" in bo.plan()
         g = torch.Generator(device="cuda"); g.manual_seed(seed)
         err = 0.0
@@ -51,7 +52,7 @@ def main(n_seeds):
             if a is None: break
             assert a.shape == b.shape
             if a.numel(): err = max(err, float((a - b).abs().max()))
-        print(f"seed {seed}: S {S} C {C} taps {taps}{' per-channel' if per_ch else ''} {eff} sel '{sel}' pre {bool(pre)} post {bool(post)} block {B} one-trip {one_trip}  max |one-trip - four-step| = {err:.2e}", flush=True)
+        print(f"seed {seed}: S {S} C {C} taps {taps}{' per-channel' if per_ch else ''} {eff} sel '{sel}' pre {bool(pre)} post {bool(post)} block {B} window {window} one-trip {one_trip} {[w for w in bo.plan().split() if w.startswith('N=')][:1]}  max |one-trip - four-step| = {err:.2e}", flush=True)
         worst = max(worst, err)
         os.remove(f)
         del bo, bs

@@ -1,5 +1,6 @@
 """The one-trip convolver for short filters behind long calls (kernels_short.hip, round 5): filters of up to 4097 taps on calls of at least 1024 frames --
-a pair's 8192-point transform in one workgroup's LDS, one read of the window and one write of the outputs per block -- against the real reference and
+a pair's 8192- or 16384-point transform in one workgroup's LDS (the larger window from about 2000 taps on where the calls fill its blocks; either one
+forced with DSP_AMD_CONV_SHORT=13 / 14), one read of the window and one write of the outputs per block -- against the real reference and
 against the four-step transforms (DSP_AMD_CONV_SHORT=0) on the same inputs: tap counts at both ends, ragged call sequences, drains, per-channel filters,
 selectors, `fir`'s latency, a stage that feeds the next convolver's rings (BASELINE config 5's shape in small), a cascade in front, reset."""
 import os
@@ -26,8 +27,9 @@ def amd():
 
 
 def build(amd, chain, C, S, B, short):
-    if not short:
-        os.environ["DSP_AMD_CONV_SHORT"] = "0"
+    """short: False = the four-step transforms, True = the planner's own window, 13 / 14 = that window"""
+    if short is not True:
+        os.environ["DSP_AMD_CONV_SHORT"] = str(int(short))
     try:
         return amd.BatchChain(chain, 48000, C, S, B)
     finally:
@@ -49,28 +51,36 @@ def run_calls(b, x, sizes):
 
 
 CASES = [
-    # (chain with {F}, taps, filter channels, S, C, call sizes)
-    ("fir_p -t pcm -e double -c 1 {F}", 4095, 1, 9, 2, (20000, 20000, 4097, 1024, 30001)),
-    ("fir_p -t pcm -e double -c 1 {F}", 4097, 1, 64, 8, (65536, 65536, 1)),
-    ("fir_p -t pcm -e double -c 1 {F}", 33, 1, 5, 4, (8192, 5000, 8192)),
-    ("fir_p -t pcm -e double -c 1 {F}", 1000, 1, 3, 3, (12288, 12288, 777)),                      # an odd channel count: a pair with one channel
-    ("fir_p -t pcm -e double -c 4 {F}", 2500, 4, 6, 4, (16384, 9999, 16384)),                     # one filter per channel
-    (":0,2 fir_p -t pcm -e double -c 1 {F}", 3000, 1, 4, 4, (16384, 16384)),                      # two of four channels convolved, the others passed through
-    ("fir -t pcm -e double -c 1 {F}", 2000, 1, 4, 2, (10000, 10000, 3000)),                        # `fir`: the same values, a transform length late
-    ("lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 {F} gain -2", 4000, 1, 16, 8, (32768, 1500, 32768)),   # a cascade writes the rings
+    # (chain with {F}, taps, filter channels, S, C, call sizes, window: True = the planner's choice (its size stated), 13 / 14 = forced)
+    ("fir_p -t pcm -e double -c 1 {F}", 4095, 1, 9, 2, (20000, 20000, 4097, 1024, 30001), (True, 8192)),
+    ("fir_p -t pcm -e double -c 1 {F}", 4095, 1, 9, 2, (20000, 20000, 4097, 1024, 30001), (14, 16384)),   # ragged calls on the larger window
+    ("fir_p -t pcm -e double -c 1 {F}", 4097, 1, 64, 8, (65536, 65536, 1), (True, 16384)),
+    ("fir_p -t pcm -e double -c 1 {F}", 4097, 1, 64, 8, (65536, 65536, 1), (13, 8192)),
+    ("fir_p -t pcm -e double -c 1 {F}", 33, 1, 5, 4, (8192, 5000, 8192), (True, 8192)),
+    ("fir_p -t pcm -e double -c 1 {F}", 33, 1, 5, 4, (8192, 5000, 8192), (14, 16384)),
+    ("fir_p -t pcm -e double -c 1 {F}", 1000, 1, 3, 3, (12288, 12288, 777), (True, 8192)),                      # an odd channel count: a pair with one channel
+    ("fir_p -t pcm -e double -c 1 {F}", 2100, 1, 3, 3, (60000, 12288, 777), (True, 16384)),
+    ("fir_p -t pcm -e double -c 4 {F}", 2500, 4, 6, 4, (16384, 9999, 16384), (True, 8192)),                     # one filter per channel
+    ("fir_p -t pcm -e double -c 4 {F}", 2500, 4, 6, 4, (16384, 9999, 16384), (14, 16384)),
+    (":0,2 fir_p -t pcm -e double -c 1 {F}", 3000, 1, 4, 4, (16384, 16384), (True, 8192)),                      # two of four channels convolved, the others passed through
+    (":0,2 fir_p -t pcm -e double -c 1 {F}", 3000, 1, 4, 4, (57344, 16384), (True, 16384)),
+    ("fir -t pcm -e double -c 1 {F}", 2000, 1, 4, 2, (10000, 10000, 3000), (True, 8192)),                        # `fir`: the same values, a transform length late
+    ("fir -t pcm -e double -c 1 {F}", 2000, 1, 4, 2, (10000, 10000, 3000), (14, 16384)),
+    ("lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 {F} gain -2", 4000, 1, 16, 8, (32768, 1500, 32768), (True, 8192)),   # a cascade writes the rings
+    ("lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 {F} gain -2", 4000, 1, 16, 8, (65536, 1500, 32768), (True, 16384)),
 ]
 
 
 @pytest.mark.skipif(not RefChain.available(), reason="oracle/_ref not present")
-@pytest.mark.parametrize("chain,taps,fch,S,C,sizes", CASES)
-def test_one_trip_vs_reference_and_four_step(amd, tmp_path, chain, taps, fch, S, C, sizes):
+@pytest.mark.parametrize("chain,taps,fch,S,C,sizes,window", CASES)
+def test_one_trip_vs_reference_and_four_step(amd, tmp_path, chain, taps, fch, S, C, sizes, window):
     import torch
     f = os.path.join(str(tmp_path), "h.raw")
     h = np.stack([make_filter(taps, seed=taps + c) for c in range(fch)], axis=1)
     np.asarray(h, dtype="<f8").tofile(f)
     chain = chain.replace("{F}", f)
-    bo, bs = build(amd, chain, C, S, max(sizes), True), build(amd, chain, C, S, max(sizes), False)
-    assert "one-trip" in bo.plan() and "N=8192" in bo.plan(), bo.plan()
+    bo, bs = build(amd, chain, C, S, max(sizes), window[0]), build(amd, chain, C, S, max(sizes), False)
+    assert "one-trip" in bo.plan() and f"N={window[1]}=" in bo.plan(), bo.plan()
     assert "one-trip" not in bs.plan(), bs.plan()
     g = torch.Generator(device="cuda"); g.manual_seed(taps)
     x = torch.rand((S, sum(sizes), C), dtype=torch.float64, device="cuda", generator=g) - 0.5
@@ -110,7 +120,7 @@ def test_one_trip_stage_feeds_the_next_convolver(amd, tmp_path):
         bo, bs = build(amd, chain, C, S, max(sizes), True), build(amd, chain, C, S, max(sizes), False)
     finally:
         os.environ.pop("DSP_AMD_NO_LTI_MERGE")
-    assert "one-trip" in bo.plan() and "fed-by-conv" in bo.plan(), bo.plan()
+    assert "one-trip" in bo.plan() and "fed-by-conv" in bo.plan() and "N=16384=" in bo.plan(), bo.plan()
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     x = torch.rand((S, sum(sizes), C), dtype=torch.float64, device="cuda", generator=g) - 0.5
     yo, ys = run_calls(bo, x, sizes), run_calls(bs, x, sizes)
