@@ -185,8 +185,9 @@ private:
 	// frame's 64 bytes per workgroup: 8.9 ms at the headline shape against 6.9)
 	bool fuse_plain = false;
 	DevBuf plain_sec, plain_op, plain_X;
-	// ---- short filters behind long calls (round 5, kernels_short.hip): taps - 1 <= 4096 and calls of at least 1024 frames -- the whole transform of a pair
-	// (8192 points) in one workgroup's LDS: a block is one read of the window and one write of the outputs instead of three trips of W through HBM
+	// ---- short filters behind long calls (round 5, kernels_short.hip): taps - 1 <= 4096 and calls of at least 1024 frames (<= 8192 where the calls fill the
+	// larger window's blocks) -- the whole transform of a pair (8192 or 16384 points) in one workgroup's LDS: a block is one read of the window and one write of
+	// the outputs instead of three trips of W through HBM
 	bool short_mode = false;
 	long short_N = CONV_SHORT_N;
 	long cur_frames = 0;
@@ -336,12 +337,15 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		const int sv = se ? atoi(se) : 1;
 		const long fn = (T - 1 + 7) & ~7L;
 		// (calls of at least 1024 frames: below that a launch is all latency; 32-bit byte offsets inside a stream's slab / a pair's ring)
-		short_mode = sv != 0 && !env && !resampler && !round_f32 && !ring_parent && !upc_block && !force_N && fn <= CONV_SHORT_N / 2
-		             && (long) max_frames >= 1024 && (long) max_frames <= (1L << 24) && (double) max_frames * sp.ch_in * sizeof(double) < 2.0e9;
+		const bool short_ok = sv != 0 && !env && !resampler && !round_f32 && !ring_parent && !upc_block && !force_N
+		                      && (long) max_frames >= 1024 && (long) max_frames <= (1L << 24) && (double) max_frames * sp.ch_in * sizeof(double) < 2.0e9;
 		// the window: a block of the 16384-point form is 14 / 13 of the transform work per point for (16384 - fn) instead of (8192 - fn) outputs, and
-		// (N + hop) / hop units of traffic -- from about 2000 taps on the larger window is less of both, provided the calls fill its blocks
-		short_N = CONV_SHORT_N;
-		if (short_mode && sv != 13 && (sv == 14 || (fn > 2048 && (long) max_frames >= 4 * (CONV_SHORT_N2 - fn)))) short_N = CONV_SHORT_N2;
+		// (N + hop) / hop units of traffic -- from about 2000 taps on the larger window is less of both, provided the calls fill its blocks; filters of
+		// 4098 ... 8193 taps have that window or the four-step transforms
+		const bool fits13 = fn <= CONV_SHORT_N / 2, fits14 = fn <= CONV_SHORT_N2 / 2, fill14 = (long) max_frames >= 4 * (CONV_SHORT_N2 - fn);
+		const bool want14 = fits14 && sv != 13 && (fits13 ? (sv == 14 || (fn > 2048 && fill14)) : fill14);
+		short_mode = short_ok && (fits13 || want14);
+		short_N = want14 ? CONV_SHORT_N2 : CONV_SHORT_N;
 	}
 	N = short_mode ? short_N : conv_plan(T, max_frames, resampler, nullptr);
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));

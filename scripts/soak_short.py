@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the one-trip convolver (kernels_short.hip): random filters of 17 ... 4097 taps (one shared or one per channel, `fir` or `fir_p`, with and without a
+"""Soak of the one-trip convolver (kernels_short.hip): random filters of 17 ... 8193 taps (one shared or one per channel, `fir` or `fir_p`, with and without a
 selector, a cascade in front, a consumer behind), random shapes and call sequences (whole multiples of the hop, ragged sizes, single frames, resets), every
 output compared with the four-step transforms (DSP_AMD_CONV_SHORT=0) on the same inputs.  usage: soak_short.py [seeds=40]"""
 import os, sys
@@ -21,7 +21,7 @@ def main(n_seeds):
     for seed in range(n_seeds):
         rng = np.random.default_rng(5000 + seed)
         C = int(rng.choice([1, 2, 3, 4, 8])); S = int(rng.choice([1, 2, 7, 33, 130]))
-        taps = int(rng.choice([17, 33, 100, 1000, 2049, 4000, 4095, 4096, 4097, int(rng.integers(17, 4098))]))
+        taps = int(rng.choice([17, 33, 100, 1000, 2049, 4000, 4095, 4096, 4097, 4098, 6000, 8192, 8193, int(rng.integers(17, 4098)), int(rng.integers(4098, 8194))]))
         per_ch = C > 1 and rng.random() < 0.25
         h = rng.standard_normal((taps, C if per_ch else 1)) * np.exp(-np.arange(taps) / 500.0)[:, None]
         h = h / np.sqrt(np.sum(h * h, axis=0)) / 4
@@ -32,7 +32,7 @@ def main(n_seeds):
         pre = "lowpass 2k 0.707 eq 300 1.5 4 " if rng.random() < 0.3 else ""
         post = " gain -1.5 highshelf 6k 0.7 2" if rng.random() < 0.3 else ""
         chain = f"{pre}{sel} {eff} -t pcm -e double -c {C if per_ch else 1} {f}{' :' if sel else ''}{post}".strip()
-        B = int(rng.choice([1024, 4096, 20000, 65536]))
+        B = int(rng.choice([1024, 4096, 20000, 65536, 49152]))
         window = [True, 13, 14][int(rng.integers(0, 3))]
         bo, bs = build(chain, C, S, B, window), build(chain, C, S, B, False)
         one_trip = "one-trip" in bo.plan()

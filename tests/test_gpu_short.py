@@ -1,4 +1,5 @@
-"""The one-trip convolver for short filters behind long calls (kernels_short.hip, round 5): filters of up to 4097 taps on calls of at least 1024 frames --
+"""The one-trip convolver for short filters behind long calls (kernels_short.hip, round 5): filters of up to 4097 taps on calls of at least 1024 frames
+(up to 8193 taps where the calls fill the larger window's blocks) --
 a pair's 8192- or 16384-point transform in one workgroup's LDS (the larger window from about 2000 taps on where the calls fill its blocks; either one
 forced with DSP_AMD_CONV_SHORT=13 / 14), one read of the window and one write of the outputs per block -- against the real reference and
 against the four-step transforms (DSP_AMD_CONV_SHORT=0) on the same inputs: tap counts at both ends, ragged call sequences, drains, per-channel filters,
@@ -68,6 +69,10 @@ CASES = [
     ("fir -t pcm -e double -c 1 {F}", 2000, 1, 4, 2, (10000, 10000, 3000), (14, 16384)),
     ("lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 {F} gain -2", 4000, 1, 16, 8, (32768, 1500, 32768), (True, 8192)),   # a cascade writes the rings
     ("lowpass 1k 0.707 eq 400 2.0 1.5 fir_p -t pcm -e double -c 1 {F} gain -2", 4000, 1, 16, 8, (65536, 1500, 32768), (True, 16384)),
+    # 4098 ... 8193 taps: the larger window only, and only where the calls fill its blocks
+    ("fir_p -t pcm -e double -c 1 {F}", 8193, 1, 6, 2, (65536, 40000, 65536, 3), (True, 16384)),
+    ("fir -t pcm -e double -c 1 {F}", 6000, 1, 4, 4, (49152, 1024, 20000), (True, 16384)),
+    ("fir_p -t pcm -e double -c 4 {F}", 5000, 4, 5, 4, (60000, 60000), (True, 16384)),
 ]
 
 
@@ -137,7 +142,11 @@ def test_where_the_one_trip_form_is_not_used(amd, tmp_path):
     np.asarray(make_filter(5000), dtype="<f8").tofile(f)
     g = os.path.join(str(tmp_path), "g.raw")
     np.asarray(make_filter(3000), dtype="<f8").tofile(g)
-    assert "one-trip" not in amd.BatchChain(f"fir_p -t pcm -e double -c 1 {f}", 48000, 2, 4, 16384).plan()          # 5000 taps
+    assert "one-trip" not in amd.BatchChain(f"fir_p -t pcm -e double -c 1 {f}", 48000, 2, 4, 16384).plan()          # 5000 taps, calls that do not fill the larger window's blocks
+    assert "one-trip" in amd.BatchChain(f"fir_p -t pcm -e double -c 1 {f}", 48000, 2, 4, 65536).plan()              # ... and calls that do
+    h9 = os.path.join(str(tmp_path), "h9.raw")
+    np.asarray(make_filter(8194), dtype="<f8").tofile(h9)
+    assert "one-trip" not in amd.BatchChain(f"fir_p -t pcm -e double -c 1 {h9}", 48000, 2, 4, 65536).plan()         # 8194 taps
     assert "one-trip" not in amd.BatchChain(f"fir_p -t pcm -e double -c 1 {g}", 48000, 2, 4, 256).plan()            # 256-frame calls
     assert "one-trip" not in amd.BatchChain(f"zita_convolver -t pcm -e double -c 1 {g}", 48000, 2, 4, 16384).plan()
     assert "one-trip" not in amd.BatchChain(f"fir_p -t pcm -e double -c 1 {g} resample 96k", 48000, 2, 4, 16384).plan()
