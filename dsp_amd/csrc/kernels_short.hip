@@ -34,45 +34,33 @@ typedef double real;
 #undef FFT_F32
 
 // Geometry of an instance: N = 2^LOG2N points of a channel pair, N / 32 threads that hold TWO sets of 16 points each (the points of "virtual threads" j and
-// j + N / 32: v[t][m] <-> position j + (N / 32) (t + 2 m), the 32 inputs of the thread's radix-32 butterfly in EVERY pass), a direct twiddle table for the
-// middle pass (W_512 / W_1024) and the lo / hi pair for W_N.
+// j + N / 32: v[t][m] <-> position j + (N / 32) (t + 2 m), the 32 inputs of the thread's radix-32 butterfly in EVERY pass).  LDS: the exchange buffer (one
+// half -- real or imaginary parts -- of the window at a time, one slot of padding per 32) and the middle pass's twiddles as a table [r][k] = W_(32 RB)^(r k),
+// k < 32: the lanes of a wave read consecutive entries at an offset that is a constant of the instruction.
 template <int LOG2N> struct ShCfg {
 	static constexpr int N = 1 << LOG2N, P = N / 16, NTH = N / 32;
-	static constexpr int TD = N / 16, TDP = TD + TD / 16, TLO = 68, THI = N / 64;
-	static constexpr size_t LDS = (size_t) N * sizeof(double) + ((size_t) TDP + TLO + THI) * sizeof(cplx);
-};
-// get<M>(e) = exp(-2 pi i e / M): M = N as hi[e >> 6] * lo[e & 63], M <= TD from the direct table (twpad: power-of-two strides conflict-free)
-template <int NSEQ, int TD> struct TwShort {
-	const cplx *td, *lo, *hi;
-	template <int M> __device__ __forceinline__ cplx get(int e) const
-	{
-		if constexpr (M == NSEQ) return cmul(hi[e >> 6], lo[twpad(e & 63)]);
-		else { static_assert(M <= TD, "no table for this pass"); return td[twpad(e * (TD / M))]; }
-	}
+	static constexpr int RB = (LOG2N == 14) ? 32 : 16;                    // radix of the middle pass
+	static constexpr int XCH = N + N / 32, TWB = RB * 32;
+	static constexpr size_t LDS = (size_t) XCH * sizeof(double) + (size_t) TWB * sizeof(cplx);
 };
 
-// The exchanges carry the real and the imaginary parts one after the other through a buffer of N doubles: twice the barriers and LDS instructions for the
+// The exchanges carry the real and the imaginary parts one after the other through a buffer of doubles: twice the barriers and LDS instructions for the
 // same bytes -- but half the LDS, so that two independent 8192-point workgroups fit a CU (one issues butterflies while the other waits), and a 16384-point
 // window fits a CU at all.  Slots: an element is 8 bytes = 2 banks of 64; a ds_read / ds_write_b64 is served in two groups of 32 lanes, conflict-free when
-// the 32 slots differ mod 32: slot = pos ^ ((pos >> 5) & 31) makes them for every access shape of the passes below (stores 32 j + r, (j - k) 32 + k + 32 r,
-// (j - k) 16 + k + 32 r; gathers j + (N / 32) m -- simulated over every pass before it ran).
-__device__ __forceinline__ int sh_slotd(int pos) { return pos ^ ((pos >> 5) & 31); }
+// the 32 slots differ mod 32.  slot = pos + (pos >> 5) -- one slot of padding per 32 -- makes them for every access shape of the passes below AND leaves every
+// address of a pass a per-thread base plus a constant of the instruction (the first form of this file XORed bits into the position: conflict-free too, but
+// three integer instructions per access -- 2500 of a wave's 5800 vector instructions per block were addresses, profiles/r06c_conv_short_config5_counters_
+// two_exchanges.json):
+//   stores of the first pass      pos = 32 j + r               slot = 33 j + r
+//   stores of the middle pass     pos = 32 RB a + k + 32 r     slot = 33 RB a + k + 33 r      (virtual thread 32 a + k)
+//   gathers                       pos = j + (N / 32) m         slot = j + (j >> 5) + (N / 32 + N / 1024) m
+// (simulated over every pass before it ran: scripts/conv_short_model.py)
 
-// One radix-32 Stockham pass on the thread's 32 points, u[2 m] = va[m], u[2 m + 1] = vb[m]: butterfly b = j, stride NS.  32 = 2 x 16: the two sets'
-// 16-point transforms, w_32^k2 on the odd set's results (constants), a radix-2 step across the sets.  Output r of the butterfly ends up in va[r] (r < 16) or
-// vb[r - 16]; its Stockham position is (j - k) 32 + k + NS r, k = j mod NS (sh_pos32).
-template <int NS, bool INV, class Tw>
-__device__ __forceinline__ void sh_pass32(cplx (&va)[16], cplx (&vb)[16], int j, const Tw &tw)
+// One radix-32 step on the thread's 32 points, u[2 m] = va[m], u[2 m + 1] = vb[m] (already multiplied by the pass's twiddles): 32 = 2 x 16 -- the two sets'
+// 16-point transforms, w_32^k2 on the odd set's results (constants), a radix-2 step across the sets.  Output r ends up in va[r] (r < 16) or vb[r - 16].
+template <bool INV>
+__device__ __forceinline__ void sh_dft32(cplx (&va)[16], cplx (&vb)[16])
 {
-	if constexpr (NS > 1) {
-		const int k = j & (NS - 1);
-#pragma unroll
-		for (int m = 0; m < 16; ++m) {
-			if (m) { const cplx w = tw.template get<32 * NS>(2 * m * k); va[m] = INV ? cmulc(va[m], w) : cmul(va[m], w); }
-			const cplx w = tw.template get<32 * NS>((2 * m + 1) * k);
-			vb[m] = INV ? cmulc(vb[m], w) : cmul(vb[m], w);
-		}
-	}
 	dft16<INV>(va);
 	dft16<INV>(vb);
 	constexpr real c1 = 0.98078528040323044913, s1 = 0.19509032201612826785, c2 = 0.92387953251128675613, s2 = 0.38268343236508977173;
@@ -88,49 +76,81 @@ __device__ __forceinline__ void sh_pass32(cplx (&va)[16], cplx (&vb)[16], int j,
 #pragma unroll
 	for (int r = 0; r < 16; ++r) { const cplx a = va[r], b = vb[r]; va[r] = cadd(a, b); vb[r] = csub(a, b); }
 }
-template <int NS> __device__ __forceinline__ int sh_pos32(int j, int r) { const int k = j & (NS - 1); return (j - k) * 32 + k + NS * r; }
-template <int NS> __device__ __forceinline__ int sh_pos16(int jv, int r) { const int k = jv & (NS - 1); return (jv - k) * 16 + k + NS * r; }
+
+// The last pass of a set (radix 16, stride N / 16: butterfly = the virtual thread jv itself, results stay where the inputs were): twiddles w^r, r < 16,
+// w = W_N^jv -- ONE table entry per set (read from the W_N table in device memory once per launch) and its powers by products at most four deep, in place of
+// fifteen look-ups in a two-level table, their products and their index arithmetic.
+template <bool INV>
+__device__ __forceinline__ void sh_last16(cplx (&v)[16], const cplx w1)
+{
+	auto tw = [&](cplx &x, const cplx w) { x = INV ? cmulc(x, w) : cmul(x, w); };
+	// w^(4 a + b) = w^(4 a) w^b: three small powers and one running multiple of four are alive at a time (the window's 128 registers leave room for little else)
+	const cplx w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+	tw(v[1], w1); tw(v[2], w2); tw(v[3], w3);
+	cplx w4a = cmul(w2, w2);
+	const cplx w4 = w4a;
+#pragma unroll
+	for (int a = 1; a < 4; ++a) {
+		tw(v[4 * a], w4a); tw(v[4 * a + 1], cmul(w4a, w1)); tw(v[4 * a + 2], cmul(w4a, w2)); tw(v[4 * a + 3], cmul(w4a, w3));
+		if (a < 3) w4a = cmul(w4a, w4);
+	}
+	dft16<INV>(v);
+}
 
 // The N-point transform of a pair's window: radix 32 / 16 / 16 at 8192 points, 32 / 32 / 16 at 16384 -- TWO exchanges (until round 6's second half: radix
 // 16 / 16 / 16 / 2 with three; a thread's 32 points are the same positions in every pass either way, so a radix-32 step costs no exchange of its own).
-// Results in natural order at the positions the thread loaded from.
-template <int LOG2N, bool INV, class Tw>
-__device__ __forceinline__ void short_fft2(cplx (&va)[16], cplx (&vb)[16], int j, double *lds, const Tw &tw)
+// Results in natural order at the positions the thread loaded from.  tk = the middle pass's twiddle table + (j & 31); wa, wb = W_N^j, W_N^(j + N / 32).
+template <int LOG2N, bool INV>
+__device__ __forceinline__ void short_fft2(cplx (&va)[16], cplx (&vb)[16], int j, double *lds, const cplx *tk, const cplx wa, const cplx wb)
 {
-	constexpr int P = ShCfg<LOG2N>::P, H = ShCfg<LOG2N>::NTH;
-	const RowMap nomap{ 0 };
-	// pa(r), pb(r): Stockham positions of va[r], vb[r]
-	auto exchange = [&](auto pa, auto pb, bool last) {
+	typedef ShCfg<LOG2N> Cfg;
+	constexpr int P = Cfg::P, H = Cfg::NTH, PP = P + P / 32, HP = H + H / 32;
+	double *const g = lds + (j + (j >> 5));                                 // gathers: set A at g[PP m], set B at g[HP + PP m]
+	// sa, sb: where va[0], vb[0] go; dr: slots from one output of the butterfly to the next
+	auto exchange = [&](double *const sa, double *const sb, auto dr_tag, bool last) {
+		constexpr int DR = decltype(dr_tag)::value;
 #pragma unroll
-		for (int r = 0; r < 16; ++r) { lds[sh_slotd(pa(r))] = va[r].x; lds[sh_slotd(pb(r))] = vb[r].x; }
+		for (int r = 0; r < 16; ++r) { sa[DR * r] = va[r].x; sb[DR * r] = vb[r].x; }
 		lds_barrier();
 		double xa[16], xb[16];
 #pragma unroll
-		for (int m = 0; m < 16; ++m) { xa[m] = lds[sh_slotd(j + P * m)]; xb[m] = lds[sh_slotd(j + H + P * m)]; }
+		for (int m = 0; m < 16; ++m) { xa[m] = g[PP * m]; xb[m] = g[HP + PP * m]; }
 		lds_barrier();
 #pragma unroll
-		for (int r = 0; r < 16; ++r) { lds[sh_slotd(pa(r))] = va[r].y; lds[sh_slotd(pb(r))] = vb[r].y; }
+		for (int r = 0; r < 16; ++r) { sa[DR * r] = va[r].y; sb[DR * r] = vb[r].y; }
 		lds_barrier();
 #pragma unroll
-		for (int m = 0; m < 16; ++m) { va[m] = mkc(xa[m], lds[sh_slotd(j + P * m)]); vb[m] = mkc(xb[m], lds[sh_slotd(j + H + P * m)]); }
+		for (int m = 0; m < 16; ++m) { va[m] = mkc(xa[m], g[PP * m]); vb[m] = mkc(xb[m], g[HP + PP * m]); }
 		if (!last) lds_barrier();            // (behind the last exchange the caller's own barrier stands in front of the next store)
 	};
-	asm volatile("" : "+v"(j));
-	sh_pass32<1, INV>(va, vb, j, tw);
-	exchange([&](int r) { return sh_pos32<1>(j, r); }, [&](int r) { return sh_pos32<1>(j, r + 16); }, false);
-	asm volatile("" : "+v"(j));
+	sh_dft32<INV>(va, vb);
+	exchange(lds + 33 * j, lds + 33 * j + 16, std::integral_constant<int, 1>{}, false);
+	auto tw = [&](cplx &x, const cplx w) { x = INV ? cmulc(x, w) : cmul(x, w); };
 	if constexpr (LOG2N == 13) {
-		pass16<LOG2N, 16, 32, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
-		pass16<LOG2N, 16, 32, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
-		exchange([&](int r) { return sh_pos16<32>(j, r); }, [&](int r) { return sh_pos16<32>(j + H, r); }, true);
+		// radix 16, stride 32, per set: virtual thread jv = 32 a + k, twiddles W_512^(r k)
+#pragma unroll
+		for (int r = 1; r < 16; ++r) { const cplx w = tk[32 * r]; tw(va[r], w); tw(vb[r], w); }      // (j and j + 256 have the same k)
+		dft16<INV>(va);
+		dft16<INV>(vb);
+		double *const s = lds + (33 * 16) * (j >> 5) + (j & 31);
+		exchange(s, s + (33 * 16) * (H / 32), std::integral_constant<int, 33>{}, true);
 	}
 	else {
-		sh_pass32<32, INV>(va, vb, j, tw);
-		exchange([&](int r) { return sh_pos32<32>(j, r); }, [&](int r) { return sh_pos32<32>(j, r + 16); }, true);
+		// radix 32, stride 32: thread j = 32 a + k, twiddles W_1024^(r k) on u[r] = (r even ? va : vb)[r / 2]
+#pragma unroll
+		for (int m = 0; m < 16; ++m) { if (m) tw(va[m], tk[32 * (2 * m)]); tw(vb[m], tk[32 * (2 * m + 1)]); }
+		sh_dft32<INV>(va, vb);
+		double *const s = lds + (33 * 32) * (j >> 5) + (j & 31);
+		exchange(s, s + 33 * 16, std::integral_constant<int, 33>{}, true);
 	}
-	asm volatile("" : "+v"(j));
-	pass16<LOG2N, 16, P, INV, true>(va, j, (cplx *) nullptr, nomap, tw);
-	pass16<LOG2N, 16, P, INV, true>(vb, j + H, (cplx *) nullptr, nomap, tw);
+	// (the powers are the same in every block: left to itself the compiler computes all thirty of them once per launch and keeps them -- in scratch memory)
+	cplx w = wa;
+	asm volatile("" : "+v"(w.x), "+v"(w.y));
+	sh_last16<INV>(va, w);
+	__builtin_amdgcn_sched_barrier(0);
+	w = wb;
+	asm volatile("" : "+v"(w.x), "+v"(w.y));
+	sh_last16<INV>(vb, w);
 }
 
 // (every address is a buffer descriptor + a 32-bit offset: the host checks that rings, slabs and outputs stay below 2 GB per stream / pair -- sixteen
@@ -143,21 +163,18 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 	typedef ShCfg<LOG2N> Cfg;
 	constexpr int N = Cfg::N, P = Cfg::P, NTH = Cfg::NTH, VT = 2;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-	double *datad = reinterpret_cast<double *>(smem_raw);                // the exchange buffer: one half (real / imaginary parts) of the row at a time
-	cplx *td = reinterpret_cast<cplx *>(smem_raw + (size_t) N * sizeof(double)), *tlo = td + Cfg::TDP, *thi = tlo + Cfg::TLO;
+	double *datad = reinterpret_cast<double *>(smem_raw);                // the exchange buffer: one half (real / imaginary parts) of the window at a time
+	cplx *twb = reinterpret_cast<cplx *>(smem_raw + (size_t) Cfg::XCH * sizeof(double));
 	int j = threadIdx.x;
 	const long pair = blockIdx.x;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long b0 = (long) blockIdx.y * p.blocks_per_wg, b1 = (b0 + p.blocks_per_wg < n_blocks) ? b0 + p.blocks_per_wg : n_blocks;
 	if (b0 >= b1) return;
-	for (int e = j; e < Cfg::TD + 64 + Cfg::THI; e += NTH) {
-		if (e < Cfg::TD) td[twpad(e)] = TAB(p.tw)[e * (N / Cfg::TD)];
-		else if (e < Cfg::TD + 64) tlo[twpad(e - Cfg::TD)] = TAB(p.tw)[e - Cfg::TD];
-		else thi[e - Cfg::TD - 64] = TAB(p.tw)[(e - Cfg::TD - 64) * 64];
-	}
+	for (int e = j; e < Cfg::TWB; e += NTH) twb[e] = TAB(p.tw)[(e >> 5) * (e & 31) * (N / Cfg::TWB)];      // [r][k] = W_(32 RB)^(r k)
+	const cplx *const tk = twb + (j & 31);
+	const cplx w_a = TAB(p.tw)[j], w_b = TAB(p.tw)[j + NTH];             // W_N^jv of the thread's two sets (the last pass's twiddles are their powers)
 	const cplx *Hrow = p.Hout ? nullptr : TAB(p.H) + (long) p.pair_h[pair] * N;
 	lds_barrier();                                                       // tables visible
-	const TwShort<N, Cfg::TD> tw{ td, tlo, thi };
 	// (the division runs on the vector unit; its result is uniform all the same and is said to be: with a per-lane stream index the slab and output
 	// descriptors are per-lane values and every load through them becomes a loop over their distinct values -- 16 such loops per block until round 6)
 	const long s = __builtin_amdgcn_readfirstlane((int) (pair / p.pairs_per_stream)), qs = pair - s * p.pairs_per_stream;
@@ -169,10 +186,11 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 	// direct mode: the pair's two channels of a slab frame are 16 contiguous bytes (channels 2 qs, 2 qs + 1: the host checked)
 	const __amdgpu_buffer_rsrc_t r_slab = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p.slab ? reinterpret_cast<const char *>(p.slab) + ((size_t) s * p.slab_stride_frames * p.C + 2 * qs) * BS : nullptr), 0,
 		p.slab ? rsrc_records((p.slab_frames * p.C - 2 * qs) * BS) : 0, 0x00020000);
-	auto slab_ld = [&](int vo) -> cplx {
-		if constexpr (BS == 8) return buf_ldc(r_slab, vo, 0);
-		else if constexpr (BS == 4) { const sh_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r_slab, vo, 0, 0); return mkc(pcm_from_word(w.x, wf_slab), pcm_from_word(w.y, wf_slab)); }
-		else { const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(r_slab, vo, 0, 0); return mkc(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16)); }
+	// (vo: the lane's byte offset, so: an offset every lane shares -- a scalar register of the instruction)
+	auto slab_ld = [&](int vo, int so) -> cplx {
+		if constexpr (BS == 8) return buf_ldc(r_slab, vo, so);
+		else if constexpr (BS == 4) { const sh_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r_slab, vo, so, 0); return mkc(pcm_from_word(w.x, wf_slab), pcm_from_word(w.y, wf_slab)); }
+		else { const uint32_t w = __builtin_amdgcn_raw_buffer_load_b32(r_slab, vo, so, 0); return mkc(pcm_from_s16(w & 0xffffu), pcm_from_s16(w >> 16)); }
 	};
 	const int cha = p.pair_out_ch[2 * qs], chb = p.pair_out_ch[2 * qs + 1];
 	double *out = p.out ? p.out + (size_t) s * p.out_stride_frames * p.C : nullptr;
@@ -193,22 +211,42 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 		const int so = (int) (-d_slab * fbi);                        // byte offset of element 0 in the stream's slab (negative while it lies in older calls)
 		cplx v[VT][16];
 		asm volatile("" : "+v"(j));                                  // (addresses are recomputed per block: kept across blocks they are 40 registers nobody has)
+		// A block in the middle of a long call reads its whole window from one place, with nothing to file and nothing to pad: the lane's offset once and
+		// a scalar offset per element (the general form below asks three questions per element: 1600 instructions in front of the block's 32 loads).
+		if (valid == N && p.slab && d_slab <= 0 && d_file >= N) {
 #pragma unroll
-		for (int t = 0; t < VT; ++t) {
-			const int jv = j + NTH * t;
+			for (int t = 0; t < VT; ++t) {
+				const int vo = so + (j + NTH * t) * fbi;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) {
-				const int n = jv + P * m;
-				if (n >= valid) v[t][m] = mkc(0.0, 0.0);
-				else if (n >= n_slab) {
-					v[t][m] = slab_ld(so + n * fbi);
-					if (n >= n_file) buf_stc(v[t][m], r_ring, ((r0 + n) & mask) * 16);
+				for (int m = 0; m < 16; ++m) v[t][m] = slab_ld(vo, (P * m) * fbi);
+			}
+		}
+		else if (valid == N && !p.slab && r0 + N <= mask + 1) {
+#pragma unroll
+			for (int t = 0; t < VT; ++t) {
+				const int vo = (r0 + j + NTH * t) * 16;
+#pragma unroll
+				for (int m = 0; m < 16; ++m) v[t][m] = buf_ldc(r_ring, vo, (P * m) * 16);
+			}
+		}
+		else {
+#pragma unroll
+			for (int t = 0; t < VT; ++t) {
+				const int jv = j + NTH * t;
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					const int n = jv + P * m;
+					if (n >= valid) v[t][m] = mkc(0.0, 0.0);
+					else if (n >= n_slab) {
+						v[t][m] = slab_ld(so + n * fbi, 0);
+						if (n >= n_file) buf_stc(v[t][m], r_ring, ((r0 + n) & mask) * 16);
+					}
+					else v[t][m] = buf_ldc(r_ring, ((r0 + n) & mask) * 16, 0);
 				}
-				else v[t][m] = buf_ldc(r_ring, ((r0 + n) & mask) * 16, 0);
 			}
 		}
 		if (b > b0) lds_barrier();                                   // the previous block's last gather is done
-		short_fft2<LOG2N, false>(v[0], v[1], j, datad, tw);
+		short_fft2<LOG2N, false>(v[0], v[1], j, datad, tk, w_a, w_b);
 		if (p.Hout) {
 #pragma unroll
 			for (int t = 0; t < VT; ++t) {
@@ -236,7 +274,7 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 				}
 		}
 		lds_barrier();                                               // every gather of the forward transform is done
-		short_fft2<LOG2N, true>(v[0], v[1], j, datad, tw);
+		short_fft2<LOG2N, true>(v[0], v[1], j, datad, tk, w_a, w_b);
 		// window sample first_n + f -> output frame mo0 + f, for f in [f_lo, f_hi)
 		const long mo0 = q_blk - p.k_origin;
 		const int f_lo = (mo0 >= 0) ? 0 : (-mo0 < in_count ? (int) -mo0 : in_count);
@@ -297,24 +335,54 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 			if (p.sink.stats) sink_stats_block(p.sink.stats, s, peak, clipped);
 			continue;
 		}
+		// A block in the middle of a long call: every window sample from first_n on is an output frame, whole pairs go to one place without a wrap --
+		// one comparison and one addition per element (the general form below asks six questions per element).
+		const bool all_frames = f_lo == 0 && f_hi == N - first_n && !p.round_f32;
+		if (all_frames && p.ring_out && chb >= 0 && rp0 + f_hi <= omask + 1) {
+			const bool rnd = p.ring_out_round_f32 != 0;
 #pragma unroll
-		for (int t = 0; t < VT; ++t) {
-			const int jv = j + NTH * t;
+			for (int t = 0; t < VT; ++t) {
+				const int f0 = j + NTH * t - first_n, vo = (rp0 + f0) * 16;
 #pragma unroll
-			for (int m = 0; m < 16; ++m) {
-				const int f = jv + P * m - first_n;
-				if (f < f_lo || f >= f_hi) continue;
-				cplx y = v[t][m];
-				if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
-				if (p.ring_out) {
-					if (p.ring_out_round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
-					if (chb < 0) y.y = 0.0;
-					buf_stc(y, r_rout, ((rp0 + f) & omask) * 16);
+				for (int m = 0; m < 16; ++m) {
+					if (f0 + P * m < 0) continue;
+					cplx y = v[t][m];
+					if (rnd) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+					buf_stc(y, r_rout, vo + (P * m) * 16);
 				}
-				else if (wide) buf_stc(y, r_out, ob + f * fb);
-				else {
-					if (cha >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.x), r_out, ob + f * fb, 0, 0);
-					if (chb >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.y), r_out, ob2 + f * fb, 0, 0);
+			}
+		}
+		else if (all_frames && !p.ring_out && wide) {
+#pragma unroll
+			for (int t = 0; t < VT; ++t) {
+				const int f0 = j + NTH * t - first_n, vo = ob + f0 * fb;
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					if (f0 + P * m < 0) continue;
+					buf_stc(v[t][m], r_out, vo + (P * m) * fb);
+				}
+			}
+		}
+		else {
+#pragma unroll
+			for (int t = 0; t < VT; ++t) {
+				const int jv = j + NTH * t;
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					const int f = jv + P * m - first_n;
+					if (f < f_lo || f >= f_hi) continue;
+					cplx y = v[t][m];
+					if (p.round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+					if (p.ring_out) {
+						if (p.ring_out_round_f32) { y.x = (double) (float) y.x; y.y = (double) (float) y.y; }
+						if (chb < 0) y.y = 0.0;
+						buf_stc(y, r_rout, ((rp0 + f) & omask) * 16);
+					}
+					else if (wide) buf_stc(y, r_out, ob + f * fb);
+					else {
+						if (cha >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.x), r_out, ob + f * fb, 0, 0);
+						if (chb >= 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sh_u32x2, y.y), r_out, ob2 + f * fb, 0, 0);
+					}
 				}
 			}
 		}
