@@ -1,22 +1,27 @@
-// kernels_short.hip -- one-trip FFT convolution for SHORT filters behind long calls (round 5).
+// kernels_short.hip -- one-trip FFT convolution for SHORT filters behind long calls (round 5; round 6's form).
 //
 // What it replaces, per block, in the reference: fir_p's / fir's block transform, spectrum product and inverse (fir_p.c:64-103, fir.c:109-149) for
-// filters of up to 4097 taps -- `hilbert -p 4095` (hilbert.c:28-92), crossover and correction FIRs, the FIRs `biquad -r` sections are designed into.
-// The four-step convolver (kernels_fft.hip) sends every window through HBM three times whatever the filter's length; a window of 8192 points of a
-// channel pair is 128 KB and fits one workgroup's LDS, so here a block is ONE read of the window (first_n frames of history + hop new ones) and ONE
-// write of hop outputs: (N + hop) / hop units of 16 bytes per pair and frame -- 3 at 4095 taps, 2.3 at 1000 -- against 6.4 for three trips of a
-// 65536-point transform.  BASELINE config 5's `hilbert -p 4095` stage was 22 of its 35 ms.
+// filters of up to 8193 taps -- `hilbert -p 4095` (hilbert.c:28-92), crossover and correction FIRs, the FIRs `biquad -r` sections are designed into.
+// The four-step convolver (kernels_fft.hip) sends every window through HBM three times whatever the filter's length; a window of 8192 or 16384 points of
+// a channel pair fits one workgroup's registers (32 points per thread) with an exchange buffer of HALF its bytes in LDS, so here a block is ONE read of the
+// window (first_n frames of history + hop new ones) and ONE write of hop outputs: (N + hop) / hop units of 16 bytes per pair and frame -- 2.3 at 4095 taps on
+// the 16384-point window (3 on the 8192-point one), 2.3 at 1000 on the small one -- against 6.4 for three trips of a 65536-point transform.
 //
-// What bounds it (BASELINE config 5's hilbert stage: 1024 pairs x 224 blocks, 44 GB): not memory -- a block is two 8192-point transforms for 4096
-// outputs, about 7.5 us of fp64 issue and 6 us of LDS exchange traffic per CU against 9 us of HBM time.  Counters (profiles/r06_conv_short_config5_
-// counters.json, round 5's one-workgroup form): waves parked at a barrier or a counter 42 % of their time, issuing VALU 27 %, stalled on an
-// instruction's operands 20 %, LDS bank conflicts 18 % of the LDS cycles.  Round 5: 15.6 - 17.5 ms; with the per-lane descriptors gone (16 loops per
-// block over one value) 16.4 - 16.7; round 6's form below 15.9.  A prefetched next window measured slower (profiles/r05_conv_short_prefetch_ab.txt).
+// Workgroup = one channel pair (z = x_a + i x_b, exact: h is real), N / 32 threads x two sets of 16 points, walking the pair's blocks.  Transform: radix
+// 32 / 16 / 16 (8192 points; 256 threads, 74 KB of LDS: two independent workgroups per CU) or 32 / 32 / 16 (16384 points; 512 threads, 148 KB: one) with TWO
+// exchanges -- the thread's 32 points are the inputs of ITS radix-32 butterfly in every pass, so a radix-32 step is two 16-point transforms, constants and a
+// radix-2 step in registers.  The exchanges carry real parts, then imaginary parts, through a buffer of N (+ N / 32) doubles.  The filter row comes from L2
+// where it is used.  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
 //
-// Workgroup = one channel pair (z = x_a + i x_b, exact: h is real), 256 threads x two sets of 16 points, walking the pair's blocks; radix 16 / 16 / 16 / 2
-// Stockham passes whose exchanges go through a buffer of 8192 DOUBLES -- real parts, then imaginary parts -- so that two independent workgroups fit a CU
-// (72 KB of LDS each) and one issues butterflies while the other waits; conflict-free slots for both access shapes (short_fft2).  The filter row comes from
-// L2 where it is used.  Same ring / slab / output conventions as K1 and K3 (fft_params.h: ShortParams).
+// What bounds it (BASELINE config 5's hilbert stage: 1024 pairs of 917504 frames at 4095 taps, 35 GB on the large window): not memory.  Round 5 (one
+// 512-thread workgroup per CU, 8192 points, radix 16 / 16 / 16 / 2, complex exchanges through 128 KB) 15.6 - 17.5 ms; wave-uniform descriptors 16.4 - 16.7;
+// two point sets per thread and half-size exchanges (two workgroups per CU) 15.9; two exchanges instead of three 14.15; the 16384-point window (hop 12288
+// instead of 4096: 14 / 13 of the work per point for three times the outputs) 11.5; then the instruction stream: 2500 of a wave's 5800 vector instructions
+// per block were ADDRESSES (XOR-swizzled slots, two-level twiddle tables, three questions per loaded element) -- exchange slots pos + (pos >> 5), a
+// twiddle table [r][k], last-pass twiddles as powers of one table entry, whole-window loads and whole-pair stores for blocks in the middle of a call:
+// 9.4 ms = 3.7 TB/s (11.7 on the 8192-point window).  profiles/r06c_conv_short_*.txt, profiles/r06c_conv_short_config5_counters_*.json.
+// A prefetched next window measured slower in round 5 (profiles/r05_conv_short_prefetch_ab.txt): there are no registers for it.  The filter row's bins asked
+// for ahead of their products (two register sets, the first request behind the forward transform's last gather) measured the same 9.35 ms: not kept.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <type_traits>

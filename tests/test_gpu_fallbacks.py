@@ -24,7 +24,7 @@ SWITCHES = [
     "DSP_AMD_RESAMPLE_NO_GEMM=1", "DSP_AMD_RESAMPLE_DIRECT=1",
     "DSP_AMD_NO_WIRE_FUSION=1", "DSP_AMD_PLUGIN_MAPPED_KB=0", "DSP_AMD_ZITA_F64=1", "DSP_AMD_CONV_UPC=0",
     "DSP_AMD_PLUGIN_STAGE=0", "DSP_AMD_PLUGIN_STAGE=0 DSP_AMD_PLUGIN_MAPPED_KB=0",
-    "DSP_AMD_FUSE=0", "DSP_AMD_CONV_SHORT=0",
+    "DSP_AMD_FUSE=0", "DSP_AMD_CONV_SHORT=0", "DSP_AMD_CONV_SHORT=14",   # (14: the one-trip convolver's 16384-point window wherever the 8192-point one would do)
 ]
 
 
