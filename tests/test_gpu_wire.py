@@ -237,6 +237,27 @@ def test_other_first_and_last_kernels(gpu, tmp_path, chain, S, Cn, in_fmt, out_f
     check_bits(bits, bits_want, plan)
 
 
+# the one-trip convolver in the middle of a long call: whole windows read from the wire-format slab by straight-line loads (the blocks above are shorter
+# than a hop: one partial window per call), on both of its window sizes
+@pytest.mark.parametrize("taps,blocks,in_fmt,out_fmt,prec,n_window", [
+    (700, [20000, 17000, 500], "s16", "s16", 16, 8192),
+    (700, [20000, 17000, 500], "float", "s24", 24, 8192),
+    (3000, [60000, 30000, 500], "s16", "s16", 16, 16384),
+    (3000, [60000, 30000, 500], "s32", "float", 0, 16384),
+])
+def test_one_trip_whole_windows_speak_the_formats(gpu, tmp_path, taps, blocks, in_fmt, out_fmt, prec, n_window):
+    path, _ = write_filter(tmp_path, taps)
+    chain = f"fir_p -t pcm -e double -c 1 {path}"
+    S, Cn = 12, 4
+    x = wire_input(gpu[2], in_fmt, S, sum(blocks), Cn, 4)
+    want, wstats, plan = separate_passes(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert "one-trip" in plan and f"N={n_window}=" in plan, plan
+    got, gstats, bits = fused(gpu, chain, 48000, Cn, S, x, blocks, in_fmt, out_fmt, prec)
+    assert same(got, want), plan
+    assert np.array_equal(gstats.view(np.uint64), wstats.view(np.uint64))
+    check_bits(bits, 3, plan)
+
+
 # ragged calls: whole tiles + a remainder (the generic kernel speaks the formats behind cascade_rows' tiles), calls shorter than a
 # tile (stand-alone passes inside the call), a single frame -- the dither sequences run on through all of them
 @pytest.mark.parametrize("chain_tail", ["", " fir_p -t pcm -e double -c 1 {F}"])
