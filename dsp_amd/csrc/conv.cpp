@@ -208,10 +208,10 @@ std::string ConvStage::describe() const
 	if (short_mode) o << " one-trip";
 	if (fuse_static) o << " cascade-fused(" << (N1 - first_n / N2) * fuse_seg << " chunks of " << N2 / fuse_seg << (feeder_ && feeder_->fuse_tables().pairs > 1 ? ", sections per pair" : "") << ")";
 	if (skip) o << " drops-first=" << skip;
-	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N;
+	if (upc_conv) o << " mid-size-calls: " << upc_conv->upc_P << "x" << upc_conv->upc_B << " taps delay line N=" << upc_conv->N << (upc_conv->short_mode ? " one-trip" : "");
 	if (fdl) {
 		o << " small-calls: head " << fP1 << "x" << fB << " taps delay line";
-		if (tail_conv && tail_conv->upc_P) o << " + tail " << tail_conv->upc_P << "x" << tail_conv->upc_B << " taps delay line N=" << tail_conv->N << " per " << fD << " frames";
+		if (tail_conv && tail_conv->upc_P) o << " + tail " << tail_conv->upc_P << "x" << tail_conv->upc_B << " taps delay line N=" << tail_conv->N << (tail_conv->short_mode ? " one-trip" : "") << " per " << fD << " frames";
 		else if (tail_conv) o << " + tail T=" << tail_conv->T << " N=" << tail_conv->N << " per " << fD << " frames";
 	}
 	o << "]";
@@ -346,6 +346,13 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		const bool want14 = fits14 && sv != 13 && (fits13 ? (sv == 14 || (fn > 2048 && fill14)) : fill14);
 		short_mode = short_ok && (fits13 || want14);
 		short_N = want14 ? CONV_SHORT_N2 : CONV_SHORT_N;
+		// the uniformly partitioned form on windows of 8192 / 16384 points (the delay-line tail of the small-call regime at the headline: 7 slots of
+		// 8192 taps; calls that are multiples of 4096 / 8192 frames): the same kernel with the delay line between its two transforms -- one launch per
+		// call in place of K1 / K2 (mode 3) / K3 per block, the two trips of W gone (16-byte offsets inside a ring row: 32 bits)
+		if (sv != 0 && !env && upc_block && (2 * upc_block == CONV_SHORT_N || 2 * upc_block == CONV_SHORT_N2) && !resampler && !round_f32 && !f32 && nph == 1) {
+			short_mode = true;
+			short_N = 2 * upc_block;
+		}
 	}
 	N = short_mode ? short_N : conv_plan(T, max_frames, resampler, nullptr);
 	const long lo = std::max<long>(next_pow2(2 * T), 1L << (FFT_MIN_LOG2_N2 + FFT_MIN_LOG2_N1));
@@ -848,9 +855,14 @@ bool ConvStage::spectrum_f32(const std::vector<double> &src, long n_taps, int st
 // filter spectra of the one-trip form: the kernel's own forward transform of the taps as a window of N points (preparation mode), natural order
 bool ConvStage::prepare_short(const Spec &sp)
 {
-	std::vector<double2> rows((size_t) n_filters * N, make_double2(0.0, 0.0));
+	// (uniformly partitioned form: row f upc_P + q = taps [q upc_B, q upc_B + upc_B) of filter f, fir_p.c:483-495)
+	const int parts = upc_P ? upc_P : 1;
+	const long part_len = upc_P ? upc_B : T;
+	std::vector<double2> rows((size_t) n_filters * parts * N, make_double2(0.0, 0.0));
 	for (int f = 0; f < n_filters; ++f)
-		for (long i = 0; i < T; ++i) rows[(size_t) f * N + i].x = sp.taps[(size_t) i * sp.fch + (sp.fch == 1 ? 0 : f)];
+		for (int q = 0; q < parts; ++q)
+			for (long i = 0; i < part_len && q * part_len + i < T_taps; ++i)
+				rows[((size_t) f * parts + q) * N + i].x = sp.taps[(size_t) (q * part_len + i) * sp.fch + (sp.fch == 1 ? 0 : f)];
 	DevBuf d_rows;
 	if (!d_rows.upload(rows.data(), rows.size() * sizeof(double2))) return false;
 	ShortParams p;
@@ -863,7 +875,7 @@ bool ConvStage::prepare_short(const Spec &sp)
 	p.Hout = H.as<double2>(); p.h_scale = 1.0 / (double) N;
 	p.tw = tw_short.as<double2>();
 	p.slab_fmt = PCM_DOUBLE;
-	p.n_pairs = n_filters; p.blocks_per_wg = 1;
+	p.n_pairs = (long) n_filters * parts; p.blocks_per_wg = 1;
 	launch_conv_short(p, nullptr);
 	return hip_ok(hipDeviceSynchronize(), "filter spectrum");
 }
@@ -885,10 +897,16 @@ void ConvStage::convolve_short(long q_lo, long q_hi, long k_origin, long out_cou
 	p.ring_out = feed_ring; p.ring_out_stride = feed_stride; p.ring_out_mask = feed_mask; p.ring_out_pos = feed_pos; p.ring_out_round_f32 = feed_round;
 	p.round_f32 = round_f32;
 	p.n_pairs = (long) S * pps;
-	// a workgroup walks one pair's blocks with the filter row in registers; few pairs: the blocks of a pair are shared out until two workgroups per CU's worth exist
+	// a workgroup walks one pair's blocks; few pairs: the blocks of a pair are shared out until two workgroups per CU's worth exist
 	const long n_blocks = (p.n_in + B - 1) / B;
 	long ranges = (512 + p.n_pairs - 1) / p.n_pairs;
 	ranges = std::max<long>(1, std::min<long>(ranges, n_blocks));
+	if (upc_P) {
+		// (the delay line: every block reads what the blocks before it wrote -- one workgroup per pair, in order)
+		p.fdl = upc_buf.as<double2>(); p.fdl_slot_stride = (long) S * pps * N; p.fdl_P = upc_P; p.fdl_slot = upc_slot;
+		upc_slot = (int) ((upc_slot + n_blocks) % upc_P);
+		ranges = 1;
+	}
 	p.blocks_per_wg = (int) ((n_blocks + ranges - 1) / ranges);
 	ProfScope ps("conv_short", st);
 	launch_conv_short(p, st);

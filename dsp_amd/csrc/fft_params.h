@@ -165,7 +165,12 @@ struct ShortParams {
 	int C, pairs_per_stream;
 	const int *pair_out_ch;             // [pairs_per_stream][2]
 	const int *pair_h;                  // [n_pairs] filter of the pair
-	const double2 *H;                   // [n_filters][N], natural order, pre-scaled by 1 / N
+	const double2 *H;                   // [n_filters][N] (fdl_P > 0: [n_filters][fdl_P][N]), natural order, pre-scaled by 1 / N
+	// uniformly partitioned form (as ConvParams' fdl fields): fdl[slot][pair][N] (slot stride in elements), fdl_P partitions of hop taps, fdl_slot = the slot block 0 of
+	// this launch writes (block b: (fdl_slot + b) % fdl_P); the launch then runs its blocks in order, one workgroup per pair
+	double2 *fdl;
+	long fdl_slot_stride;
+	int fdl_P, fdl_slot;
 	double2 *Hout;                      // preparation mode: h_scale x forward transform of the window goes here ([n_pairs][N]) and the kernel stops
 	double h_scale;
 	const double2 *tw;                  // exp(-2 pi i k / N), k < N

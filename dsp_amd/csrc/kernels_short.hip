@@ -162,9 +162,12 @@ __device__ __forceinline__ void short_fft2(cplx (&va)[16], cplx (&vb)[16], int j
 // 64-bit address pairs per direction do not fit beside the 64 registers of the window and the 64 of the filter row)
 typedef unsigned int sh_u32x2 __attribute__((ext_vector_type(2)));
 // BS: bytes per sample of the slab in direct mode (8: fp64; 4: s24 / s32 / float; 2: s16 -- read_buf_<fmt> of pcm_device.h in the loads)
-template <int LOG2N, int BS>
+// FDL: the uniformly partitioned form (windows from the rings only; an instance of its own: the plain instances do not carry its descriptors)
+template <int LOG2N, int BS, bool FDL = false>
 __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_short(ShortParams p)
 {
+	static_assert(!FDL || BS == 8, "the delay-line form reads the rings");
+	if constexpr (FDL) p.slab = nullptr;
 	typedef ShCfg<LOG2N> Cfg;
 	constexpr int N = Cfg::N, P = Cfg::P, NTH = Cfg::NTH, VT = 2;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -261,8 +264,63 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 			}
 			return;
 		}
-		{
-			// (no room for the filter row beside two sets of points: it comes from L2 where it is used -- the same 128 KB for every pair of a filter;
+		if constexpr (FDL) {
+			// Uniformly partitioned form (the delay-line tail of the small-call regime, mid-size calls: conv.cpp): the window's spectrum becomes the newest
+			// entry of the pair's frequency-domain delay line, Y = sum_q X[now - q] H_q over the fdl_P partitions of the pair's filter -- conv_row's mode 3
+			// (fft_core.inc) without the two trips of W around it.  A thread owns the same 32 bins in every block and every launch, so an entry is only
+			// ever re-read by the thread that wrote it (the blocks of a launch in order in ONE workgroup; the launches of a stream are ordered anyway).
+			// One descriptor per slot and per partition: offsets stay inside one window whatever the batch's size.
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the entries this thread wrote in earlier blocks of this launch have left it)
+			const int slot = __builtin_amdgcn_readfirstlane((p.fdl_slot + (int) (b - b0)) % p.fdl_P);   // (a division runs on the vector unit: its result is said to be uniform, or the descriptors below are per-lane values)
+			const cplx *Hf = TAB(p.H) + (long) p.pair_h[pair] * p.fdl_P * N;
+			cplx *line = reinterpret_cast<cplx *>(p.fdl) + pair * N;
+			int vh = j * 16;
+			asm volatile("" : "+v"(vh));
+			// (FG bins per request group.  Four: 0.594 ms per run of the headline's seven-slot tail at 2048-frame calls (1024 pairs; K1 + K2 + K3: 0.62);
+			// eight -- half the round trips, twice the requests in flight -- measured 0.617: the run is the bytes, 2.2 GB of windows and entries from HBM and
+			// 1.8 GB of partition spectra from L2, not the chain of requests)
+			constexpr int FG = 4;
+			{
+				const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(line + (long) slot * p.fdl_slot_stride, 0, rsrc_records((long) N * 16), 0x00020000);
+				const __amdgpu_buffer_rsrc_t r_hq = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(Hf), 0, rsrc_records((long) N * 16), 0x00020000);
+#pragma unroll
+				for (int t = 0; t < VT; ++t)
+#pragma unroll
+					for (int g = 0; g < 16 / FG; ++g) {
+						cplx hh[FG];
+#pragma unroll
+						for (int m = 0; m < FG; ++m) hh[m] = buf_ldc(r_hq, vh + NTH * 16 * t, P * 16 * (FG * g + m));
+#pragma unroll
+						for (int m = 0; m < FG; ++m) {
+							buf_stc(v[t][FG * g + m], r_x, vh + NTH * 16 * t + P * 16 * (FG * g + m));
+							v[t][FG * g + m] = cmul(v[t][FG * g + m], hh[m]);
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+			}
+			for (int q = 1; q < p.fdl_P; ++q) {
+				const int sl = (slot >= q) ? slot - q : slot + p.fdl_P - q;
+				const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(line + (long) sl * p.fdl_slot_stride, 0, rsrc_records((long) N * 16), 0x00020000);
+				const __amdgpu_buffer_rsrc_t r_hq = __builtin_amdgcn_make_buffer_rsrc(const_cast<cplx *>(Hf + (long) q * N), 0, rsrc_records((long) N * 16), 0x00020000);
+#pragma unroll
+				for (int t = 0; t < VT; ++t)
+#pragma unroll
+					for (int g = 0; g < 16 / FG; ++g) {
+						cplx x[FG], hh[FG];
+#pragma unroll
+						for (int m = 0; m < FG; ++m) { x[m] = buf_ldc(r_x, vh + NTH * 16 * t, P * 16 * (FG * g + m)); hh[m] = buf_ldc(r_hq, vh + NTH * 16 * t, P * 16 * (FG * g + m)); }
+#pragma unroll
+						for (int m = 0; m < FG; ++m) {
+							cplx &a = v[t][FG * g + m];
+							a.x = fma(x[m].x, hh[m].x, fma(-x[m].y, hh[m].y, a.x));
+							a.y = fma(x[m].x, hh[m].y, fma(x[m].y, hh[m].x, a.y));
+						}
+						__builtin_amdgcn_sched_barrier(0);
+					}
+			}
+		}
+		else {
+			// (no room for the filter row beside two sets of points: it comes from L2 where it is used -- the same 128 / 256 KB for every pair of a filter;
 			// asked for HERE, from an index the compiler cannot see through: hoisted above the forward transform the loads are 32 spilled registers)
 			int jh = j;
 			asm volatile("" : "+v"(jh));
@@ -396,10 +454,10 @@ __global__ __launch_bounds__(ShCfg<LOG2N>::NTH) __attribute__((amdgpu_waves_per_
 
 }  // namespace psh
 
-template <int LOG2N, int BS> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
+template <int LOG2N, int BS, bool FDL = false> static void launch_short_t(const ShortParams &p, dim3 grid, hipStream_t st)
 {
-	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<LOG2N, BS>), psh::ShCfg<LOG2N>::LDS);
-	hipLaunchKernelGGL((psh::conv_short<LOG2N, BS>), grid, dim3(psh::ShCfg<LOG2N>::NTH), psh::ShCfg<LOG2N>::LDS, st, p);
+	grant_dynamic_lds(reinterpret_cast<const void *>(psh::conv_short<LOG2N, BS, FDL>), psh::ShCfg<LOG2N>::LDS);
+	hipLaunchKernelGGL((psh::conv_short<LOG2N, BS, FDL>), grid, dim3(psh::ShCfg<LOG2N>::NTH), psh::ShCfg<LOG2N>::LDS, st, p);
 }
 
 void launch_conv_short(const ShortParams &p, hipStream_t st)
@@ -408,6 +466,12 @@ void launch_conv_short(const ShortParams &p, hipStream_t st)
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
 	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
 	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges);
+	if (p.fdl_P > 0) {
+		// (every block of a pair in ONE workgroup, in order: each reads what the ones before wrote)
+		if (ranges != 1 || p.Hout) return;
+		if (p.N == CONV_SHORT_N) launch_short_t<13, 8, true>(p, grid, st); else launch_short_t<14, 8, true>(p, grid, st);
+		return;
+	}
 	const int bs = (!p.slab || p.slab_fmt == PCM_DOUBLE) ? 8 : (p.slab_fmt == PCM_S16) ? 2 : 4;
 	if (p.N == CONV_SHORT_N) { if (bs == 8) launch_short_t<13, 8>(p, grid, st); else if (bs == 4) launch_short_t<13, 4>(p, grid, st); else launch_short_t<13, 2>(p, grid, st); }
 	else { if (bs == 8) launch_short_t<14, 8>(p, grid, st); else if (bs == 4) launch_short_t<14, 4>(p, grid, st); else launch_short_t<14, 2>(p, grid, st); }
