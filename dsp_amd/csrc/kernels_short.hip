@@ -460,15 +460,16 @@ template <int LOG2N, int BS, bool FDL = false> static void launch_short_t(const 
 	hipLaunchKernelGGL((psh::conv_short<LOG2N, BS, FDL>), grid, dim3(psh::ShCfg<LOG2N>::NTH), psh::ShCfg<LOG2N>::LDS, st, p);
 }
 
-void launch_conv_short(const ShortParams &p, hipStream_t st)
+void launch_conv_short(const ShortParams &p_in, hipStream_t st)
 {
+	ShortParams p = p_in;
 	if ((p.N != CONV_SHORT_N && p.N != CONV_SHORT_N2) || p.n_pairs < 1 || p.n_in < 1) return;
 	const long n_blocks = (p.n_in + p.hop - 1) / p.hop;
+	// (the delay-line form: every block of a pair in ONE workgroup, in order -- each reads what the ones before wrote)
+	if (p.fdl_P > 0) p.blocks_per_wg = (int) n_blocks;
 	const long ranges = (n_blocks + p.blocks_per_wg - 1) / p.blocks_per_wg;
 	const dim3 grid((unsigned) p.n_pairs, (unsigned) ranges);
-	if (p.fdl_P > 0) {
-		// (every block of a pair in ONE workgroup, in order: each reads what the ones before wrote)
-		if (ranges != 1 || p.Hout) return;
+	if (p.fdl_P > 0 && !p.Hout) {
 		if (p.N == CONV_SHORT_N) launch_short_t<13, 8, true>(p, grid, st); else launch_short_t<14, 8, true>(p, grid, st);
 		return;
 	}
