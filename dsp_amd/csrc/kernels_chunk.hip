@@ -46,33 +46,78 @@ __global__ __launch_bounds__(1024) void cascade_chunk_carry(ChunkParams p)
 	if (tid < D) a[tid] = v;
 	__syncthreads();
 	// level 1: inside every group, T[c] = M T[c - 1] + e[c]
-	const int q1 = tid / D, r1 = tid - q1 * D;                  // thread = (group, row)
-	for (int j = 1; j < g; ++j) {
-		const int c = q1 * g + j;
-		if (q1 < G && c < K) {
-			const double *src = a + (c - 1) * D;
-			double acc = a[c * D + r1], acc2 = 0.0;
+	// Where a group's D rows fit half a wave and the groups fit the workgroup (D <= 32, G <= 32: every plan the host makes for up to twelve sections and a
+	// thousand chunks), group q is lanes 32 (q mod 2) .. of wave q / 2: a step's results are read back by the SAME wave, whose LDS traffic is processed in
+	// order -- the g steps need no workgroup barrier (two per step until round 6: 32 of config 2's 109 us per call were this kernel's barriers).
+	const bool wave_groups = (D <= 32) && (G <= 32) && (blockDim.x == 1024);
+	auto wave_sync = [] {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
+	if (wave_groups) {
+		const int q1 = tid >> 5, r1 = tid & 31;
+		const bool on = q1 < G && r1 < D;
+		for (int j = 1; j < g; ++j) {
+			const int c = q1 * g + j;
+			if (on && c < K) {
+				const double *src = a + (c - 1) * D;
+				double acc = a[c * D + r1], acc2 = 0.0;
 #pragma unroll
-			for (int k = 0; k + 1 < D; k += 2) { acc = fma(mt[k * D + r1], src[k], acc); acc2 = fma(mt[(k + 1) * D + r1], src[k + 1], acc2); }
-			v = acc + acc2;
+				for (int k = 0; k + 1 < D; k += 2) { acc = fma(mt[k * D + r1], src[k], acc); acc2 = fma(mt[(k + 1) * D + r1], src[k + 1], acc2); }
+				a[c * D + r1] = acc + acc2;
+			}
+			wave_sync();
 		}
 		__syncthreads();
-		if (q1 < G && c < K) a[c * D + r1] = v;
-		__syncthreads();
+	}
+	else {
+		const int q1 = tid / D, r1 = tid - q1 * D;                  // thread = (group, row)
+		for (int j = 1; j < g; ++j) {
+			const int c = q1 * g + j;
+			if (q1 < G && c < K) {
+				const double *src = a + (c - 1) * D;
+				double acc = a[c * D + r1], acc2 = 0.0;
+#pragma unroll
+				for (int k = 0; k + 1 < D; k += 2) { acc = fma(mt[k * D + r1], src[k], acc); acc2 = fma(mt[(k + 1) * D + r1], src[k + 1], acc2); }
+				v = acc + acc2;
+			}
+			__syncthreads();
+			if (q1 < G && c < K) a[c * D + r1] = v;
+			__syncthreads();
+		}
 	}
 	// level 2: carry into group q = true end state of group q - 1 = T[end of q - 1] + M^g carry[q - 1]
 	for (int e = tid; e < D * D; e += blockDim.x) { const int r = e / D, k = e - r * D; mt[k * D + r] = Mp[(size_t) (g - 1) * D * D + e]; }   // M^g
 	if (tid < D) carry[tid] = 0.0;
 	__syncthreads();
-	for (int q = 1; q < G; ++q) {
-		if (tid < D) {
-			const double *src = carry + (q - 1) * D;
-			double acc = a[(q * g - 1) * D + tid];
+	if (D <= 64) {
+		// (the D rows are lanes of wave 0: its steps order themselves)
+		if (tid < 64) {
+			for (int q = 1; q < G; ++q) {
+				if (tid < D) {
+					const double *src = carry + (q - 1) * D;
+					double acc = a[(q * g - 1) * D + tid];
 #pragma unroll
-			for (int k = 0; k < D; ++k) acc = fma(mt[k * D + tid], src[k], acc);
-			carry[q * D + tid] = acc;
+					for (int k = 0; k < D; ++k) acc = fma(mt[k * D + tid], src[k], acc);
+					carry[q * D + tid] = acc;
+				}
+				wave_sync();
+			}
 		}
 		__syncthreads();
+	}
+	else {
+		for (int q = 1; q < G; ++q) {
+			if (tid < D) {
+				const double *src = carry + (q - 1) * D;
+				double acc = a[(q * g - 1) * D + tid];
+#pragma unroll
+				for (int k = 0; k < D; ++k) acc = fma(mt[k * D + tid], src[k], acc);
+				carry[q * D + tid] = acc;
+			}
+			__syncthreads();
+		}
 	}
 	// level 3: T[c] += M^(j + 1) carry[q], c = q g + j; then T[c] = state at the END of chunk c = at the start of chunk c + 1
 	for (int e = tid; e < n; e += blockDim.x) {
