@@ -451,7 +451,8 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 	pairs_per_chunk = (long) S * pps;
 	w_stride = N + 272;                     // (the same padding between the pairs of W)
 	// (at least one fp64 row set: the filter spectra of a float32 stage are computed by the fp64 kernels in this buffer)
-	if (!W.alloc(std::max((size_t) nph * pairs_per_chunk * w_stride * elem(), (size_t) nph * w_stride * sizeof(double2)), false)) return false;
+	// (the one-trip kernel keeps a pair's window in registers: no W)
+	if (!W.alloc(std::max(short_mode ? (size_t) 0 : (size_t) nph * pairs_per_chunk * w_stride * elem(), (size_t) nph * w_stride * sizeof(double2)), false)) return false;
 	if (!H.alloc((size_t) (upc_P ? (size_t) upc_P * n_filters : (size_t) n_filters * nph) * N * elem(), false)) return false;
 	if (upc_P && !upc_buf.alloc((size_t) upc_P * S * pps * N * elem())) return false;      // (a float32 stage's delay line holds float2: half the traffic)
 	log_msg(LL_VERBOSE, "%s: info: device buffers ring %p (%zu MB) W %p (%zu MB) H %p", name.c_str(), ring_dev, ring.bytes >> 20, W.p, W.bytes >> 20, H.p);
