@@ -340,10 +340,11 @@ bool ConvStage::init(const Spec &sp, ssize_t max_frames, CascadeStage *feeder, S
 		const bool short_ok = sv != 0 && !env && !resampler && !round_f32 && !ring_parent && !upc_block && !force_N
 		                      && (long) max_frames >= 1024 && (long) max_frames <= (1L << 24) && (double) max_frames * sp.ch_in * sizeof(double) < 2.0e9;
 		// the window: a block of the 16384-point form is 14 / 13 of the transform work per point for (16384 - fn) instead of (8192 - fn) outputs, and
-		// (N + hop) / hop units of traffic -- from about 2000 taps on the larger window is less of both, provided the calls fill its blocks; filters of
-		// 4098 ... 8193 taps have that window or the four-step transforms
+		// (N + hop) / hop units of traffic -- measured on BASELINE config 5's shape a block costs 51 ns of the chip on the small window (two workgroups per
+		// CU) and 122 ns on the large one: the same per frame at first_n = 2308 --, provided the calls fill its blocks; filters of 4098 ... 8193 taps have
+		// that window or the four-step transforms
 		const bool fits13 = fn <= CONV_SHORT_N / 2, fits14 = fn <= CONV_SHORT_N2 / 2, fill14 = (long) max_frames >= 4 * (CONV_SHORT_N2 - fn);
-		const bool want14 = fits14 && sv != 13 && (fits13 ? (sv == 14 || (fn > 2048 && fill14)) : fill14);
+		const bool want14 = fits14 && sv != 13 && (fits13 ? (sv == 14 || (fn > 2304 && fill14)) : fill14);
 		short_mode = short_ok && (fits13 || want14);
 		short_N = want14 ? CONV_SHORT_N2 : CONV_SHORT_N;
 		// the uniformly partitioned form on windows of 8192 / 16384 points (the delay-line tail of the small-call regime at the headline: 7 slots of
